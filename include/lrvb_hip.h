@@ -1,0 +1,244 @@
+/*
+ * lrvb_hip.h -- C ABI of liblrvb_hip.so, the MI355X (gfx950) implementation of the
+ * LinearResponseVariationalBayes hot path: dense ELBO-Hessian assembly, Hessian-vector
+ * product, per-observation gradient matrix G / Gram G^T G, and the linear-response solve
+ * (Cholesky and conjugate gradient).
+ *
+ * The reference (pure Python on autograd) has no FFI; the boundary this library slots in
+ * behind is the callable surface of `Objective` / `TwoParameterObjective` /
+ * `ParametricSensitivityLinearApproximation` / `ConjugateGradientSolver`.  Every entry point
+ * below cites the reference interface it replaces (paths relative to the reference checkout,
+ * LRVB/ = LinearResponseVariationalBayes/).
+ *
+ * Conventions
+ *   - Every function returns an int status: 0 = OK, negative = error; the message is then
+ *     available from lrvb_last_error() (thread-local string).
+ *   - All matrices are C-contiguous (row-major) IEEE fp64.
+ *   - Pointers are caller-owned HOST pointers unless the parameter name ends in `_dev`
+ *     (then it is a device pointer valid on the context's device).  The library owns only
+ *     what lives inside the opaque context.
+ *   - A context is bound to one HIP device and one HIP stream; one in-flight call per
+ *     context (the reference's Objective is equally non-re-entrant:
+ *     LRVB/SparseObjectives.py:131-150).
+ *   - "free" = unconstrained flat vector theta (length D); "vector" = constrained flat
+ *     vector eta (length V).  Layout = concatenation of blocks in push order
+ *     (LRVB/ParameterDictionary.py:39-46, 55-65, 88-99).
+ */
+#ifndef LRVB_HIP_H
+#define LRVB_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LRVB_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------------------- */
+#define LRVB_OK                0
+#define LRVB_ERR_INVALID      -1   /* bad argument (maps to ValueError on the Python side)  */
+#define LRVB_ERR_SIZE         -2   /* wrong vector length (ValueError,
+                                      LRVB/ParameterDictionary.py:56-60, 89-93)            */
+#define LRVB_ERR_HIP          -3   /* HIP runtime error                                     */
+#define LRVB_ERR_STATE        -4   /* call sequence error (e.g. solve before factor)        */
+#define LRVB_ERR_NOT_POSDEF   -5   /* Cholesky breakdown (scipy raises LinAlgError)         */
+#define LRVB_ERR_UNSUPPORTED  -6   /* layout/model combination not built                    */
+
+/* ---- packing layout (free <-> vector maps) --------------------------------------------
+ * One descriptor per parameter block, in ModelParamsDict push order.                     */
+#define LRVB_BLOCK_BOX      0  /* ScalarParam/VectorParam/ArrayParam: elementwise box
+                                  constraint, LRVB/Parameters.py:31-61                     */
+#define LRVB_BLOCK_PSD      1  /* PosDefMatrixParam: log-Cholesky,
+                                  LRVB/MatrixParameters.py:101-112                          */
+#define LRVB_BLOCK_SIMPLEX  2  /* SimplexParam: row softmax with reference category 0,
+                                  LRVB/SimplexParams.py:11-23                               */
+
+typedef struct lrvb_block_desc {
+    int32_t kind;        /* LRVB_BLOCK_*                                                    */
+    int32_t reserved;
+    int64_t free_off;    /* first index in theta                                            */
+    int64_t vec_off;     /* first index in eta                                              */
+    int64_t free_size;   /* box: n; psd: k(k+1)/2; simplex: rows*(K-1)                       */
+    int64_t vec_size;    /* box: n; psd: k(k+1)/2; simplex: rows*K                           */
+    int64_t dim0;        /* psd: k; simplex: rows; box: n                                    */
+    int64_t dim1;        /* simplex: K; otherwise 0                                          */
+    double  lb;          /* box lower bound (-inf allowed); psd: diag_lb                     */
+    double  ub;          /* box upper bound (+inf allowed)                                   */
+} lrvb_block_desc;
+
+/* ---- model description -----------------------------------------------------------------
+ * The objective the context differentiates, written in VECTOR coordinates:
+ *
+ *   f(eta) = sum_n w_n * loss(y_n, x_n . eta[glm_off : glm_off+n_cols])      (data term)
+ *          + quad_scale * ( 1/2 (eta-m)^T A (eta-m) + b^T eta )             (quadratic term)
+ *
+ * and f_free(theta) = f(eta(theta)).  This replaces the opaque zero-argument closure `fun`
+ * of LRVB/SparseObjectives.py:95-129 with a declared model, because a device kernel cannot
+ * trace Python.                                                                          */
+#define LRVB_LOSS_NONE      0
+#define LRVB_LOSS_GAUSSIAN  1  /* loss = 1/2 * lik_info * (y - z)^2                         */
+#define LRVB_LOSS_LOGISTIC  2  /* loss = log(1 + e^z) - y z                                  */
+#define LRVB_LOSS_POISSON   3  /* loss = e^z - y z                                           */
+
+#define LRVB_QUAD_NONE      0
+#define LRVB_QUAD_DIAG      1  /* A = diag(a), a has length V                                */
+#define LRVB_QUAD_DENSE     2  /* A is V x V symmetric                                       */
+
+typedef struct lrvb_model_desc {
+    int32_t n_blocks;
+    int32_t loss;                  /* LRVB_LOSS_*                                           */
+    const lrvb_block_desc* blocks; /* n_blocks entries                                       */
+    int64_t n_obs;                 /* rows of X held by THIS context (its shard)             */
+    int64_t n_cols;                /* columns of X                                           */
+    int64_t glm_off;               /* offset of the coefficient slice inside eta             */
+    double  lik_info;              /* Gaussian precision                                     */
+    int32_t quad_kind;             /* LRVB_QUAD_*                                            */
+    int32_t reserved;
+} lrvb_model_desc;
+
+typedef struct lrvb_ctx lrvb_ctx;
+
+/* data slots for lrvb_set_data */
+#define LRVB_SLOT_X        0   /* n_obs x n_cols design                                     */
+#define LRVB_SLOT_Y        1   /* n_obs responses                                           */
+#define LRVB_SLOT_QUAD_A   2   /* V (diag) or V x V (dense)                                  */
+#define LRVB_SLOT_QUAD_M   3   /* V, centre of the quadratic term (default 0)               */
+#define LRVB_SLOT_QUAD_B   4   /* V, linear tilt (default 0)                                 */
+
+/* ---- library ------------------------------------------------------------------------- */
+int         lrvb_version(void);
+const char* lrvb_last_error(void);
+int         lrvb_device_count(int* out);
+
+/* ---- context: replaces Objective.__init__ (LRVB/SparseObjectives.py:96-116) ----------- */
+int lrvb_ctx_create (lrvb_ctx** out, int device_id, const lrvb_model_desc* model);
+int lrvb_ctx_destroy(lrvb_ctx* ctx);
+int lrvb_ctx_sync   (lrvb_ctx* ctx);                 /* hipStreamSynchronize on the ctx stream */
+int lrvb_ctx_sizes  (lrvb_ctx* ctx, int64_t* D, int64_t* V, int64_t* n_obs);
+
+/* Observations / constants: uploaded once, resident in HBM afterwards.  rows/cols must
+ * match the model description.  The `_dev` form adopts (does not copy, does not free) a
+ * device buffer, e.g. one a torch tensor owns.                                             */
+int lrvb_set_data    (lrvb_ctx* ctx, int slot, const double* host, int64_t rows, int64_t cols);
+int lrvb_set_data_dev(lrvb_ctx* ctx, int slot, const double* data_dev, int64_t rows, int64_t cols);
+/* Per-observation weights w (Example.ipynb:254, `self.weights`); default all ones.        */
+int lrvb_set_weights    (lrvb_ctx* ctx, const double* w, int64_t n);
+int lrvb_set_weights_dev(lrvb_ctx* ctx, const double* w_dev, int64_t n);
+/* Multiplier of the quadratic term (the `z*y` keyword pass-through of
+ * LRVB/test_objectives.py:161-217).                                                        */
+int lrvb_set_quad_scale (lrvb_ctx* ctx, double scale);
+
+/* ---- packing: A15-A18 forward maps ---------------------------------------------------- */
+/* eta = constrain(theta): ModelParamsDict.set_free + get_vector
+ * (LRVB/ParameterDictionary.py:55-63, 97-99)                                               */
+int lrvb_constrain  (lrvb_ctx* ctx, const double* free_in, int64_t D, double* vec_out, int64_t V);
+/* theta = unconstrain(eta): set_vector + get_free (LRVB/ParameterDictionary.py:64-65, 88-96);
+ * LRVB_ERR_INVALID if a value is out of bounds (LRVB/Parameters.py:15-28)                   */
+int lrvb_unconstrain(lrvb_ctx* ctx, const double* vec_in, int64_t V, double* free_out, int64_t D);
+/* Dense Jacobian d eta / d theta (V x D): ModelParamsDict.free_to_vector_jac(...).todense()
+ * (LRVB/ParameterDictionary.py:70-78)                                                       */
+int lrvb_free_to_vector_jac(lrvb_ctx* ctx, const double* free_in, int64_t D, double* jac_out);
+/* H_free = J^T H_vec J + sum_k g_k d2 eta_k : convert_vector_to_free_hessian
+ * (LRVB/Parameters.py:397-424)                                                              */
+int lrvb_free_hessian_from_vector(lrvb_ctx* ctx, const double* free_in, const double* g_vec,
+                                  const double* H_vec, double* H_free_out);
+
+/* ---- objective in free coordinates ---------------------------------------------------- */
+/* Objective.fun_free (LRVB/SparseObjectives.py:120-125)                                    */
+int lrvb_value  (lrvb_ctx* ctx, const double* free_in, int64_t D, double* out);
+/* Objective.fun_free_grad (LRVB/SparseObjectives.py:152-154); value_out may be NULL        */
+int lrvb_grad   (lrvb_ctx* ctx, const double* free_in, int64_t D, double* value_out, double* g_out);
+/* Objective.fun_free_hessian (LRVB/SparseObjectives.py:156-158, autograd.hessian at :103).
+ * H_out is D x D with leading dimension ld (>= D).  Both triangles are written.            */
+int lrvb_hessian(lrvb_ctx* ctx, const double* free_in, int64_t D, double* H_out, int64_t ld);
+/* Objective.fun_free_hvp (LRVB/SparseObjectives.py:183-187): out = H(theta) v               */
+int lrvb_hvp    (lrvb_ctx* ctx, const double* free_in, const double* v, int64_t D, double* out);
+
+/* ---- objective in vector coordinates: Objective.fun_vector* (:127-129, 164-174, 189-193) */
+int lrvb_value_vec  (lrvb_ctx* ctx, const double* vec_in, int64_t V, double* out);
+int lrvb_grad_vec   (lrvb_ctx* ctx, const double* vec_in, int64_t V, double* value_out, double* g_out);
+int lrvb_hessian_vec(lrvb_ctx* ctx, const double* vec_in, int64_t V, double* H_out, int64_t ld);
+int lrvb_hvp_vec    (lrvb_ctx* ctx, const double* vec_in, const double* v, int64_t V, double* out);
+
+/* ---- cross Hessians: TwoParameterObjective.fun_hessian_free1_vector2
+ * (LRVB/SparseObjectives.py:429-438) for the two hyper-parameters a declared model has ---- */
+/* Rows n0..n1 of G (shape (n1-n0) x D): G[n,:] = d/dtheta of d f/d w_n, i.e. the transpose
+ * of the D x N cross Hessian w.r.t. the observation weights (Example.ipynb:425-441).        */
+int lrvb_obs_grad(lrvb_ctx* ctx, const double* free_in, int64_t D, int64_t n0, int64_t n1,
+                  double* G_out);
+/* Same in vector coordinates ((n1-n0) x V): TwoParameterObjective.fun_vector_hessian21
+ * (LRVB/SparseObjectives.py:418-427) with par2 = the weights.                               */
+int lrvb_obs_grad_vec(lrvb_ctx* ctx, const double* vec_in, int64_t V, int64_t n0, int64_t n1,
+                      double* G_out);
+/* D x V cross Hessian w.r.t. the linear tilt b of the quadratic term
+ * (the `hyper_param @ theta` term of LRVB/test_model_sensitivity.py:56-66).                 */
+int lrvb_cross_hessian_tilt(lrvb_ctx* ctx, const double* free_in, int64_t D, double* C_out);
+/* Gram matrix G^T G (D x D) of the per-observation gradient matrix; G is generated on chip
+ * and never materialised.                                                                   */
+int lrvb_gram(lrvb_ctx* ctx, const double* free_in, int64_t D, double* GtG_out, int64_t ld);
+
+/* ---- linear-response solve ------------------------------------------------------------ */
+/* scipy.linalg.cho_factor at LRVB/ModelSensitivity.py:594 / SparseObjectives.py:539.
+ * The factor stays on the device inside the context.                                        */
+int lrvb_chol_factor(lrvb_ctx* ctx, const double* H, int64_t D);
+/* Factor the Hessian the context last built on the device (no host round trip).            */
+int lrvb_chol_factor_last(lrvb_ctx* ctx);
+/* scipy.linalg.cho_solve at LRVB/ModelSensitivity.py:600-602: X = H^{-1} B, B is D x nrhs   */
+int lrvb_chol_solve (lrvb_ctx* ctx, const double* B, int64_t D, int64_t nrhs, double* X_out);
+/* Device-resident forms (H_dev has leading dimension ld; B_dev is D x nrhs, overwritten
+ * with the solution; cov_dev is Q x Q).                                                     */
+int lrvb_chol_factor_dev(lrvb_ctx* ctx, const double* H_dev, int64_t D, int64_t ld);
+int lrvb_chol_solve_dev (lrvb_ctx* ctx, double* B_dev, int64_t D, int64_t nrhs);
+int lrvb_lrvb_cov_dev   (lrvb_ctx* ctx, const double* M_dev, int64_t Q, int64_t D, double* cov_dev);
+/* LRVB covariance M H^{-1} M^T (Q x Q) for a moment Jacobian M (Q x D)
+ * (Example.ipynb:398-415; LRVB/SparseObjectives.py:541-558)                                 */
+int lrvb_lrvb_cov   (lrvb_ctx* ctx, const double* M, int64_t Q, int64_t D, double* cov_out);
+/* ConjugateGradientSolver.get_hinv_vec (LRVB/ConjugateGradient.py:81-85): solves
+ * H(theta) x = b by CG on device HVPs.  Stopping rule of scipy cg with tol (legacy) =
+ * rtol, atol = 0: ||b - Hx|| <= tol*||b||; x0 NULL = zeros; Minv NULL = no preconditioner
+ * (else a dense D x D approximate inverse, applied as z = Minv r); maxiter <= 0 = 10*D.
+ * info_out: 0 converged, >0 = iterations at which it stopped unconverged (scipy's code).    */
+int lrvb_cg_solve(lrvb_ctx* ctx, const double* free_in, const double* b, const double* x0,
+                  const double* Minv, double tol, int64_t maxiter, int64_t D,
+                  double* x_out, int* info_out, int64_t* iters_out);
+
+/* ---- device-resident / multi-GPU entry points -----------------------------------------
+ * Observations shard over ranks (one process, one context per GPU).  A build is
+ *   lrvb_hessian_partial_dev  on every rank  -> stats buffer (this shard's sums)
+ *   sum all-reduce of the stats buffer       (torch.distributed / RCCL, outside this lib)
+ *   lrvb_hessian_finish_dev   on every rank  -> full free-coordinate Hessian
+ * stats layout: [ value (1) | d f_data / d beta (n_cols) | tile-packed lower triangle of
+ * X^T diag(w loss'') X (lrvb_stats_size - 1 - n_cols) ] -- sums over observations only; the
+ * N-independent quadratic term is added by `finish` on every rank after the reduction.     */
+int lrvb_stats_size(lrvb_ctx* ctx, int64_t* n_doubles);
+int lrvb_hessian_partial_dev(lrvb_ctx* ctx, const double* free_dev, double* stats_dev);
+int lrvb_hessian_finish_dev (lrvb_ctx* ctx, const double* free_dev, const double* stats_dev,
+                             double* H_dev, int64_t ld);
+/* Single-GPU convenience = partial + finish with everything resident.                      */
+int lrvb_hessian_dev(lrvb_ctx* ctx, const double* free_dev, double* H_dev, int64_t ld);
+int lrvb_hvp_dev    (lrvb_ctx* ctx, const double* free_dev, const double* v_dev, double* out_dev);
+int lrvb_gram_dev   (lrvb_ctx* ctx, const double* free_dev, double* GtG_dev, int64_t ld);
+
+/* ---- profiling (bench.py's roofline.achieved) ------------------------------------------ */
+typedef struct lrvb_prof {
+    double  wsyrk_ms;       /* HIP-event time of the weighted-SYRK kernel, summed           */
+    int64_t wsyrk_calls;
+    double  wsyrk_flops;    /* algorithmic flops per launch: n_obs * n_cols * (n_cols + 1)   */
+    double  wsyrk_bytes;    /* algorithmic bytes per launch: 8*(n_obs*(n_cols+1)) + tri      */
+    double  pass_ms;        /* HIP-event time of the fused value/grad/curvature pass         */
+    int64_t pass_calls;
+    double  pass_bytes;     /* 8 * n_obs * (n_cols + 3)                                       */
+    double  build_ms;       /* whole lrvb_hessian_dev calls                                  */
+    int64_t build_calls;
+} lrvb_prof;
+int lrvb_profile_enable(lrvb_ctx* ctx, int on);   /* off by default (event overhead)        */
+int lrvb_profile_get   (lrvb_ctx* ctx, lrvb_prof* out);
+int lrvb_profile_reset (lrvb_ctx* ctx);
+/* Tuning knob: number of row splits of the weighted-SYRK grid (0 = automatic).             */
+int lrvb_set_tuning(lrvb_ctx* ctx, int n_splits, int reserved);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LRVB_HIP_H */

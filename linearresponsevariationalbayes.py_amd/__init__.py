@@ -1,0 +1,39 @@
+"""MI355X-native linear-response variational Bayes hot path.
+
+Public surface = the reference package's (LRVB/__init__.py:1-24) plus the declared-objective
+constructors that replace opaque closures on the device path.  Typical use:
+
+    import lrvb_amd as vb                       # loads this package (see lrvb_amd.py at the repo root)
+    par = vb.ModelParamsDict('params'); par.push_param(vb.VectorParam('beta', D, lb=0.))
+    fun = vb.GLMObjective(par, x, y, loss='gaussian', glm_param='beta', prior_info=1.0)
+    objective = vb.Objective(par, fun)          # same class and methods as the reference
+    H = objective.fun_free_hessian(theta)       # one weighted-SYRK pass on the GPU
+
+Reference module names are importable as attributes for drop-in code
+(`vb.SparseObjectives.Objective`, `vb.ModelSensitivity...`, `vb.ConjugateGradient...`,
+`vb.OptimizationUtils...`, `vb.ExponentialFamilies...`, `vb.Parameters...`).
+"""
+__version__ = '0.1.0'
+
+from .packing import (ScalarParam, VectorParam, ArrayParam, PosDefMatrixParam, SimplexParam,
+                      ModelParamsDict, ModelParamsDictValues, convert_vector_to_free_hessian)
+from .families import (UVNParam, UVNParamVector, UVNParamArray, UVNMomentParamArray, MVNParam,
+                       MVNArray, GammaParam, WishartParam, DirichletParamArray)
+from .objectives import (Objective, TwoParameterObjective, ParameterConverter, ParametricSensitivity,
+                         LinearConverter, ElementwiseConverter, Logger, Timer)
+from .sensitivity import ParametricSensitivityLinearApproximation
+from .cg import ConjugateGradientSolver
+from .models import (DeviceContext, DeviceObjective, GLMObjective, QuadraticObjective, LinearMoments)
+
+# reference-style module aliases
+from . import packing as Parameters
+from . import packing as MatrixParameters
+from . import packing as SimplexParams
+from . import packing as ParameterDictionary
+from . import objectives as SparseObjectives
+from . import sensitivity as ModelSensitivity
+from . import cg as ConjugateGradient
+from . import optim as OptimizationUtils
+from . import expfam as ExponentialFamilies
+from . import families as NormalParams
+from . import distributed

@@ -1,0 +1,153 @@
+"""ctypes binding of liblrvb_hip.so (the C ABI declared in include/lrvb_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a call fails, an exception
+is raised.  Status codes are translated into the exception types the reference raises for the
+same mistake (ValueError for wrong sizes / bounds: LRVB/ParameterDictionary.py:56-60,
+LRVB/Parameters.py:15-28; numpy.linalg.LinAlgError for a failed Cholesky, as scipy's cho_factor
+at LRVB/ModelSensitivity.py:594).
+"""
+import ctypes
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'liblrvb_hip.so')
+
+OK, ERR_INVALID, ERR_SIZE, ERR_HIP, ERR_STATE, ERR_NOT_POSDEF, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
+BLOCK_BOX, BLOCK_PSD, BLOCK_SIMPLEX = 0, 1, 2
+LOSS_NONE, LOSS_GAUSSIAN, LOSS_LOGISTIC, LOSS_POISSON = 0, 1, 2, 3
+QUAD_NONE, QUAD_DIAG, QUAD_DENSE = 0, 1, 2
+SLOT_X, SLOT_Y, SLOT_QUAD_A, SLOT_QUAD_M, SLOT_QUAD_B = 0, 1, 2, 3, 4
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_i64 = ctypes.c_int64
+
+
+class BlockDesc(ctypes.Structure):
+    _fields_ = [('kind', ctypes.c_int32), ('reserved', ctypes.c_int32),
+                ('free_off', c_i64), ('vec_off', c_i64), ('free_size', c_i64), ('vec_size', c_i64),
+                ('dim0', c_i64), ('dim1', c_i64), ('lb', ctypes.c_double), ('ub', ctypes.c_double)]
+
+
+class ModelDesc(ctypes.Structure):
+    _fields_ = [('n_blocks', ctypes.c_int32), ('loss', ctypes.c_int32),
+                ('blocks', ctypes.POINTER(BlockDesc)),
+                ('n_obs', c_i64), ('n_cols', c_i64), ('glm_off', c_i64),
+                ('lik_info', ctypes.c_double), ('quad_kind', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+
+
+class Prof(ctypes.Structure):
+    _fields_ = [('wsyrk_ms', ctypes.c_double), ('wsyrk_calls', c_i64),
+                ('wsyrk_flops', ctypes.c_double), ('wsyrk_bytes', ctypes.c_double),
+                ('pass_ms', ctypes.c_double), ('pass_calls', c_i64), ('pass_bytes', ctypes.c_double),
+                ('build_ms', ctypes.c_double), ('build_calls', c_i64)]
+
+
+# name -> argtypes; every function returns int except the two noted.  This table is also what
+# tests/test_abi_symbols.py checks against include/lrvb_hip.h.
+_VP = ctypes.c_void_p
+_SIGNATURES = {
+    'lrvb_version': [],
+    'lrvb_device_count': [ctypes.POINTER(ctypes.c_int)],
+    'lrvb_ctx_create': [ctypes.POINTER(_VP), ctypes.c_int, ctypes.POINTER(ModelDesc)],
+    'lrvb_ctx_destroy': [_VP],
+    'lrvb_ctx_sync': [_VP],
+    'lrvb_ctx_sizes': [_VP, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)],
+    'lrvb_set_data': [_VP, ctypes.c_int, _VP, c_i64, c_i64],
+    'lrvb_set_data_dev': [_VP, ctypes.c_int, _VP, c_i64, c_i64],
+    'lrvb_set_weights': [_VP, _VP, c_i64],
+    'lrvb_set_weights_dev': [_VP, _VP, c_i64],
+    'lrvb_set_quad_scale': [_VP, ctypes.c_double],
+    'lrvb_constrain': [_VP, _VP, c_i64, _VP, c_i64],
+    'lrvb_unconstrain': [_VP, _VP, c_i64, _VP, c_i64],
+    'lrvb_free_to_vector_jac': [_VP, _VP, c_i64, _VP],
+    'lrvb_free_hessian_from_vector': [_VP, _VP, _VP, _VP, _VP],
+    'lrvb_value': [_VP, _VP, c_i64, _VP],
+    'lrvb_grad': [_VP, _VP, c_i64, _VP, _VP],
+    'lrvb_hessian': [_VP, _VP, c_i64, _VP, c_i64],
+    'lrvb_hvp': [_VP, _VP, _VP, c_i64, _VP],
+    'lrvb_value_vec': [_VP, _VP, c_i64, _VP],
+    'lrvb_grad_vec': [_VP, _VP, c_i64, _VP, _VP],
+    'lrvb_hessian_vec': [_VP, _VP, c_i64, _VP, c_i64],
+    'lrvb_hvp_vec': [_VP, _VP, _VP, c_i64, _VP],
+    'lrvb_obs_grad': [_VP, _VP, c_i64, c_i64, c_i64, _VP],
+    'lrvb_obs_grad_vec': [_VP, _VP, c_i64, c_i64, c_i64, _VP],
+    'lrvb_cross_hessian_tilt': [_VP, _VP, c_i64, _VP],
+    'lrvb_gram': [_VP, _VP, c_i64, _VP, c_i64],
+    'lrvb_chol_factor': [_VP, _VP, c_i64],
+    'lrvb_chol_factor_last': [_VP],
+    'lrvb_chol_solve': [_VP, _VP, c_i64, c_i64, _VP],
+    'lrvb_lrvb_cov': [_VP, _VP, c_i64, c_i64, _VP],
+    'lrvb_chol_factor_dev': [_VP, _VP, c_i64, c_i64],
+    'lrvb_chol_solve_dev': [_VP, _VP, c_i64, c_i64],
+    'lrvb_lrvb_cov_dev': [_VP, _VP, c_i64, c_i64, _VP],
+    'lrvb_cg_solve': [_VP, _VP, _VP, _VP, _VP, ctypes.c_double, c_i64, c_i64, _VP,
+                      ctypes.POINTER(ctypes.c_int), ctypes.POINTER(c_i64)],
+    'lrvb_stats_size': [_VP, ctypes.POINTER(c_i64)],
+    'lrvb_hessian_partial_dev': [_VP, _VP, _VP],
+    'lrvb_hessian_finish_dev': [_VP, _VP, _VP, _VP, c_i64],
+    'lrvb_hessian_dev': [_VP, _VP, _VP, c_i64],
+    'lrvb_hvp_dev': [_VP, _VP, _VP, _VP],
+    'lrvb_gram_dev': [_VP, _VP, _VP, c_i64],
+    'lrvb_profile_enable': [_VP, ctypes.c_int],
+    'lrvb_profile_get': [_VP, ctypes.POINTER(Prof)],
+    'lrvb_profile_reset': [_VP],
+    'lrvb_set_tuning': [_VP, ctypes.c_int, ctypes.c_int],
+}
+
+_lib = None
+
+
+def load():
+    """Loads the shared library (once).  Raises OSError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError(
+            'liblrvb_hip.so not found at {}: build it with `python -c "import __graft_entry__ as g; '
+            'g.build()"` (or csrc/build.sh).  There is no CPU fallback.'.format(LIB_PATH))
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    lib.lrvb_last_error.argtypes = []
+    lib.lrvb_last_error.restype = ctypes.c_char_p
+    _lib = lib
+    return lib
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    check(load().lrvb_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def last_error():
+    return load().lrvb_last_error().decode('utf-8', 'replace')
+
+
+def check(status):
+    if status == OK:
+        return
+    msg = last_error()
+    if status in (ERR_INVALID, ERR_SIZE):
+        raise ValueError(msg)
+    if status == ERR_NOT_POSDEF:
+        raise np.linalg.LinAlgError(msg)
+    if status == ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise RuntimeError('liblrvb_hip: {} (status {})'.format(msg, status))
+
+
+def as_f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def ptr(a):
+    """Host pointer of a C-contiguous float64 array (None -> NULL)."""
+    if a is None:
+        return None
+    assert a.dtype == np.float64 and a.flags['C_CONTIGUOUS']
+    return a.ctypes.data_as(ctypes.c_void_p)

@@ -1,0 +1,288 @@
+// k_glm.hip -- one streaming pass over the observations: value, gradient, per-observation
+// curvature, and the Hessian-vector product of the data term
+//
+//     f_data(beta) = sum_n w_n loss(y_n, x_n . beta).
+//
+// Replaces what autograd executes for Objective.fun_free / fun_free_grad / fun_free_hvp
+// (LRVB/SparseObjectives.py:120-125, 152-154, 183-187: forward + reverse (+ reverse-over-
+// reverse) tape walks over N-sized numpy arrays).  HBM-bound: each row of X is read exactly
+// once per pass and kept in registers between the dot product and the rank-1 update:
+//
+//   wavefront <- 2 rows at a time; lane l holds columns {128 it + 2l, 128 it + 2l + 1};
+//   z = x.beta (and t = x.u in HVP mode) by __shfl_xor butterflies;
+//   coef = w loss'(y, z)             (PASS_GRAD; also stores loss' and w loss'')
+//        = w loss''(y, z) t          (PASS_HVP)
+//        = cw_n t                    (PASS_HVP_C, curvature cached by an earlier PASS_GRAD)
+//   acc[columns of this lane] += coef * x
+//
+// Block partials (4 waves combined through LDS) go to part_vec[block][P]; a second kernel
+// sums them in a fixed order (deterministic, no atomics).
+#include "lrvb_internal.h"
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ void loss_eval(int loss, double lik_info, double y, double z,
+                                          double& l0, double& l1, double& l2) {
+    if (loss == LRVB_LOSS_GAUSSIAN) {
+        const double d = z - y;
+        l0 = 0.5 * lik_info * d * d; l1 = lik_info * d; l2 = lik_info;
+    } else if (loss == LRVB_LOSS_LOGISTIC) {
+        // softplus(z) - y z, evaluated without overflow
+        const double az = fabs(z);
+        const double e = exp(-az);
+        const double sp = (z > 0.0 ? z : 0.0) + log1p(e);
+        const double sig = z >= 0.0 ? 1.0 / (1.0 + e) : e / (1.0 + e);
+        l0 = sp - y * z; l1 = sig - y; l2 = sig * (1.0 - sig);
+    } else {   // LRVB_LOSS_POISSON
+        const double ez = exp(z);
+        l0 = ez - y * z; l1 = ez - y; l2 = ez;
+    }
+}
+
+template <int NIT, int MODE>
+__global__ __launch_bounds__(PASS_THREADS)
+void glm_pass_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
+                     const double* __restrict__ y, const double* __restrict__ w,
+                     const double* __restrict__ beta, const double* __restrict__ u,
+                     int loss, double lik_info,
+                     double* __restrict__ lp_out, double* __restrict__ cw_io,
+                     double* __restrict__ part_vec, double* __restrict__ part_val,
+                     int vec_ok_i, int store_obs)
+{
+    __shared__ double red[3][NIT * 128];
+    __shared__ double redv[4];
+    const bool vec_ok = vec_ok_i != 0;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+
+    double bt[NIT][2], ut[NIT][2], acc[NIT][2];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int col = it * 128 + 2 * lane;
+        bt[it][0] = (MODE != PASS_HVP_C && col < P) ? beta[col] : 0.0;
+        bt[it][1] = (MODE != PASS_HVP_C && col + 1 < P) ? beta[col + 1] : 0.0;
+        ut[it][0] = (MODE != PASS_GRAD && col < P) ? u[col] : 0.0;
+        ut[it][1] = (MODE != PASS_GRAD && col + 1 < P) ? u[col + 1] : 0.0;
+        acc[it][0] = 0.0; acc[it][1] = 0.0;
+    }
+    double val = 0.0;
+
+    const i64 wave_global = (i64)blockIdx.x * 4 + wave;
+    const i64 wave_stride = (i64)gridDim.x * 4;
+    // two rows per iteration: rows 2*k and 2*k+1 of this wave's strided sequence
+    for (i64 base = wave_global * 2; base < N; base += wave_stride * 2) {
+        double xr[2][NIT][2];
+        const bool has1 = (base + 1 < N);
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const i64 n = base + rr;
+            const bool ok = (rr == 0) || has1;
+            const double* rowp = X + (ok ? n : base) * ldx;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int col = it * 128 + 2 * lane;
+                double v0 = 0.0, v1 = 0.0;
+                if (ok) {
+                    if (col + 1 < P) {
+                        if (vec_ok) { const double2 tv = *reinterpret_cast<const double2*>(rowp + col); v0 = tv.x; v1 = tv.y; }
+                        else { v0 = rowp[col]; v1 = rowp[col + 1]; }
+                    } else if (col < P) { v0 = rowp[col]; }
+                }
+                xr[rr][it][0] = v0; xr[rr][it][1] = v1;
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            if (rr == 1 && !has1) break;
+            const i64 n = base + rr;
+            double z = 0.0, tt = 0.0;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                if (MODE != PASS_HVP_C) z += xr[rr][it][0] * bt[it][0] + xr[rr][it][1] * bt[it][1];
+                if (MODE != PASS_GRAD)  tt += xr[rr][it][0] * ut[it][0] + xr[rr][it][1] * ut[it][1];
+            }
+            if (MODE != PASS_HVP_C) z = wave_sum(z);
+            if (MODE != PASS_GRAD)  tt = wave_sum(tt);
+            double coef;
+            if (MODE == PASS_HVP_C) {
+                coef = cw_io[n] * tt;
+            } else {
+                double l0, l1, l2;
+                loss_eval(loss, lik_info, y[n], z, l0, l1, l2);
+                const double wn = w[n];
+                if (MODE == PASS_GRAD) {
+                    coef = wn * l1;
+                    val += wn * l0;
+                    if (store_obs && lane == 0) { lp_out[n] = l1; cw_io[n] = wn * l2; }
+                } else {
+                    coef = wn * l2 * tt;
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                acc[it][0] += coef * xr[rr][it][0];
+                acc[it][1] += coef * xr[rr][it][1];
+            }
+        }
+    }
+
+    // combine the 4 waves of the block (fixed order: wave 0 + 1 + 2 + 3)
+    if (wave > 0) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            red[wave - 1][it * 128 + 2 * lane] = acc[it][0];
+            red[wave - 1][it * 128 + 2 * lane + 1] = acc[it][1];
+        }
+    }
+    if (lane == 0) redv[wave] = val;     // every lane holds the same val (wave-uniform z)
+    __syncthreads();
+    if (wave == 0) {
+        double* dst = part_vec + (i64)blockIdx.x * P;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int col = it * 128 + 2 * lane;
+            const double s0 = ((acc[it][0] + red[0][col]) + red[1][col]) + red[2][col];
+            const double s1 = ((acc[it][1] + red[0][col + 1]) + red[1][col + 1]) + red[2][col + 1];
+            if (col < P) dst[col] = s0;
+            if (col + 1 < P) dst[col + 1] = s1;
+        }
+        if (lane == 0 && MODE == PASS_GRAD) part_val[blockIdx.x] = ((redv[0] + redv[1]) + redv[2]) + redv[3];
+    }
+}
+
+// out[col] = sum_b part_vec[b][col]; value = sum_b part_val[b]  (fixed order)
+__global__ __launch_bounds__(256)
+void pass_reduce_kernel(const double* __restrict__ part_vec, const double* __restrict__ part_val,
+                        int nblk, int P, double* __restrict__ out_vec, double* __restrict__ out_val)
+{
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col < P) {
+        double s = 0.0;
+        for (int b = 0; b < nblk; ++b) s += part_vec[(i64)b * P + col];
+        out_vec[col] = s;
+    }
+    if (out_val != nullptr && blockIdx.x == 0) {
+        __shared__ double sh[256];
+        double s = 0.0;
+        for (int b = threadIdx.x; b < nblk; b += 256) s += part_val[b];
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        for (int off = 128; off >= 1; off >>= 1) {
+            if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) *out_val = sh[0];
+    }
+}
+
+template <int NIT>
+static int launch_pass_nit(lrvb_ctx* c, PassMode mode, const double* beta, const double* u,
+                           int grid, int vec_ok, int store_obs) {
+    dim3 g(grid), b(PASS_THREADS);
+    switch (mode) {
+    case PASS_GRAD:
+        hipLaunchKernelGGL((glm_pass_kernel<NIT, PASS_GRAD>), g, b, 0, c->stream, c->X.p, c->P, c->N, (int)c->P,
+                           c->y.p, c->w.p, beta, u, c->loss, c->lik_info, c->lp.p, c->cw.p,
+                           c->part_vec.p, c->part_val.p, vec_ok, store_obs);
+        break;
+    case PASS_HVP:
+        hipLaunchKernelGGL((glm_pass_kernel<NIT, PASS_HVP>), g, b, 0, c->stream, c->X.p, c->P, c->N, (int)c->P,
+                           c->y.p, c->w.p, beta, u, c->loss, c->lik_info, c->lp.p, c->cw.p,
+                           c->part_vec.p, c->part_val.p, vec_ok, store_obs);
+        break;
+    default:
+        hipLaunchKernelGGL((glm_pass_kernel<NIT, PASS_HVP_C>), g, b, 0, c->stream, c->X.p, c->P, c->N, (int)c->P,
+                           c->y.p, c->w.p, beta, u, c->loss, c->lik_info, c->lp.p, c->cw.p,
+                           c->part_vec.p, c->part_val.p, vec_ok, store_obs);
+        break;
+    }
+    HIP_TRY(hipGetLastError());
+    return LRVB_OK;
+}
+
+int launch_glm_pass(lrvb_ctx* c, PassMode mode, const double* beta_dev, const double* u_dev,
+                    double* out_vec_P, double* value_out_dev, bool store_obs) {
+    if (c->P > PASS_MAX_COLS)
+        LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "fused pass supports n_cols <= %d (got %lld)", PASS_MAX_COLS, (long long)c->P);
+    // 8 blocks per CU worth of row pairs, capped by the work available
+    i64 pairs = (c->N + 1) / 2;
+    i64 grid = (pairs + 3) / 4;
+    if (grid > 2048) grid = 2048;
+    if (grid < 1) grid = 1;
+    LRVB_TRY(buf_reserve(c, c->part_vec, (size_t)(grid * c->P)));
+    LRVB_TRY(buf_reserve(c, c->part_val, (size_t)grid));
+    LRVB_TRY(buf_reserve(c, c->lp, (size_t)c->N));
+    LRVB_TRY(buf_reserve(c, c->cw, (size_t)c->N));
+    const int vec_ok = ((c->P % 2) == 0) && ((((uintptr_t)c->X.p) & 15) == 0);
+    if (c->prof_on && mode == PASS_GRAD) LRVB_TRY(prof_mark(c, PROF_PASS));
+    int st;
+    const int so = store_obs ? 1 : 0;
+    if (c->P <= 128)      st = launch_pass_nit<1>(c, mode, beta_dev, u_dev, (int)grid, vec_ok, so);
+    else if (c->P <= 256) st = launch_pass_nit<2>(c, mode, beta_dev, u_dev, (int)grid, vec_ok, so);
+    else if (c->P <= 512) st = launch_pass_nit<4>(c, mode, beta_dev, u_dev, (int)grid, vec_ok, so);
+    else                  st = launch_pass_nit<8>(c, mode, beta_dev, u_dev, (int)grid, vec_ok, so);
+    LRVB_TRY(st);
+    if (c->prof_on && mode == PASS_GRAD) LRVB_TRY(prof_mark(c, PROF_PASS));
+    hipLaunchKernelGGL(pass_reduce_kernel, dim3((unsigned)((c->P + 255) / 256)), dim3(256), 0, c->stream,
+                       c->part_vec.p, c->part_val.p, (int)grid, (int)c->P, out_vec_P,
+                       (mode == PASS_GRAD) ? value_out_dev : (double*)nullptr);
+    HIP_TRY(hipGetLastError());
+    if (c->prof_on && mode == PASS_GRAD) {
+        c->prof.pass_bytes = 8.0 * (double)c->N * (double)(c->P + 3);
+    }
+    return LRVB_OK;
+}
+
+// Rows n0..n1 of the per-observation gradient matrix in VECTOR coordinates of the
+// coefficient slice:  Gv[n, :] = loss'(y_n, z_n) * x_n   (the caller applies J).
+// For an all-box layout J is diagonal and is fused here: G[n, j] = lp_n x_nj j1[glm_off + j],
+// written into a (n1-n0) x D matrix whose other columns are zero.
+__global__ __launch_bounds__(256)
+void obs_grad_box_kernel(const double* __restrict__ X, i64 ldx, int P, const double* __restrict__ lp,
+                         const double* __restrict__ j1, i64 glm_off, i64 D, i64 n0, i64 n1,
+                         double* __restrict__ G)
+{
+    const i64 n = n0 + blockIdx.y;
+    if (n >= n1) return;
+    const double lpn = lp[n];
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < D; j += (i64)gridDim.x * blockDim.x) {
+        const i64 jc = j - glm_off;
+        double v = 0.0;
+        if (jc >= 0 && jc < P) v = lpn * X[n * ldx + jc] * j1[j];
+        G[(n - n0) * D + j] = v;
+    }
+}
+
+__global__ __launch_bounds__(256)
+void obs_grad_vec_kernel(const double* __restrict__ X, i64 ldx, int P, const double* __restrict__ lp,
+                         i64 n0, i64 n1, double* __restrict__ Gv)
+{
+    const i64 n = n0 + blockIdx.y;
+    if (n >= n1) return;
+    const double lpn = lp[n];
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < P; j += (i64)gridDim.x * blockDim.x)
+        Gv[(n - n0) * P + j] = lpn * X[n * ldx + j];
+}
+
+int launch_obs_grad(lrvb_ctx* c, i64 n0, i64 n1, double* G_dev, int mode, const double* scale_vec) {
+    // mode 0: (n1-n0) x D, columns scaled by scale_vec (= j1 of an all-box layout, or ones with D := V)
+    // mode 1: (n1-n0) x P raw coefficient-slice columns
+    if (n1 <= n0) return LRVB_OK;
+    const i64 rows = n1 - n0;
+    if (rows > 65535) LRVB_FAIL(LRVB_ERR_INVALID, "obs_grad: at most 65535 rows per call (got %lld)", (long long)rows);
+    if (mode == 0) {
+        const i64 width = c->all_box && scale_vec == c->j1.p ? c->D : c->V;
+        dim3 grid((unsigned)((width + 255) / 256), (unsigned)rows);
+        hipLaunchKernelGGL(obs_grad_box_kernel, grid, dim3(256), 0, c->stream, c->X.p, c->P, (int)c->P,
+                           c->lp.p, scale_vec, c->glm_off, width, n0, n1, G_dev);
+    } else {
+        dim3 grid((unsigned)((c->P + 255) / 256), (unsigned)rows);
+        hipLaunchKernelGGL(obs_grad_vec_kernel, grid, dim3(256), 0, c->stream, c->X.p, c->P, (int)c->P,
+                           c->lp.p, n0, n1, G_dev);
+    }
+    HIP_TRY(hipGetLastError());
+    return LRVB_OK;
+}

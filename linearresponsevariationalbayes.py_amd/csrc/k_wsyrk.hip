@@ -1,0 +1,252 @@
+// k_wsyrk.hip -- weighted SYRK  S = X^T diag(c) X  in fp64 on the gfx950 matrix cores.
+//
+// This is the O(N D^2) part of Objective.fun_free_hessian (reference: autograd.hessian at
+// LRVB/SparseObjectives.py:103, 156-158 -- D reverse passes over the N observations) and of
+// the Gram matrix G^T G (c = loss'^2).  The reference has no kernel to translate; the layout
+// below is designed for CDNA4:
+//
+//   * output-stationary 128x128 tiles of the LOWER triangle of S, one tile per workgroup
+//     (4 wavefronts, each a 64x64 sub-tile = 4x4 v_mfma_f64_16x16x4_f64 accumulators);
+//   * the observation axis is split n_splits ways; a workgroup streams its row range through
+//     a double-buffered LDS stage of 16 observations x (128 + 128) columns, register-staged
+//     (global_load_dwordx4 issued one stage ahead of the MFMAs that consume it);
+//   * blockIdx -> (split, tile) is XCD-aware: workgroups that share an XCD (blockIdx % 8)
+//     walk the same row range, so every X line is pulled from HBM into one L2 only and the
+//     35 other tiles of that split hit in L2;
+//   * split partials are reduced by a second, deterministic kernel (no atomics -> results do
+//     not depend on dispatch order).
+//
+// MFMA operand maps (v_mfma_f64_16x16x4_f64, one f64 per lane for A and B):
+//   A[i = lane & 15][k = lane >> 4],  B[k = lane >> 4][j = lane & 15],
+//   D: 4 f64 per lane, reg r -> row i = (lane >> 4) + 4 r, col j = lane & 15.
+// With S_ij = sum_n c_n X_ni X_nj the contraction index k is the observation, so both
+// operands are read from the staged rows with the SAME (row = k, col = i or j) pattern.
+#include "lrvb_internal.h"
+#include <math.h>
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// (stride mod 32 doubles) == 16: the two 16-lane halves of a ds_read_b64 lane group read
+// consecutive observations and land on disjoint banks.
+constexpr int WS_LDS_STRIDE = WS_TILE + 16;
+
+int wsyrk_num_tiles(i64 P) {
+    i64 nb = (P + WS_TILE - 1) / WS_TILE;
+    return (int)(nb * (nb + 1) / 2);
+}
+
+int wsyrk_auto_splits(const lrvb_ctx* c) {
+    if (c->n_splits_user > 0) return ((c->n_splits_user + 7) / 8) * 8;
+    int T = wsyrk_num_tiles(c->P);
+    // aim at ~9 uniform work items per CU (256 CUs), keep >= 256 observations per split
+    i64 s = (2304 + T / 2) / T;
+    s = ((s + 7) / 8) * 8;
+    i64 max_by_rows = c->N / 256;
+    max_by_rows = (max_by_rows / 8) * 8;
+    if (s > max_by_rows) s = max_by_rows;
+    if (s > 128) s = 128;
+    if (s < 8) s = 8;
+    return (int)s;
+}
+
+__device__ __forceinline__ void ws_load_pair(const double* __restrict__ rowp, int col, int P,
+                                             bool vec_ok, double& v0, double& v1) {
+    if (col + 1 < P) {
+        if (vec_ok) {
+            double2 t = *reinterpret_cast<const double2*>(rowp + col);
+            v0 = t.x; v1 = t.y;
+        } else {
+            v0 = rowp[col]; v1 = rowp[col + 1];
+        }
+    } else if (col < P) {
+        v0 = rowp[col]; v1 = 0.0;
+    } else {
+        v0 = 0.0; v1 = 0.0;
+    }
+}
+
+__global__ __launch_bounds__(WS_THREADS, 2)
+void wsyrk_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
+                  const double* __restrict__ cvec, int n_splits, int T, i64 rows_per_split,
+                  double* __restrict__ partial, int vec_ok_i)
+{
+    __shared__ double lds[2][2][WS_KC][WS_LDS_STRIDE];   // [stage][A|B][obs][col]
+
+    const bool vec_ok = vec_ok_i != 0;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    const int xcd = b & 7;                  // label of the workgroups that share an XCD
+    const int q = b >> 3;
+    const int split_local = q / T;
+    const int t = q - split_local * T;
+    const int split = split_local * 8 + xcd;
+
+    int bi = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+    while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+    while (bi * (bi + 1) / 2 > t) --bi;
+    const int bj = t - bi * (bi + 1) / 2;
+    const bool diag = (bi == bj);
+
+    i64 r0 = (i64)split * rows_per_split;
+    i64 r1 = r0 + rows_per_split;
+    if (r1 > N) r1 = N;
+    if (r0 > N) r0 = N;
+    const int nch = (int)((r1 - r0 + WS_KC - 1) / WS_KC);
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wr = wave >> 1, wc = wave & 1;
+    const bool skip = diag && (wr == 0) && (wc == 1);   // strictly-upper 64x64 of a diagonal tile
+
+    d4 acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = (d4){0.0, 0.0, 0.0, 0.0};
+
+    // staging registers: 4 pairs per panel per thread
+    double sa[4][2], sb[4][2];
+    const int colA0 = bi * WS_TILE, colB0 = bj * WS_TILE;
+
+    auto load_stage = [&](int ch) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = it * WS_THREADS + tid;
+            const int row = idx >> 6;
+            const int c2 = (idx & 63) * 2;
+            const i64 n = r0 + (i64)ch * WS_KC + row;
+            if (n < r1) {
+                const double* rowp = X + n * ldx;
+                const double cv = cvec[n];
+                double a0, a1;
+                ws_load_pair(rowp, colA0 + c2, P, vec_ok, a0, a1);
+                if (diag) { sb[it][0] = a0; sb[it][1] = a1; }
+                else      { ws_load_pair(rowp, colB0 + c2, P, vec_ok, sb[it][0], sb[it][1]); }
+                sa[it][0] = a0 * cv; sa[it][1] = a1 * cv;
+            } else {
+                sa[it][0] = sa[it][1] = sb[it][0] = sb[it][1] = 0.0;
+            }
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = it * WS_THREADS + tid;
+            const int row = idx >> 6;
+            const int c2 = (idx & 63) * 2;
+            *reinterpret_cast<double2*>(&lds[buf][0][row][c2]) = make_double2(sa[it][0], sa[it][1]);
+            *reinterpret_cast<double2*>(&lds[buf][1][row][c2]) = make_double2(sb[it][0], sb[it][1]);
+        }
+    };
+
+    if (nch > 0) {
+        load_stage(0);
+        store_stage(0);
+    }
+    __syncthreads();
+
+    int buf = 0;
+    for (int ch = 0; ch < nch; ++ch) {
+        const bool more = (ch + 1 < nch);
+        if (more) load_stage(ch + 1);
+        if (!skip) {
+#pragma unroll
+            for (int kk = 0; kk < WS_KC / 4; ++kk) {
+                const int krow = kk * 4 + (lane >> 4);
+                double af[4], bf[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) af[m] = lds[buf][0][krow][wr * 64 + m * 16 + (lane & 15)];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) bf[n] = lds[buf][1][krow][wc * 64 + n * 16 + (lane & 15)];
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m], bf[n], acc[m][n], 0, 0, 0);
+            }
+        }
+        if (more) store_stage(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    double* out = partial + ((i64)split * T + t) * (i64)(WS_TILE * WS_TILE);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = wr * 64 + m * 16 + (lane >> 4) + 4 * r;
+                const int j = wc * 64 + n * 16 + (lane & 15);
+                out[i * WS_TILE + j] = acc[m][n][r];
+            }
+}
+
+// Deterministic second stage: tiles[t][e] = sum_s partial[s][t][e]  (fixed order).
+__global__ __launch_bounds__(256)
+void wsyrk_reduce_kernel(const double* __restrict__ partial, int n_splits, i64 tile_elems_total,
+                         double* __restrict__ tiles)
+{
+    const i64 e2 = ((i64)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    if (e2 >= tile_elems_total) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int s = 0; s < n_splits; ++s) {
+        const double2 v = *reinterpret_cast<const double2*>(partial + (i64)s * tile_elems_total + e2);
+        s0 += v.x; s1 += v.y;
+    }
+    *reinterpret_cast<double2*>(tiles + e2) = make_double2(s0, s1);
+}
+
+int launch_wsyrk(lrvb_ctx* c, const double* cvec_dev, double* tiles_out_dev) {
+    const int T = wsyrk_num_tiles(c->P);
+    const int S = wsyrk_auto_splits(c);
+    i64 rps = (c->N + S - 1) / S;
+    rps = ((rps + WS_KC - 1) / WS_KC) * WS_KC;
+    if (rps < WS_KC) rps = WS_KC;
+    const i64 tile_elems = (i64)T * WS_TILE * WS_TILE;
+    LRVB_TRY(buf_reserve(c, c->tile_part, (size_t)(tile_elems * S)));
+    const i64 ldx = c->P;
+    const int vec_ok = ((ldx % 2) == 0) && ((((uintptr_t)c->X.p) & 15) == 0);
+    const int grid = S * T;
+    if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
+    hipLaunchKernelGGL(wsyrk_kernel, dim3(grid), dim3(WS_THREADS), 0, c->stream,
+                       c->X.p, ldx, c->N, (int)c->P, cvec_dev, S, T, rps, c->tile_part.p, vec_ok);
+    HIP_TRY(hipGetLastError());
+    if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
+    const i64 nthreads = tile_elems / 2;
+    hipLaunchKernelGGL(wsyrk_reduce_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, c->stream,
+                       c->tile_part.p, S, tile_elems, tiles_out_dev);
+    HIP_TRY(hipGetLastError());
+    if (c->prof_on) {
+        c->prof.wsyrk_flops = (double)c->N * (double)c->P * (double)(c->P + 1);
+        c->prof.wsyrk_bytes = 8.0 * ((double)c->N * (double)(c->P + 1)) + 8.0 * 0.5 * (double)c->P * (double)(c->P + 1);
+    }
+    return LRVB_OK;
+}
+
+// Expand tile-packed lower triangle into a dense symmetric block of `dense` at
+// (row_off, col_off); element (a, b), a >= b, lives in tile (a/128, b/128).
+__global__ __launch_bounds__(256)
+void tiles_to_dense_kernel(const double* __restrict__ tiles, i64 P, double* __restrict__ dense,
+                           i64 ld, i64 row_off, i64 col_off, int accumulate)
+{
+    const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 i = blockIdx.y;
+    if (j >= P || i >= P) return;
+    const i64 a = i > j ? i : j, b = i > j ? j : i;
+    const i64 ba = a / WS_TILE, bb = b / WS_TILE;
+    const i64 t = ba * (ba + 1) / 2 + bb;
+    const double v = tiles[t * (WS_TILE * WS_TILE) + (a % WS_TILE) * WS_TILE + (b % WS_TILE)];
+    double* dst = dense + (row_off + i) * ld + col_off + j;
+    if (accumulate) *dst += v; else *dst = v;
+}
+
+int launch_tiles_to_dense(lrvb_ctx* c, const double* tiles_dev, i64 P, double* dense_dev, i64 ld,
+                          i64 row_off, i64 col_off, bool accumulate) {
+    if (P <= 0) return LRVB_OK;
+    dim3 grid((unsigned)((P + 255) / 256), (unsigned)P);
+    hipLaunchKernelGGL(tiles_to_dense_kernel, grid, dim3(256), 0, c->stream,
+                       tiles_dev, P, dense_dev, ld, row_off, col_off, accumulate ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    return LRVB_OK;
+}

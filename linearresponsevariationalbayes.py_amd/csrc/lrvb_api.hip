@@ -1,0 +1,890 @@
+// lrvb_api.hip -- the C ABI declared in include/lrvb_hip.h (context, orchestration, host<->device
+// staging).  Kernels live in the k_*.hip files.
+#include "lrvb_internal.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include <new>
+
+static thread_local char g_err[1024] = "";
+
+void lrvb_set_error(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* lrvb_last_error(void) { return g_err; }
+extern "C" int lrvb_version(void) { return LRVB_ABI_VERSION; }
+extern "C" int lrvb_device_count(int* out) {
+    if (!out) LRVB_FAIL(LRVB_ERR_INVALID, "null out");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    *out = n;
+    return LRVB_OK;
+}
+
+int buf_reserve(lrvb_ctx* c, DevBuf& b, size_t n) {
+    if (n == 0) n = 1;
+    if (b.p != nullptr && b.n >= n && b.owned) return LRVB_OK;
+    if (b.p != nullptr && !b.owned && b.n >= n) return LRVB_OK;
+    if (b.p != nullptr && b.owned) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipFree(b.p));
+    }
+    b.p = nullptr; b.n = 0; b.owned = true;
+    HIP_TRY(hipMalloc((void**)&b.p, n * sizeof(double)));
+    b.n = n;
+    return LRVB_OK;
+}
+void buf_free(DevBuf& b) {
+    if (b.p && b.owned) (void)hipFree(b.p);
+    b.p = nullptr; b.n = 0; b.owned = true;
+}
+
+static int ctx_bind(lrvb_ctx* c) {
+    if (!c) LRVB_FAIL(LRVB_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    return LRVB_OK;
+}
+
+static int pinned_reserve(lrvb_ctx* c, size_t n) {
+    if (c->host_pinned_n >= n) return LRVB_OK;
+    if (c->host_pinned) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipHostFree(c->host_pinned)); c->host_pinned = nullptr; c->host_pinned_n = 0; }
+    HIP_TRY(hipHostMalloc((void**)&c->host_pinned, n * sizeof(double), hipHostMallocDefault));
+    c->host_pinned_n = n;
+    return LRVB_OK;
+}
+
+static int h2d(lrvb_ctx* c, double* dst, const double* src, size_t n) {
+    if (n == 0) return LRVB_OK;
+    HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));      // src is pageable caller memory
+    return LRVB_OK;
+}
+static int d2h(lrvb_ctx* c, double* dst, const double* src, size_t n) {
+    if (n == 0) return LRVB_OK;
+    HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LRVB_OK;
+}
+
+// ---- context -------------------------------------------------------------------------
+extern "C" int lrvb_ctx_create(lrvb_ctx** out, int device_id, const lrvb_model_desc* m) {
+    if (!out || !m) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (m->n_blocks <= 0 || !m->blocks) LRVB_FAIL(LRVB_ERR_INVALID, "model needs at least one parameter block");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) LRVB_FAIL(LRVB_ERR_INVALID, "device %d out of range (%d devices)", device_id, ndev);
+    lrvb_ctx* c = new (std::nothrow) lrvb_ctx();
+    if (!c) LRVB_FAIL(LRVB_ERR_HIP, "out of host memory");
+    c->device = device_id;
+    i64 D = 0, V = 0;
+    for (int i = 0; i < m->n_blocks; ++i) {
+        lrvb_block_desc b = m->blocks[i];
+        if (b.free_off != D || b.vec_off != V) { delete c; LRVB_FAIL(LRVB_ERR_INVALID, "block %d: offsets must be the running sums of the preceding sizes", i); }
+        if (b.kind == LRVB_BLOCK_BOX) {
+            if (b.free_size != b.vec_size || b.free_size < 0) { delete c; LRVB_FAIL(LRVB_ERR_INVALID, "block %d: box sizes", i); }
+            if (!(b.lb < b.ub)) { delete c; LRVB_FAIL(LRVB_ERR_INVALID, "block %d: upper bound must strictly exceed lower bound", i); }
+        } else if (b.kind == LRVB_BLOCK_PSD) {
+            const i64 k = b.dim0;
+            if (k <= 0 || b.free_size != k * (k + 1) / 2 || b.vec_size != b.free_size || b.lb < 0.0) { delete c; LRVB_FAIL(LRVB_ERR_INVALID, "block %d: psd sizes", i); }
+            c->all_box = false;
+        } else if (b.kind == LRVB_BLOCK_SIMPLEX) {
+            if (b.dim0 <= 0 || b.dim1 < 2 || b.free_size != b.dim0 * (b.dim1 - 1) || b.vec_size != b.dim0 * b.dim1) { delete c; LRVB_FAIL(LRVB_ERR_INVALID, "block %d: simplex sizes", i); }
+            c->all_box = false;
+        } else { delete c; LRVB_FAIL(LRVB_ERR_INVALID, "block %d: unknown kind %d", i, b.kind); }
+        D += b.free_size; V += b.vec_size;
+        c->blocks.push_back(b);
+    }
+    c->D = D; c->V = V;
+    c->loss = m->loss;
+    if (m->loss != LRVB_LOSS_NONE) {
+        if (m->loss < LRVB_LOSS_GAUSSIAN || m->loss > LRVB_LOSS_POISSON) { delete c; LRVB_FAIL(LRVB_ERR_INVALID, "unknown loss %d", m->loss); }
+        if (m->n_obs <= 0 || m->n_cols <= 0) { delete c; LRVB_FAIL(LRVB_ERR_INVALID, "data term needs n_obs > 0 and n_cols > 0"); }
+        if (m->glm_off < 0 || m->glm_off + m->n_cols > V) { delete c; LRVB_FAIL(LRVB_ERR_SIZE, "coefficient slice [%lld, %lld) exceeds vector size %lld", (long long)m->glm_off, (long long)(m->glm_off + m->n_cols), (long long)V); }
+        c->N = m->n_obs; c->P = m->n_cols; c->glm_off = m->glm_off; c->lik_info = m->lik_info;
+    }
+    c->quad_kind = m->quad_kind;
+    if (c->quad_kind < LRVB_QUAD_NONE || c->quad_kind > LRVB_QUAD_DENSE) { delete c; LRVB_FAIL(LRVB_ERR_INVALID, "unknown quad_kind"); }
+    if (c->loss == LRVB_LOSS_NONE && c->quad_kind == LRVB_QUAD_NONE) { delete c; LRVB_FAIL(LRVB_ERR_INVALID, "model has neither a data term nor a quadratic term"); }
+
+    hipError_t e = hipSetDevice(device_id);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { lrvb_set_error("context init: %s", hipGetErrorString(e)); delete c; return LRVB_ERR_HIP; }
+
+    int st = LRVB_OK;
+    auto need = [&](DevBuf& b, size_t n) { if (st == LRVB_OK) st = buf_reserve(c, b, n); };
+    need(c->theta, (size_t)(V > D ? V : D)); need(c->eta, (size_t)V); need(c->j1, (size_t)D); need(c->j2, (size_t)D);
+    need(c->g_eta, (size_t)V); need(c->g_free, (size_t)D);
+    need(c->vtmp, (size_t)(V > D ? V : D)); need(c->vtmp2, (size_t)(V > D ? V : D)); need(c->vtmp3, (size_t)(V > D ? V : D));
+    need(c->scal, 16);
+    if (c->loss != LRVB_LOSS_NONE) {
+        need(c->w, (size_t)c->N);
+        need(c->lp, (size_t)c->N); need(c->cw, (size_t)c->N);
+        const size_t tiles = (size_t)wsyrk_num_tiles(c->P) * WS_TILE * WS_TILE;
+        need(c->stats, 1 + (size_t)c->P + tiles);
+    } else {
+        need(c->stats, 2);
+    }
+    if (c->quad_kind != LRVB_QUAD_NONE) {
+        need(c->quadA, c->quad_kind == LRVB_QUAD_DIAG ? (size_t)V : (size_t)V * (size_t)V);
+        need(c->quadM, (size_t)V); need(c->quadB, (size_t)V);
+    }
+    if (st == LRVB_OK) {
+        if (c->loss != LRVB_LOSS_NONE) {
+            // w = 1
+            std::vector<double> ones((size_t)c->N, 1.0);
+            st = h2d(c, c->w.p, ones.data(), (size_t)c->N);
+        }
+    }
+    if (st == LRVB_OK && c->quad_kind != LRVB_QUAD_NONE) {
+        if (hipMemsetAsync(c->quadA.p, 0, c->quadA.n * sizeof(double), c->stream) != hipSuccess ||
+            hipMemsetAsync(c->quadM.p, 0, (size_t)V * sizeof(double), c->stream) != hipSuccess ||
+            hipMemsetAsync(c->quadB.p, 0, (size_t)V * sizeof(double), c->stream) != hipSuccess) {
+            lrvb_set_error("memset failed"); st = LRVB_ERR_HIP;
+        }
+    }
+    if (st != LRVB_OK) { lrvb_ctx_destroy(c); return st; }
+    *out = c;
+    return LRVB_OK;
+}
+
+extern "C" int lrvb_ctx_destroy(lrvb_ctx* c) {
+    if (!c) return LRVB_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    DevBuf* all[] = { &c->X, &c->y, &c->w, &c->quadA, &c->quadM, &c->quadB, &c->theta, &c->eta, &c->j1, &c->j2,
+                      &c->vtmp, &c->vtmp2, &c->vtmp3, &c->g_eta, &c->g_free, &c->lp, &c->cw, &c->zbuf,
+                      &c->part_vec, &c->part_val, &c->stats, &c->tile_part, &c->Heta, &c->Hfree, &c->Jdense,
+                      &c->Tdense, &c->work1, &c->chol, &c->rhs, &c->cgx, &c->cgr, &c->cgp, &c->cgq, &c->cgz, &c->scal };
+    for (DevBuf* b : all) buf_free(*b);
+    if (c->host_pinned) (void)hipHostFree(c->host_pinned);
+    for (int k = 0; k < 3; ++k) for (hipEvent_t e : c->ev_pool[k]) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return LRVB_OK;
+}
+
+extern "C" int lrvb_ctx_sync(lrvb_ctx* c) {
+    LRVB_TRY(ctx_bind(c));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LRVB_OK;
+}
+
+extern "C" int lrvb_ctx_sizes(lrvb_ctx* c, int64_t* D, int64_t* V, int64_t* n_obs) {
+    if (!c) LRVB_FAIL(LRVB_ERR_INVALID, "null context");
+    if (D) *D = c->D;
+    if (V) *V = c->V;
+    if (n_obs) *n_obs = c->N;
+    return LRVB_OK;
+}
+
+static int slot_shape_check(lrvb_ctx* c, int slot, i64 rows, i64 cols, DevBuf** buf, size_t* n) {
+    switch (slot) {
+    case LRVB_SLOT_X:
+        if (c->loss == LRVB_LOSS_NONE) LRVB_FAIL(LRVB_ERR_STATE, "model has no data term");
+        if (rows != c->N || cols != c->P) LRVB_FAIL(LRVB_ERR_SIZE, "X must be %lld x %lld (got %lld x %lld)", (long long)c->N, (long long)c->P, (long long)rows, (long long)cols);
+        *buf = &c->X; *n = (size_t)rows * (size_t)cols; return LRVB_OK;
+    case LRVB_SLOT_Y:
+        if (c->loss == LRVB_LOSS_NONE) LRVB_FAIL(LRVB_ERR_STATE, "model has no data term");
+        if (rows * cols != c->N) LRVB_FAIL(LRVB_ERR_SIZE, "y must have %lld entries (got %lld)", (long long)c->N, (long long)(rows * cols));
+        *buf = &c->y; *n = (size_t)c->N; return LRVB_OK;
+    case LRVB_SLOT_QUAD_A:
+        if (c->quad_kind == LRVB_QUAD_NONE) LRVB_FAIL(LRVB_ERR_STATE, "model has no quadratic term");
+        if (c->quad_kind == LRVB_QUAD_DIAG) { if (rows * cols != c->V) LRVB_FAIL(LRVB_ERR_SIZE, "diagonal A must have %lld entries", (long long)c->V); *n = (size_t)c->V; }
+        else { if (rows != c->V || cols != c->V) LRVB_FAIL(LRVB_ERR_SIZE, "A must be %lld x %lld", (long long)c->V, (long long)c->V); *n = (size_t)c->V * (size_t)c->V; }
+        *buf = &c->quadA; return LRVB_OK;
+    case LRVB_SLOT_QUAD_M:
+    case LRVB_SLOT_QUAD_B:
+        if (c->quad_kind == LRVB_QUAD_NONE) LRVB_FAIL(LRVB_ERR_STATE, "model has no quadratic term");
+        if (rows * cols != c->V) LRVB_FAIL(LRVB_ERR_SIZE, "vector must have %lld entries", (long long)c->V);
+        *buf = (slot == LRVB_SLOT_QUAD_M) ? &c->quadM : &c->quadB; *n = (size_t)c->V; return LRVB_OK;
+    default:
+        LRVB_FAIL(LRVB_ERR_INVALID, "unknown data slot %d", slot);
+    }
+}
+
+extern "C" int lrvb_set_data(lrvb_ctx* c, int slot, const double* host, int64_t rows, int64_t cols) {
+    LRVB_TRY(ctx_bind(c));
+    if (!host) LRVB_FAIL(LRVB_ERR_INVALID, "null data");
+    DevBuf* b = nullptr; size_t n = 0;
+    LRVB_TRY(slot_shape_check(c, slot, rows, cols, &b, &n));
+    if (!b->owned) { b->p = nullptr; b->n = 0; b->owned = true; }
+    LRVB_TRY(buf_reserve(c, *b, n));
+    LRVB_TRY(h2d(c, b->p, host, n));
+    if (slot == LRVB_SLOT_X) c->have_X = true;
+    if (slot == LRVB_SLOT_Y) c->have_y = true;
+    return LRVB_OK;
+}
+
+extern "C" int lrvb_set_data_dev(lrvb_ctx* c, int slot, const double* data_dev, int64_t rows, int64_t cols) {
+    LRVB_TRY(ctx_bind(c));
+    if (!data_dev) LRVB_FAIL(LRVB_ERR_INVALID, "null data");
+    DevBuf* b = nullptr; size_t n = 0;
+    LRVB_TRY(slot_shape_check(c, slot, rows, cols, &b, &n));
+    if (b->p && b->owned) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(b->p)); }
+    b->p = const_cast<double*>(data_dev); b->n = n; b->owned = false;
+    if (slot == LRVB_SLOT_X) c->have_X = true;
+    if (slot == LRVB_SLOT_Y) c->have_y = true;
+    return LRVB_OK;
+}
+
+extern "C" int lrvb_set_weights(lrvb_ctx* c, const double* w, int64_t n) {
+    LRVB_TRY(ctx_bind(c));
+    if (c->loss == LRVB_LOSS_NONE) LRVB_FAIL(LRVB_ERR_STATE, "model has no data term");
+    if (!w || n != c->N) LRVB_FAIL(LRVB_ERR_SIZE, "weights must have %lld entries (got %lld)", (long long)c->N, (long long)n);
+    if (!c->w.owned) { c->w.p = nullptr; c->w.n = 0; c->w.owned = true; }
+    LRVB_TRY(buf_reserve(c, c->w, (size_t)n));
+    return h2d(c, c->w.p, w, (size_t)n);
+}
+
+extern "C" int lrvb_set_weights_dev(lrvb_ctx* c, const double* w_dev, int64_t n) {
+    LRVB_TRY(ctx_bind(c));
+    if (c->loss == LRVB_LOSS_NONE) LRVB_FAIL(LRVB_ERR_STATE, "model has no data term");
+    if (!w_dev || n != c->N) LRVB_FAIL(LRVB_ERR_SIZE, "weights must have %lld entries (got %lld)", (long long)c->N, (long long)n);
+    if (c->w.p && c->w.owned) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->w.p)); }
+    c->w.p = const_cast<double*>(w_dev); c->w.n = (size_t)n; c->w.owned = false;
+    return LRVB_OK;
+}
+
+extern "C" int lrvb_set_quad_scale(lrvb_ctx* c, double scale) {
+    if (!c) LRVB_FAIL(LRVB_ERR_INVALID, "null context");
+    c->quad_scale = scale;
+    return LRVB_OK;
+}
+
+extern "C" int lrvb_set_tuning(lrvb_ctx* c, int n_splits, int reserved) {
+    (void)reserved;
+    if (!c) LRVB_FAIL(LRVB_ERR_INVALID, "null context");
+    if (n_splits < 0 || n_splits > 1024) LRVB_FAIL(LRVB_ERR_INVALID, "n_splits out of range");
+    c->n_splits_user = n_splits;
+    return LRVB_OK;
+}
+
+static int data_ready(lrvb_ctx* c) {
+    if (c->loss != LRVB_LOSS_NONE && !(c->have_X && c->have_y))
+        LRVB_FAIL(LRVB_ERR_STATE, "observations not set: call lrvb_set_data for LRVB_SLOT_X and LRVB_SLOT_Y first");
+    return LRVB_OK;
+}
+
+// ---- small elementwise kernels used only by the orchestration -------------------------
+__global__ void mul_kernel(i64 n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ o) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = a[i] * b[i];
+}
+__global__ void fma3_kernel(i64 n, const double* __restrict__ a, const double* __restrict__ b, const double* __restrict__ v,
+                            const double* __restrict__ j1, const double* __restrict__ he, double* __restrict__ o) {
+    // o = j1 * he + a * b * v     (box HVP epilogue: j1 (H_eta u) + g_eta eta'' v)
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = j1[i] * he[i] + a[i] * b[i] * v[i];
+}
+__global__ void square_kernel(i64 n, const double* __restrict__ a, double* __restrict__ o) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = a[i] * a[i];
+}
+__global__ void transpose_kernel(i64 rows, i64 cols, const double* __restrict__ a, double* __restrict__ o) {
+    // o (cols x rows) = a^T (a is rows x cols)
+    const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 i = blockIdx.y;
+    if (j < cols && i < rows) o[j * rows + i] = a[i * cols + j];
+}
+__global__ void diag_scale_kernel(i64 D, i64 V, double scale, const double* __restrict__ j1, double* __restrict__ C) {
+    const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 i = blockIdx.y;
+    if (j < V && i < D) C[i * V + j] = (i == j) ? scale * j1[i] : 0.0;
+}
+__global__ void symmetrize_lower_kernel(i64 n, double* __restrict__ A, i64 ld) {
+    const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 i = blockIdx.y;
+    if (j < n && i < n && j > i) A[i * ld + j] = A[j * ld + i];
+}
+static inline unsigned nb256(i64 n) { return (unsigned)((n + 255) / 256); }
+#define EW(kernel, n, ...) do { if ((n) > 0) { hipLaunchKernelGGL(kernel, dim3(nb256(n)), dim3(256), 0, c->stream, n, __VA_ARGS__); HIP_TRY(hipGetLastError()); } } while (0)
+
+// ---- evaluation state -----------------------------------------------------------------
+// eta (and j1/j2 for box blocks) from theta; in vector mode eta is the input itself.
+static int set_point(lrvb_ctx* c, const double* point_dev, bool is_free) {
+    if (is_free) {
+        LRVB_TRY(launch_constrain(c, point_dev, c->eta.p, c->j1.p, c->j2.p));
+    } else {
+        HIP_TRY(hipMemcpyAsync(c->eta.p, point_dev, (size_t)c->V * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    }
+    return LRVB_OK;
+}
+
+// value and d f / d eta at the current eta; per-observation lp, cw stored.  stats: [value | g_glm].
+static int eval_grad_eta(lrvb_ctx* c, double* stats_dev, bool include_quad) {
+    if (c->loss != LRVB_LOSS_NONE) {
+        LRVB_TRY(launch_glm_pass(c, PASS_GRAD, c->eta.p + c->glm_off, nullptr, stats_dev + 1, stats_dev, true));
+        LRVB_TRY(launch_scatter_glm(c, stats_dev + 1, c->g_eta.p));
+    } else {
+        HIP_TRY(hipMemsetAsync(stats_dev, 0, sizeof(double), c->stream));
+        LRVB_TRY(launch_scatter_glm(c, nullptr, c->g_eta.p));
+    }
+    if (include_quad) LRVB_TRY(launch_quad_grad_value(c, c->eta.p, c->g_eta.p, stats_dev));
+    return LRVB_OK;
+}
+
+static int ensure_dense_J(lrvb_ctx* c, const double* theta_dev) {
+    LRVB_TRY(buf_reserve(c, c->Jdense, (size_t)c->V * (size_t)c->D));
+    return launch_dense_jac(c, theta_dev, c->Jdense.p);
+}
+
+// g_free = J^T g_eta
+static int grad_to_free(lrvb_ctx* c, const double* theta_dev, double* g_free_dev) {
+    if (c->all_box) { EW(mul_kernel, c->D, c->j1.p, c->g_eta.p, g_free_dev); return LRVB_OK; }
+    LRVB_TRY(ensure_dense_J(c, theta_dev));
+    return launch_gemv(c, true, c->V, c->D, 1.0, c->Jdense.p, c->D, c->g_eta.p, 0.0, g_free_dev);
+}
+
+// out_eta (V) = H_eta u   using the cached per-observation curvature cw
+static int heta_apply(lrvb_ctx* c, const double* u_vec, double* out_vec) {
+    if (c->loss != LRVB_LOSS_NONE) {
+        LRVB_TRY(buf_reserve(c, c->vtmp3, (size_t)(c->V > c->P ? c->V : c->P)));
+        LRVB_TRY(launch_glm_pass(c, PASS_HVP_C, nullptr, u_vec + c->glm_off, c->vtmp3.p, nullptr, false));
+        // vtmp3 holds the P-vector; scatter into out_vec
+        LRVB_TRY(launch_scatter_glm(c, c->vtmp3.p, out_vec));
+    } else {
+        LRVB_TRY(launch_scatter_glm(c, nullptr, out_vec));
+    }
+    return launch_quad_hvp(c, u_vec, out_vec);
+}
+
+// full HVP at the current point.  Requires set_point + eval_grad_eta done (g_eta, cw valid).
+static int hvp_apply(lrvb_ctx* c, const double* theta_dev, bool is_free, const double* v_dev, double* out_dev) {
+    if (!is_free) return heta_apply(c, v_dev, out_dev);
+    if (c->all_box) {
+        EW(mul_kernel, c->D, c->j1.p, v_dev, c->vtmp.p);                   // u = J v
+        LRVB_TRY(heta_apply(c, c->vtmp.p, c->vtmp2.p));                   // H_eta u
+        EW(fma3_kernel, c->D, c->g_eta.p, c->j2.p, v_dev, c->j1.p, c->vtmp2.p, out_dev);
+        return LRVB_OK;
+    }
+    // general layouts: dense J and dense third-order matrix (built by the caller once per point)
+    LRVB_TRY(launch_gemv(c, false, c->V, c->D, 1.0, c->Jdense.p, c->D, v_dev, 0.0, c->vtmp.p));
+    LRVB_TRY(heta_apply(c, c->vtmp.p, c->vtmp2.p));
+    LRVB_TRY(launch_gemv(c, true, c->V, c->D, 1.0, c->Jdense.p, c->D, c->vtmp2.p, 0.0, out_dev));
+    LRVB_TRY(launch_gemv(c, false, c->D, c->D, 1.0, c->Tdense.p, c->D, v_dev, 1.0, out_dev));
+    return LRVB_OK;
+}
+
+static int prepare_general_hvp(lrvb_ctx* c, const double* theta_dev) {
+    if (c->all_box) return LRVB_OK;
+    LRVB_TRY(ensure_dense_J(c, theta_dev));
+    LRVB_TRY(buf_reserve(c, c->Tdense, (size_t)c->D * (size_t)c->D));
+    HIP_TRY(hipMemsetAsync(c->Tdense.p, 0, (size_t)c->D * (size_t)c->D * sizeof(double), c->stream));
+    return launch_third_order(c, theta_dev, c->g_eta.p, c->Tdense.p);
+}
+
+// ---- Hessian build ---------------------------------------------------------------------
+extern "C" int lrvb_stats_size(lrvb_ctx* c, int64_t* n) {
+    if (!c || !n) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    if (c->loss == LRVB_LOSS_NONE) { *n = 2; return LRVB_OK; }
+    *n = 1 + c->P + (i64)wsyrk_num_tiles(c->P) * WS_TILE * WS_TILE;
+    return LRVB_OK;
+}
+
+static int hessian_partial(lrvb_ctx* c, const double* point_dev, bool is_free, double* stats_dev) {
+    LRVB_TRY(data_ready(c));
+    LRVB_TRY(set_point(c, point_dev, is_free));
+    LRVB_TRY(eval_grad_eta(c, stats_dev, false));
+    if (c->loss != LRVB_LOSS_NONE)
+        LRVB_TRY(launch_wsyrk(c, c->cw.p, stats_dev + 1 + c->P));
+    return LRVB_OK;
+}
+
+static int hessian_finish(lrvb_ctx* c, const double* point_dev, bool is_free, const double* stats_dev,
+                          double* H_dev, i64 ld) {
+    const i64 n = is_free ? c->D : c->V;
+    if (ld < n) LRVB_FAIL(LRVB_ERR_SIZE, "leading dimension %lld < %lld", (long long)ld, (long long)n);
+    LRVB_TRY(set_point(c, point_dev, is_free));
+    const double* tiles = (c->loss != LRVB_LOSS_NONE) ? stats_dev + 1 + c->P : nullptr;
+    LRVB_TRY(launch_scatter_glm(c, (c->loss != LRVB_LOSS_NONE) ? stats_dev + 1 : nullptr, c->g_eta.p));
+    LRVB_TRY(launch_quad_grad_value(c, c->eta.p, c->g_eta.p, nullptr));
+    if (!is_free) {
+        if (ld == c->V) return launch_build_Heta(c, tiles, H_dev);
+        LRVB_TRY(buf_reserve(c, c->Heta, (size_t)c->V * (size_t)c->V));
+        LRVB_TRY(launch_build_Heta(c, tiles, c->Heta.p));
+        HIP_TRY(hipMemcpy2DAsync(H_dev, (size_t)ld * 8, c->Heta.p, (size_t)c->V * 8, (size_t)c->V * 8, (size_t)c->V, hipMemcpyDeviceToDevice, c->stream));
+        return LRVB_OK;
+    }
+    if (c->all_box)
+        return launch_finish_box(c, tiles, c->g_eta.p, c->j1.p, c->j2.p, true, H_dev, ld);
+    // general: H = J^T H_eta J + T
+    LRVB_TRY(buf_reserve(c, c->Heta, (size_t)c->V * (size_t)c->V));
+    LRVB_TRY(buf_reserve(c, c->work1, (size_t)c->V * (size_t)c->D));
+    LRVB_TRY(launch_build_Heta(c, tiles, c->Heta.p));
+    LRVB_TRY(ensure_dense_J(c, point_dev));
+    LRVB_TRY(launch_gemm(c, false, false, c->V, c->D, c->V, 1.0, c->Heta.p, c->V, c->Jdense.p, c->D, 0.0, c->work1.p, c->D));
+    // T into H_dev (respecting ld), then H += J^T work1
+    if (ld == c->D) {
+        HIP_TRY(hipMemsetAsync(H_dev, 0, (size_t)c->D * (size_t)c->D * sizeof(double), c->stream));
+        LRVB_TRY(launch_third_order(c, point_dev, c->g_eta.p, H_dev));
+        return launch_gemm(c, true, false, c->D, c->D, c->V, 1.0, c->Jdense.p, c->D, c->work1.p, c->D, 1.0, H_dev, ld);
+    }
+    LRVB_TRY(buf_reserve(c, c->Tdense, (size_t)c->D * (size_t)c->D));
+    HIP_TRY(hipMemsetAsync(c->Tdense.p, 0, (size_t)c->D * (size_t)c->D * sizeof(double), c->stream));
+    LRVB_TRY(launch_third_order(c, point_dev, c->g_eta.p, c->Tdense.p));
+    LRVB_TRY(launch_gemm(c, true, false, c->D, c->D, c->V, 1.0, c->Jdense.p, c->D, c->work1.p, c->D, 1.0, c->Tdense.p, c->D));
+    HIP_TRY(hipMemcpy2DAsync(H_dev, (size_t)ld * 8, c->Tdense.p, (size_t)c->D * 8, (size_t)c->D * 8, (size_t)c->D, hipMemcpyDeviceToDevice, c->stream));
+    return LRVB_OK;
+}
+
+extern "C" int lrvb_hessian_partial_dev(lrvb_ctx* c, const double* free_dev, double* stats_dev) {
+    LRVB_TRY(ctx_bind(c));
+    if (!free_dev || !stats_dev) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    return hessian_partial(c, free_dev, true, stats_dev);
+}
+extern "C" int lrvb_hessian_finish_dev(lrvb_ctx* c, const double* free_dev, const double* stats_dev, double* H_dev, int64_t ld) {
+    LRVB_TRY(ctx_bind(c));
+    if (!free_dev || !stats_dev || !H_dev) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    return hessian_finish(c, free_dev, true, stats_dev, H_dev, ld);
+}
+extern "C" int lrvb_hessian_dev(lrvb_ctx* c, const double* free_dev, double* H_dev, int64_t ld) {
+    LRVB_TRY(ctx_bind(c));
+    if (!free_dev || !H_dev) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_BUILD));
+    LRVB_TRY(hessian_partial(c, free_dev, true, c->stats.p));
+    LRVB_TRY(hessian_finish(c, free_dev, true, c->stats.p, H_dev, ld));
+    if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_BUILD));
+    return LRVB_OK;
+}
+
+static int check_len(i64 got, i64 want, const char* what) {
+    if (got != want) LRVB_FAIL(LRVB_ERR_SIZE, "Wrong size for %s.  Expected %lld, got %lld", what, (long long)want, (long long)got);
+    return LRVB_OK;
+}
+
+static int hessian_host(lrvb_ctx* c, const double* point, i64 n_in, bool is_free, double* H_out, i64 ld) {
+    LRVB_TRY(ctx_bind(c));
+    if (!point || !H_out) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    const i64 n = is_free ? c->D : c->V;
+    LRVB_TRY(check_len(n_in, n, is_free ? "free vector" : "vector"));
+    if (ld < n) LRVB_FAIL(LRVB_ERR_SIZE, "leading dimension too small");
+    LRVB_TRY(h2d(c, c->theta.p, point, (size_t)n));           // theta buffer doubles as the vector-mode input
+    LRVB_TRY(buf_reserve(c, c->Hfree, (size_t)n * (size_t)n));
+    LRVB_TRY(hessian_partial(c, c->theta.p, is_free, c->stats.p));
+    LRVB_TRY(hessian_finish(c, c->theta.p, is_free, c->stats.p, c->Hfree.p, n));
+    HIP_TRY(hipMemcpy2DAsync(H_out, (size_t)ld * 8, c->Hfree.p, (size_t)n * 8, (size_t)n * 8, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LRVB_OK;
+}
+extern "C" int lrvb_hessian(lrvb_ctx* c, const double* free_in, int64_t D, double* H_out, int64_t ld) {
+    return hessian_host(c, free_in, D, true, H_out, ld);
+}
+extern "C" int lrvb_hessian_vec(lrvb_ctx* c, const double* vec_in, int64_t V, double* H_out, int64_t ld) {
+    return hessian_host(c, vec_in, V, false, H_out, ld);
+}
+
+// ---- value / gradient ------------------------------------------------------------------
+static int grad_host(lrvb_ctx* c, const double* point, i64 n_in, bool is_free, double* value_out, double* g_out) {
+    LRVB_TRY(ctx_bind(c));
+    if (!point) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    const i64 n = is_free ? c->D : c->V;
+    LRVB_TRY(check_len(n_in, n, is_free ? "free vector" : "vector"));
+    LRVB_TRY(data_ready(c));
+    LRVB_TRY(h2d(c, c->theta.p, point, (size_t)n));
+    LRVB_TRY(set_point(c, c->theta.p, is_free));
+    LRVB_TRY(eval_grad_eta(c, c->stats.p, true));
+    if (g_out) {
+        if (is_free) { LRVB_TRY(grad_to_free(c, c->theta.p, c->g_free.p)); LRVB_TRY(d2h(c, g_out, c->g_free.p, (size_t)n)); }
+        else LRVB_TRY(d2h(c, g_out, c->g_eta.p, (size_t)n));
+    }
+    if (value_out) LRVB_TRY(d2h(c, value_out, c->stats.p, 1));
+    return LRVB_OK;
+}
+extern "C" int lrvb_value(lrvb_ctx* c, const double* free_in, int64_t D, double* out) {
+    if (!out) LRVB_FAIL(LRVB_ERR_INVALID, "null out");
+    return grad_host(c, free_in, D, true, out, nullptr);
+}
+extern "C" int lrvb_grad(lrvb_ctx* c, const double* free_in, int64_t D, double* value_out, double* g_out) {
+    if (!g_out) LRVB_FAIL(LRVB_ERR_INVALID, "null out");
+    return grad_host(c, free_in, D, true, value_out, g_out);
+}
+extern "C" int lrvb_value_vec(lrvb_ctx* c, const double* vec_in, int64_t V, double* out) {
+    if (!out) LRVB_FAIL(LRVB_ERR_INVALID, "null out");
+    return grad_host(c, vec_in, V, false, out, nullptr);
+}
+extern "C" int lrvb_grad_vec(lrvb_ctx* c, const double* vec_in, int64_t V, double* value_out, double* g_out) {
+    if (!g_out) LRVB_FAIL(LRVB_ERR_INVALID, "null out");
+    return grad_host(c, vec_in, V, false, value_out, g_out);
+}
+
+// ---- HVP --------------------------------------------------------------------------------
+static int hvp_dev_impl(lrvb_ctx* c, const double* point_dev, bool is_free, const double* v_dev, double* out_dev) {
+    LRVB_TRY(data_ready(c));
+    LRVB_TRY(set_point(c, point_dev, is_free));
+    LRVB_TRY(eval_grad_eta(c, c->stats.p, true));
+    if (is_free) LRVB_TRY(prepare_general_hvp(c, point_dev));
+    return hvp_apply(c, point_dev, is_free, v_dev, out_dev);
+}
+extern "C" int lrvb_hvp_dev(lrvb_ctx* c, const double* free_dev, const double* v_dev, double* out_dev) {
+    LRVB_TRY(ctx_bind(c));
+    if (!free_dev || !v_dev || !out_dev) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    return hvp_dev_impl(c, free_dev, true, v_dev, out_dev);
+}
+static int hvp_host(lrvb_ctx* c, const double* point, const double* v, i64 n_in, bool is_free, double* out) {
+    LRVB_TRY(ctx_bind(c));
+    if (!point || !v || !out) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    const i64 n = is_free ? c->D : c->V;
+    LRVB_TRY(check_len(n_in, n, is_free ? "free vector" : "vector"));
+    LRVB_TRY(buf_reserve(c, c->cgp, (size_t)n));
+    LRVB_TRY(buf_reserve(c, c->cgq, (size_t)n));
+    LRVB_TRY(h2d(c, c->theta.p, point, (size_t)n));
+    LRVB_TRY(h2d(c, c->cgp.p, v, (size_t)n));
+    LRVB_TRY(hvp_dev_impl(c, c->theta.p, is_free, c->cgp.p, c->cgq.p));
+    return d2h(c, out, c->cgq.p, (size_t)n);
+}
+extern "C" int lrvb_hvp(lrvb_ctx* c, const double* free_in, const double* v, int64_t D, double* out) {
+    return hvp_host(c, free_in, v, D, true, out);
+}
+extern "C" int lrvb_hvp_vec(lrvb_ctx* c, const double* vec_in, const double* v, int64_t V, double* out) {
+    return hvp_host(c, vec_in, v, V, false, out);
+}
+
+// ---- packing entry points ----------------------------------------------------------------
+extern "C" int lrvb_constrain(lrvb_ctx* c, const double* free_in, int64_t D, double* vec_out, int64_t V) {
+    LRVB_TRY(ctx_bind(c));
+    if (!free_in || !vec_out) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    LRVB_TRY(check_len(D, c->D, "free vector")); LRVB_TRY(check_len(V, c->V, "vector"));
+    LRVB_TRY(h2d(c, c->theta.p, free_in, (size_t)D));
+    LRVB_TRY(launch_constrain(c, c->theta.p, c->eta.p, c->j1.p, c->j2.p));
+    return d2h(c, vec_out, c->eta.p, (size_t)V);
+}
+extern "C" int lrvb_unconstrain(lrvb_ctx* c, const double* vec_in, int64_t V, double* free_out, int64_t D) {
+    LRVB_TRY(ctx_bind(c));
+    if (!vec_in || !free_out) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    LRVB_TRY(check_len(D, c->D, "free vector")); LRVB_TRY(check_len(V, c->V, "vector"));
+    LRVB_TRY(h2d(c, c->eta.p, vec_in, (size_t)V));
+    int* flag = reinterpret_cast<int*>(c->scal.p);
+    HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), c->stream));
+    LRVB_TRY(launch_unconstrain(c, c->eta.p, c->theta.p, flag));
+    int bad = 0;
+    HIP_TRY(hipMemcpyAsync(&bad, flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (bad & 1) LRVB_FAIL(LRVB_ERR_INVALID, "Elements outside the bounds");
+    if (bad & 2) LRVB_FAIL(LRVB_ERR_INVALID, "Matrix is not positive definite above diag_lb");
+    return d2h(c, free_out, c->theta.p, (size_t)D);
+}
+extern "C" int lrvb_free_to_vector_jac(lrvb_ctx* c, const double* free_in, int64_t D, double* jac_out) {
+    LRVB_TRY(ctx_bind(c));
+    if (!free_in || !jac_out) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    LRVB_TRY(check_len(D, c->D, "free vector"));
+    LRVB_TRY(h2d(c, c->theta.p, free_in, (size_t)D));
+    LRVB_TRY(ensure_dense_J(c, c->theta.p));
+    return d2h(c, jac_out, c->Jdense.p, (size_t)c->V * (size_t)c->D);
+}
+extern "C" int lrvb_free_hessian_from_vector(lrvb_ctx* c, const double* free_in, const double* g_vec,
+                                             const double* H_vec, double* H_free_out) {
+    LRVB_TRY(ctx_bind(c));
+    if (!free_in || !g_vec || !H_vec || !H_free_out) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    const i64 D = c->D, V = c->V;
+    LRVB_TRY(h2d(c, c->theta.p, free_in, (size_t)D));
+    LRVB_TRY(h2d(c, c->g_eta.p, g_vec, (size_t)V));
+    LRVB_TRY(buf_reserve(c, c->Heta, (size_t)V * (size_t)V));
+    LRVB_TRY(buf_reserve(c, c->work1, (size_t)V * (size_t)D));
+    LRVB_TRY(buf_reserve(c, c->Hfree, (size_t)D * (size_t)D));
+    LRVB_TRY(h2d(c, c->Heta.p, H_vec, (size_t)V * (size_t)V));
+    LRVB_TRY(ensure_dense_J(c, c->theta.p));
+    LRVB_TRY(launch_gemm(c, false, false, V, D, V, 1.0, c->Heta.p, V, c->Jdense.p, D, 0.0, c->work1.p, D));
+    HIP_TRY(hipMemsetAsync(c->Hfree.p, 0, (size_t)D * (size_t)D * sizeof(double), c->stream));
+    LRVB_TRY(launch_third_order(c, c->theta.p, c->g_eta.p, c->Hfree.p));
+    LRVB_TRY(launch_gemm(c, true, false, D, D, V, 1.0, c->Jdense.p, D, c->work1.p, D, 1.0, c->Hfree.p, D));
+    return d2h(c, H_free_out, c->Hfree.p, (size_t)D * (size_t)D);
+}
+
+// ---- cross Hessians ----------------------------------------------------------------------
+__global__ void fill_kernel(i64 n, double v, double* __restrict__ o) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = v;
+}
+
+static int obs_grad_impl(lrvb_ctx* c, const double* point, i64 n_in, bool is_free, i64 n0, i64 n1, double* G_out) {
+    LRVB_TRY(ctx_bind(c));
+    if (!point || !G_out) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    const i64 width = is_free ? c->D : c->V;
+    LRVB_TRY(check_len(n_in, width, is_free ? "free vector" : "vector"));
+    if (c->loss == LRVB_LOSS_NONE) LRVB_FAIL(LRVB_ERR_STATE, "model has no data term");
+    if (n0 < 0 || n1 > c->N || n0 > n1) LRVB_FAIL(LRVB_ERR_INVALID, "row range [%lld, %lld) outside [0, %lld)", (long long)n0, (long long)n1, (long long)c->N);
+    LRVB_TRY(data_ready(c));
+    LRVB_TRY(h2d(c, c->theta.p, point, (size_t)width));
+    LRVB_TRY(set_point(c, c->theta.p, is_free));
+    LRVB_TRY(eval_grad_eta(c, c->stats.p, false));
+    const bool diag_path = !is_free || c->all_box;
+    if (!is_free) EW(fill_kernel, c->V, 1.0, c->vtmp.p);
+    if (is_free && !c->all_box) LRVB_TRY(ensure_dense_J(c, c->theta.p));
+    const i64 chunk = 16384;
+    for (i64 a = n0; a < n1; a += chunk) {
+        const i64 b = (a + chunk < n1) ? a + chunk : n1;
+        const i64 rows = b - a;
+        LRVB_TRY(buf_reserve(c, c->rhs, (size_t)rows * (size_t)width));
+        if (diag_path) {
+            LRVB_TRY(launch_obs_grad(c, a, b, c->rhs.p, 0, is_free ? c->j1.p : c->vtmp.p));
+        } else {
+            LRVB_TRY(buf_reserve(c, c->work1, (size_t)rows * (size_t)c->P));
+            LRVB_TRY(launch_obs_grad(c, a, b, c->work1.p, 1, nullptr));
+            LRVB_TRY(launch_gemm(c, false, false, rows, c->D, c->P, 1.0, c->work1.p, c->P,
+                                 c->Jdense.p + c->glm_off * c->D, c->D, 0.0, c->rhs.p, c->D));
+        }
+        LRVB_TRY(d2h(c, G_out + (a - n0) * width, c->rhs.p, (size_t)rows * (size_t)width));
+    }
+    return LRVB_OK;
+}
+extern "C" int lrvb_obs_grad(lrvb_ctx* c, const double* free_in, int64_t D, int64_t n0, int64_t n1, double* G_out) {
+    return obs_grad_impl(c, free_in, D, true, n0, n1, G_out);
+}
+extern "C" int lrvb_obs_grad_vec(lrvb_ctx* c, const double* vec_in, int64_t V, int64_t n0, int64_t n1, double* G_out) {
+    return obs_grad_impl(c, vec_in, V, false, n0, n1, G_out);
+}
+
+extern "C" int lrvb_cross_hessian_tilt(lrvb_ctx* c, const double* free_in, int64_t D, double* C_out) {
+    LRVB_TRY(ctx_bind(c));
+    if (!free_in || !C_out) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    LRVB_TRY(check_len(D, c->D, "free vector"));
+    if (c->quad_kind == LRVB_QUAD_NONE) LRVB_FAIL(LRVB_ERR_STATE, "model has no quadratic term");
+    LRVB_TRY(h2d(c, c->theta.p, free_in, (size_t)D));
+    LRVB_TRY(buf_reserve(c, c->work1, (size_t)c->V * (size_t)c->D));
+    if (c->all_box) {
+        LRVB_TRY(set_point(c, c->theta.p, true));
+        dim3 grid(nb256(c->V), (unsigned)c->D);
+        hipLaunchKernelGGL(diag_scale_kernel, grid, dim3(256), 0, c->stream, c->D, c->V, c->quad_scale, c->j1.p, c->work1.p);
+        HIP_TRY(hipGetLastError());
+    } else {
+        LRVB_TRY(ensure_dense_J(c, c->theta.p));
+        LRVB_TRY(buf_reserve(c, c->Heta, (size_t)c->V * (size_t)c->D));
+        dim3 grid(nb256(c->D), (unsigned)c->V);
+        hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, c->stream, c->V, c->D, c->Jdense.p, c->work1.p);
+        HIP_TRY(hipGetLastError());
+        LRVB_TRY(launch_axpby(c, c->V * c->D, c->quad_scale, c->work1.p, 0.0, c->work1.p));
+    }
+    return d2h(c, C_out, c->work1.p, (size_t)c->D * (size_t)c->V);
+}
+
+static int gram_dev_impl(lrvb_ctx* c, const double* free_dev, double* G_dev, i64 ld) {
+    if (c->loss == LRVB_LOSS_NONE) LRVB_FAIL(LRVB_ERR_STATE, "model has no data term");
+    if (ld < c->D) LRVB_FAIL(LRVB_ERR_SIZE, "leading dimension too small");
+    LRVB_TRY(data_ready(c));
+    LRVB_TRY(set_point(c, free_dev, true));
+    LRVB_TRY(eval_grad_eta(c, c->stats.p, false));
+    LRVB_TRY(buf_reserve(c, c->zbuf, (size_t)c->N));
+    EW(square_kernel, c->N, c->lp.p, c->zbuf.p);
+    double* tiles = c->stats.p + 1 + c->P;
+    LRVB_TRY(launch_wsyrk(c, c->zbuf.p, tiles));
+    const int saved_quad = c->quad_kind;
+    c->quad_kind = LRVB_QUAD_NONE;               // G^T G has no quadratic-term contribution
+    int st;
+    if (c->all_box) {
+        st = launch_finish_box(c, tiles, nullptr, c->j1.p, nullptr, false, G_dev, ld);
+    } else {
+        st = buf_reserve(c, c->Heta, (size_t)c->V * (size_t)c->V);
+        if (st == LRVB_OK) st = buf_reserve(c, c->work1, (size_t)c->V * (size_t)c->D);
+        if (st == LRVB_OK) st = launch_build_Heta(c, tiles, c->Heta.p);
+        if (st == LRVB_OK) st = ensure_dense_J(c, free_dev);
+        if (st == LRVB_OK) st = launch_gemm(c, false, false, c->V, c->D, c->V, 1.0, c->Heta.p, c->V, c->Jdense.p, c->D, 0.0, c->work1.p, c->D);
+        if (st == LRVB_OK) st = launch_gemm(c, true, false, c->D, c->D, c->V, 1.0, c->Jdense.p, c->D, c->work1.p, c->D, 0.0, G_dev, ld);
+    }
+    c->quad_kind = saved_quad;
+    return st;
+}
+extern "C" int lrvb_gram_dev(lrvb_ctx* c, const double* free_dev, double* GtG_dev, int64_t ld) {
+    LRVB_TRY(ctx_bind(c));
+    if (!free_dev || !GtG_dev) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    return gram_dev_impl(c, free_dev, GtG_dev, ld);
+}
+extern "C" int lrvb_gram(lrvb_ctx* c, const double* free_in, int64_t D, double* GtG_out, int64_t ld) {
+    LRVB_TRY(ctx_bind(c));
+    if (!free_in || !GtG_out) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    LRVB_TRY(check_len(D, c->D, "free vector"));
+    if (ld < D) LRVB_FAIL(LRVB_ERR_SIZE, "leading dimension too small");
+    LRVB_TRY(h2d(c, c->theta.p, free_in, (size_t)D));
+    LRVB_TRY(buf_reserve(c, c->Hfree, (size_t)D * (size_t)D));
+    LRVB_TRY(gram_dev_impl(c, c->theta.p, c->Hfree.p, D));
+    HIP_TRY(hipMemcpy2DAsync(GtG_out, (size_t)ld * 8, c->Hfree.p, (size_t)D * 8, (size_t)D * 8, (size_t)D, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LRVB_OK;
+}
+
+// ---- Cholesky / linear response ------------------------------------------------------------
+static int chol_factor_dev_impl(lrvb_ctx* c, const double* H_dev, i64 D, i64 ld) {
+    LRVB_TRY(buf_reserve(c, c->chol, (size_t)D * (size_t)D));
+    HIP_TRY(hipMemcpy2DAsync(c->chol.p, (size_t)D * 8, H_dev, (size_t)ld * 8, (size_t)D * 8, (size_t)D, hipMemcpyDeviceToDevice, c->stream));
+    int* info = reinterpret_cast<int*>(c->scal.p);
+    c->chol_valid = false;
+    LRVB_TRY(launch_potrf_lower(c, c->chol.p, D, D, info));
+    int h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (h != 0) LRVB_FAIL(LRVB_ERR_NOT_POSDEF, "%d-th leading minor of the array is not positive definite", h);
+    c->chol_valid = true; c->chol_n = D;
+    return LRVB_OK;
+}
+extern "C" int lrvb_chol_factor_dev(lrvb_ctx* c, const double* H_dev, int64_t D, int64_t ld) {
+    LRVB_TRY(ctx_bind(c));
+    if (!H_dev || D <= 0 || ld < D) LRVB_FAIL(LRVB_ERR_INVALID, "bad argument");
+    return chol_factor_dev_impl(c, H_dev, D, ld);
+}
+extern "C" int lrvb_chol_factor(lrvb_ctx* c, const double* H, int64_t D) {
+    LRVB_TRY(ctx_bind(c));
+    if (!H || D <= 0) LRVB_FAIL(LRVB_ERR_INVALID, "bad argument");
+    LRVB_TRY(buf_reserve(c, c->Hfree, (size_t)D * (size_t)D));
+    LRVB_TRY(h2d(c, c->Hfree.p, H, (size_t)D * (size_t)D));
+    return chol_factor_dev_impl(c, c->Hfree.p, D, D);
+}
+extern "C" int lrvb_chol_factor_last(lrvb_ctx* c) {
+    LRVB_TRY(ctx_bind(c));
+    if (!c->Hfree.p || c->Hfree.n < (size_t)c->D * (size_t)c->D) LRVB_FAIL(LRVB_ERR_STATE, "no Hessian has been built through the host API yet");
+    return chol_factor_dev_impl(c, c->Hfree.p, c->D, c->D);
+}
+extern "C" int lrvb_chol_solve_dev(lrvb_ctx* c, double* B_dev, int64_t D, int64_t nrhs) {
+    LRVB_TRY(ctx_bind(c));
+    if (!c->chol_valid || c->chol_n != D) LRVB_FAIL(LRVB_ERR_STATE, "no Cholesky factor of size %lld: call lrvb_chol_factor first", (long long)D);
+    if (!B_dev || nrhs <= 0) LRVB_FAIL(LRVB_ERR_INVALID, "bad argument");
+    return launch_potrs_lower(c, c->chol.p, D, D, B_dev, nrhs, nrhs);
+}
+extern "C" int lrvb_chol_solve(lrvb_ctx* c, const double* B, int64_t D, int64_t nrhs, double* X_out) {
+    LRVB_TRY(ctx_bind(c));
+    if (!c->chol_valid || c->chol_n != D) LRVB_FAIL(LRVB_ERR_STATE, "no Cholesky factor of size %lld: call lrvb_chol_factor first", (long long)D);
+    if (!B || !X_out || nrhs <= 0) LRVB_FAIL(LRVB_ERR_INVALID, "bad argument");
+    LRVB_TRY(buf_reserve(c, c->rhs, (size_t)D * (size_t)nrhs));
+    LRVB_TRY(h2d(c, c->rhs.p, B, (size_t)D * (size_t)nrhs));
+    LRVB_TRY(launch_potrs_lower(c, c->chol.p, D, D, c->rhs.p, nrhs, nrhs));
+    return d2h(c, X_out, c->rhs.p, (size_t)D * (size_t)nrhs);
+}
+static int lrvb_cov_dev_impl(lrvb_ctx* c, const double* M_dev, i64 Q, i64 D, double* cov_dev) {
+    if (!c->chol_valid || c->chol_n != D) LRVB_FAIL(LRVB_ERR_STATE, "no Cholesky factor of size %lld: call lrvb_chol_factor first", (long long)D);
+    LRVB_TRY(buf_reserve(c, c->rhs, (size_t)D * (size_t)Q));
+    dim3 grid(nb256(D), (unsigned)Q);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, c->stream, Q, D, M_dev, c->rhs.p);   // rhs = M^T (D x Q)
+    HIP_TRY(hipGetLastError());
+    LRVB_TRY(launch_potrs_lower(c, c->chol.p, D, D, c->rhs.p, Q, Q));
+    return launch_gemm(c, false, false, Q, Q, D, 1.0, M_dev, D, c->rhs.p, Q, 0.0, cov_dev, Q);
+}
+extern "C" int lrvb_lrvb_cov_dev(lrvb_ctx* c, const double* M_dev, int64_t Q, int64_t D, double* cov_dev) {
+    LRVB_TRY(ctx_bind(c));
+    if (!M_dev || !cov_dev || Q <= 0) LRVB_FAIL(LRVB_ERR_INVALID, "bad argument");
+    return lrvb_cov_dev_impl(c, M_dev, Q, D, cov_dev);
+}
+extern "C" int lrvb_lrvb_cov(lrvb_ctx* c, const double* M, int64_t Q, int64_t D, double* cov_out) {
+    LRVB_TRY(ctx_bind(c));
+    if (!M || !cov_out || Q <= 0) LRVB_FAIL(LRVB_ERR_INVALID, "bad argument");
+    LRVB_TRY(buf_reserve(c, c->work1, (size_t)Q * (size_t)D));
+    LRVB_TRY(buf_reserve(c, c->Heta, (size_t)Q * (size_t)Q));
+    LRVB_TRY(h2d(c, c->work1.p, M, (size_t)Q * (size_t)D));
+    LRVB_TRY(lrvb_cov_dev_impl(c, c->work1.p, Q, D, c->Heta.p));
+    return d2h(c, cov_out, c->Heta.p, (size_t)Q * (size_t)Q);
+}
+
+// ---- conjugate gradient ----------------------------------------------------------------------
+extern "C" int lrvb_cg_solve(lrvb_ctx* c, const double* free_in, const double* b, const double* x0,
+                             const double* Minv, double tol, int64_t maxiter, int64_t D,
+                             double* x_out, int* info_out, int64_t* iters_out) {
+    LRVB_TRY(ctx_bind(c));
+    if (!free_in || !b || !x_out) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    LRVB_TRY(check_len(D, c->D, "free vector"));
+    LRVB_TRY(data_ready(c));
+    if (maxiter <= 0) maxiter = 10 * D;
+    DevBuf* vecs[] = { &c->rhs, &c->cgx, &c->cgr, &c->cgp, &c->cgq, &c->cgz };
+    for (DevBuf* v : vecs) LRVB_TRY(buf_reserve(c, *v, (size_t)D));
+    if (Minv) { LRVB_TRY(buf_reserve(c, c->Hfree, (size_t)D * (size_t)D)); LRVB_TRY(h2d(c, c->Hfree.p, Minv, (size_t)D * (size_t)D)); }
+    LRVB_TRY(h2d(c, c->theta.p, free_in, (size_t)D));
+    LRVB_TRY(h2d(c, c->rhs.p, b, (size_t)D));
+    // point state once: eta, J, g_eta, cached curvature
+    LRVB_TRY(set_point(c, c->theta.p, true));
+    LRVB_TRY(eval_grad_eta(c, c->stats.p, true));
+    LRVB_TRY(prepare_general_hvp(c, c->theta.p));
+
+    double* s = c->scal.p;                     // s[0] = ||b||^2, s[1] = ||r||^2, s[2] = r.z, s[3] = p.q
+    double hs[4];
+    LRVB_TRY(launch_dot(c, c->rhs.p, c->rhs.p, D, s + 0));
+    if (x0) {
+        LRVB_TRY(h2d(c, c->cgx.p, x0, (size_t)D));
+        LRVB_TRY(hvp_apply(c, c->theta.p, true, c->cgx.p, c->cgq.p));
+        LRVB_TRY(launch_axpby(c, D, 1.0, c->rhs.p, 0.0, c->cgr.p));
+        LRVB_TRY(launch_axpby(c, D, -1.0, c->cgq.p, 1.0, c->cgr.p));
+    } else {
+        HIP_TRY(hipMemsetAsync(c->cgx.p, 0, (size_t)D * sizeof(double), c->stream));
+        LRVB_TRY(launch_axpby(c, D, 1.0, c->rhs.p, 0.0, c->cgr.p));
+    }
+    LRVB_TRY(d2h(c, hs, s, 1));
+    const double bnorm = sqrt(hs[0]);
+    const double atol = tol * bnorm;
+    int info = 0; i64 it = 0;
+    double rho_prev = 0.0;
+    if (bnorm == 0.0) {
+        HIP_TRY(hipMemsetAsync(c->cgx.p, 0, (size_t)D * sizeof(double), c->stream));
+    } else {
+        info = (int)maxiter;
+        for (it = 0; it < maxiter; ++it) {
+            if (Minv) LRVB_TRY(launch_gemv(c, false, D, D, 1.0, c->Hfree.p, D, c->cgr.p, 0.0, c->cgz.p));
+            const double* z = Minv ? c->cgz.p : c->cgr.p;
+            LRVB_TRY(launch_dot(c, c->cgr.p, c->cgr.p, D, s + 1));
+            LRVB_TRY(launch_dot(c, c->cgr.p, z, D, s + 2));
+            LRVB_TRY(d2h(c, hs + 1, s + 1, 2));
+            if (sqrt(hs[1]) < atol) { info = 0; break; }
+            const double rho = hs[2];
+            if (it > 0) LRVB_TRY(launch_axpby(c, D, 1.0, z, rho / rho_prev, c->cgp.p));
+            else        LRVB_TRY(launch_axpby(c, D, 1.0, z, 0.0, c->cgp.p));
+            LRVB_TRY(hvp_apply(c, c->theta.p, true, c->cgp.p, c->cgq.p));
+            LRVB_TRY(launch_dot(c, c->cgp.p, c->cgq.p, D, s + 3));
+            LRVB_TRY(d2h(c, hs + 3, s + 3, 1));
+            const double alpha = rho / hs[3];
+            LRVB_TRY(launch_axpby(c, D, alpha, c->cgp.p, 1.0, c->cgx.p));
+            LRVB_TRY(launch_axpby(c, D, -alpha, c->cgq.p, 1.0, c->cgr.p));
+            rho_prev = rho;
+        }
+    }
+    LRVB_TRY(d2h(c, x_out, c->cgx.p, (size_t)D));
+    if (info_out) *info_out = info;
+    if (iters_out) *iters_out = it;
+    return LRVB_OK;
+}
+
+// ---- profiling ----------------------------------------------------------------------------------
+extern "C" int lrvb_profile_enable(lrvb_ctx* c, int on) {
+    if (!c) LRVB_FAIL(LRVB_ERR_INVALID, "null context");
+    c->prof_on = on != 0;
+    return LRVB_OK;
+}
+int prof_mark(lrvb_ctx* c, int which) {
+    std::vector<hipEvent_t>& pool = c->ev_pool[which];
+    if (c->ev_used[which] == pool.size()) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreate(&e));
+        pool.push_back(e);
+    }
+    HIP_TRY(hipEventRecord(pool[c->ev_used[which]++], c->stream));
+    return LRVB_OK;
+}
+static int prof_collect(lrvb_ctx* c) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < 3; ++k) {
+        double ms_sum = 0.0; int64_t calls = 0;
+        for (size_t i = 0; i + 1 < c->ev_used[k]; i += 2) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, c->ev_pool[k][i], c->ev_pool[k][i + 1]));
+            ms_sum += ms; ++calls;
+        }
+        c->ev_used[k] = 0;
+        if (k == PROF_WSYRK) { c->prof.wsyrk_ms += ms_sum; c->prof.wsyrk_calls += calls; }
+        if (k == PROF_PASS)  { c->prof.pass_ms  += ms_sum; c->prof.pass_calls  += calls; }
+        if (k == PROF_BUILD) { c->prof.build_ms += ms_sum; c->prof.build_calls += calls; }
+    }
+    return LRVB_OK;
+}
+extern "C" int lrvb_profile_get(lrvb_ctx* c, lrvb_prof* out) {
+    if (!c || !out) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    LRVB_TRY(ctx_bind(c));
+    LRVB_TRY(prof_collect(c));
+    *out = c->prof;
+    return LRVB_OK;
+}
+extern "C" int lrvb_profile_reset(lrvb_ctx* c) {
+    if (!c) LRVB_FAIL(LRVB_ERR_INVALID, "null context");
+    LRVB_TRY(ctx_bind(c));
+    LRVB_TRY(prof_collect(c));
+    c->prof = lrvb_prof{};
+    return LRVB_OK;
+}

@@ -1,0 +1,120 @@
+// lrvb_internal.h -- shared declarations of liblrvb_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/lrvb_hip.h"
+
+typedef int64_t i64;
+
+// ---- error plumbing -----------------------------------------------------------------
+void lrvb_set_error(const char* fmt, ...);
+#define LRVB_FAIL(code, ...) do { lrvb_set_error(__VA_ARGS__); return (code); } while (0)
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) {                    \
+    lrvb_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    return LRVB_ERR_HIP; } } while (0)
+#define LRVB_TRY(expr) do { int s_ = (expr); if (s_ != LRVB_OK) return s_; } while (0)
+
+// ---- geometry of the weighted-SYRK kernel -------------------------------------------
+constexpr int WS_TILE = 128;          // output tile edge (block)
+constexpr int WS_KC   = 16;           // observations staged per LDS stage
+constexpr int WS_THREADS = 256;       // 4 waves, each a 64x64 sub-tile
+constexpr int PASS_THREADS = 256;     // fused pass: 4 waves per block
+constexpr int PASS_MAX_COLS = 1024;   // register-resident row: 8 x 128 columns
+
+struct DevBuf {
+    double* p = nullptr;
+    size_t  n = 0;          // capacity in doubles
+    bool    owned = true;
+};
+
+struct lrvb_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+
+    // layout
+    std::vector<lrvb_block_desc> blocks;
+    lrvb_block_desc* blocks_dev = nullptr;
+    i64 D = 0, V = 0;
+    bool all_box = true;
+
+    // model
+    int loss = LRVB_LOSS_NONE;
+    i64 N = 0, P = 0, glm_off = 0;
+    double lik_info = 1.0;
+    int quad_kind = LRVB_QUAD_NONE;
+    double quad_scale = 1.0;
+
+    // resident data
+    DevBuf X, y, w, quadA, quadM, quadB;
+    bool have_X = false, have_y = false;
+
+    // per-evaluation state (device)
+    DevBuf theta, eta, j1, j2, vtmp, vtmp2, vtmp3, g_eta, g_free;
+    DevBuf lp, cw, zbuf;            // per-observation: loss', w*loss'', linear predictor
+    DevBuf part_vec, part_val;     // fused-pass block partials
+    DevBuf stats;                  // [value | g_glm (P) | S tiles]
+    DevBuf tile_part;              // weighted-SYRK split partials
+    DevBuf Heta, Hfree, Jdense, Tdense, work1;   // dense V x V / D x D scratch
+    DevBuf chol;                   // D x D Cholesky factor (lower)
+    bool chol_valid = false;
+    i64 chol_n = 0;
+    DevBuf rhs, cgx, cgr, cgp, cgq, cgz, scal;
+    double* host_pinned = nullptr; size_t host_pinned_n = 0;
+
+    int n_splits_user = 0;
+    int pass_grid = 0;
+
+    // profiling: event pairs are recorded without host synchronisation and summed in
+    // lrvb_profile_get (so the timed region of bench.py is not perturbed)
+    bool prof_on = false;
+    std::vector<hipEvent_t> ev_pool[3];     // 0 = wsyrk, 1 = pass, 2 = build
+    size_t ev_used[3] = {0, 0, 0};
+    lrvb_prof prof{};
+};
+
+enum { PROF_WSYRK = 0, PROF_PASS = 1, PROF_BUILD = 2 };
+int prof_mark(lrvb_ctx* c, int which);      // records the next event of pool `which` on the ctx stream
+
+int  buf_reserve(lrvb_ctx* c, DevBuf& b, size_t n);
+void buf_free(DevBuf& b);
+
+// ---- kernel launchers (each returns an lrvb status) ----------------------------------
+// k_pack.hip
+int launch_constrain(lrvb_ctx* c, const double* theta_dev, double* eta_dev, double* j1_dev, double* j2_dev);
+int launch_unconstrain(lrvb_ctx* c, const double* eta_dev, double* theta_dev, int* bad_flag_dev);
+int launch_dense_jac(lrvb_ctx* c, const double* theta_dev, double* J_dev /* V x D */);
+int launch_third_order(lrvb_ctx* c, const double* theta_dev, const double* g_eta_dev, double* T_dev /* D x D */);
+
+// k_glm.hip
+enum PassMode { PASS_GRAD = 0, PASS_HVP = 1, PASS_HVP_C = 2 };
+int launch_glm_pass(lrvb_ctx* c, PassMode mode, const double* beta_dev, const double* u_dev,
+                    double* out_vec_P /* reduced */, double* value_out_dev /* nullable */,
+                    bool store_obs);
+int launch_obs_grad(lrvb_ctx* c, i64 n0, i64 n1, double* G_dev, int mode, const double* scale_vec);
+
+// k_wsyrk.hip
+int  wsyrk_num_tiles(i64 P);
+int  wsyrk_auto_splits(const lrvb_ctx* c);
+int  launch_wsyrk(lrvb_ctx* c, const double* cvec_dev, double* tiles_out_dev /* T*128*128 */);
+int  launch_tiles_to_dense(lrvb_ctx* c, const double* tiles_dev, i64 P, double* dense_dev, i64 ld,
+                           i64 row_off, i64 col_off, bool accumulate);
+
+// k_linalg.hip
+int launch_gemm(lrvb_ctx* c, bool transA, bool transB, i64 M, i64 Nn, i64 K, double alpha,
+                const double* A, i64 lda, const double* B, i64 ldb, double beta, double* C, i64 ldc);
+int launch_potrf_lower(lrvb_ctx* c, double* A, i64 n, i64 lda, int* info_dev);
+int launch_potrs_lower(lrvb_ctx* c, const double* L, i64 n, i64 ldl, double* B, i64 nrhs, i64 ldb);
+int launch_dot(lrvb_ctx* c, const double* a, const double* b, i64 n, double* out_dev);
+int launch_axpby(lrvb_ctx* c, i64 n, double alpha, const double* x, double beta, double* y);
+int launch_gemv(lrvb_ctx* c, bool trans, i64 M, i64 Nn, double alpha, const double* A, i64 lda,
+                const double* x, double beta, double* y);
+
+// k_finish.hip
+int launch_quad_grad_value(lrvb_ctx* c, const double* eta_dev, double* g_eta_dev /* += */, double* value_dev /* += */);
+int launch_quad_hvp(lrvb_ctx* c, const double* u_vec_V, double* out_vec_V /* += scale*A u */);
+int launch_finish_box(lrvb_ctx* c, const double* tiles_dev, const double* g_eta_dev,
+                      const double* j1, const double* j2, bool with_third, double* H_dev, i64 ld);
+int launch_build_Heta(lrvb_ctx* c, const double* tiles_dev, double* Heta_dev /* V x V */);
+int launch_scatter_glm(lrvb_ctx* c, const double* g_glm_P, double* g_eta_V /* zero + scatter */);

@@ -1,0 +1,449 @@
+"""Declared objectives evaluated on the MI355X through liblrvb_hip.so.
+
+The reference's `Objective(par, fun)` takes an opaque zero-argument Python closure and lets
+autograd trace it (LRVB/SparseObjectives.py:95-116).  A HIP kernel cannot trace Python, so the
+objective is DECLARED instead: a `DeviceObjective` is a functor that is still callable with no
+arguments (it returns the value at the current state of `par`, like the reference's `fun`) but
+also tells the device what to differentiate:
+
+    f(eta) = sum_n w_n loss(y_n, x_n . eta[off:off+P]) + s (1/2 (eta-m)^T A (eta-m) + b^T eta)
+
+`Objective`, `TwoParameterObjective`, `ParametricSensitivityLinearApproximation` and
+`ConjugateGradientSolver` accept such a functor where the reference accepts a closure and route
+every derivative to the C ABI.  There is no CPU path: without the HIP library, construction
+raises.
+"""
+import ctypes
+import numpy as np
+
+from . import _hip
+from .packing import VectorParam
+
+_LOSSES = {None: _hip.LOSS_NONE, 'none': _hip.LOSS_NONE, 'gaussian': _hip.LOSS_GAUSSIAN,
+           'logistic': _hip.LOSS_LOGISTIC, 'poisson': _hip.LOSS_POISSON}
+
+
+def _block_array(blocks):
+    arr = (_hip.BlockDesc * len(blocks))()
+    fo = vo = 0
+    for i, b in enumerate(blocks):
+        arr[i].kind = b['kind']
+        arr[i].free_off, arr[i].vec_off = fo, vo
+        arr[i].free_size, arr[i].vec_size = b['free_size'], b['vec_size']
+        arr[i].dim0, arr[i].dim1 = b['dim0'], b['dim1']
+        arr[i].lb, arr[i].ub = b['lb'], b['ub']
+        fo += b['free_size']
+        vo += b['vec_size']
+    return arr, fo, vo
+
+
+class DeviceContext(object):
+    """Owns one lrvb_ctx (one HIP device + stream).  Thin, typed wrappers over the C ABI."""
+
+    def __init__(self, blocks, loss=None, n_obs=0, n_cols=0, glm_off=0, lik_info=1.0,
+                 quad_kind=_hip.QUAD_NONE, device=0):
+        self._lib = _hip.load()
+        self._blocks, self.D, self.V = _block_array(blocks)
+        desc = _hip.ModelDesc()
+        desc.n_blocks = len(blocks)
+        desc.loss = _LOSSES[loss] if not isinstance(loss, int) else loss
+        desc.blocks = self._blocks
+        desc.n_obs, desc.n_cols, desc.glm_off = int(n_obs), int(n_cols), int(glm_off)
+        desc.lik_info = float(lik_info)
+        desc.quad_kind = int(quad_kind)
+        self._h = ctypes.c_void_p()
+        _hip.check(self._lib.lrvb_ctx_create(ctypes.byref(self._h), int(device), ctypes.byref(desc)))
+        self.n_obs, self.n_cols = int(n_obs), int(n_cols)
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h.value:
+            self._lib.lrvb_ctx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- data -------------------------------------------------------------------------
+    def set_data(self, slot, arr):
+        a = _hip.as_f64(arr)
+        rows, cols = (a.shape[0], a.shape[1]) if a.ndim == 2 else (a.size, 1)
+        _hip.check(self._lib.lrvb_set_data(self._h, slot, _hip.ptr(a), rows, cols))
+
+    def set_data_dev(self, slot, dev_ptr, rows, cols):
+        _hip.check(self._lib.lrvb_set_data_dev(self._h, slot, ctypes.c_void_p(dev_ptr), rows, cols))
+
+    def set_weights(self, w):
+        a = _hip.as_f64(w).ravel()
+        _hip.check(self._lib.lrvb_set_weights(self._h, _hip.ptr(a), a.size))
+
+    def set_weights_dev(self, dev_ptr, n):
+        _hip.check(self._lib.lrvb_set_weights_dev(self._h, ctypes.c_void_p(dev_ptr), n))
+
+    def set_quad_scale(self, s):
+        _hip.check(self._lib.lrvb_set_quad_scale(self._h, float(s)))
+
+    def set_tuning(self, n_splits=0):
+        _hip.check(self._lib.lrvb_set_tuning(self._h, int(n_splits), 0))
+
+    def sync(self):
+        _hip.check(self._lib.lrvb_ctx_sync(self._h))
+
+    # -- packing ------------------------------------------------------------------------
+    def constrain(self, free):
+        f = _hip.as_f64(free).ravel()
+        out = np.empty(self.V)
+        _hip.check(self._lib.lrvb_constrain(self._h, _hip.ptr(f), f.size, _hip.ptr(out), out.size))
+        return out
+
+    def unconstrain(self, vec):
+        v = _hip.as_f64(vec).ravel()
+        out = np.empty(self.D)
+        _hip.check(self._lib.lrvb_unconstrain(self._h, _hip.ptr(v), v.size, _hip.ptr(out), out.size))
+        return out
+
+    def free_to_vector_jac(self, free):
+        f = _hip.as_f64(free).ravel()
+        if f.size != self.D:
+            raise ValueError('Wrong size for free vector.  Expected {}, got {}'.format(self.D, f.size))
+        out = np.empty((self.V, self.D))
+        _hip.check(self._lib.lrvb_free_to_vector_jac(self._h, _hip.ptr(f), f.size, _hip.ptr(out)))
+        return out
+
+    def free_hessian_from_vector(self, free, g_vec, H_vec):
+        f, g, H = _hip.as_f64(free).ravel(), _hip.as_f64(g_vec).ravel(), _hip.as_f64(H_vec)
+        if f.size != self.D or g.size != self.V or H.shape != (self.V, self.V):
+            raise ValueError('Wrong sizes for free_hessian_from_vector')
+        out = np.empty((self.D, self.D))
+        _hip.check(self._lib.lrvb_free_hessian_from_vector(self._h, _hip.ptr(f), _hip.ptr(g), _hip.ptr(H), _hip.ptr(out)))
+        return out
+
+    # -- objective ----------------------------------------------------------------------
+    def _n(self, is_free):
+        return self.D if is_free else self.V
+
+    def value(self, x, is_free=True):
+        x = _hip.as_f64(x).ravel()
+        out = np.empty(1)
+        fn = self._lib.lrvb_value if is_free else self._lib.lrvb_value_vec
+        _hip.check(fn(self._h, _hip.ptr(x), x.size, _hip.ptr(out)))
+        return float(out[0])
+
+    def grad(self, x, is_free=True):
+        x = _hip.as_f64(x).ravel()
+        g = np.empty(self._n(is_free))
+        fn = self._lib.lrvb_grad if is_free else self._lib.lrvb_grad_vec
+        _hip.check(fn(self._h, _hip.ptr(x), x.size, None, _hip.ptr(g)))
+        return g
+
+    def hessian(self, x, is_free=True):
+        x = _hip.as_f64(x).ravel()
+        n = self._n(is_free)
+        H = np.empty((n, n))
+        fn = self._lib.lrvb_hessian if is_free else self._lib.lrvb_hessian_vec
+        _hip.check(fn(self._h, _hip.ptr(x), x.size, _hip.ptr(H), n))
+        return H
+
+    def hvp(self, x, v, is_free=True):
+        x, v = _hip.as_f64(x).ravel(), _hip.as_f64(v).ravel()
+        if v.size != x.size:
+            raise ValueError('Wrong size for the vector of a Hessian-vector product')
+        out = np.empty(self._n(is_free))
+        fn = self._lib.lrvb_hvp if is_free else self._lib.lrvb_hvp_vec
+        _hip.check(fn(self._h, _hip.ptr(x), _hip.ptr(v), x.size, _hip.ptr(out)))
+        return out
+
+    def obs_grad(self, x, n0=0, n1=None, is_free=True):
+        x = _hip.as_f64(x).ravel()
+        n1 = self.n_obs if n1 is None else n1
+        G = np.empty((max(n1 - n0, 0), self._n(is_free)))
+        fn = self._lib.lrvb_obs_grad if is_free else self._lib.lrvb_obs_grad_vec
+        _hip.check(fn(self._h, _hip.ptr(x), x.size, n0, n1, _hip.ptr(G)))
+        return G
+
+    def cross_hessian_tilt(self, free):
+        f = _hip.as_f64(free).ravel()
+        C = np.empty((self.D, self.V))
+        _hip.check(self._lib.lrvb_cross_hessian_tilt(self._h, _hip.ptr(f), f.size, _hip.ptr(C)))
+        return C
+
+    def gram(self, free):
+        f = _hip.as_f64(free).ravel()
+        G = np.empty((self.D, self.D))
+        _hip.check(self._lib.lrvb_gram(self._h, _hip.ptr(f), f.size, _hip.ptr(G), self.D))
+        return G
+
+    # -- solves ---------------------------------------------------------------------------
+    def chol_factor(self, H):
+        H = _hip.as_f64(H)
+        if H.ndim != 2 or H.shape[0] != H.shape[1]:
+            raise ValueError('expected a square matrix')
+        _hip.check(self._lib.lrvb_chol_factor(self._h, _hip.ptr(H), H.shape[0]))
+
+    def chol_factor_last(self):
+        _hip.check(self._lib.lrvb_chol_factor_last(self._h))
+
+    def chol_solve(self, B):
+        B = _hip.as_f64(B)
+        B2 = B.reshape(B.shape[0], -1)
+        X = np.empty_like(B2)
+        _hip.check(self._lib.lrvb_chol_solve(self._h, _hip.ptr(B2), B2.shape[0], B2.shape[1], _hip.ptr(X)))
+        return X.reshape(B.shape)
+
+    def lrvb_cov(self, M):
+        M = _hip.as_f64(M)
+        Q, D = M.shape
+        out = np.empty((Q, Q))
+        _hip.check(self._lib.lrvb_lrvb_cov(self._h, _hip.ptr(M), Q, D, _hip.ptr(out)))
+        return out
+
+    def cg_solve(self, free, b, x0=None, Minv=None, tol=1e-8, maxiter=0):
+        f, b = _hip.as_f64(free).ravel(), _hip.as_f64(b).ravel()
+        if b.size != self.D:
+            raise ValueError('Wrong size for the right-hand side.  Expected {}, got {}'.format(self.D, b.size))
+        x0 = None if x0 is None else _hip.as_f64(x0).ravel()
+        Minv = None if Minv is None else _hip.as_f64(Minv)
+        x = np.empty(self.D)
+        info = ctypes.c_int(0)
+        iters = ctypes.c_int64(0)
+        _hip.check(self._lib.lrvb_cg_solve(self._h, _hip.ptr(f), _hip.ptr(b), _hip.ptr(x0), _hip.ptr(Minv),
+                                           float(tol), int(maxiter), f.size, _hip.ptr(x),
+                                           ctypes.byref(info), ctypes.byref(iters)))
+        return x, info.value, iters.value
+
+    # -- device-resident / multi-GPU -------------------------------------------------------
+    def stats_size(self):
+        n = ctypes.c_int64(0)
+        _hip.check(self._lib.lrvb_stats_size(self._h, ctypes.byref(n)))
+        return n.value
+
+    def hessian_partial_dev(self, free_ptr, stats_ptr):
+        _hip.check(self._lib.lrvb_hessian_partial_dev(self._h, ctypes.c_void_p(free_ptr), ctypes.c_void_p(stats_ptr)))
+
+    def hessian_finish_dev(self, free_ptr, stats_ptr, H_ptr, ld):
+        _hip.check(self._lib.lrvb_hessian_finish_dev(self._h, ctypes.c_void_p(free_ptr), ctypes.c_void_p(stats_ptr),
+                                                     ctypes.c_void_p(H_ptr), ld))
+
+    def hessian_dev(self, free_ptr, H_ptr, ld):
+        _hip.check(self._lib.lrvb_hessian_dev(self._h, ctypes.c_void_p(free_ptr), ctypes.c_void_p(H_ptr), ld))
+
+    def hvp_dev(self, free_ptr, v_ptr, out_ptr):
+        _hip.check(self._lib.lrvb_hvp_dev(self._h, ctypes.c_void_p(free_ptr), ctypes.c_void_p(v_ptr), ctypes.c_void_p(out_ptr)))
+
+    def gram_dev(self, free_ptr, G_ptr, ld):
+        _hip.check(self._lib.lrvb_gram_dev(self._h, ctypes.c_void_p(free_ptr), ctypes.c_void_p(G_ptr), ld))
+
+    def chol_factor_dev(self, H_ptr, D, ld):
+        _hip.check(self._lib.lrvb_chol_factor_dev(self._h, ctypes.c_void_p(H_ptr), D, ld))
+
+    def chol_solve_dev(self, B_ptr, D, nrhs):
+        _hip.check(self._lib.lrvb_chol_solve_dev(self._h, ctypes.c_void_p(B_ptr), D, nrhs))
+
+    def lrvb_cov_dev(self, M_ptr, Q, D, cov_ptr):
+        _hip.check(self._lib.lrvb_lrvb_cov_dev(self._h, ctypes.c_void_p(M_ptr), Q, D, ctypes.c_void_p(cov_ptr)))
+
+    # -- profiling ---------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        _hip.check(self._lib.lrvb_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self):
+        _hip.check(self._lib.lrvb_profile_reset(self._h))
+
+    def profile_get(self):
+        p = _hip.Prof()
+        _hip.check(self._lib.lrvb_profile_get(self._h, ctypes.byref(p)))
+        return {name: getattr(p, name) for name, _ in _hip.Prof._fields_}
+
+
+class DeviceObjective(object):
+    """A declared objective bound to a parameter object `par` (any object with the packing
+    protocol and `layout_blocks()`).
+
+    Callable like the reference's `fun`: `objective_fun()` returns the value at the current
+    state of `par`.  Extra positional / keyword arguments given to the Objective methods are
+    forwarded to `scale_fun(*argv, **argk)`, whose result multiplies the quadratic term -- the
+    declared counterpart of the keyword pass-through at LRVB/test_objectives.py:161-217.
+
+    Hyper-parameters (for TwoParameterObjective / ParametricSensitivityLinearApproximation):
+      `weights_par`  VectorParam('weights', N) holding the per-observation weights
+                     (Example.ipynb:254, 425-441);
+      `tilt_par`     VectorParam('tilt', V) holding the linear tilt b
+                     (the `hyper_param @ theta` term of LRVB/test_model_sensitivity.py:56-66).
+    Their current values are pushed to the device before every evaluation.
+    """
+    _lrvb_device_functor = True
+
+    def __init__(self, par, x=None, y=None, loss=None, glm_param=None, lik_info=1.0,
+                 quad_A=None, quad_m=None, quad_b=None, scale_fun=None, weights=None, device=0):
+        self.par = par
+        blocks = par.layout_blocks()
+        glm_off = 0
+        if loss is not None and loss != 'none':
+            x = _hip.as_f64(x)
+            if x.ndim != 2:
+                raise ValueError('x must be a 2-d array (observations x columns)')
+            n_obs, n_cols = x.shape
+            if glm_param is not None:
+                glm_off = par.vector_indices_dict[glm_param].start
+                if len(par.vector_indices_dict[glm_param]) != n_cols:
+                    raise ValueError('Wrong size for the coefficient parameter {}.  Expected {}, got {}'.format(
+                        glm_param, n_cols, len(par.vector_indices_dict[glm_param])))
+        else:
+            n_obs = n_cols = 0
+            loss = None
+        V = par.vector_size()
+        if quad_A is None:
+            quad_kind = _hip.QUAD_NONE if (quad_b is None and quad_m is None) else _hip.QUAD_DIAG
+            if quad_kind == _hip.QUAD_DIAG:
+                quad_A = np.zeros(V)
+        else:
+            quad_A = _hip.as_f64(quad_A)
+            quad_kind = _hip.QUAD_DIAG if quad_A.ndim == 1 else _hip.QUAD_DENSE
+        self.ctx = DeviceContext(blocks, loss=loss, n_obs=n_obs, n_cols=n_cols, glm_off=glm_off,
+                                 lik_info=lik_info, quad_kind=quad_kind, device=device)
+        if self.ctx.D != par.free_size() or self.ctx.V != par.vector_size():
+            raise ValueError('layout_blocks() of the parameter disagrees with its free/vector sizes')
+        self.n_obs = n_obs
+        self.scale_fun = scale_fun
+        self.weights_par = None
+        self.tilt_par = None
+        self._w_cache = None
+        self._b_cache = None
+        if loss is not None:
+            self.ctx.set_data(_hip.SLOT_X, x)
+            self.ctx.set_data(_hip.SLOT_Y, _hip.as_f64(y).ravel())
+            w0 = np.ones(n_obs) if weights is None else _hip.as_f64(weights).ravel().copy()
+            self.weights_par = VectorParam('weights', n_obs, val=w0)
+        if quad_kind != _hip.QUAD_NONE:
+            self.ctx.set_data(_hip.SLOT_QUAD_A, quad_A)
+            if quad_m is not None:
+                self.ctx.set_data(_hip.SLOT_QUAD_M, _hip.as_f64(quad_m).ravel())
+            b0 = np.zeros(V) if quad_b is None else _hip.as_f64(quad_b).ravel().copy()
+            self.tilt_par = VectorParam('tilt', V, val=b0)
+        self._push()
+
+    # ---- state pushed before every evaluation ------------------------------------------
+    def _push(self, argv=(), argk=None):
+        if self.weights_par is not None:
+            w = np.asarray(self.weights_par.get_vector(), dtype=np.float64)
+            if self._w_cache is None or not np.array_equal(w, self._w_cache):
+                self.ctx.set_weights(w)
+                self._w_cache = w.copy()
+        if self.tilt_par is not None:
+            b = np.asarray(self.tilt_par.get_vector(), dtype=np.float64)
+            if self._b_cache is None or not np.array_equal(b, self._b_cache):
+                self.ctx.set_data(_hip.SLOT_QUAD_B, b)
+                self._b_cache = b.copy()
+        if self.scale_fun is not None:
+            self.ctx.set_quad_scale(self.scale_fun(*argv, **(argk or {})))
+        elif argv or argk:
+            raise TypeError('this objective takes no extra arguments (no scale_fun declared)')
+
+    # ---- the reference's `fun` protocol --------------------------------------------------
+    def __call__(self, *argv, **argk):
+        self._push(argv, argk)
+        return self.ctx.value(np.asarray(self.par.get_free(), dtype=np.float64), True)
+
+    # ---- derivative protocol used by Objective / TwoParameterObjective ---------------------
+    def value(self, x, is_free, *argv, **argk):
+        self._push(argv, argk)
+        return self.ctx.value(x, is_free)
+
+    def grad(self, x, is_free, *argv, **argk):
+        self._push(argv, argk)
+        return self.ctx.grad(x, is_free)
+
+    def hessian(self, x, is_free, *argv, **argk):
+        self._push(argv, argk)
+        return self.ctx.hessian(x, is_free)
+
+    def hvp(self, x, v, is_free, *argv, **argk):
+        self._push(argv, argk)
+        return self.ctx.hvp(x, v, is_free)
+
+    def jacobian(self, x, is_free, *argv, **argk):
+        # scalar objective: the Jacobian is the gradient (shape (D,)), as autograd.jacobian gives
+        return self.grad(x, is_free, *argv, **argk)
+
+    def hyper_kind(self, hyper_par):
+        if hyper_par is self.weights_par:
+            return 'weights'
+        if hyper_par is self.tilt_par:
+            return 'tilt'
+        raise NotImplementedError(
+            'the second parameter must be this objective\'s `weights_par` or `tilt_par`; other '
+            'hyper-parameters would need tracing of a Python closure, which the device path cannot do')
+
+    def cross_hessian(self, hyper_par, val1, val1_is_free, *argv, **argk):
+        """d2 f / d par1 d hyper^T with hyper in VECTOR coordinates; shape (n1, hyper size)."""
+        kind = self.hyper_kind(hyper_par)
+        self._push(argv, argk)
+        if kind == 'weights':
+            return np.ascontiguousarray(self.ctx.obs_grad(val1, 0, self.n_obs, val1_is_free).T)
+        if val1_is_free:
+            return self.ctx.cross_hessian_tilt(val1)
+        s = self.scale_fun(*argv, **argk) if self.scale_fun is not None else 1.0
+        return s * np.eye(self.ctx.V)
+
+    def gram(self, free_val):
+        self._push()
+        return self.ctx.gram(free_val)
+
+
+def GLMObjective(par, x, y, loss='gaussian', glm_param=None, lik_info=1.0, prior_info=None,
+                 prior_mean=None, weights=None, device=0):
+    """Dense-design GLM-type objective (the headline workload of BASELINE.json):
+    sum_n w_n loss(y_n, x_n . beta) + 1/2 (eta - prior_mean)^T diag(prior_info) (eta - prior_mean)."""
+    V = par.vector_size()
+    A = None
+    if prior_info is not None:
+        A = np.full(V, float(prior_info)) if np.isscalar(prior_info) else _hip.as_f64(prior_info)
+    return DeviceObjective(par, x=x, y=y, loss=loss, glm_param=glm_param, lik_info=lik_info,
+                           quad_A=A, quad_m=prior_mean, weights=weights, device=device)
+
+
+def QuadraticObjective(par, A, m=None, b=None, scale_fun=None, device=0):
+    """s (1/2 (eta-m)^T A (eta-m) + b^T eta): the closed-form models of the reference's tests
+    (LRVB/test_objectives.py:14-57, 161-217; LRVB/test_model_sensitivity.py:36-88;
+    LRVB/test_optimization_utils.py:10-24)."""
+    return DeviceObjective(par, quad_A=A, quad_m=m, quad_b=b, scale_fun=scale_fun, device=device)
+
+
+class LinearMoments(object):
+    """Vector-valued functor m(eta) = B eta (B: Q x V), or a sub-parameter's vector when built
+    with `select=name` -- the `summary` of Example.ipynb:380-396.  Its free-coordinate Jacobian
+    B J(theta) is what `Objective.fun_free_jacobian` returns for a vector-valued `fun`
+    (LRVB/SparseObjectives.py:160-162)."""
+    _lrvb_device_functor = True
+
+    def __init__(self, par, B=None, select=None, device=0):
+        self.par = par
+        V = par.vector_size()
+        if select is not None:
+            idx = np.asarray(list(par.vector_indices_dict[select]))
+            B = np.zeros((idx.size, V))
+            B[np.arange(idx.size), idx] = 1.0
+        self.B = _hip.as_f64(B)
+        if self.B.shape[1] != V:
+            raise ValueError('B must have {} columns'.format(V))
+        self._layout = DeviceContext(par.layout_blocks(), quad_kind=_hip.QUAD_DIAG, device=device)
+
+    def __call__(self):
+        return self.B @ np.asarray(self.par.get_vector(), dtype=np.float64)
+
+    def value(self, x, is_free):
+        eta = self._layout.constrain(x) if is_free else _hip.as_f64(x).ravel()
+        return self.B @ eta
+
+    def jacobian(self, x, is_free):
+        if not is_free:
+            return self.B.copy()
+        return self.B @ self._layout.free_to_vector_jac(x)
+
+    def grad(self, *a, **k):
+        raise TypeError('gradient of a vector-valued functor; use the Jacobian')
+
+    hessian = hvp = grad

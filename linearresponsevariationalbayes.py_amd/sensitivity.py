@@ -1,0 +1,100 @@
+"""Linear-response sensitivity of an optimum to hyper-parameters.
+
+Drop-in for `ParametricSensitivityLinearApproximation` and the module-level `set_par` of
+LRVB/ModelSensitivity.py:13-17, 555-612:
+
+    d theta_hat / d eps^T = -H^-1  d2 f / d theta d eps^T        (doc/sensitivity.lyx:137-155)
+
+The Hessian (Objective.fun_free_hessian), the cross Hessian
+(TwoParameterObjective.fun_hessian_free1_vector2), the Cholesky factorisation and the solve all
+run on the device; the factor stays resident in the objective's context.  The higher-order
+`ParametricSensitivityTaylorExpansion` of the reference (:382-515) needs arbitrary-order
+forward-mode AD of a closure and is outside the accelerated path.
+"""
+from copy import deepcopy
+
+import numpy as np
+
+from . import objectives as obj_lib
+
+
+def set_par(par, val, is_free):
+    if is_free:
+        par.set_free(val)
+    else:
+        par.set_vector(val)
+
+
+class DeviceCholesky(object):
+    """Handle on a Cholesky factor held inside a device context (the counterpart of the
+    `(c, lower)` tuple scipy.linalg.cho_factor returns at LRVB/ModelSensitivity.py:594)."""
+
+    def __init__(self, ctx, hess):
+        self.ctx = ctx
+        self.dim = int(np.shape(hess)[0])
+        ctx.chol_factor(hess)
+
+    def solve(self, rhs):
+        return self.ctx.chol_solve(rhs)
+
+    def lrvb_cov(self, moment_jac):
+        return self.ctx.lrvb_cov(moment_jac)
+
+
+def _factor_and_solve(functor, hess, rhs):
+    ctx = getattr(functor, 'ctx', None)
+    if ctx is None:
+        raise NotImplementedError('the objective functor exposes no device context for the solve')
+    chol = DeviceCholesky(ctx, hess)
+    return chol, chol.solve(np.asarray(rhs, dtype=np.float64))
+
+
+class ParametricSensitivityLinearApproximation(object):
+    def __init__(self, objective_functor, input_par, hyper_par, input_val0, hyper_val0,
+                 input_is_free=True, hyper_is_free=False, hess0=None, hyper_par_objective_functor=None):
+        self.objective_functor = objective_functor
+        self.input_par = input_par
+        self.hyper_par = hyper_par
+        self.input_is_free = input_is_free
+        self.hyper_is_free = hyper_is_free
+        if hyper_par_objective_functor is None:
+            self.hyper_par_objective_functor = objective_functor
+        else:
+            self.hyper_par_objective_functor = hyper_par_objective_functor
+        self.objective = obj_lib.Objective(self.input_par, self.objective_functor)
+        self.joint_objective = obj_lib.TwoParameterObjective(
+            self.input_par, self.hyper_par, self.hyper_par_objective_functor)
+        self.set_base_values(input_val0, hyper_val0, hess0=hess0)
+
+    def set_par_to_base_values(self):
+        set_par(self.input_par, self.input_val0, self.input_is_free)
+        set_par(self.hyper_par, self.hyper_val0, self.hyper_is_free)
+
+    def set_base_values(self, input_val0, hyper_val0, hess0=None):
+        self.input_val0 = deepcopy(input_val0)
+        self.hyper_val0 = deepcopy(hyper_val0)
+        self.set_par_to_base_values()
+        if hess0 is None:
+            if self.input_is_free:
+                self.hess0 = self.objective.fun_free_hessian(self.input_val0)
+            else:
+                self.hess0 = self.objective.fun_vector_hessian(self.input_val0)
+        else:
+            self.hess0 = hess0
+        self.hyper_par_cross_hessian0 = self.joint_objective._cross12(
+            self.input_val0, self.hyper_val0, self.input_is_free, self.hyper_is_free)
+        self.hess0_chol, solved = _factor_and_solve(
+            self.objective_functor, self.hess0, self.hyper_par_cross_hessian0)
+        self.hyper_par_sensitivity = -1 * solved
+
+    def get_dinput_dhyper(self):
+        return self.hyper_par_sensitivity
+
+    def predict_input_par_from_hyperparameters(self, new_hyper_par_value):
+        hyper_par_diff = new_hyper_par_value - self.hyper_val0
+        return self.input_val0 + self.hyper_par_sensitivity @ hyper_par_diff
+
+    def get_lrvb_cov(self, moment_jac):
+        """LRVB covariance M H^-1 M^T of moments with Jacobian M (Example.ipynb:398-415), reusing
+        the resident factor."""
+        return self.hess0_chol.lrvb_cov(np.asarray(moment_jac, dtype=np.float64))

@@ -1,0 +1,244 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+fp64 tolerance: 1e-11 relative to the largest entry of the expected result for sums over
+observations (reduction order differs), 1e-9 for H^-1-type outputs."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import models as om
+from oracle import solvers as osv
+from helpers import make_par, glm_data, rel_err, LOSS_NAME
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL = 1e-11
+
+
+@pytest.fixture(scope='module')
+def vb():
+    import lrvb_amd
+    assert lrvb_amd._hip.device_count() >= 1, 'no HIP device visible'
+    return lrvb_amd
+
+
+def test_mfma_f64_operand_maps():
+    exe = os.path.join(ROOT, 'tools', 'mfma_f64_probe')
+    if not os.path.exists(exe):
+        pytest.skip('probe binary not built')
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    print(out.stdout)
+    assert out.returncode == 0, out.stdout + out.stderr
+
+
+MIXED = [('box', 'a', 3, -np.inf, np.inf), ('box', 'b', 2, 0.5, np.inf), ('box', 'c', 2, -np.inf, 3.0),
+         ('box', 'd', 3, -2.0, 5.0), ('psd', 'm', 3, 0.3), ('simplex', 's', 2, 4)]
+
+
+def test_packing_maps(vb):
+    rng = np.random.default_rng(1)
+    par, lay = make_par(vb, MIXED)
+    ctx = vb.DeviceContext(par.layout_blocks(), quad_kind=1)
+    theta = rng.normal(size=lay.D) * 0.7
+    eta = lay.constrain(theta)
+    assert rel_err(ctx.constrain(theta), eta) < 1e-14
+    assert np.max(np.abs(ctx.unconstrain(eta) - theta)) < 1e-12
+    assert rel_err(ctx.free_to_vector_jac(theta), lay.jac(theta)) < 1e-14
+    # host-side packing classes agree with the device and the oracle
+    par.set_free(theta)
+    assert rel_err(par.get_vector(), eta) < 1e-14
+    assert rel_err(np.asarray(par.free_to_vector_jac(theta).todense()), lay.jac(theta)) < 1e-14
+    g = rng.normal(size=lay.V)
+    Hv = rng.normal(size=(lay.V, lay.V)); Hv = Hv + Hv.T
+    from oracle import packing as opk
+    want = opk.convert_vector_to_free_hessian(lay, theta, g, Hv)
+    assert rel_err(ctx.free_hessian_from_vector(theta, g, Hv), want) < 1e-13
+    assert rel_err(np.asarray(vb.convert_vector_to_free_hessian(par, theta, g, Hv)), want) < 1e-13
+    with pytest.raises(ValueError):
+        ctx.constrain(theta[:-1])
+    bad = eta.copy(); bad[3] = 0.1          # below lb = 0.5 of block b
+    with pytest.raises(ValueError):
+        ctx.unconstrain(bad)
+
+
+@pytest.mark.parametrize('loss', [om.GAUSSIAN, om.LOGISTIC, om.POISSON])
+@pytest.mark.parametrize('N,P', [(1, 3), (37, 5), (1000, 130), (4099, 254), (3000, 256), (2500, 300)])
+def test_glm_box_layout(vb, loss, N, P):
+    rng = np.random.default_rng(100 + N + P + loss)
+    p1 = P // 3
+    spec = [('box', 'u', p1, -np.inf, np.inf), ('box', 'pos', P - p1, 0.0, np.inf)]
+    par, lay = make_par(vb, spec)
+    x, y, w = glm_data(rng, N, P, loss)
+    prior = 0.7
+    m_centre = rng.normal(size=P) * 0.1
+    fun = vb.DeviceObjective(par, x=x, y=y, loss=LOSS_NAME[loss], lik_info=1.3,
+                             quad_A=np.full(P, prior), quad_m=m_centre, weights=w)
+    model = om.DeclaredModel(lay, loss=loss, x=x, y=y, w=w, lik_info=1.3, quad_A=np.full(P, prior), quad_m=m_centre)
+    obj = vb.Objective(par, fun)
+    theta = rng.normal(size=lay.D) * 0.3
+    v = rng.normal(size=lay.D)
+    assert abs(obj.fun_free(theta) - model.value(theta)) <= 1e-12 * max(1.0, abs(model.value(theta)))
+    assert rel_err(obj.fun_free_grad(theta), model.grad(theta)) < TOL
+    H = obj.fun_free_hessian(theta)
+    Hw = model.hessian(theta)
+    assert rel_err(H, Hw) < TOL
+    assert np.array_equal(H, H.T)
+    assert rel_err(obj.fun_free_hvp(theta, v), Hw @ v) < TOL
+    # vector coordinates
+    eta = lay.constrain(theta)
+    assert rel_err(obj.fun_vector_grad(eta), model.grad_vec(eta)) < TOL
+    assert rel_err(obj.fun_vector_hessian(eta), model.hessian_vec(eta)) < TOL
+    assert rel_err(obj.fun_vector_hvp(eta, v), model.hessian_vec(eta) @ v) < TOL
+    # per-observation gradient matrix and its Gram matrix
+    G = fun.ctx.obs_grad(theta)
+    Gw = model.obs_grad(theta)
+    assert rel_err(G, Gw) < TOL
+    assert rel_err(fun.gram(theta), Gw.T @ Gw) < TOL
+    # side effect: par holds the evaluation point
+    assert np.max(np.abs(par.get_free() - theta)) < 1e-12
+
+
+def test_glm_general_layout(vb):
+    rng = np.random.default_rng(7)
+    spec = [('box', 'pre', 2, -np.inf, np.inf), ('box', 'beta', 6, -1.0, np.inf), ('psd', 'm', 3, 0.2), ('simplex', 's', 2, 3)]
+    par, lay = make_par(vb, spec)
+    N, P = 500, 6
+    x, y, w = glm_data(rng, N, P, om.LOGISTIC)
+    A = rng.normal(size=(lay.V, lay.V)); A = A @ A.T / lay.V + np.eye(lay.V)
+    m, b = rng.normal(size=lay.V) * 0.2, rng.normal(size=lay.V) * 0.3
+    fun = vb.DeviceObjective(par, x=x, y=y, loss='logistic', glm_param='beta', quad_A=A, quad_m=m, quad_b=b, weights=w)
+    model = om.DeclaredModel(lay, loss=om.LOGISTIC, x=x, y=y, w=w, glm_off=2, quad_A=A, quad_m=m, quad_b=b)
+    obj = vb.Objective(par, fun)
+    theta = rng.normal(size=lay.D) * 0.4
+    v = rng.normal(size=lay.D)
+    Hw = model.hessian(theta)
+    assert abs(obj.fun_free(theta) - model.value(theta)) < 1e-11 * abs(model.value(theta))
+    assert rel_err(obj.fun_free_grad(theta), model.grad(theta)) < TOL
+    assert rel_err(obj.fun_free_hessian(theta), Hw) < TOL
+    assert rel_err(obj.fun_free_hvp(theta, v), Hw @ v) < TOL
+    assert rel_err(fun.ctx.obs_grad(theta), model.obs_grad(theta)) < TOL
+    assert rel_err(fun.gram(theta), model.gram(theta)) < TOL
+    assert rel_err(fun.ctx.cross_hessian_tilt(theta), model.cross_hessian_tilt(theta)) < 1e-14
+
+
+def test_reference_keyword_passthrough_known_answers(vb):
+    """LRVB/test_objectives.py:161-243: f = sum(x^2) z y has Hessian 2 z y I, gradient 2 z y x,
+    HVP 2 z y v; x16 under the preconditioner 4 I."""
+    x = vb.VectorParam('x', size=2)
+    fun = vb.QuadraticObjective(x, A=2.0 * np.ones(2), scale_fun=lambda y, z=1.: y * z)
+    objective = vb.Objective(par=x, fun=fun)
+    x_val = np.array([0., 1.])
+    hvp_vec = np.array([2., 3.])
+    np.testing.assert_array_almost_equal(1 * 2 * 1, objective.fun_free(x_val, 2))
+    np.testing.assert_array_almost_equal(1 * 2 * 3, objective.fun_free(x_val, 2, z=3))
+    np.testing.assert_array_almost_equal(1 * 2 * 3, objective.fun_free(x_val, 2, z=3, verbose=True))
+    np.testing.assert_array_almost_equal(1 * 2 * 3, objective.fun_vector(x_val, 2, z=3))
+    np.testing.assert_array_almost_equal(2 * x_val * 2 * 3, objective.fun_free_grad(x_val, 2, z=3))
+    np.testing.assert_array_almost_equal(2 * x_val * 2 * 3, objective.fun_vector_grad(x_val, 2, z=3))
+    np.testing.assert_array_almost_equal(2 * x_val * 2 * 3, objective.fun_free_jacobian(x_val, 2, z=3))
+    np.testing.assert_array_almost_equal(2 * np.eye(2) * 2 * 3, objective.fun_free_hessian(x_val, 2, z=3))
+    np.testing.assert_array_almost_equal(2 * np.eye(2) * 2 * 3, objective.fun_vector_hessian(x_val, 2, z=3))
+    np.testing.assert_array_almost_equal(2 * hvp_vec * 2 * 3, objective.fun_free_hvp(x_val, 2, hvp_vec, z=3))
+    np.testing.assert_array_almost_equal(2 * hvp_vec * 2 * 3, objective.fun_vector_hvp(x_val, 2, hvp_vec, z=3))
+    objective.preconditioner = 4 * np.eye(2)
+    np.testing.assert_array_almost_equal(1 * 2 * 3 * 16, objective.fun_free_cond(x_val, 2, z=3))
+    np.testing.assert_array_almost_equal(2 * x_val * 2 * 3 * 16, objective.fun_free_grad_cond(x_val, 2, z=3))
+    np.testing.assert_array_almost_equal(2 * np.eye(2) * 2 * 3 * 16, objective.fun_free_hessian_cond(x_val, 2, z=3))
+    np.testing.assert_array_almost_equal(2 * hvp_vec * 2 * 3 * 16, objective.fun_free_hvp_cond(x_val, 2, hvp_vec, z=3))
+
+
+def test_cholesky_lrvb_cov_and_cg(vb):
+    rng = np.random.default_rng(11)
+    N, P = 3000, 200
+    spec = [('box', 'beta', P, 0.0, np.inf)]
+    par, lay = make_par(vb, spec)
+    x, y, w = glm_data(rng, N, P, om.POISSON)
+    fun = vb.GLMObjective(par, x, y, loss='poisson', prior_info=1.0, weights=w)
+    model = om.DeclaredModel(lay, loss=om.POISSON, x=x, y=y, w=w, quad_A=np.ones(P))
+    obj = vb.Objective(par, fun)
+    theta = rng.normal(size=P) * 0.2
+    H = obj.fun_free_hessian(theta)
+    Hw = model.hessian(theta)
+    # Cholesky solve and LRVB covariance
+    B = rng.normal(size=(P, 17))
+    fun.ctx.chol_factor(H)
+    assert rel_err(fun.ctx.chol_solve(B), np.linalg.solve(Hw, B)) < 1e-9
+    M = rng.normal(size=(23, P))
+    assert rel_err(fun.ctx.lrvb_cov(M), osv.lrvb_covariance(Hw, M)) < 1e-9
+    with pytest.raises(np.linalg.LinAlgError):
+        fun.ctx.chol_factor(-np.eye(P))
+    # CG: device loop vs Cholesky, the reference's own criterion (< 1e-8, test_objectives.py:552-554)
+    solver = vb.ConjugateGradientSolver(obj.fun_free_hvp, theta)
+    masks = vb.ConjugateGradient.get_masks(P, 40)
+    vec = rng.normal(size=P)
+    solver.get_hinv_vec_subsets(vec, masks)
+    for rhs, sol, info in zip(solver.vecs, solver.hinv_vecs, solver.cg_infos):
+        assert info == 0
+        assert np.max(np.abs(sol - np.linalg.solve(Hw, rhs))) < 1e-8
+    # preconditioned, with a warm start
+    Minv = np.diag(1.0 / np.diag(Hw))
+    xs, info, iters = fun.ctx.cg_solve(theta, vec, x0=0.1 * vec, Minv=Minv, tol=1e-10)
+    assert info == 0 and np.max(np.abs(xs - np.linalg.solve(Hw, vec))) < 1e-8
+
+
+def test_linear_response_quadratic_model(vb):
+    """LRVB/test_model_sensitivity.py:36-88, 367-424: theta_hat(eps) = -A^-1 eps has the free
+    form log(theta_hat + 10); dinput/dhyper equals its Jacobian."""
+    dim = 3
+    param = vb.VectorParam('theta', size=dim, lb=-10.0)
+    vec = np.linspace(0.1, 0.3, num=dim)
+    matrix = np.outer(vec, vec) + np.eye(dim)
+    hyper0 = np.linspace(0.5, 10.0, num=dim)
+    fun = vb.QuadraticObjective(param, A=matrix, b=hyper0)
+    theta_opt = -np.linalg.solve(matrix, hyper0)
+    theta0 = np.log(theta_opt + 10.0)
+    sens = vb.ParametricSensitivityLinearApproximation(
+        objective_functor=fun, input_par=param, hyper_par=fun.tilt_par, input_val0=theta0, hyper_val0=hyper0)
+    # analytic Jacobian of log(-A^-1 eps + 10) w.r.t. eps
+    want = np.diag(1.0 / (theta_opt + 10.0)) @ (-np.linalg.inv(matrix))
+    np.testing.assert_array_almost_equal(want, sens.get_dinput_dhyper())
+    eps = 0.01
+    pred = sens.predict_input_par_from_hyperparameters(hyper0 + eps) - theta0
+    true = np.log(-np.linalg.solve(matrix, hyper0 + eps) + 10.0) - theta0
+    assert np.linalg.norm(true - pred) <= eps * np.linalg.norm(true)
+
+
+def test_weight_sensitivity_example_shape(vb):
+    """Example.ipynb:398-441 restated for a declared model: summary sensitivity operator
+    -H^-1 M^T, cross Hessian w.r.t. the weights, influence matrix G H^-1 M^T."""
+    rng = np.random.default_rng(5)
+    N, P = 400, 4
+    par, lay = make_par(vb, [('box', 'beta', P, 0.0, np.inf)])
+    x, y, w = glm_data(rng, N, P, om.GAUSSIAN, scale=1.0)
+    fun = vb.GLMObjective(par, x, y, loss='gaussian', glm_param='beta', lik_info=2.0, prior_info=0.1)
+    model = om.DeclaredModel(lay, loss=om.GAUSSIAN, x=x, y=y, lik_info=2.0, quad_A=np.full(P, 0.1))
+    theta = rng.normal(size=P) * 0.2
+    w0 = np.ones(N)
+    sens = vb.ParametricSensitivityLinearApproximation(
+        objective_functor=fun, input_par=par, hyper_par=fun.weights_par, input_val0=theta, hyper_val0=w0)
+    Hw = model.hessian(theta)
+    Gw = model.obs_grad(theta)
+    assert rel_err(sens.get_dinput_dhyper(), -np.linalg.solve(Hw, Gw.T)) < 1e-9
+    summary = vb.LinearMoments(par, select='beta')
+    M = vb.Objective(par, summary).fun_free_jacobian(theta)
+    assert rel_err(M, lay.jac(theta)) < 1e-14
+    assert rel_err(sens.get_lrvb_cov(M), osv.lrvb_covariance(Hw, lay.jac(theta))) < 1e-9
+
+
+def test_errors_and_loud_failures(vb):
+    par, lay = make_par(vb, [('box', 'beta', 4, -np.inf, np.inf)])
+    rng = np.random.default_rng(3)
+    x, y, w = glm_data(rng, 10, 4, om.GAUSSIAN)
+    fun = vb.GLMObjective(par, x, y)
+    obj = vb.Objective(par, fun)
+    with pytest.raises(ValueError):
+        obj.fun_free_hessian(np.zeros(5))
+    with pytest.raises(ValueError):
+        fun.ctx.set_weights(np.ones(9))
+    with pytest.raises(AssertionError):
+        obj.fun_free_hessian_cond(np.zeros(4))
+    closure_obj = vb.Objective(par, lambda: float(np.sum(par.get_vector() ** 2)))
+    assert closure_obj.fun_free(np.ones(4)) == 4.0
+    with pytest.raises(NotImplementedError):
+        closure_obj.fun_free_hessian(np.ones(4))

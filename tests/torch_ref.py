@@ -1,0 +1,72 @@
+"""Independent torch-fp64 restatement of the packing maps and the declared objective, written
+only so that exact AD (torch.func) can check the oracle's ANALYTIC derivatives.  Exact
+derivatives are unique, so agreement here pins the oracle's Hessians to what autograd (the
+reference's engine, absent from this image) would return for the same function."""
+import math
+import torch
+
+torch.set_default_dtype(torch.float64)
+BOX, PSD, SIMPLEX = 0, 1, 2
+
+
+def constrain_block(f, b):
+    if b.kind == BOX:
+        lo, hi = b.lb, b.ub
+        if math.isinf(lo) and math.isinf(hi):
+            return f
+        if not math.isinf(lo) and math.isinf(hi):
+            return torch.exp(f) + lo
+        if math.isinf(lo):
+            return hi - torch.exp(-f)
+        return (hi - lo) * torch.sigmoid(f) + lo
+    if b.kind == PSD:
+        k = b.dim0
+        idx = torch.tril_indices(k, k)
+        L = torch.zeros(k, k, dtype=f.dtype)
+        L = L.index_put((idx[0], idx[1]), f)
+        d = torch.diagonal(L)
+        L = L - torch.diag(d) + torch.diag(torch.exp(d))
+        A = L @ L.T + b.lb * torch.eye(k)
+        return A[idx[0], idx[1]]
+    rows, K = b.dim0, b.dim1
+    F = f.reshape(rows, K - 1)
+    Faug = torch.cat([torch.zeros(rows, 1), F], dim=1)
+    return torch.softmax(Faug, dim=1).reshape(-1)
+
+
+def constrain(theta, layout):
+    return torch.cat([constrain_block(theta[b.free_off:b.free_off + b.free_size], b) for b in layout.blocks])
+
+
+def make_objective(model):
+    """Returns f_vec(eta) as a torch function for an oracle.models.DeclaredModel."""
+    x = None if model.x is None else torch.tensor(model.x)
+    y = None if model.y is None else torch.tensor(model.y)
+    w = None if model.w is None else torch.tensor(model.w)
+    A = None if model.quad_A is None else torch.tensor(model.quad_A)
+    m = torch.tensor(model.quad_m)
+    bq = torch.tensor(model.quad_b)
+
+    def f_vec(eta):
+        val = torch.zeros((), dtype=eta.dtype)
+        if model.loss:
+            z = x @ eta[model.glm_off:model.glm_off + model.P]
+            if model.loss == 1:
+                l = 0.5 * model.lik_info * (y - z) ** 2
+            elif model.loss == 2:
+                l = torch.nn.functional.softplus(z) - y * z
+            else:
+                l = torch.exp(z) - y * z
+            val = val + torch.sum(w * l)
+        if A is not None:
+            d = eta - m
+            Ad = A * d if A.dim() == 1 else A @ d
+            val = val + model.quad_scale * (0.5 * torch.dot(d, Ad) + torch.dot(bq, eta))
+        return val
+
+    return f_vec
+
+
+def make_free_objective(model):
+    f_vec = make_objective(model)
+    return lambda theta: f_vec(constrain(theta, model.layout))
