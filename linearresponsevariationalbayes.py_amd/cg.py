@@ -83,7 +83,7 @@ class ConjugateGradientSolver(object):
     def get_hinv_vec(self, vec, x0=None):
         if self._device is not None:
             objective, fun = self._device
-            fun._push()
+            fun._push_state()
             minv = None if self.preconditioner is None else np.asarray(self.preconditioner, dtype=np.float64)
             hinv_vec, cg_info, _ = fun.ctx.cg_solve(self.x0, vec, x0=x0, Minv=minv, tol=self.tol)
             objective.par.set_free(self.x0)

@@ -323,10 +323,10 @@ class DeviceObjective(object):
                 self.ctx.set_data(_hip.SLOT_QUAD_M, _hip.as_f64(quad_m).ravel())
             b0 = np.zeros(V) if quad_b is None else _hip.as_f64(quad_b).ravel().copy()
             self.tilt_par = VectorParam('tilt', V, val=b0)
-        self._push()
+        self._push_state()
 
     # ---- state pushed before every evaluation ------------------------------------------
-    def _push(self, argv=(), argk=None):
+    def _push_state(self):
         if self.weights_par is not None:
             w = np.asarray(self.weights_par.get_vector(), dtype=np.float64)
             if self._w_cache is None or not np.array_equal(w, self._w_cache):
@@ -337,6 +337,9 @@ class DeviceObjective(object):
             if self._b_cache is None or not np.array_equal(b, self._b_cache):
                 self.ctx.set_data(_hip.SLOT_QUAD_B, b)
                 self._b_cache = b.copy()
+
+    def _push(self, argv=(), argk=None):
+        self._push_state()
         if self.scale_fun is not None:
             self.ctx.set_quad_scale(self.scale_fun(*argv, **(argk or {})))
         elif argv or argk:
@@ -389,7 +392,7 @@ class DeviceObjective(object):
         return s * np.eye(self.ctx.V)
 
     def gram(self, free_val):
-        self._push()
+        self._push_state()
         return self.ctx.gram(free_val)
 
 

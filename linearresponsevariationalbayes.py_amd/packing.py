@@ -375,9 +375,9 @@ def _psd_hess_dense(free_val, k):
                 cc, d = r[q], c[q]
                 v = 0.0
                 if b == d:
-                    v += dL[p] * dL[q] * ((i == a and j == cc) + (j == a and i == cc))
+                    v += dL[p] * dL[q] * (float(i == a and j == cc) + float(j == a and i == cc))
                 if p == q and a == b:
-                    v += L[a, a] * ((i == a) * L[j, a] + (j == a) * L[i, a])
+                    v += L[a, a] * (float(i == a) * L[j, a] + float(j == a) * L[i, a])
                 H[row, p, q] = v
     return H
 
