@@ -153,28 +153,46 @@ void glm_pass_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
     }
 }
 
-// out[col] = sum_b part_vec[b][col]; value = sum_b part_val[b]  (fixed order)
-__global__ __launch_bounds__(256)
+// out[col] = sum_b part_vec[b][col]; value = sum_b part_val[b].  Fixed summation order
+// (deterministic): 64 columns x 8 row slices per block, 4 loads in flight per thread, slices
+// combined through LDS in slice order.
+__global__ __launch_bounds__(512)
 void pass_reduce_kernel(const double* __restrict__ part_vec, const double* __restrict__ part_val,
                         int nblk, int P, double* __restrict__ out_vec, double* __restrict__ out_val)
 {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ double sh[8][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cx;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     if (col < P) {
-        double s = 0.0;
-        for (int b = 0; b < nblk; ++b) s += part_vec[(i64)b * P + col];
+        int b = ry;
+        for (; b + 24 < nblk; b += 32) {
+            s0 += part_vec[(i64)b * P + col];
+            s1 += part_vec[(i64)(b + 8) * P + col];
+            s2 += part_vec[(i64)(b + 16) * P + col];
+            s3 += part_vec[(i64)(b + 24) * P + col];
+        }
+        for (; b < nblk; b += 8) s0 += part_vec[(i64)b * P + col];
+    }
+    sh[ry][cx] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (ry == 0 && col < P) {
+        double s = sh[0][cx];
+#pragma unroll
+        for (int r = 1; r < 8; ++r) s += sh[r][cx];
         out_vec[col] = s;
     }
     if (out_val != nullptr && blockIdx.x == 0) {
-        __shared__ double sh[256];
+        __shared__ double shv[512];
         double s = 0.0;
-        for (int b = threadIdx.x; b < nblk; b += 256) s += part_val[b];
-        sh[threadIdx.x] = s;
+        for (int b = threadIdx.x; b < nblk; b += 512) s += part_val[b];
+        shv[threadIdx.x] = s;
         __syncthreads();
-        for (int off = 128; off >= 1; off >>= 1) {
-            if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+        for (int off = 256; off >= 1; off >>= 1) {
+            if ((int)threadIdx.x < off) shv[threadIdx.x] += shv[threadIdx.x + off];
             __syncthreads();
         }
-        if (threadIdx.x == 0) *out_val = sh[0];
+        if (threadIdx.x == 0) *out_val = shv[0];
     }
 }
 
@@ -226,7 +244,7 @@ int launch_glm_pass(lrvb_ctx* c, PassMode mode, const double* beta_dev, const do
     else                  st = launch_pass_nit<8>(c, mode, beta_dev, u_dev, (int)grid, vec_ok, so);
     LRVB_TRY(st);
     if (c->prof_on && mode == PASS_GRAD) LRVB_TRY(prof_mark(c, PROF_PASS));
-    hipLaunchKernelGGL(pass_reduce_kernel, dim3((unsigned)((c->P + 255) / 256)), dim3(256), 0, c->stream,
+    hipLaunchKernelGGL(pass_reduce_kernel, dim3((unsigned)((c->P + 63) / 64)), dim3(512), 0, c->stream,
                        c->part_vec.p, c->part_val.p, (int)grid, (int)c->P, out_vec_P,
                        (mode == PASS_GRAD) ? value_out_dev : (double*)nullptr);
     HIP_TRY(hipGetLastError());

@@ -49,30 +49,29 @@ int wsyrk_auto_splits(const lrvb_ctx* c) {
     return (int)s;
 }
 
-__device__ __forceinline__ void ws_load_pair(const double* __restrict__ rowp, int col, int P,
-                                             bool vec_ok, double& v0, double& v1) {
-    if (col + 1 < P) {
-        if (vec_ok) {
-            double2 t = *reinterpret_cast<const double2*>(rowp + col);
-            v0 = t.x; v1 = t.y;
-        } else {
-            v0 = rowp[col]; v1 = rowp[col + 1];
-        }
-    } else if (col < P) {
-        v0 = rowp[col]; v1 = 0.0;
+// Raw pair load from a clamped (always readable) address.  Out-of-range values are zeroed later,
+// in store_stage: anything that CONSUMES a loaded value here would make hipcc wait for the load
+// before the MFMA block instead of behind it.
+template <bool VEC>
+__device__ __forceinline__ void ws_load_pair_raw(const double* __restrict__ rowp, int col, int P,
+                                                 double& v0, double& v1) {
+    if (VEC) {                      // P even, 16-byte aligned rows: a pair never straddles column P
+        const double2 t = *reinterpret_cast<const double2*>(rowp + (col < P ? col : 0));
+        v0 = t.x; v1 = t.y;
     } else {
-        v0 = 0.0; v1 = 0.0;
+        v0 = rowp[col < P ? col : 0];
+        v1 = rowp[col + 1 < P ? col + 1 : 0];
     }
 }
 
+template <bool VEC>
 __global__ __launch_bounds__(WS_THREADS, 2)
 void wsyrk_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
                   const double* __restrict__ cvec, int n_splits, int T, i64 rows_per_split,
-                  double* __restrict__ partial, int vec_ok_i)
+                  double* __restrict__ partial)
 {
     __shared__ double lds[2][2][WS_KC][WS_LDS_STRIDE];   // [stage][A|B][obs][col]
 
-    const bool vec_ok = vec_ok_i != 0;
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
     const int xcd = b & 7;                  // label of the workgroups that share an XCD
@@ -104,7 +103,7 @@ void wsyrk_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
         for (int n = 0; n < 4; ++n) acc[m][n] = (d4){0.0, 0.0, 0.0, 0.0};
 
     // staging registers: 4 pairs per panel per thread
-    double sa[4][2], sb[4][2];
+    double sa[4][2], sb[4][2], sc[4];
     const int colA0 = bi * WS_TILE, colB0 = bj * WS_TILE;
 
     auto load_stage = [&](int ch) {
@@ -114,33 +113,37 @@ void wsyrk_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
             const int row = idx >> 6;
             const int c2 = (idx & 63) * 2;
             const i64 n = r0 + (i64)ch * WS_KC + row;
-            if (n < r1) {
-                const double* rowp = X + n * ldx;
-                const double cv = cvec[n];
-                double a0, a1;
-                ws_load_pair(rowp, colA0 + c2, P, vec_ok, a0, a1);
-                if (diag) { sb[it][0] = a0; sb[it][1] = a1; }
-                else      { ws_load_pair(rowp, colB0 + c2, P, vec_ok, sb[it][0], sb[it][1]); }
-                sa[it][0] = a0 * cv; sa[it][1] = a1 * cv;
-            } else {
-                sa[it][0] = sa[it][1] = sb[it][0] = sb[it][1] = 0.0;
-            }
+            const i64 ne = n < r1 ? n : r1 - 1;            // clamped: always a readable row
+            const double* rowp = X + ne * ldx;
+            sc[it] = cvec[ne];
+            ws_load_pair_raw<VEC>(rowp, colA0 + c2, P, sa[it][0], sa[it][1]);
+            ws_load_pair_raw<VEC>(rowp, colB0 + c2, P, sb[it][0], sb[it][1]);   // diagonal tiles: same lines, L1 hits
         }
     };
-    auto store_stage = [&](int buf) {
+    auto store_stage = [&](int ch, int buf) {
+        // pin the staged values here: every consumer of a loaded value (masking, c_n scaling) sits
+        // behind this point, so the one vmcnt wait of the stage lands after the MFMA block
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+            asm volatile("" : "+v"(sa[it][0]), "+v"(sa[it][1]), "+v"(sb[it][0]), "+v"(sb[it][1]), "+v"(sc[it]));
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int idx = it * WS_THREADS + tid;
             const int row = idx >> 6;
             const int c2 = (idx & 63) * 2;
-            *reinterpret_cast<double2*>(&lds[buf][0][row][c2]) = make_double2(sa[it][0], sa[it][1]);
-            *reinterpret_cast<double2*>(&lds[buf][1][row][c2]) = make_double2(sb[it][0], sb[it][1]);
+            const i64 n = r0 + (i64)ch * WS_KC + row;
+            const double cv = n < r1 ? sc[it] : 0.0;       // dead rows contribute 0 * finite
+            const int ca = colA0 + c2, cb = colB0 + c2;
+            const double a0 = ca < P ? sa[it][0] * cv : 0.0, a1 = ca + 1 < P ? sa[it][1] * cv : 0.0;
+            const double b0 = cb < P ? sb[it][0] : 0.0, b1 = cb + 1 < P ? sb[it][1] : 0.0;
+            *reinterpret_cast<double2*>(&lds[buf][0][row][c2]) = make_double2(a0, a1);
+            *reinterpret_cast<double2*>(&lds[buf][1][row][c2]) = make_double2(b0, b1);
         }
     };
 
     if (nch > 0) {
         load_stage(0);
-        store_stage(0);
+        store_stage(0, 0);
     }
     __syncthreads();
 
@@ -164,7 +167,7 @@ void wsyrk_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
                         acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m], bf[n], acc[m][n], 0, 0, 0);
             }
         }
-        if (more) store_stage(buf ^ 1);
+        if (more) store_stage(ch + 1, buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }
@@ -209,8 +212,12 @@ int launch_wsyrk(lrvb_ctx* c, const double* cvec_dev, double* tiles_out_dev) {
     const int vec_ok = ((ldx % 2) == 0) && ((((uintptr_t)c->X.p) & 15) == 0);
     const int grid = S * T;
     if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
-    hipLaunchKernelGGL(wsyrk_kernel, dim3(grid), dim3(WS_THREADS), 0, c->stream,
-                       c->X.p, ldx, c->N, (int)c->P, cvec_dev, S, T, rps, c->tile_part.p, vec_ok);
+    if (vec_ok)
+        hipLaunchKernelGGL(wsyrk_kernel<true>, dim3(grid), dim3(WS_THREADS), 0, c->stream,
+                           c->X.p, ldx, c->N, (int)c->P, cvec_dev, S, T, rps, c->tile_part.p);
+    else
+        hipLaunchKernelGGL(wsyrk_kernel<false>, dim3(grid), dim3(WS_THREADS), 0, c->stream,
+                           c->X.p, ldx, c->N, (int)c->P, cvec_dev, S, T, rps, c->tile_part.p);
     HIP_TRY(hipGetLastError());
     if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
     const i64 nthreads = tile_elems / 2;
