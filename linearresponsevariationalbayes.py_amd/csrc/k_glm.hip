@@ -233,7 +233,7 @@ int launch_glm_pass(lrvb_ctx* c, PassMode mode, const double* beta_dev, const do
     LRVB_TRY(buf_reserve(c, c->part_vec, (size_t)(grid * c->P)));
     LRVB_TRY(buf_reserve(c, c->part_val, (size_t)grid));
     LRVB_TRY(buf_reserve(c, c->lp, (size_t)c->N));
-    LRVB_TRY(buf_reserve(c, c->cw, (size_t)c->N));
+    LRVB_TRY(reserve_obs_vec(c, c->cw));
     const int vec_ok = ((c->P % 2) == 0) && ((((uintptr_t)c->X.p) & 15) == 0);
     if (c->prof_on && mode == PASS_GRAD) LRVB_TRY(prof_mark(c, PROF_PASS));
     int st;

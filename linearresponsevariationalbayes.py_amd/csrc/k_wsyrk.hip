@@ -185,6 +185,146 @@ void wsyrk_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
             }
 }
 
+// ---- LDS-DMA variant (the fast path: even P, 16-byte aligned rows) ------------------------------
+// Same tiling, but the stage is filled by global_load_lds_dwordx4 (one 1 KiB panel row per wave
+// instruction, no staging registers, no ds_write, no masking VALU) issued one stage ahead; the
+// c_n scaling moves to the A-fragment read (4 v_mul_f64 per 16 MFMAs, issued in their shadow).
+// Out-of-range rows are clamped to a readable row and neutralised by c = 0 (the c vector carries
+// >= 32 zeros of padding past N); out-of-range columns produce garbage only in tile entries that
+// nobody reads.  ALL LDS lives in one array (a second __shared__ object next to an LDS-DMA target
+// makes hipcc drain vmcnt(0) before every ds_read).
+constexpr int WS_PANEL = WS_KC * WS_LDS_STRIDE;          // doubles per panel
+constexpr int WS_BUF = 2 * WS_PANEL + 32;                // A panel, B panel, 32 c values
+
+#define WS_GLDS16(gp, lp) __builtin_amdgcn_global_load_lds( \
+    (const __attribute__((address_space(1))) void*)(gp), (__attribute__((address_space(3))) void*)(lp), 16, 0, 0)
+#define WS_GLDS4(gp, lp) __builtin_amdgcn_global_load_lds( \
+    (const __attribute__((address_space(1))) void*)(gp), (__attribute__((address_space(3))) void*)(lp), 4, 0, 0)
+
+template <int DBG>     // timing-lab bits (0 in production): 1 = no global loads, 2 = no barrier, 4 = no LDS reads
+__global__ __launch_bounds__(WS_THREADS, 2)
+void wsyrk_glds_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
+                       const double* __restrict__ cpad, int n_splits, int T, i64 rows_per_split,
+                       double* __restrict__ partial)
+{
+    __shared__ double lds[2 * WS_BUF];
+
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    const int xcd = b & 7;
+    const int q = b >> 3;
+    const int split_local = q / T;
+    const int t = q - split_local * T;
+    const int split = split_local * 8 + xcd;
+
+    int bi = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+    while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+    while (bi * (bi + 1) / 2 > t) --bi;
+    const int bj = t - bi * (bi + 1) / 2;
+    const bool diag = (bi == bj);
+
+    i64 r0 = (i64)split * rows_per_split;
+    i64 r1 = r0 + rows_per_split;
+    if (r1 > N) r1 = N;
+    if (r0 > N) r0 = N;
+    const int nch = (int)((r1 - r0 + WS_KC - 1) / WS_KC);
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wr = wave >> 1, wc = wave & 1;
+    const bool skip = diag && (wr == 0) && (wc == 1);
+
+    d4 acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = (d4){0.0, 0.0, 0.0, 0.0};
+
+    // this lane's column inside each panel (clamped so the 16-byte load stays inside the row)
+    int ca = bi * WS_TILE + 2 * lane; if (ca > P - 2) ca = P - 2;
+    int cb = bj * WS_TILE + 2 * lane; if (cb > P - 2) cb = P - 2;
+
+    // one panel row (1 KiB) of stage `ch` per call; i = 0..3 selects this wave's row wave + 4 i
+    auto issue_row = [&](int ch, int buf, int i, bool panelB) {
+        double* base = lds + buf * WS_BUF;
+        const int row = wave + 4 * i;
+        i64 n = r0 + (i64)ch * WS_KC + row; if (n > N - 1) n = N - 1;
+        const double* rowp = X + n * ldx;
+        if (!panelB) WS_GLDS16(rowp + ca, base + row * WS_LDS_STRIDE);
+        else         WS_GLDS16(rowp + cb, base + WS_PANEL + row * WS_LDS_STRIDE);
+    };
+    auto issue_c = [&](int ch, int buf) {     // 64 dwords = c[n0 .. n0+31]; reads past N hit the zero padding
+        const i64 n0 = r0 + (i64)ch * WS_KC;
+        WS_GLDS4(reinterpret_cast<const float*>(cpad + n0) + lane, lds + buf * WS_BUF + 2 * WS_PANEL);
+    };
+
+    auto issue_stage = [&](int ch, int buf) {
+        if (DBG & 1) return;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { issue_row(ch, buf, i, false); if (!diag) issue_row(ch, buf, i, true); }
+        if (wave == 0) issue_c(ch, buf);
+    };
+
+    if (nch > 0) issue_stage(0, 0);
+    __syncthreads();
+
+    int buf = 0;
+    for (int ch = 0; ch < nch; ++ch) {
+        if (ch + 1 < nch) issue_stage(ch + 1, buf ^ 1);
+        if (!skip) {
+            const double* As = lds + buf * WS_BUF;
+            const double* Bs = diag ? As : As + WS_PANEL;
+            const double* Cs = As + 2 * WS_PANEL;
+            // fragments of k-step kk+1 are read while the 16 MFMAs of k-step kk run (explicit
+            // register double buffer; sched_barrier keeps hipcc from sinking the reads to their use)
+            double af[2][4], bf[2][4], cv[2];
+            auto read_frags = [&](int kk, int set) {
+                const int krow = kk * 4 + (lane >> 4);
+                if (DBG & 4) {
+                    cv[set] = 1.0 + krow;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) { af[set][m] = 0.5 + m + lane; bf[set][m] = 0.25 + m - lane; }
+                    return;
+                }
+                cv[set] = Cs[krow];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) af[set][m] = As[krow * WS_LDS_STRIDE + wr * 64 + m * 16 + (lane & 15)];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) bf[set][n] = Bs[krow * WS_LDS_STRIDE + wc * 64 + n * 16 + (lane & 15)];
+            };
+            read_frags(0, 0);
+#pragma unroll
+            for (int kk = 0; kk < WS_KC / 4; ++kk) {
+                const int set = kk & 1;
+                if (kk + 1 < WS_KC / 4) read_frags(kk + 1, set ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                double as[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) as[m] = af[set][m] * cv[set];
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[m], bf[set][n], acc[m][n], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (!(DBG & 2)) __syncthreads();          // with LDS-DMA in flight this is s_waitcnt vmcnt(0) + s_barrier
+        buf ^= 1;
+    }
+
+    double* out = partial + ((i64)split * T + t) * (i64)(WS_TILE * WS_TILE);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = wr * 64 + m * 16 + (lane >> 4) + 4 * r;
+                const int j = wc * 64 + n * 16 + (lane & 15);
+                out[i * WS_TILE + j] = acc[m][n][r];
+            }
+}
+
 // Deterministic second stage: tiles[t][e] = sum_s partial[s][t][e]  (fixed order).
 __global__ __launch_bounds__(256)
 void wsyrk_reduce_kernel(const double* __restrict__ partial, int n_splits, i64 tile_elems_total,
@@ -212,7 +352,16 @@ int launch_wsyrk(lrvb_ctx* c, const double* cvec_dev, double* tiles_out_dev) {
     const int vec_ok = ((ldx % 2) == 0) && ((((uintptr_t)c->X.p) & 15) == 0);
     const int grid = S * T;
     if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
-    if (vec_ok)
+    if (vec_ok && c->P >= 2 && !c->force_generic_wsyrk)     // cvec_dev carries >= 32 zeros past N (reserve_obs_vec)
+        switch (c->dbg_bits) {
+#define WS_LAUNCH(D) hipLaunchKernelGGL(wsyrk_glds_kernel<D>, dim3(grid), dim3(WS_THREADS), 0, c->stream, \
+                           c->X.p, ldx, c->N, (int)c->P, cvec_dev, S, T, rps, c->tile_part.p)
+        case 1: WS_LAUNCH(1); break; case 2: WS_LAUNCH(2); break; case 3: WS_LAUNCH(3); break;
+        case 4: WS_LAUNCH(4); break; case 5: WS_LAUNCH(5); break; case 7: WS_LAUNCH(7); break;
+        default: WS_LAUNCH(0); break;
+#undef WS_LAUNCH
+        }
+    else if (vec_ok)
         hipLaunchKernelGGL(wsyrk_kernel<true>, dim3(grid), dim3(WS_THREADS), 0, c->stream,
                            c->X.p, ldx, c->N, (int)c->P, cvec_dev, S, T, rps, c->tile_part.p);
     else

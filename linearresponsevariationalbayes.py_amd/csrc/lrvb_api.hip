@@ -39,6 +39,13 @@ int buf_reserve(lrvb_ctx* c, DevBuf& b, size_t n) {
     b.n = n;
     return LRVB_OK;
 }
+int reserve_obs_vec(lrvb_ctx* c, DevBuf& b) {
+    const size_t need = (size_t)c->N + 64;
+    if (b.p != nullptr && b.owned && b.n >= need) return LRVB_OK;
+    LRVB_TRY(buf_reserve(c, b, need));
+    HIP_TRY(hipMemsetAsync(b.p + c->N, 0, 64 * sizeof(double), c->stream));
+    return LRVB_OK;
+}
 void buf_free(DevBuf& b) {
     if (b.p && b.owned) (void)hipFree(b.p);
     b.p = nullptr; b.n = 0; b.owned = true;
@@ -124,7 +131,8 @@ extern "C" int lrvb_ctx_create(lrvb_ctx** out, int device_id, const lrvb_model_d
     need(c->scal, 16);
     if (c->loss != LRVB_LOSS_NONE) {
         need(c->w, (size_t)c->N);
-        need(c->lp, (size_t)c->N); need(c->cw, (size_t)c->N);
+        need(c->lp, (size_t)c->N);
+        if (st == LRVB_OK) st = reserve_obs_vec(c, c->cw);
         const size_t tiles = (size_t)wsyrk_num_tiles(c->P) * WS_TILE * WS_TILE;
         need(c->stats, 1 + (size_t)c->P + tiles);
     } else {
@@ -258,10 +266,11 @@ extern "C" int lrvb_set_quad_scale(lrvb_ctx* c, double scale) {
 }
 
 extern "C" int lrvb_set_tuning(lrvb_ctx* c, int n_splits, int reserved) {
-    (void)reserved;
     if (!c) LRVB_FAIL(LRVB_ERR_INVALID, "null context");
     if (n_splits < 0 || n_splits > 1024) LRVB_FAIL(LRVB_ERR_INVALID, "n_splits out of range");
     c->n_splits_user = n_splits;
+    c->force_generic_wsyrk = (reserved & 1) != 0;
+    c->dbg_bits = (reserved >> 8) & 7;
     return LRVB_OK;
 }
 
@@ -669,7 +678,7 @@ static int gram_dev_impl(lrvb_ctx* c, const double* free_dev, double* G_dev, i64
     LRVB_TRY(data_ready(c));
     LRVB_TRY(set_point(c, free_dev, true));
     LRVB_TRY(eval_grad_eta(c, c->stats.p, false));
-    LRVB_TRY(buf_reserve(c, c->zbuf, (size_t)c->N));
+    LRVB_TRY(reserve_obs_vec(c, c->zbuf));
     EW(square_kernel, c->N, c->lp.p, c->zbuf.p);
     double* tiles = c->stats.p + 1 + c->P;
     LRVB_TRY(launch_wsyrk(c, c->zbuf.p, tiles));

@@ -64,6 +64,8 @@ struct lrvb_ctx {
     double* host_pinned = nullptr; size_t host_pinned_n = 0;
 
     int n_splits_user = 0;
+    int  dbg_bits = 0;                  // timing-lab variants of the weighted-SYRK kernel (wrong results)
+    bool force_generic_wsyrk = false;   // tuning/testing: use the register-staged kernel
     int pass_grid = 0;
 
     // profiling: event pairs are recorded without host synchronisation and summed in
@@ -78,6 +80,7 @@ enum { PROF_WSYRK = 0, PROF_PASS = 1, PROF_BUILD = 2 };
 int prof_mark(lrvb_ctx* c, int which);      // records the next event of pool `which` on the ctx stream
 
 int  buf_reserve(lrvb_ctx* c, DevBuf& b, size_t n);
+int  reserve_obs_vec(lrvb_ctx* c, DevBuf& b);   // N doubles + 64 zeros of padding (LDS-DMA over-read)
 void buf_free(DevBuf& b);
 
 // ---- kernel launchers (each returns an lrvb status) ----------------------------------

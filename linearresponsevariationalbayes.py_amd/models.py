@@ -86,8 +86,8 @@ class DeviceContext(object):
     def set_quad_scale(self, s):
         _hip.check(self._lib.lrvb_set_quad_scale(self._h, float(s)))
 
-    def set_tuning(self, n_splits=0):
-        _hip.check(self._lib.lrvb_set_tuning(self._h, int(n_splits), 0))
+    def set_tuning(self, n_splits=0, flags=0):
+        _hip.check(self._lib.lrvb_set_tuning(self._h, int(n_splits), int(flags)))
 
     def sync(self):
         _hip.check(self._lib.lrvb_ctx_sync(self._h))

@@ -6,6 +6,7 @@ import lrvb_amd as vb
 N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1000000
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 splits = [int(s) for s in sys.argv[3].split(',')] if len(sys.argv) > 3 else [0]
+flags = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 dev = torch.device('cuda:0')
 g = torch.Generator(device=dev); g.manual_seed(1)
 X = torch.randn((N, P), dtype=torch.float64, device=dev, generator=g) / P ** 0.5
@@ -20,7 +21,7 @@ ctx = vb.DeviceContext(blocks, loss='gaussian', n_obs=N, n_cols=P, lik_info=2.0,
 ctx.set_data_dev(0, X.data_ptr(), N, P); ctx.set_data_dev(1, y.data_ptr(), N, 1); ctx.set_weights_dev(w.data_ptr(), N)
 ctx.set_data(2, np.ones(P))
 for s in splits:
-    ctx.set_tuning(s)
+    ctx.set_tuning(s, flags)
     ctx.hessian_dev(theta.data_ptr(), H.data_ptr(), P); ctx.sync()
     ctx.profile_enable(True); ctx.profile_reset()
     t0 = time.time(); K = 5
