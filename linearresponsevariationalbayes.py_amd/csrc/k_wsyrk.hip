@@ -204,24 +204,39 @@ constexpr int WS_BUF = 2 * WS_PANEL + 32;                // A panel, B panel, 32
 template <int DBG>     // timing-lab bits (0 in production): 1 = no global loads, 2 = no barrier, 4 = no LDS reads
 __global__ __launch_bounds__(WS_THREADS, 2)
 void wsyrk_glds_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
-                       const double* __restrict__ cpad, int n_splits, int T, i64 rows_per_split,
+                       const double* __restrict__ cpad, int n_splits, int nb, i64 rows_per_split,
                        double* __restrict__ partial)
 {
     __shared__ double lds[2 * WS_BUF];
 
     const int tid = threadIdx.x;
-    const int b = blockIdx.x;
-    const int xcd = b & 7;
-    const int q = b >> 3;
-    const int split_local = q / T;
-    const int t = q - split_local * T;
-    const int split = split_local * 8 + xcd;
-
-    int bi = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
-    while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
-    while (bi * (bi + 1) / 2 > t) --bi;
-    const int bj = t - bi * (bi + 1) / 2;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: wave-uniform branches below
+    // Work order inside one XCD's queue (blockIdx % 8 = XCD label, blockIdx / 8 = position):
+    // first every off-diagonal tile of every split this XCD owns (16 MFMA tiles per wave and
+    // k-step), then the diagonal tiles (9 per wave and k-step, i.e. 9/16 of the duration):
+    // longest-first keeps the 2-blocks-per-CU schedule free of a ragged tail.
+    const int xcd = blockIdx.x & 7;
+    const int q = blockIdx.x >> 3;
+    const int S8 = n_splits >> 3;
+    const int n_off = nb * (nb - 1) / 2;
+    int bi, bj, split_local;
+    if (q < n_off * S8) {
+        split_local = q / n_off;
+        const int u = q - split_local * n_off;
+        bi = (int)((1.f + sqrtf(1.f + 8.f * (float)u)) * 0.5f);
+        while (bi * (bi - 1) / 2 > u) --bi;
+        while ((bi + 1) * bi / 2 <= u) ++bi;
+        bj = u - bi * (bi - 1) / 2;
+    } else {
+        const int qd = q - n_off * S8;
+        split_local = qd / nb;
+        bi = bj = qd - split_local * nb;
+    }
     const bool diag = (bi == bj);
+    const int t = bi * (bi + 1) / 2 + bj;
+    const int T = nb * (nb + 1) / 2;
+    const int split = split_local * 8 + xcd;
 
     i64 r0 = (i64)split * rows_per_split;
     i64 r1 = r0 + rows_per_split;
@@ -229,56 +244,49 @@ void wsyrk_glds_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
     if (r0 > N) r0 = N;
     const int nch = (int)((r1 - r0 + WS_KC - 1) / WS_KC);
 
-    const int wave = tid >> 6, lane = tid & 63;
-    const int wr = wave >> 1, wc = wave & 1;
-    const bool skip = diag && (wr == 0) && (wc == 1);
-
-    d4 acc[4][4];
+    // accumulators: full tile = 4 x 4 MFMA tiles (64 x 64 per wave); diagonal tile = the 16-row
+    // blocks {wave, 7 - wave} of the lower triangle: (wave + 1) + (8 - wave) = 9 MFMA tiles per wave
+    d4 acc[16];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int n = 0; n < 4; ++n) acc[m][n] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int i = 0; i < 16; ++i) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
 
     // this lane's column inside each panel (clamped so the 16-byte load stays inside the row)
     int ca = bi * WS_TILE + 2 * lane; if (ca > P - 2) ca = P - 2;
     int cb = bj * WS_TILE + 2 * lane; if (cb > P - 2) cb = P - 2;
 
-    // one panel row (1 KiB) of stage `ch` per call; i = 0..3 selects this wave's row wave + 4 i
-    auto issue_row = [&](int ch, int buf, int i, bool panelB) {
-        double* base = lds + buf * WS_BUF;
-        const int row = wave + 4 * i;
-        i64 n = r0 + (i64)ch * WS_KC + row; if (n > N - 1) n = N - 1;
-        const double* rowp = X + n * ldx;
-        if (!panelB) WS_GLDS16(rowp + ca, base + row * WS_LDS_STRIDE);
-        else         WS_GLDS16(rowp + cb, base + WS_PANEL + row * WS_LDS_STRIDE);
-    };
-    auto issue_c = [&](int ch, int buf) {     // 64 dwords = c[n0 .. n0+31]; reads past N hit the zero padding
-        const i64 n0 = r0 + (i64)ch * WS_KC;
-        WS_GLDS4(reinterpret_cast<const float*>(cpad + n0) + lane, lds + buf * WS_BUF + 2 * WS_PANEL);
-    };
-
     auto issue_stage = [&](int ch, int buf) {
         if (DBG & 1) return;
+        double* base = lds + buf * WS_BUF;
+        const i64 n0 = r0 + (i64)ch * WS_KC;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { issue_row(ch, buf, i, false); if (!diag) issue_row(ch, buf, i, true); }
-        if (wave == 0) issue_c(ch, buf);
+        for (int i = 0; i < 4; ++i) {
+            const int row = wave + 4 * i;
+            i64 n = n0 + row; if (n > N - 1) n = N - 1;
+            const double* rowp = X + n * ldx;
+            WS_GLDS16(rowp + ca, base + row * WS_LDS_STRIDE);
+            if (!diag) WS_GLDS16(rowp + cb, base + WS_PANEL + row * WS_LDS_STRIDE);
+        }
+        if (wave == 0)       // 64 dwords = c[n0 .. n0+31]; reads past N hit the zero padding
+            WS_GLDS4(reinterpret_cast<const float*>(cpad + n0) + lane, base + 2 * WS_PANEL);
     };
 
     if (nch > 0) issue_stage(0, 0);
     __syncthreads();
 
+    const int l15 = lane & 15, l4 = lane >> 4;
     int buf = 0;
-    for (int ch = 0; ch < nch; ++ch) {
-        if (ch + 1 < nch) issue_stage(ch + 1, buf ^ 1);
-        if (!skip) {
+    if (!diag) {
+        const int wr = wave >> 1, wc = wave & 1;
+        for (int ch = 0; ch < nch; ++ch) {
+            if (ch + 1 < nch) issue_stage(ch + 1, buf ^ 1);
             const double* As = lds + buf * WS_BUF;
-            const double* Bs = diag ? As : As + WS_PANEL;
+            const double* Bs = As + WS_PANEL;
             const double* Cs = As + 2 * WS_PANEL;
             // fragments of k-step kk+1 are read while the 16 MFMAs of k-step kk run (explicit
             // register double buffer; sched_barrier keeps hipcc from sinking the reads to their use)
             double af[2][4], bf[2][4], cv[2];
             auto read_frags = [&](int kk, int set) {
-                const int krow = kk * 4 + (lane >> 4);
+                const int krow = kk * 4 + l4;
                 if (DBG & 4) {
                     cv[set] = 1.0 + krow;
 #pragma unroll
@@ -287,9 +295,9 @@ void wsyrk_glds_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
                 }
                 cv[set] = Cs[krow];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) af[set][m] = As[krow * WS_LDS_STRIDE + wr * 64 + m * 16 + (lane & 15)];
+                for (int m = 0; m < 4; ++m) af[set][m] = As[krow * WS_LDS_STRIDE + wr * 64 + m * 16 + l15];
 #pragma unroll
-                for (int n = 0; n < 4; ++n) bf[set][n] = Bs[krow * WS_LDS_STRIDE + wc * 64 + n * 16 + (lane & 15)];
+                for (int n = 0; n < 4; ++n) bf[set][n] = Bs[krow * WS_LDS_STRIDE + wc * 64 + n * 16 + l15];
             };
             read_frags(0, 0);
 #pragma unroll
@@ -304,25 +312,73 @@ void wsyrk_glds_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
                     for (int n = 0; n < 4; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[m], bf[set][n], acc[m][n], 0, 0, 0);
+                        acc[m * 4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[m], bf[set][n], acc[m * 4 + n], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (!(DBG & 2)) __syncthreads();      // with LDS-DMA in flight: s_waitcnt vmcnt(0) + s_barrier
+            buf ^= 1;
         }
-        if (!(DBG & 2)) __syncthreads();          // with LDS-DMA in flight this is s_waitcnt vmcnt(0) + s_barrier
-        buf ^= 1;
-    }
-
-    double* out = partial + ((i64)split * T + t) * (i64)(WS_TILE * WS_TILE);
+        double* out = partial + ((i64)split * T + t) * (i64)(WS_TILE * WS_TILE);
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    out[(wr * 64 + m * 16 + l4 + 4 * r) * WS_TILE + wc * 64 + n * 16 + l15] = acc[m * 4 + n][r];
+    } else {
+        const int rb0 = wave, rb1 = 7 - wave;        // this wave's two 16-row blocks
+        for (int ch = 0; ch < nch; ++ch) {
+            if (ch + 1 < nch) issue_stage(ch + 1, buf ^ 1);
+            const double* As = lds + buf * WS_BUF;
+            const double* Cs = As + 2 * WS_PANEL;
+            double a0[2], a1[2], bf[2][8], cv[2];
+            auto read_frags = [&](int kk, int set) {
+                const int krow = kk * 4 + l4;
+                if (DBG & 4) {
+                    cv[set] = 1.0 + krow; a0[set] = 0.5 + lane; a1[set] = 0.75 - lane;
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) bf[set][n] = 0.25 + n - lane;
+                    return;
+                }
+                const double* rowp = As + krow * WS_LDS_STRIDE + l15;
+                cv[set] = Cs[krow];
+                a0[set] = rowp[rb0 * 16];
+                a1[set] = rowp[rb1 * 16];
+#pragma unroll
+                for (int n = 0; n < 8; ++n) bf[set][n] = rowp[n * 16];
+            };
+            read_frags(0, 0);
+#pragma unroll
+            for (int kk = 0; kk < WS_KC / 4; ++kk) {
+                const int set = kk & 1;
+                if (kk + 1 < WS_KC / 4) read_frags(kk + 1, set ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                const double s0 = a0[set] * cv[set], s1 = a1[set] * cv[set];
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    if (n <= rb0) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(s0, bf[set][n], acc[n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < 8; ++n)
+                    if (n <= rb1) acc[4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(s1, bf[set][n], acc[4 + n], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (!(DBG & 2)) __syncthreads();
+            buf ^= 1;
+        }
+        // lower-triangle blocks get the sums, the rest of the two block rows is zeroed (never read,
+        // but kept finite for the split reduction / all-reduce)
+        double* out = partial + ((i64)split * T + t) * (i64)(WS_TILE * WS_TILE);
+#pragma unroll
+        for (int n = 0; n < 8; ++n)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int i = wr * 64 + m * 16 + (lane >> 4) + 4 * r;
-                const int j = wc * 64 + n * 16 + (lane & 15);
-                out[i * WS_TILE + j] = acc[m][n][r];
+                const double v0 = (n < 4 && n <= rb0) ? acc[n < 4 ? n : 0][r] : 0.0;
+                const double v1 = (n <= rb1) ? acc[4 + n][r] : 0.0;
+                out[(rb0 * 16 + l4 + 4 * r) * WS_TILE + n * 16 + l15] = v0;
+                out[(rb1 * 16 + l4 + 4 * r) * WS_TILE + n * 16 + l15] = v1;
             }
+    }
 }
 
 // Deterministic second stage: tiles[t][e] = sum_s partial[s][t][e]  (fixed order).
@@ -355,7 +411,7 @@ int launch_wsyrk(lrvb_ctx* c, const double* cvec_dev, double* tiles_out_dev) {
     if (vec_ok && c->P >= 2 && !c->force_generic_wsyrk)     // cvec_dev carries >= 32 zeros past N (reserve_obs_vec)
         switch (c->dbg_bits) {
 #define WS_LAUNCH(D) hipLaunchKernelGGL(wsyrk_glds_kernel<D>, dim3(grid), dim3(WS_THREADS), 0, c->stream, \
-                           c->X.p, ldx, c->N, (int)c->P, cvec_dev, S, T, rps, c->tile_part.p)
+                           c->X.p, ldx, c->N, (int)c->P, cvec_dev, S, (int)((c->P + WS_TILE - 1) / WS_TILE), rps, c->tile_part.p)
         case 1: WS_LAUNCH(1); break; case 2: WS_LAUNCH(2); break; case 3: WS_LAUNCH(3); break;
         case 4: WS_LAUNCH(4); break; case 5: WS_LAUNCH(5); break; case 7: WS_LAUNCH(7); break;
         default: WS_LAUNCH(0); break;
