@@ -205,7 +205,7 @@ template <int DBG>     // timing-lab bits (0 in production): 1 = no global loads
 __global__ __launch_bounds__(WS_THREADS, 2)
 void wsyrk_glds_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
                        const double* __restrict__ cpad, int n_splits, int nb, i64 rows_per_split,
-                       double* __restrict__ partial)
+                       double* __restrict__ partial, int stagger_shift)
 {
     __shared__ double lds[2 * WS_BUF];
 
@@ -271,6 +271,7 @@ void wsyrk_glds_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
     };
 
     if (nch > 0) issue_stage(0, 0);
+    if (stagger_shift >= 0 && (((blockIdx.x >> 3) >> stagger_shift) & 1)) __builtin_amdgcn_s_sleep(77);
     __syncthreads();
 
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -303,16 +304,22 @@ void wsyrk_glds_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
 #pragma unroll
             for (int kk = 0; kk < WS_KC / 4; ++kk) {
                 const int set = kk & 1;
-                if (kk + 1 < WS_KC / 4) read_frags(kk + 1, set ^ 1);
-                __builtin_amdgcn_sched_barrier(0);
+                // order: (wait for set kk, all that is outstanding) -> scale -> issue reads of set
+                // kk+1 -> 16 MFMAs.  The only lgkmcnt wait of the k-step then sits a full MFMA
+                // block after the reads it covers.
                 double as[4];
 #pragma unroll
                 for (int m = 0; m < 4; ++m) as[m] = af[set][m] * cv[set];
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk + 1 < WS_KC / 4) read_frags(kk + 1, set ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
                     for (int n = 0; n < 4; ++n)
                         acc[m * 4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[m], bf[set][n], acc[m * 4 + n], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (!(DBG & 2)) __syncthreads();      // with LDS-DMA in flight: s_waitcnt vmcnt(0) + s_barrier
@@ -352,9 +359,10 @@ void wsyrk_glds_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
 #pragma unroll
             for (int kk = 0; kk < WS_KC / 4; ++kk) {
                 const int set = kk & 1;
+                const double s0 = a0[set] * cv[set], s1 = a1[set] * cv[set];
+                __builtin_amdgcn_sched_barrier(0);
                 if (kk + 1 < WS_KC / 4) read_frags(kk + 1, set ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
-                const double s0 = a0[set] * cv[set], s1 = a1[set] * cv[set];
 #pragma unroll
                 for (int n = 0; n < 4; ++n)
                     if (n <= rb0) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(s0, bf[set][n], acc[n], 0, 0, 0);
@@ -411,7 +419,7 @@ int launch_wsyrk(lrvb_ctx* c, const double* cvec_dev, double* tiles_out_dev) {
     if (vec_ok && c->P >= 2 && !c->force_generic_wsyrk)     // cvec_dev carries >= 32 zeros past N (reserve_obs_vec)
         switch (c->dbg_bits) {
 #define WS_LAUNCH(D) hipLaunchKernelGGL(wsyrk_glds_kernel<D>, dim3(grid), dim3(WS_THREADS), 0, c->stream, \
-                           c->X.p, ldx, c->N, (int)c->P, cvec_dev, S, (int)((c->P + WS_TILE - 1) / WS_TILE), rps, c->tile_part.p)
+                           c->X.p, ldx, c->N, (int)c->P, cvec_dev, S, (int)((c->P + WS_TILE - 1) / WS_TILE), rps, c->tile_part.p, c->stagger_shift)
         case 1: WS_LAUNCH(1); break; case 2: WS_LAUNCH(2); break; case 3: WS_LAUNCH(3); break;
         case 4: WS_LAUNCH(4); break; case 5: WS_LAUNCH(5); break; case 7: WS_LAUNCH(7); break;
         default: WS_LAUNCH(0); break;

@@ -64,6 +64,7 @@ struct lrvb_ctx {
     double* host_pinned = nullptr; size_t host_pinned_n = 0;
 
     int n_splits_user = 0;
+    int  stagger_shift = -1;            // timing lab: delay blocks whose queue position has this bit set
     int  dbg_bits = 0;                  // timing-lab variants of the weighted-SYRK kernel (wrong results)
     bool force_generic_wsyrk = false;   // tuning/testing: use the register-staged kernel
     int pass_grid = 0;
