@@ -1,0 +1,120 @@
+"""The N > 1 path on CPU: two processes, `gloo` backend, the same ShardedHessian logic the GPU
+ranks run (shard rows -> per-rank statistics -> ONE sum all-reduce -> replicated assembly), with
+an oracle-backed engine standing in for the device engine.  The result must equal the
+single-process Hessian of the full data set."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+class OracleEngine(object):
+    """Host engine with the device engine's interface and stats layout
+    ([value | d f_data / d beta | tile-packed X^T diag(w loss'') X])."""
+
+    def __init__(self, model):
+        self.model = model
+
+    def partial(self, theta):
+        from lrvb_amd.distributed import pack_tiles
+        from oracle import models as om
+        m = self.model
+        th = theta.numpy()
+        eta = m.layout.constrain(th)
+        z = m.x @ eta[m.glm_off:m.glm_off + m.P]
+        l0, l1, l2 = om.loss_terms(m.loss, m.y, z, m.lik_info)
+        stats = np.concatenate([[np.sum(m.w * l0)], m.x.T @ (m.w * l1), pack_tiles(m.x.T @ ((m.w * l2)[:, None] * m.x))])
+        return torch.from_numpy(stats)
+
+    def finish(self, theta, stats):
+        from lrvb_amd.distributed import unpack_tiles
+        from oracle import packing as opk
+        m = self.model
+        th = theta.numpy()
+        st = stats.numpy()
+        P, V = m.P, m.layout.V
+        eta = m.layout.constrain(th)
+        g = np.zeros(V); g[m.glm_off:m.glm_off + P] = st[1:1 + P]
+        H = np.zeros((V, V)); H[m.glm_off:m.glm_off + P, m.glm_off:m.glm_off + P] = unpack_tiles(st[1 + P:], P)
+        if m.quad_A is not None:                     # N-independent term: added once, after the reduction
+            g += m.quad_scale * (m._A_apply(eta - m.quad_m) + m.quad_b)
+            H += m.quad_scale * m._A_dense()
+        return torch.from_numpy(opk.convert_vector_to_free_hessian(m.layout, th, g, H))
+
+
+def _make_problem():
+    from oracle import packing as opk, models as om
+    rng = np.random.default_rng(77)
+    N, P = 1003, 150                 # odd N (uneven shards), P spans two 128-column tiles
+    x = rng.normal(size=(N, P)) / np.sqrt(P)
+    y = rng.poisson(1.0, size=N).astype(np.float64)
+    w = rng.uniform(0.5, 1.5, size=N)
+    theta = rng.normal(size=P) * 0.2
+    def model(rows):
+        lay = opk.Layout([opk.box_block(100), opk.box_block(50, lb=0.0)])
+        return om.DeclaredModel(lay, loss=om.POISSON, x=x[rows], y=y[rows], w=w[rows], quad_A=np.full(P, 0.7))
+    return N, theta, model
+
+
+def _worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from lrvb_amd.distributed import ShardedHessian, shard_rows
+    N, theta, model = _make_problem()
+    r0, r1 = shard_rows(N, rank, world)
+    H = ShardedHessian(OracleEngine(model(slice(r0, r1)))).build(torch.from_numpy(theta))
+    # every rank holds the same matrix
+    gathered = [torch.empty_like(H) for _ in range(world)]
+    dist.all_gather(gathered, H)
+    if rank == 0:
+        assert all(torch.equal(gathered[0], g) for g in gathered)
+        np.save(out_path, H.numpy())
+    dist.destroy_process_group()
+
+
+def test_shard_rows_partition():
+    from lrvb_amd.distributed import shard_rows
+    for n, w in ((10, 3), (1000000, 8), (7, 8), (1003, 2)):
+        cuts = [shard_rows(n, r, w) for r in range(w)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+        sizes = [b - a for a, b in cuts]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_tile_packing_roundtrip():
+    from lrvb_amd.distributed import pack_tiles, unpack_tiles, stats_layout
+    rng = np.random.default_rng(0)
+    for P in (5, 128, 150, 300):
+        a = rng.normal(size=(P, P)); S = a + a.T
+        flat = pack_tiles(S)
+        assert flat.size == stats_layout(P)[3] - 1 - P
+        np.testing.assert_array_equal(unpack_tiles(flat, P), S)
+
+
+def test_two_rank_gloo_build_equals_single_process(tmp_path):
+    world = 2
+    port = _free_port()
+    out_path = str(tmp_path / 'H.npy')
+    mp.spawn(_worker, args=(world, port, out_path), nprocs=world, join=True)
+    H = np.load(out_path)
+    N, theta, model = _make_problem()
+    want = model(slice(0, N)).hessian(theta)
+    assert np.max(np.abs(H - want)) < 1e-11 * np.max(np.abs(want))

@@ -1,0 +1,126 @@
+"""Closed-form known answers asserted by the reference's own tests, applied to the oracle
+(no autograd needed as comparator).  Each test cites the reference test it restates."""
+import numpy as np
+import scipy.stats
+
+from oracle import packing as opk
+from oracle import models as om
+from oracle import solvers as osv
+from oracle import expfam as oef
+
+
+def test_sum_sq_scaled_objective():
+    """LRVB/test_objectives.py:161-217: f = sum(x^2) z y -> value z y |x|^2, grad 2 z y x,
+    Hessian 2 z y I, HVP 2 z y v."""
+    lay = opk.Layout([opk.box_block(2)])
+    z, y = 3.0, 2.0
+    m = om.DeclaredModel(lay, quad_A=2.0 * np.ones(2), quad_scale=z * y)
+    x = np.array([0., 1.])
+    v = np.array([2., 3.])
+    assert np.isclose(m.value(x), 1 * 2 * 3)
+    np.testing.assert_allclose(m.grad(x), 2 * x * 2 * 3)
+    np.testing.assert_allclose(m.hessian(x), 2 * np.eye(2) * 2 * 3)
+    np.testing.assert_allclose(m.hvp(x, v), 2 * v * 2 * 3)
+    np.testing.assert_allclose(m.hessian_vec(x), 2 * np.eye(2) * 2 * 3)
+
+
+def test_unconstrained_quadratic_hessian_is_matrix():
+    """LRVB/test_optimization_utils.py:10-24, 57-59: f = 1/2 x^T A x + b^T x."""
+    rng = np.random.default_rng(3)
+    dim = 4
+    a = rng.random((dim, dim)); a = 0.5 * (a + a.T) + dim * np.eye(dim)
+    b = rng.random(dim)
+    lay = opk.Layout([opk.box_block(dim)])
+    m = om.DeclaredModel(lay, quad_A=a, quad_b=b)
+    x = rng.random(dim)
+    np.testing.assert_allclose(m.hessian(x), a, atol=1e-14)
+    np.testing.assert_allclose(m.grad(-np.linalg.solve(a, b)), 0.0, atol=1e-13)
+
+
+def test_box_constrained_quadratic_hg_equals_hvp():
+    """LRVB/test_objectives.py:14-57, 108-117: Model with bounds [-2, 5], f = (x-x*)^T A (x-x*)."""
+    dim = 3
+    lay = opk.Layout([opk.box_block(dim, lb=-2.0, ub=5.0)])
+    a_mat = np.full((dim, dim), 0.1) + np.eye(dim)
+    opt_x = np.linspace(1., 2., dim)
+    m = om.DeclaredModel(lay, quad_A=2.0 * a_mat, quad_m=opt_x)
+    x_free = lay.unconstrain(np.linspace(0.1, 1., dim))
+    g = m.grad(x_free)
+    H = m.hessian(x_free)
+    np.testing.assert_allclose(H @ g, m.hvp(x_free, g), rtol=1e-12)
+    # the optimum in free coordinates is the unconstrained opt_x
+    np.testing.assert_allclose(m.grad(lay.unconstrain(opt_x)), 0.0, atol=1e-12)
+
+
+def test_quadratic_model_linear_response():
+    """LRVB/test_model_sensitivity.py:36-88, 367-424: theta_hat(eps) = -A^-1 eps, free form
+    log(theta_hat + 10); get_dinput_dhyper equals the Jacobian of that map."""
+    dim = 3
+    lay = opk.Layout([opk.box_block(dim, lb=-10.0)])
+    vec = np.linspace(0.1, 0.3, num=dim)
+    A = np.outer(vec, vec) + np.eye(dim)
+    eps0 = np.linspace(0.5, 10.0, num=dim)
+    m = om.DeclaredModel(lay, quad_A=A, quad_b=eps0)
+    theta_opt = -np.linalg.solve(A, eps0)
+    theta0 = np.log(theta_opt + 10.0)
+    np.testing.assert_allclose(m.grad(theta0), 0.0, atol=1e-12)
+    S = osv.linear_response(m.hessian(theta0), m.cross_hessian_tilt(theta0))
+    want = np.diag(1.0 / (theta_opt + 10.0)) @ (-np.linalg.inv(A))
+    np.testing.assert_allclose(S, want, rtol=1e-10)
+    e = 0.01
+    pred = S @ np.full(dim, e)
+    true = np.log(-np.linalg.solve(A, eps0 + e) + 10.0) - theta0
+    assert np.linalg.norm(true - pred) <= e * np.linalg.norm(true)
+
+
+def test_constrain_roundtrips_and_bounds_errors():
+    """LRVB/test_variational_bayes.py:282-319 and Parameters.py:15-28."""
+    rng = np.random.default_rng(0)
+    for lb, ub in ((-np.inf, np.inf), (0.5, np.inf), (-np.inf, 3.0), (-2.0, 5.0)):
+        f = rng.normal(size=7)
+        e = opk.box_constrain(f, lb, ub)[0]
+        assert np.all(e >= lb) and np.all(e <= ub)
+        np.testing.assert_allclose(opk.box_unconstrain(e, lb, ub), f, rtol=1e-12, atol=1e-12)
+    import pytest
+    with pytest.raises(ValueError):
+        opk.box_unconstrain(np.array([0.0]), 0.5, np.inf)
+    with pytest.raises(ValueError):
+        opk.box_unconstrain(np.array([4.0]), -np.inf, 3.0)
+    # psd: free -> matrix is symmetric positive definite above diag_lb; pack(unpack) = id
+    k = 4
+    f = rng.normal(size=opk.psd_size(k))
+    A = opk.psd_matrix_from_vector(opk.psd_constrain(f, k, 0.2), k)
+    assert np.all(np.linalg.eigvalsh(A - 0.2 * np.eye(k)) > 0)
+    np.testing.assert_allclose(opk.psd_unconstrain(opk.psd_constrain(f, k, 0.2), k, 0.2), f, rtol=1e-11, atol=1e-12)
+    # row-major lower-triangle index (MatrixParameters.py:16-23)
+    assert [opk.ld_index(a, b) for a in range(3) for b in range(a + 1)] == list(range(6))
+    # simplex rows sum to one, reference category 0
+    P = opk.simplex_constrain(rng.normal(size=10), 2, 6)
+    np.testing.assert_allclose(P.sum(axis=1), 1.0)
+    np.testing.assert_allclose(opk.simplex_constrain(np.zeros(5), 1, 6), 1.0 / 6)
+
+
+def test_entropies_and_moments_against_scipy_stats():
+    """LRVB/test_exponential_families.py:16-75."""
+    rng = np.random.default_rng(1)
+    info = 1.7
+    assert np.isclose(oef.univariate_normal_entropy(info), scipy.stats.norm.entropy(scale=np.sqrt(1 / info)))
+    k = 3
+    a = rng.normal(size=(k, k)); cov = a @ a.T + np.eye(k)
+    assert np.isclose(oef.multivariate_normal_entropy(np.linalg.inv(cov)),
+                      scipy.stats.multivariate_normal.entropy(cov=cov))
+    shape, rate = 3.0, 2.4
+    assert np.isclose(oef.gamma_entropy(shape, rate), scipy.stats.gamma.entropy(shape, scale=1 / rate))
+    alpha = np.array([[2.0, 1.5], [3.0, 0.7], [0.9, 4.0]])
+    want = [scipy.stats.dirichlet.entropy(alpha[:, j]) for j in range(2)]
+    np.testing.assert_allclose(oef.dirichlet_entropy(alpha), want)
+    df = 7.3
+    assert np.isclose(oef.wishart_entropy(df, cov), scipy.stats.wishart.entropy(df, cov))
+    # E log|W| by Monte Carlo (3 sigma), as test_wishart_moments does
+    draws = scipy.stats.wishart.rvs(df, cov, size=20000, random_state=5)
+    ld = np.linalg.slogdet(draws)[1]
+    assert abs(oef.e_log_det_wishart(df, cov) - ld.mean()) < 3 * ld.std() / np.sqrt(len(ld))
+    assert np.isclose(oef.get_e_log_gamma(shape, rate), scipy.special.digamma(shape) - np.log(rate))
+    np.testing.assert_allclose(oef.get_e_dirichlet(alpha).sum(axis=0), 1.0)
+    p = np.array([[0.2, 0.3, 0.5]])
+    assert np.isclose(oef.multinoulli_entropy(p)[0], scipy.stats.multinomial.entropy(1, p[0]), atol=1e-12)
