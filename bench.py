@@ -38,7 +38,7 @@ def parse():
     ap.add_argument('--n-free', type=int, default=1024)
     ap.add_argument('--loss', default='gaussian', choices=['gaussian', 'logistic', 'poisson'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample-rows', type=int, default=4096)
+    ap.add_argument('--cpu-sample-rows', type=int, default=16384)
     ap.add_argument('--n-splits', type=int, default=0)
     return ap.parse_args()
 
@@ -74,8 +74,13 @@ def cpu_baseline(x_sample, y_sample, n_total, D, n_pos, loss, lik_info, prior_in
     t0 = time.time()
     model.hessian(theta)
     t_strong = (time.time() - t0) * (n_total / ns)
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except Exception:
+        affinity = None
     return {
         'value': 1.0 / t_full, 'unit': 'hessian_builds/s', 'cores': int(threads), 'kind': 'port',
+        'cpu_affinity': affinity,
         'sample': '{} of {} rows x {} of {} HVP columns, numpy oracle (gradient + D Hessian-vector '
                   'products = the passes autograd.hessian makes), extrapolated linearly in rows and '
                   'columns'.format(ns, int(n_total), ncol, D),

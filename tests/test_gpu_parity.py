@@ -242,3 +242,78 @@ def test_errors_and_loud_failures(vb):
     assert closure_obj.fun_free(np.ones(4)) == 4.0
     with pytest.raises(NotImplementedError):
         closure_obj.fun_free_hessian(np.ones(4))
+
+
+def test_sharded_engine_single_rank_matches_direct_build(vb):
+    """The multi-GPU code path (partial statistics -> [all-reduce] -> finish) on one rank equals
+    the fused single-GPU entry point and the oracle; also pins the statistics layout."""
+    import torch
+    from lrvb_amd.distributed import ShardedHessian, DeviceEngine, unpack_tiles, stats_layout
+    rng = np.random.default_rng(21)
+    N, P = 5000, 300
+    spec = [('box', 'u', 200, -np.inf, np.inf), ('box', 'pos', 100, 0.0, np.inf)]
+    par, lay = make_par(vb, spec)
+    x, y, w = glm_data(rng, N, P, om.LOGISTIC)
+    fun = vb.GLMObjective(par, x, y, loss='logistic', prior_info=0.3, weights=w)
+    model = om.DeclaredModel(lay, loss=om.LOGISTIC, x=x, y=y, w=w, quad_A=np.full(P, 0.3))
+    theta = rng.normal(size=P) * 0.2
+    dev = torch.device('cuda', 0)
+    th = torch.tensor(theta, device=dev)
+    H = ShardedHessian(DeviceEngine(fun.ctx, dev)).build(th).cpu().numpy()
+    Hw = model.hessian(theta)
+    assert rel_err(H, Hw) < TOL
+    H2 = torch.empty((P, P), dtype=torch.float64, device=dev)
+    fun.ctx.hessian_dev(th.data_ptr(), H2.data_ptr(), P); fun.ctx.sync()
+    assert np.array_equal(H2.cpu().numpy(), H)          # same kernels, same order: bitwise equal
+    eng = DeviceEngine(fun.ctx, dev)
+    st = eng.partial(th).cpu().numpy()
+    o_val, o_g, o_t, total = stats_layout(P)
+    assert st.size == total == fun.ctx.stats_size()
+    eta = lay.constrain(theta)
+    z = x @ eta
+    l0, l1, l2 = om.loss_terms(om.LOGISTIC, y, z)
+    assert abs(st[o_val] - np.sum(w * l0)) < 1e-11 * abs(np.sum(w * l0))
+    assert rel_err(st[o_g:o_t], x.T @ (w * l1)) < TOL
+    assert rel_err(unpack_tiles(st[o_t:], P), x.T @ ((w * l2)[:, None] * x)) < TOL
+
+
+def test_full_size_properties_headline_shape(vb):
+    """Size-independent properties at the BASELINE.json shape (D = 1024) with N reduced to what the
+    oracle-free checks need: symmetry, linearity in the weights, H v == HVP, G^T G PSD, and the
+    registered-staged (generic) kernel agreeing with the LDS-DMA kernel."""
+    import torch
+    rng = np.random.default_rng(31)
+    N, P = 200000, 1024
+    dev = torch.device('cuda', 0)
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    X = torch.randn((N, P), dtype=torch.float64, device=dev, generator=g) / P ** 0.5
+    yv = torch.randn((N,), dtype=torch.float64, device=dev, generator=g)
+    w1 = torch.rand((N,), dtype=torch.float64, device=dev, generator=g) + 0.5
+    w2 = torch.rand((N,), dtype=torch.float64, device=dev, generator=g) + 0.5
+    blocks = [dict(kind=0, free_size=P, vec_size=P, dim0=P, dim1=0, lb=-np.inf, ub=np.inf)]
+    ctx = vb.DeviceContext(blocks, loss='gaussian', n_obs=N, n_cols=P, lik_info=1.5, quad_kind=0)
+    ctx.set_data_dev(0, X.data_ptr(), N, P); ctx.set_data_dev(1, yv.data_ptr(), N, 1)
+    theta = torch.zeros((P,), dtype=torch.float64, device=dev)
+    def build(wt):
+        H = torch.empty((P, P), dtype=torch.float64, device=dev)
+        ctx.set_weights_dev(wt.data_ptr(), N)
+        ctx.hessian_dev(theta.data_ptr(), H.data_ptr(), P); ctx.sync()
+        return H
+    H1, H2, H12 = build(w1), build(w2), build(w1 + w2)
+    scale = H12.abs().max().item()
+    assert torch.equal(H1, H1.T)
+    assert (H1 + H2 - H12).abs().max().item() < 1e-12 * scale            # linear in the weights
+    ref = 1.5 * (X[:, :96].T * w1) @ X[:, 900:1024]                        # an off-diagonal block, torch fp64
+    assert (H1[:96, 900:1024] - ref).abs().max().item() < 1e-12 * scale
+    v = torch.randn((P,), dtype=torch.float64, device=dev, generator=g)
+    out = torch.empty_like(v)
+    ctx.set_weights_dev(w1.data_ptr(), N)
+    ctx.hvp_dev(theta.data_ptr(), v.data_ptr(), out.data_ptr()); ctx.sync()
+    assert (out - H1 @ v).abs().max().item() < 1e-11 * (H1 @ v).abs().max().item()
+    ctx.set_tuning(0, 1)                                                  # force the register-staged kernel
+    Hg = build(w1)
+    ctx.set_tuning(0, 0)
+    assert (Hg - H1).abs().max().item() < 1e-12 * scale
+    G = torch.empty((P, P), dtype=torch.float64, device=dev)
+    ctx.gram_dev(theta.data_ptr(), G.data_ptr(), P); ctx.sync()
+    assert torch.equal(G, G.T) and torch.linalg.eigvalsh(G).min().item() > -1e-9 * G.abs().max().item()
