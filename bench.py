@@ -101,8 +101,13 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
+    # LRVB_BENCH_FORCE_SHARDED=1 runs the multi-GPU code path (process group, stats all-reduce,
+    # finish) even with one rank -- used to rehearse the N > 1 path on a one-GPU box
+    force_sharded = os.environ.get('LRVB_BENCH_FORCE_SHARDED', '0') == '1'
+    use_dist = world > 1 or force_sharded
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29531')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', rank=rank, world_size=world)
     if args.gpus != world and rank == 0:
@@ -160,11 +165,11 @@ def main():
         ctx.set_tuning(args.n_splits)
 
     H = torch.empty((D, D), dtype=torch.float64, device=dev)
-    engine = DeviceEngine(ctx, dev) if world > 1 else None
-    sharded = ShardedHessian(engine) if world > 1 else None
+    engine = DeviceEngine(ctx, dev) if use_dist else None
+    sharded = ShardedHessian(engine) if use_dist else None
 
     def step():
-        if world == 1:
+        if not use_dist:
             ctx.hessian_dev(theta.data_ptr(), H.data_ptr(), D)
             return H
         return sharded.build(theta)
@@ -172,7 +177,7 @@ def main():
     def fence():
         ctx.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -190,7 +195,7 @@ def main():
     ctx.profile_enable(False)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
@@ -251,7 +256,7 @@ def main():
             # parity of the timed result on the sample's leading block (cheap sanity, not the test suite)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

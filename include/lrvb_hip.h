@@ -115,6 +115,12 @@ int         lrvb_device_count(int* out);
 int lrvb_ctx_create (lrvb_ctx** out, int device_id, const lrvb_model_desc* model);
 int lrvb_ctx_destroy(lrvb_ctx* ctx);
 int lrvb_ctx_sync   (lrvb_ctx* ctx);                 /* hipStreamSynchronize on the ctx stream */
+/* use_caller_stream != 0: run the context on the caller-owned HIP stream `hip_stream` (e.g.
+ * torch's current stream -- whose handle is NULL for the legacy default stream -- so that
+ * kernels, RCCL collectives and the caller's own work are ordered without host
+ * synchronisation).  use_caller_stream == 0: back to a private non-blocking stream.  The
+ * previous stream is drained first.                                                         */
+int lrvb_ctx_set_stream(lrvb_ctx* ctx, void* hip_stream, int use_caller_stream);
 int lrvb_ctx_sizes  (lrvb_ctx* ctx, int64_t* D, int64_t* V, int64_t* n_obs);
 
 /* Observations / constants: uploaded once, resident in HBM afterwards.  rows/cols must

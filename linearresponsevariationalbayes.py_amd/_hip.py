@@ -52,6 +52,7 @@ _SIGNATURES = {
     'lrvb_ctx_create': [ctypes.POINTER(_VP), ctypes.c_int, ctypes.POINTER(ModelDesc)],
     'lrvb_ctx_destroy': [_VP],
     'lrvb_ctx_sync': [_VP],
+    'lrvb_ctx_set_stream': [_VP, _VP, ctypes.c_int],
     'lrvb_ctx_sizes': [_VP, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)],
     'lrvb_set_data': [_VP, ctypes.c_int, _VP, c_i64, c_i64],
     'lrvb_set_data_dev': [_VP, ctypes.c_int, _VP, c_i64, c_i64],
@@ -103,6 +104,15 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.  If this library
+    # (linked against the system ROCm) initialises HIP first and torch is imported afterwards, the
+    # two copies can disagree ("No HIP GPUs are available" in torch).  Importing torch first makes
+    # the dynamic linker resolve libamdhip64.so.7 once for both.  LRVB_NO_TORCH_PRELOAD=1 skips it.
+    if os.environ.get('LRVB_NO_TORCH_PRELOAD', '0') != '1':
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     if not os.path.exists(LIB_PATH):
         raise OSError(
             'liblrvb_hip.so not found at {}: build it with `python -c "import __graft_entry__ as g; '

@@ -172,7 +172,7 @@ extern "C" int lrvb_ctx_destroy(lrvb_ctx* c) {
     for (DevBuf* b : all) buf_free(*b);
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
     for (int k = 0; k < 3; ++k) for (hipEvent_t e : c->ev_pool[k]) (void)hipEventDestroy(e);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream && c->stream_owned) (void)hipStreamDestroy(c->stream);
     delete c;
     return LRVB_OK;
 }
@@ -180,6 +180,20 @@ extern "C" int lrvb_ctx_destroy(lrvb_ctx* c) {
 extern "C" int lrvb_ctx_sync(lrvb_ctx* c) {
     LRVB_TRY(ctx_bind(c));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return LRVB_OK;
+}
+
+extern "C" int lrvb_ctx_set_stream(lrvb_ctx* c, void* hip_stream, int use_caller_stream) {
+    LRVB_TRY(ctx_bind(c));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->stream && c->stream_owned) HIP_TRY(hipStreamDestroy(c->stream));
+    if (!use_caller_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->stream_owned = true;
+    } else {
+        c->stream = reinterpret_cast<hipStream_t>(hip_stream);
+        c->stream_owned = false;
+    }
     return LRVB_OK;
 }
 

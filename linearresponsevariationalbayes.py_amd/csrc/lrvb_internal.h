@@ -32,6 +32,7 @@ struct DevBuf {
 struct lrvb_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    bool stream_owned = true;
 
     // layout
     std::vector<lrvb_block_desc> blocks;

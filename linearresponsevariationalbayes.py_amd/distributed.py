@@ -36,19 +36,17 @@ class DeviceEngine(object):
         self.device = torch_device
         self.stats = torch.empty(ctx.stats_size(), dtype=torch.float64, device=torch_device)
         self.H = torch.empty((ctx.D, ctx.D), dtype=torch.float64, device=torch_device)
+        # The context runs on torch's current stream: the kernels, the RCCL all-reduce (which
+        # orders itself after the current stream) and the assembly are stream-ordered, with no
+        # host synchronisation between them.
+        ctx.set_stream(torch.cuda.current_stream(torch_device).cuda_stream)
 
     def partial(self, theta):
-        # theta: float64 tensor on self.device.  The context runs on its own stream: make the
-        # producer of theta visible first, and wait for the kernels before the collective.
-        self.torch.cuda.current_stream(self.device).synchronize()
         self.ctx.hessian_partial_dev(theta.data_ptr(), self.stats.data_ptr())
-        self.ctx.sync()
         return self.stats
 
     def finish(self, theta, stats):
-        self.torch.cuda.current_stream(self.device).synchronize()
         self.ctx.hessian_finish_dev(theta.data_ptr(), stats.data_ptr(), self.H.data_ptr(), self.ctx.D)
-        self.ctx.sync()
         return self.H
 
 
@@ -68,7 +66,7 @@ class ShardedHessian(object):
     def build(self, theta):
         dist, world = self._world()
         stats = self.engine.partial(theta)
-        if world > 1:
+        if dist is not None:            # also with one rank: keeps the collective path exercised
             dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=self.group)
         return self.engine.finish(theta, stats)
 

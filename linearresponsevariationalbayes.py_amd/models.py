@@ -92,6 +92,14 @@ class DeviceContext(object):
     def sync(self):
         _hip.check(self._lib.lrvb_ctx_sync(self._h))
 
+    def set_stream(self, hip_stream_handle):
+        """Run on a caller-owned HIP stream (an integer handle such as
+        torch.cuda.current_stream().cuda_stream); None restores a private stream."""
+        if hip_stream_handle is None:
+            _hip.check(self._lib.lrvb_ctx_set_stream(self._h, None, 0))
+        else:       # 0 is a valid handle: the legacy default stream
+            _hip.check(self._lib.lrvb_ctx_set_stream(self._h, ctypes.c_void_p(int(hip_stream_handle)), 1))
+
     # -- packing ------------------------------------------------------------------------
     def constrain(self, free):
         f = _hip.as_f64(free).ravel()

@@ -267,6 +267,7 @@ def test_sharded_engine_single_rank_matches_direct_build(vb):
     assert np.array_equal(H2.cpu().numpy(), H)          # same kernels, same order: bitwise equal
     eng = DeviceEngine(fun.ctx, dev)
     st = eng.partial(th).cpu().numpy()
+    fun.ctx.set_stream(None)
     o_val, o_g, o_t, total = stats_layout(P)
     assert st.size == total == fun.ctx.stats_size()
     eta = lay.constrain(theta)
