@@ -22,6 +22,8 @@ void gemm_f64_kernel(int transA, int transB, i64 M, i64 N, i64 K, double alpha,
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wr = wave >> 1, wc = wave & 1;
     const i64 m0 = (i64)blockIdx.y * GM_TILE, n0 = (i64)blockIdx.x * GM_TILE;
+    if ((transB & 2) && blockIdx.x > blockIdx.y) return;      // lower tiles only
+    transB &= 1;
 
     d4 acc[2][2];
 #pragma unroll
@@ -79,6 +81,17 @@ void gemm_f64_kernel(int transA, int transB, i64 M, i64 N, i64 K, double alpha,
             }
 }
 
+// C (M x M, lower 64 x 64 tiles only) = alpha * A A^T + beta * C, A is M x K row-major
+int launch_gemm_lower(lrvb_ctx* c, i64 M, i64 K, double alpha, const double* A, i64 lda,
+                      double beta, double* C, i64 ldc) {
+    if (M <= 0) return LRVB_OK;
+    const unsigned t = (unsigned)((M + GM_TILE - 1) / GM_TILE);
+    hipLaunchKernelGGL(gemm_f64_kernel, dim3(t, t), dim3(256), 0, c->stream, 0, 1 | 2,
+                       M, M, K, alpha, A, lda, A, lda, beta, C, ldc);
+    HIP_TRY(hipGetLastError());
+    return LRVB_OK;
+}
+
 int launch_gemm(lrvb_ctx* c, bool transA, bool transB, i64 M, i64 Nn, i64 K, double alpha,
                 const double* A, i64 lda, const double* B, i64 ldb, double beta, double* C, i64 ldc) {
     if (M <= 0 || Nn <= 0) return LRVB_OK;
@@ -90,128 +103,101 @@ int launch_gemm(lrvb_ctx* c, bool transA, bool transB, i64 M, i64 Nn, i64 K, dou
 }
 
 // ---- Cholesky ------------------------------------------------------------------------
+// Right-looking blocked factorisation, block size 64:
+//   (1) one wavefront factors the 64 x 64 diagonal block held in registers (lane i = row i,
+//       broadcasts by v_readlane) and also forms W = L_jj^-1 (lane c = column c of W);
+//   (2) panel  P <- P W^T           (MFMA GEMM, in place: one 64-column tile per row tile);
+//   (3) trailing A22 -= P P^T       (MFMA GEMM, lower tiles only).
+// The solves use the stored W blocks: X_j = W_j B_j / W_j^T B_j are GEMMs too.
 constexpr int CH_NB = 64;
 
-// factor the nb x nb diagonal block at A (lower, in place); one workgroup of 64 threads
-__global__ __launch_bounds__(64)
-void potrf_diag_kernel(double* __restrict__ A, i64 lda, int nb, int* __restrict__ info, int col0)
-{
-    __shared__ double L[CH_NB][CH_NB + 1];
-    const int t = threadIdx.x;
-    for (int i = 0; i < nb; ++i) if (t < nb) L[i][t] = (t <= i) ? A[(i64)i * lda + t] : 0.0;
-    __syncthreads();
-    for (int j = 0; j < nb; ++j) {
-        if (t == 0) {
-            double d = L[j][j];
-            for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
-            if (!(d > 0.0)) { if (*info == 0) *info = col0 + j + 1; d = NAN; }
-            L[j][j] = sqrt(d);
-        }
-        __syncthreads();
-        if (t > j && t < nb) {
-            double s = L[t][j];
-            for (int k = 0; k < j; ++k) s -= L[t][k] * L[j][k];
-            L[t][j] = s / L[j][j];
-        }
-        __syncthreads();
-    }
-    for (int i = 0; i < nb; ++i) if (t < nb && t <= i) A[(i64)i * lda + t] = L[i][t];
+__device__ __forceinline__ double lane_bcast(double v, int src_lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
 }
 
-// rows below the diagonal block: P <- P * Ljj^{-T}  (one thread per row)
-__global__ __launch_bounds__(256)
-void trsm_panel_kernel(const double* __restrict__ Ljj, double* __restrict__ P, i64 lda, int nb, i64 rows)
+__global__ __launch_bounds__(64)
+void potrf_inv_diag_kernel(double* __restrict__ A, i64 lda, int nb, double* __restrict__ W /* 64 x 64 */,
+                           int* __restrict__ info, int col0)
 {
-    __shared__ double L[CH_NB][CH_NB + 1];
-    for (int e = threadIdx.x; e < nb * nb; e += blockDim.x) {
-        const int i = e / nb, j = e % nb;
-        L[i][j] = (j <= i) ? Ljj[(i64)i * lda + j] : 0.0;
+    const int lane = threadIdx.x;
+    double a[CH_NB];
+    // rows/columns past nb are padded with the identity, so partial blocks need no special code
+#pragma unroll
+    for (int k = 0; k < CH_NB; ++k)
+        a[k] = (lane < nb && k < nb) ? ((k <= lane) ? A[(i64)lane * lda + k] : 0.0) : ((k == lane) ? 1.0 : 0.0);
+    // symmetric fill of the upper part is not needed: the update below only ever reads a[j] of
+    // lanes >= j and a[k] (k > j) of lanes >= k
+    int bad = 0;
+#pragma unroll
+    for (int j = 0; j < CH_NB; ++j) {
+        const double d = lane_bcast(a[j], j);
+        if (!(d > 0.0) && bad == 0) bad = j + 1;
+        const double r = 1.0 / sqrt(d);
+        a[j] = a[j] * r;                         // lane j now holds sqrt(d); lanes > j hold L[i][j]
+#pragma unroll
+        for (int k = j + 1; k < CH_NB; ++k)
+            a[k] -= a[j] * lane_bcast(a[j], k);  // A[i][k] -= L[i][j] L[k][j]
     }
-    __syncthreads();
-    const i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows) return;
-    double* row = P + r * lda;
-    double x[CH_NB];
-#pragma unroll 4
-    for (int j = 0; j < nb; ++j) {
-        double s = row[j];
-        for (int k = 0; k < j; ++k) s -= x[k] * L[j][k];
-        x[j] = s / L[j][j];
+    if (lane == 0 && bad != 0 && *info == 0) *info = col0 + bad;
+    // store L (lower part of the real block)
+#pragma unroll
+    for (int k = 0; k < CH_NB; ++k)
+        if (lane < nb && k <= lane) A[(i64)lane * lda + k] = a[k];
+    // W = L^-1: lane c solves L w = e_c by forward substitution; L[i][k] is a[k] of lane i
+    double w[CH_NB];
+#pragma unroll
+    for (int i = 0; i < CH_NB; ++i) {
+        double s = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= lane_bcast(a[k], i) * w[k];
+        w[i] = s / lane_bcast(a[i], i);
     }
-    for (int j = 0; j < nb; ++j) row[j] = x[j];
+#pragma unroll
+    for (int i = 0; i < CH_NB; ++i) W[i * CH_NB + lane] = w[i];    // W[i][c], coalesced over c
 }
 
 int launch_potrf_lower(lrvb_ctx* c, double* A, i64 n, i64 lda, int* info_dev) {
     HIP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int), c->stream));
-    for (i64 j0 = 0; j0 < n; j0 += CH_NB) {
+    const i64 nblk = (n + CH_NB - 1) / CH_NB;
+    LRVB_TRY(buf_reserve(c, c->cholW, (size_t)(nblk * CH_NB * CH_NB)));
+    for (i64 j0 = 0, jb = 0; j0 < n; j0 += CH_NB, ++jb) {
         const int nb = (int)((n - j0 < CH_NB) ? (n - j0) : CH_NB);
         double* Ajj = A + j0 * lda + j0;
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(64), 0, c->stream, Ajj, lda, nb, info_dev, (int)j0);
+        double* Wj = c->cholW.p + jb * CH_NB * CH_NB;
+        hipLaunchKernelGGL(potrf_inv_diag_kernel, dim3(1), dim3(64), 0, c->stream, Ajj, lda, nb, Wj, info_dev, (int)j0);
         HIP_TRY(hipGetLastError());
         const i64 rows = n - j0 - nb;
         if (rows > 0) {
             double* Pn = A + (j0 + nb) * lda + j0;
-            hipLaunchKernelGGL(trsm_panel_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, c->stream,
-                               Ajj, Pn, lda, nb, rows);
-            HIP_TRY(hipGetLastError());
-            // trailing update A22 -= P P^T (full square; only the lower part is read later)
+            // P <- P W^T (in place: each workgroup reads and writes only its own 64 rows)
+            LRVB_TRY(launch_gemm(c, false, true, rows, nb, nb, 1.0, Pn, lda, Wj, CH_NB, 0.0, Pn, lda));
+            // trailing update A22 -= P P^T, lower tiles only
             double* A22 = A + (j0 + nb) * lda + (j0 + nb);
-            LRVB_TRY(launch_gemm(c, false, true, rows, rows, nb, -1.0, Pn, lda, Pn, lda, 1.0, A22, lda));
+            LRVB_TRY(launch_gemm_lower(c, rows, nb, -1.0, Pn, lda, 1.0, A22, lda));
         }
     }
     return LRVB_OK;
 }
 
-// X_j <- Ljj^{-1} B_j (forward) or Ljj^{-T} B_j (backward); one thread per right-hand side
-__global__ __launch_bounds__(256)
-void trsv_block_kernel(const double* __restrict__ Ljj, i64 ldl, int nb, double* __restrict__ Bj, i64 ldb,
-                       i64 nrhs, int backward)
-{
-    __shared__ double L[CH_NB][CH_NB + 1];
-    for (int e = threadIdx.x; e < nb * nb; e += blockDim.x) {
-        const int i = e / nb, j = e % nb;
-        L[i][j] = (j <= i) ? Ljj[(i64)i * ldl + j] : 0.0;
-    }
-    __syncthreads();
-    const i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nrhs) return;
-    double x[CH_NB];
-    if (!backward) {
-        for (int i = 0; i < nb; ++i) {
-            double s = Bj[(i64)i * ldb + q];
-            for (int k = 0; k < i; ++k) s -= L[i][k] * x[k];
-            x[i] = s / L[i][i];
-        }
-    } else {
-        for (int i = nb - 1; i >= 0; --i) {
-            double s = Bj[(i64)i * ldb + q];
-            for (int k = i + 1; k < nb; ++k) s -= L[k][i] * x[k];
-            x[i] = s / L[i][i];
-        }
-    }
-    for (int i = 0; i < nb; ++i) Bj[(i64)i * ldb + q] = x[i];
-}
-
 int launch_potrs_lower(lrvb_ctx* c, const double* L, i64 n, i64 ldl, double* B, i64 nrhs, i64 ldb) {
-    const unsigned gq = (unsigned)((nrhs + 255) / 256);
     // forward: L Y = B
-    for (i64 j0 = 0; j0 < n; j0 += CH_NB) {
+    for (i64 j0 = 0, jb = 0; j0 < n; j0 += CH_NB, ++jb) {
         const int nb = (int)((n - j0 < CH_NB) ? (n - j0) : CH_NB);
-        hipLaunchKernelGGL(trsv_block_kernel, dim3(gq), dim3(256), 0, c->stream,
-                           L + j0 * ldl + j0, ldl, nb, B + j0 * ldb, ldb, nrhs, 0);
-        HIP_TRY(hipGetLastError());
+        const double* Wj = c->cholW.p + jb * CH_NB * CH_NB;
+        LRVB_TRY(launch_gemm(c, false, false, nb, nrhs, nb, 1.0, Wj, CH_NB, B + j0 * ldb, ldb, 0.0, B + j0 * ldb, ldb));
         const i64 rows = n - j0 - nb;
         if (rows > 0)
             LRVB_TRY(launch_gemm(c, false, false, rows, nrhs, nb, -1.0, L + (j0 + nb) * ldl + j0, ldl,
                                  B + j0 * ldb, ldb, 1.0, B + (j0 + nb) * ldb, ldb));
     }
     // backward: L^T X = Y
-    i64 last = ((n - 1) / CH_NB) * CH_NB;
-    for (i64 j0 = last; j0 >= 0; j0 -= CH_NB) {
+    const i64 last = ((n - 1) / CH_NB) * CH_NB;
+    for (i64 j0 = last, jb = last / CH_NB; j0 >= 0; j0 -= CH_NB, --jb) {
         const int nb = (int)((n - j0 < CH_NB) ? (n - j0) : CH_NB);
-        hipLaunchKernelGGL(trsv_block_kernel, dim3(gq), dim3(256), 0, c->stream,
-                           L + j0 * ldl + j0, ldl, nb, B + j0 * ldb, ldb, nrhs, 1);
-        HIP_TRY(hipGetLastError());
+        const double* Wj = c->cholW.p + jb * CH_NB * CH_NB;
+        LRVB_TRY(launch_gemm(c, true, false, nb, nrhs, nb, 1.0, Wj, CH_NB, B + j0 * ldb, ldb, 0.0, B + j0 * ldb, ldb));
         if (j0 > 0)
             LRVB_TRY(launch_gemm(c, true, false, j0, nrhs, nb, -1.0, L + j0 * ldl, ldl,
                                  B + j0 * ldb, ldb, 1.0, B, ldb));

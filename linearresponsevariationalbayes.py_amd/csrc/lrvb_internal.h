@@ -58,7 +58,7 @@ struct lrvb_ctx {
     DevBuf stats;                  // [value | g_glm (P) | S tiles]
     DevBuf tile_part;              // weighted-SYRK split partials
     DevBuf Heta, Hfree, Jdense, Tdense, work1;   // dense V x V / D x D scratch
-    DevBuf chol;                   // D x D Cholesky factor (lower)
+    DevBuf chol, cholW;            // D x D Cholesky factor (lower); inverses of its 64 x 64 diagonal blocks
     bool chol_valid = false;
     i64 chol_n = 0;
     DevBuf rhs, cgx, cgr, cgp, cgq, cgz, scal;
@@ -109,6 +109,8 @@ int  launch_tiles_to_dense(lrvb_ctx* c, const double* tiles_dev, i64 P, double* 
 // k_linalg.hip
 int launch_gemm(lrvb_ctx* c, bool transA, bool transB, i64 M, i64 Nn, i64 K, double alpha,
                 const double* A, i64 lda, const double* B, i64 ldb, double beta, double* C, i64 ldc);
+int launch_gemm_lower(lrvb_ctx* c, i64 M, i64 K, double alpha, const double* A, i64 lda,
+                      double beta, double* C, i64 ldc);
 int launch_potrf_lower(lrvb_ctx* c, double* A, i64 n, i64 lda, int* info_dev);
 int launch_potrs_lower(lrvb_ctx* c, const double* L, i64 n, i64 ldl, double* B, i64 nrhs, i64 ldb);
 int launch_dot(lrvb_ctx* c, const double* a, const double* b, i64 n, double* out_dev);
