@@ -44,7 +44,7 @@ __device__ __forceinline__ void loss_eval(int loss, double lik_info, double y, d
 }
 
 template <int NIT, int MODE>
-__global__ __launch_bounds__(PASS_THREADS)
+__global__ __launch_bounds__(PASS_THREADS)      // (PASS_THREADS, 2) spills at NIT = 8: 3.1 ms instead of 1.6
 void glm_pass_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
                      const double* __restrict__ y, const double* __restrict__ w,
                      const double* __restrict__ beta, const double* __restrict__ u,
@@ -53,12 +53,15 @@ void glm_pass_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
                      double* __restrict__ part_vec, double* __restrict__ part_val,
                      int vec_ok_i, int store_obs)
 {
+    // rows per stage: two, except in the mode that needs both coefficient vectors in registers
+    constexpr int R = (MODE == PASS_HVP) ? 1 : 2;
     __shared__ double red[3][NIT * 128];
     __shared__ double redv[4];
     const bool vec_ok = vec_ok_i != 0;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 
     double bt[NIT][2], ut[NIT][2], acc[NIT][2];
+    int colc[NIT];                                  // clamped column of this lane's pair (always readable)
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int col = it * 128 + 2 * lane;
@@ -67,65 +70,85 @@ void glm_pass_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
         ut[it][0] = (MODE != PASS_GRAD && col < P) ? u[col] : 0.0;
         ut[it][1] = (MODE != PASS_GRAD && col + 1 < P) ? u[col + 1] : 0.0;
         acc[it][0] = 0.0; acc[it][1] = 0.0;
+        colc[it] = vec_ok ? (col < P ? col : 0) : col;
     }
     double val = 0.0;
 
-    const i64 wave_global = (i64)blockIdx.x * 4 + wave;
-    const i64 wave_stride = (i64)gridDim.x * 4;
-    // two rows per iteration: rows 2*k and 2*k+1 of this wave's strided sequence
-    for (i64 base = wave_global * 2; base < N; base += wave_stride * 2) {
-        double xr[2][NIT][2];
-        const bool has1 = (base + 1 < N);
+    // Branch-free raw loads from clamped addresses (rows past N re-read row N-1 and get a zero
+    // coefficient; columns past P meet zero entries of beta / u and are never written back), so
+    // every load of a stage is in flight before anything waits.
+    auto load_stage = [&](double (&x)[R][NIT][2], i64 base) {
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const i64 n = base + rr;
-            const bool ok = (rr == 0) || has1;
-            const double* rowp = X + (ok ? n : base) * ldx;
+        for (int rr = 0; rr < R; ++rr) {
+            i64 n = base + rr; if (n > N - 1) n = N - 1;
+            const double* rowp = X + n * ldx;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                const int col = it * 128 + 2 * lane;
-                double v0 = 0.0, v1 = 0.0;
-                if (ok) {
-                    if (col + 1 < P) {
-                        if (vec_ok) { const double2 tv = *reinterpret_cast<const double2*>(rowp + col); v0 = tv.x; v1 = tv.y; }
-                        else { v0 = rowp[col]; v1 = rowp[col + 1]; }
-                    } else if (col < P) { v0 = rowp[col]; }
+                if (vec_ok) {
+                    const double2 tv = *reinterpret_cast<const double2*>(rowp + colc[it]);
+                    x[rr][it][0] = tv.x; x[rr][it][1] = tv.y;
+                } else {
+                    const int c0 = colc[it] < P ? colc[it] : 0, c1 = colc[it] + 1 < P ? colc[it] + 1 : 0;
+                    x[rr][it][0] = rowp[c0]; x[rr][it][1] = rowp[c1];
                 }
-                xr[rr][it][0] = v0; xr[rr][it][1] = v1;
             }
         }
+    };
+    auto consume = [&](double (&x)[R][NIT][2], i64 base) {
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            if (rr == 1 && !has1) break;
+        for (int rr = 0; rr < R; ++rr) {
             const i64 n = base + rr;
+            const bool live = n < N;
+            const i64 ne = live ? n : N - 1;
             double z = 0.0, tt = 0.0;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                if (MODE != PASS_HVP_C) z += xr[rr][it][0] * bt[it][0] + xr[rr][it][1] * bt[it][1];
-                if (MODE != PASS_GRAD)  tt += xr[rr][it][0] * ut[it][0] + xr[rr][it][1] * ut[it][1];
+                if (MODE != PASS_HVP_C) z += x[rr][it][0] * bt[it][0] + x[rr][it][1] * bt[it][1];
+                if (MODE != PASS_GRAD)  tt += x[rr][it][0] * ut[it][0] + x[rr][it][1] * ut[it][1];
             }
             if (MODE != PASS_HVP_C) z = wave_sum(z);
             if (MODE != PASS_GRAD)  tt = wave_sum(tt);
             double coef;
             if (MODE == PASS_HVP_C) {
-                coef = cw_io[n] * tt;
+                coef = cw_io[ne] * tt;
             } else {
                 double l0, l1, l2;
-                loss_eval(loss, lik_info, y[n], z, l0, l1, l2);
-                const double wn = w[n];
+                loss_eval(loss, lik_info, y[ne], z, l0, l1, l2);
+                const double wn = w[ne];
                 if (MODE == PASS_GRAD) {
                     coef = wn * l1;
-                    val += wn * l0;
-                    if (store_obs && lane == 0) { lp_out[n] = l1; cw_io[n] = wn * l2; }
+                    if (live) val += wn * l0;
+                    if (store_obs && live && lane == 0) { lp_out[n] = l1; cw_io[n] = wn * l2; }
                 } else {
                     coef = wn * l2 * tt;
                 }
             }
+            if (!live) coef = 0.0;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                acc[it][0] += coef * xr[rr][it][0];
-                acc[it][1] += coef * xr[rr][it][1];
+                acc[it][0] += coef * x[rr][it][0];
+                acc[it][1] += coef * x[rr][it][1];
             }
+        }
+    };
+
+    // software pipeline: the loads of stage k+1 are issued before stage k is consumed (explicit
+    // ping-pong between two statically named register sets)
+    const i64 step = (i64)gridDim.x * 4 * R;
+    i64 base = ((i64)blockIdx.x * 4 + wave) * R;
+    if (base < N) {
+        double xa[R][NIT][2], xb[R][NIT][2];
+        load_stage(xa, base);
+        for (;;) {
+            i64 nxt = base + step;
+            if (nxt < N) load_stage(xb, nxt);
+            consume(xa, base);
+            if (nxt >= N) break;
+            base = nxt; nxt = base + step;
+            if (nxt < N) load_stage(xa, nxt);
+            consume(xb, base);
+            if (nxt >= N) break;
+            base = nxt;
         }
     }
 
@@ -226,7 +249,8 @@ int launch_glm_pass(lrvb_ctx* c, PassMode mode, const double* beta_dev, const do
     if (c->P > PASS_MAX_COLS)
         LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "fused pass supports n_cols <= %d (got %lld)", PASS_MAX_COLS, (long long)c->P);
     // 8 blocks per CU worth of row pairs, capped by the work available
-    i64 pairs = (c->N + 1) / 2;
+    const i64 rows_per_stage = (mode == PASS_HVP) ? 1 : 2;
+    i64 pairs = (c->N + rows_per_stage - 1) / rows_per_stage;
     i64 grid = (pairs + 3) / 4;
     if (grid > 2048) grid = 2048;
     if (grid < 1) grid = 1;
