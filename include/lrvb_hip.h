@@ -80,6 +80,12 @@ typedef struct lrvb_block_desc {
 #define LRVB_LOSS_GAUSSIAN  1  /* loss = 1/2 * lik_info * (y - z)^2                         */
 #define LRVB_LOSS_LOGISTIC  2  /* loss = log(1 + e^z) - y z                                  */
 #define LRVB_LOSS_POISSON   3  /* loss = e^z - y z                                           */
+#define LRVB_LOSS_DATA_ONLY 4  /* no GLM term: the context only holds the weighted data matrix Z
+                                  (slot X, n_obs x n_cols) for objectives that are QUADRATIC IN
+                                  THE DATA, f = 1/2 tr(Q(eta) Z^T diag(w) Z) + W c(eta) + R(eta)
+                                  (Example.ipynb:247-274 and the conjugate-normal configs): the
+                                  O(N) work is lrvb_weighted_gram / lrvb_obs_quadform, the
+                                  N-independent closed forms stay with the caller.              */
 
 #define LRVB_QUAD_NONE      0
 #define LRVB_QUAD_DIAG      1  /* A = diag(a), a has length V                                */
@@ -183,6 +189,18 @@ int lrvb_cross_hessian_tilt(lrvb_ctx* ctx, const double* free_in, int64_t D, dou
 /* Gram matrix G^T G (D x D) of the per-observation gradient matrix; G is generated on chip
  * and never materialised.                                                                   */
 int lrvb_gram(lrvb_ctx* ctx, const double* free_in, int64_t D, double* GtG_out, int64_t ld);
+
+/* ---- objectives that are quadratic in the data ------------------------------------------
+ * S = Z^T diag(w) Z (n_cols x n_cols, both triangles) with the context's current weights: the
+ * weighted sufficient statistics sum_n w_n z_n z_n^T that `np.einsum('ni,ij,nj,n', ...)` at
+ * Example.ipynb:262 and LRVB/regression_utils.py:59-88 contract on the host.                  */
+int lrvb_weighted_gram(lrvb_ctx* ctx, double* S_out, int64_t ld);
+/* out[n - n0, k] = 1/2 z_n^T M_k z_n + c_k for K symmetric matrices M_k (K x n_cols x n_cols)
+ * and offsets c (K): rows of the cross Hessian d2 f / d w_n d eta_k of such an objective
+ * (TwoParameterObjective.fun_vector_hessian21 with par2 = weights,
+ * LRVB/SparseObjectives.py:418-427; Example.ipynb:425-441).                                   */
+int lrvb_obs_quadform(lrvb_ctx* ctx, const double* M, const double* c, int64_t K,
+                      int64_t n0, int64_t n1, double* out);
 
 /* ---- linear-response solve ------------------------------------------------------------ */
 /* scipy.linalg.cho_factor at LRVB/ModelSensitivity.py:594 / SparseObjectives.py:539.

@@ -24,6 +24,7 @@ from .objectives import (Objective, TwoParameterObjective, ParameterConverter, P
 from .sensitivity import ParametricSensitivityLinearApproximation
 from .cg import ConjugateGradientSolver
 from .models import (DeviceContext, DeviceObjective, GLMObjective, QuadraticObjective, LinearMoments)
+from .quadform import QuadraticDataObjective, NormalRegressionObjective
 
 # reference-style module aliases
 from . import packing as Parameters

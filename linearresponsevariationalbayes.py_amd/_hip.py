@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, 'liblrvb_hip.so')
 
 OK, ERR_INVALID, ERR_SIZE, ERR_HIP, ERR_STATE, ERR_NOT_POSDEF, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 BLOCK_BOX, BLOCK_PSD, BLOCK_SIMPLEX = 0, 1, 2
-LOSS_NONE, LOSS_GAUSSIAN, LOSS_LOGISTIC, LOSS_POISSON = 0, 1, 2, 3
+LOSS_NONE, LOSS_GAUSSIAN, LOSS_LOGISTIC, LOSS_POISSON, LOSS_DATA_ONLY = 0, 1, 2, 3, 4
 QUAD_NONE, QUAD_DIAG, QUAD_DENSE = 0, 1, 2
 SLOT_X, SLOT_Y, SLOT_QUAD_A, SLOT_QUAD_M, SLOT_QUAD_B = 0, 1, 2, 3, 4
 
@@ -75,6 +75,8 @@ _SIGNATURES = {
     'lrvb_obs_grad_vec': [_VP, _VP, c_i64, c_i64, c_i64, _VP],
     'lrvb_cross_hessian_tilt': [_VP, _VP, c_i64, _VP],
     'lrvb_gram': [_VP, _VP, c_i64, _VP, c_i64],
+    'lrvb_weighted_gram': [_VP, _VP, c_i64],
+    'lrvb_obs_quadform': [_VP, _VP, _VP, c_i64, c_i64, c_i64, _VP],
     'lrvb_chol_factor': [_VP, _VP, c_i64],
     'lrvb_chol_factor_last': [_VP],
     'lrvb_chol_solve': [_VP, _VP, c_i64, c_i64, _VP],

@@ -110,14 +110,15 @@ extern "C" int lrvb_ctx_create(lrvb_ctx** out, int device_id, const lrvb_model_d
     c->D = D; c->V = V;
     c->loss = m->loss;
     if (m->loss != LRVB_LOSS_NONE) {
-        if (m->loss < LRVB_LOSS_GAUSSIAN || m->loss > LRVB_LOSS_POISSON) { delete c; LRVB_FAIL(LRVB_ERR_INVALID, "unknown loss %d", m->loss); }
+        if (m->loss < LRVB_LOSS_GAUSSIAN || m->loss > LRVB_LOSS_DATA_ONLY) { delete c; LRVB_FAIL(LRVB_ERR_INVALID, "unknown loss %d", m->loss); }
         if (m->n_obs <= 0 || m->n_cols <= 0) { delete c; LRVB_FAIL(LRVB_ERR_INVALID, "data term needs n_obs > 0 and n_cols > 0"); }
-        if (m->glm_off < 0 || m->glm_off + m->n_cols > V) { delete c; LRVB_FAIL(LRVB_ERR_SIZE, "coefficient slice [%lld, %lld) exceeds vector size %lld", (long long)m->glm_off, (long long)(m->glm_off + m->n_cols), (long long)V); }
+        if (m->loss != LRVB_LOSS_DATA_ONLY && (m->glm_off < 0 || m->glm_off + m->n_cols > V)) { delete c; LRVB_FAIL(LRVB_ERR_SIZE, "coefficient slice [%lld, %lld) exceeds vector size %lld", (long long)m->glm_off, (long long)(m->glm_off + m->n_cols), (long long)V); }
         c->N = m->n_obs; c->P = m->n_cols; c->glm_off = m->glm_off; c->lik_info = m->lik_info;
     }
     c->quad_kind = m->quad_kind;
     if (c->quad_kind < LRVB_QUAD_NONE || c->quad_kind > LRVB_QUAD_DENSE) { delete c; LRVB_FAIL(LRVB_ERR_INVALID, "unknown quad_kind"); }
     if (c->loss == LRVB_LOSS_NONE && c->quad_kind == LRVB_QUAD_NONE) { delete c; LRVB_FAIL(LRVB_ERR_INVALID, "model has neither a data term nor a quadratic term"); }
+    c->data_only = (c->loss == LRVB_LOSS_DATA_ONLY);
 
     hipError_t e = hipSetDevice(device_id);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -290,6 +291,8 @@ extern "C" int lrvb_set_tuning(lrvb_ctx* c, int n_splits, int reserved) {
 }
 
 static int data_ready(lrvb_ctx* c) {
+    if (c->data_only)
+        LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "this context only holds data (LRVB_LOSS_DATA_ONLY): use lrvb_weighted_gram / lrvb_obs_quadform and the packing entry points");
     if (c->loss != LRVB_LOSS_NONE && !(c->have_X && c->have_y))
         LRVB_FAIL(LRVB_ERR_STATE, "observations not set: call lrvb_set_data for LRVB_SLOT_X and LRVB_SLOT_Y first");
     return LRVB_OK;
@@ -728,6 +731,67 @@ extern "C" int lrvb_gram(lrvb_ctx* c, const double* free_in, int64_t D, double* 
     LRVB_TRY(gram_dev_impl(c, c->theta.p, c->Hfree.p, D));
     HIP_TRY(hipMemcpy2DAsync(GtG_out, (size_t)ld * 8, c->Hfree.p, (size_t)D * 8, (size_t)D * 8, (size_t)D, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return LRVB_OK;
+}
+
+// ---- objectives quadratic in the data -----------------------------------------------------------
+__global__ __launch_bounds__(256)
+void obs_quadform_kernel(const double* __restrict__ Z, i64 ldz, int q, const double* __restrict__ M,
+                         const double* __restrict__ cvec, i64 K, i64 n0, i64 n1, double* __restrict__ out)
+{
+    const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 n = n0 + blockIdx.y;
+    if (k >= K || n >= n1) return;
+    const double* z = Z + n * ldz;
+    const double* Mk = M + k * (i64)q * q;
+    double s = 0.0;
+    for (int a = 0; a < q; ++a) {
+        double t = 0.0;
+        for (int b = 0; b < q; ++b) t += Mk[a * q + b] * z[b];
+        s += z[a] * t;
+    }
+    out[(n - n0) * K + k] = 0.5 * s + (cvec ? cvec[k] : 0.0);
+}
+
+extern "C" int lrvb_weighted_gram(lrvb_ctx* c, double* S_out, int64_t ld) {
+    LRVB_TRY(ctx_bind(c));
+    if (!S_out) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    if (c->loss == LRVB_LOSS_NONE || !c->have_X) LRVB_FAIL(LRVB_ERR_STATE, "no data matrix: call lrvb_set_data(LRVB_SLOT_X) first");
+    if (ld < c->P) LRVB_FAIL(LRVB_ERR_SIZE, "leading dimension too small");
+    // c = w (padded copy: the LDS-DMA stage over-reads up to 31 entries past N)
+    LRVB_TRY(reserve_obs_vec(c, c->zbuf));
+    HIP_TRY(hipMemcpyAsync(c->zbuf.p, c->w.p, (size_t)c->N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    double* tiles = c->stats.p + 1 + c->P;
+    LRVB_TRY(launch_wsyrk(c, c->zbuf.p, tiles));
+    LRVB_TRY(buf_reserve(c, c->Hfree, (size_t)c->P * (size_t)c->P));
+    LRVB_TRY(launch_tiles_to_dense(c, tiles, c->P, c->Hfree.p, c->P, 0, 0, false));
+    HIP_TRY(hipMemcpy2DAsync(S_out, (size_t)ld * 8, c->Hfree.p, (size_t)c->P * 8, (size_t)c->P * 8, (size_t)c->P, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LRVB_OK;
+}
+
+extern "C" int lrvb_obs_quadform(lrvb_ctx* c, const double* M, const double* cvec, int64_t K,
+                                 int64_t n0, int64_t n1, double* out) {
+    LRVB_TRY(ctx_bind(c));
+    if (!M || !out || K <= 0) LRVB_FAIL(LRVB_ERR_INVALID, "bad argument");
+    if (c->loss == LRVB_LOSS_NONE || !c->have_X) LRVB_FAIL(LRVB_ERR_STATE, "no data matrix: call lrvb_set_data(LRVB_SLOT_X) first");
+    if (n0 < 0 || n1 > c->N || n0 > n1) LRVB_FAIL(LRVB_ERR_INVALID, "row range [%lld, %lld) outside [0, %lld)", (long long)n0, (long long)n1, (long long)c->N);
+    const size_t msz = (size_t)K * (size_t)c->P * (size_t)c->P;
+    LRVB_TRY(buf_reserve(c, c->work1, msz + (size_t)K));
+    LRVB_TRY(h2d(c, c->work1.p, M, msz));
+    double* cdev = nullptr;
+    if (cvec) { cdev = c->work1.p + msz; LRVB_TRY(h2d(c, cdev, cvec, (size_t)K)); }
+    const i64 chunk = 32768;
+    for (i64 a = n0; a < n1; a += chunk) {
+        const i64 b = (a + chunk < n1) ? a + chunk : n1;
+        const i64 rows = b - a;
+        LRVB_TRY(buf_reserve(c, c->rhs, (size_t)rows * (size_t)K));
+        dim3 grid(nb256(K), (unsigned)rows);
+        hipLaunchKernelGGL(obs_quadform_kernel, grid, dim3(256), 0, c->stream, c->X.p, c->P, (int)c->P,
+                           c->work1.p, cdev, (i64)K, a, b, c->rhs.p);
+        HIP_TRY(hipGetLastError());
+        LRVB_TRY(d2h(c, out + (a - n0) * K, c->rhs.p, (size_t)rows * (size_t)K));
+    }
     return LRVB_OK;
 }
 

@@ -42,6 +42,7 @@ struct lrvb_ctx {
 
     // model
     int loss = LRVB_LOSS_NONE;
+    bool data_only = false;
     i64 N = 0, P = 0, glm_off = 0;
     double lik_info = 1.0;
     int quad_kind = LRVB_QUAD_NONE;

@@ -20,7 +20,7 @@ from . import _hip
 from .packing import VectorParam
 
 _LOSSES = {None: _hip.LOSS_NONE, 'none': _hip.LOSS_NONE, 'gaussian': _hip.LOSS_GAUSSIAN,
-           'logistic': _hip.LOSS_LOGISTIC, 'poisson': _hip.LOSS_POISSON}
+           'logistic': _hip.LOSS_LOGISTIC, 'poisson': _hip.LOSS_POISSON, 'data_only': _hip.LOSS_DATA_ONLY}
 
 
 def _block_array(blocks):
@@ -183,6 +183,23 @@ class DeviceContext(object):
         G = np.empty((self.D, self.D))
         _hip.check(self._lib.lrvb_gram(self._h, _hip.ptr(f), f.size, _hip.ptr(G), self.D))
         return G
+
+    # -- objectives quadratic in the data -------------------------------------------------
+    def weighted_gram(self):
+        S = np.empty((self.n_cols, self.n_cols))
+        _hip.check(self._lib.lrvb_weighted_gram(self._h, _hip.ptr(S), self.n_cols))
+        return S
+
+    def obs_quadform(self, M, c=None, n0=0, n1=None):
+        M = _hip.as_f64(M)
+        K = M.shape[0]
+        if M.shape[1:] != (self.n_cols, self.n_cols):
+            raise ValueError('M must be K x {0} x {0}'.format(self.n_cols))
+        c = None if c is None else _hip.as_f64(c).ravel()
+        n1 = self.n_obs if n1 is None else n1
+        out = np.empty((max(n1 - n0, 0), K))
+        _hip.check(self._lib.lrvb_obs_quadform(self._h, _hip.ptr(M), _hip.ptr(c), K, n0, n1, _hip.ptr(out)))
+        return out
 
     # -- solves ---------------------------------------------------------------------------
     def chol_factor(self, H):

@@ -70,3 +70,20 @@ def make_objective(model):
 def make_free_objective(model):
     f_vec = make_objective(model)
     return lambda theta: f_vec(constrain(theta, model.layout))
+
+
+def example_objective(layout, x, y):
+    """Example.ipynb:247-274 in torch; returns f(theta, w)."""
+    xt, yt = torch.tensor(x), torch.tensor(y)
+    dx, dy = x.shape[1], y.shape[1]
+    idx = torch.tril_indices(dy, dy)
+
+    def f(theta, w):
+        eta = constrain(theta, layout)
+        beta = eta[:dx * dy].reshape(dx, dy)
+        lam_l = torch.zeros(dy, dy, dtype=eta.dtype).index_put((idx[0], idx[1]), eta[dx * dy:])
+        lam = lam_l + lam_l.T - torch.diag(torch.diagonal(lam_l))
+        r = yt - xt @ beta
+        y_term = -0.5 * torch.einsum('ni,ij,nj,n', r, lam, r, w)
+        return -(y_term + 0.5 * torch.sum(w) * torch.logdet(lam))
+    return f
