@@ -24,7 +24,7 @@ from .objectives import (Objective, TwoParameterObjective, ParameterConverter, P
 from .sensitivity import ParametricSensitivityLinearApproximation
 from .cg import ConjugateGradientSolver
 from .models import (DeviceContext, DeviceObjective, GLMObjective, QuadraticObjective, LinearMoments)
-from .quadform import QuadraticDataObjective, NormalRegressionObjective
+from .quadform import QuadraticDataObjective, NormalRegressionObjective, MVNRegressionObjective
 
 # reference-style module aliases
 from . import packing as Parameters
@@ -37,4 +37,5 @@ from . import cg as ConjugateGradient
 from . import optim as OptimizationUtils
 from . import expfam as ExponentialFamilies
 from . import families as NormalParams
+from . import regression as regression_utils
 from . import distributed

@@ -192,3 +192,123 @@ class NormalRegressionObjective(QuadraticDataObjective):
                 M[k] = B.T @ Eij @ B
                 c[k] = -0.5 * (P[i, j] if i == j else 2.0 * P[i, j])
         return M, c
+
+
+class MVNRegressionObjective(QuadraticDataObjective):
+    """BASELINE.json config 2: conjugate-normal regression y_n = x_n^T beta + eps with
+    q(beta) = MVNParam(k) (mean m, information matrix Lambda), q(tau) = GammaParam (shape a, rate b):
+
+      -ELBO = sum_n w_n [ 1/2 E[tau] ((y_n - x_n^T m)^2 + x_n^T Sigma x_n) - 1/2 E[log tau] ]
+              - mvn_prior(mu0, Lambda0; m, Sigma) - gamma_prior(a0, b0; E tau, E log tau)
+              - multivariate_normal_entropy(Lambda) - gamma_entropy(a, b),         Sigma = Lambda^-1,
+
+    assembled from the reference's building blocks: NormalParams.py:6-23, GammaParams.py:4-16,
+    ExponentialFamilies.py:27-35 (entropies), :111-112 (E log tau), :186-195 (priors).  `par` is a
+    ModelParamsDict holding an MVNParam named `beta_name` and a GammaParam named `tau_name`.
+    Per observation l_n = 1/2 z_n^T Q z_n + c with z = [x; y],
+    Q = E[tau] [[m m^T + Sigma, -m], [-m^T, 1]], c = -1/2 E[log tau]."""
+
+    def __init__(self, par, x, y, prior_mean=None, prior_info=None, prior_shape=1.0, prior_rate=1.0,
+                 beta_name='beta', tau_name='tau', weights=None, device=0):
+        from scipy import special
+        self._special = special
+        x = _hip.as_f64(x)
+        y = _hip.as_f64(y).reshape(-1, 1)
+        self.k = k = x.shape[1]
+        b0 = par.vector_indices_dict[beta_name].start
+        sub = par[beta_name]
+        self._ms = range(b0 + sub.vector_indices_dict['mean'].start, b0 + sub.vector_indices_dict['mean'].stop)
+        self._ls = range(b0 + sub.vector_indices_dict['info'].start, b0 + sub.vector_indices_dict['info'].stop)
+        t0 = par.vector_indices_dict[tau_name].start
+        tsub = par[tau_name]
+        self._ia = t0 + tsub.vector_indices_dict['shape'].start
+        self._ib = t0 + tsub.vector_indices_dict['rate'].start
+        if len(self._ms) != k or len(self._ls) != k * (k + 1) // 2:
+            raise ValueError('Wrong size for {}.  Expected dimension {}'.format(beta_name, k))
+        self.mu0 = np.zeros(k) if prior_mean is None else _hip.as_f64(prior_mean).ravel()
+        self.lam0 = np.eye(k) if prior_info is None else _hip.as_f64(prior_info)
+        self.a0, self.b0 = float(prior_shape), float(prior_rate)
+        self._dup = duplication_matrix(k)
+        super().__init__(par, np.hstack([x, y]), weights=weights, device=device)
+
+    def _unpack(self, eta):
+        k = self.k
+        m = eta[self._ms.start:self._ms.stop]
+        lam = (self._dup @ eta[self._ls.start:self._ls.stop]).reshape(k, k)
+        return m, lam, eta[self._ia], eta[self._ib]
+
+    def _terms(self, eta, S, W):
+        sp = self._special
+        k = self.k
+        m, lam, a, b = self._unpack(eta)
+        Sxx, Sxy, Syy = S[:k, :k], S[:k, k], S[k, k]
+        sign, logdet = np.linalg.slogdet(lam)
+        if sign <= 0:
+            raise ValueError('Matrix is not positive definite')
+        P = np.linalg.inv(lam)
+        e, L = a / b, sp.digamma(a) - np.log(b)
+        psi1, psi2 = sp.polygamma(1, a), sp.polygamma(2, a)
+        u = Sxx @ m - Sxy
+        rss = Syy - 2.0 * m @ Sxy + m @ Sxx @ m
+        C = e * Sxx + self.lam0
+        dm = m - self.mu0
+        entropy_gamma = a - np.log(b) + sp.gammaln(a) + (1.0 - a) * sp.digamma(a)
+        value = (0.5 * e * rss + 0.5 * np.sum(C * P) - 0.5 * W * L + 0.5 * dm @ self.lam0 @ dm
+                 - (self.a0 - 1.0) * L + self.b0 * e + 0.5 * logdet - entropy_gamma
+                 - 0.5 * (k + k * np.log(2.0 * np.pi)))
+        V = eta.size
+        g = np.zeros(V)
+        H = np.zeros((V, V))
+        ms, ls = slice(self._ms.start, self._ms.stop), slice(self._ls.start, self._ls.stop)
+        ia, ib = self._ia, self._ib
+        G = P @ C @ P
+        Gs = -0.5 * (P @ Sxx @ P)                              # d g_vecLambda / d e
+        f_e = 0.5 * rss + 0.5 * np.sum(Sxx * P) + self.b0
+        f_L = -0.5 * W - (self.a0 - 1.0)
+        g[ms] = e * u + self.lam0 @ dm
+        g[ls] = self._dup.T @ (-0.5 * G + 0.5 * P).ravel()
+        g[ia] = f_e / b + f_L * psi1 - (1.0 + (1.0 - a) * psi1)
+        g[ib] = -f_e * a / b ** 2 - f_L / b + 1.0 / b
+        H[ms, ms] = C
+        H[ls, ls] = self._dup.T @ (0.5 * (np.kron(G, P) + np.kron(P, G)) - 0.5 * np.kron(P, P)) @ self._dup
+        H[ia, ia] = f_L * psi2 + psi1 - (1.0 - a) * psi2
+        H[ia, ib] = H[ib, ia] = -f_e / b ** 2
+        H[ib, ib] = 2.0 * f_e * a / b ** 3 + f_L / b ** 2 - 1.0 / b ** 2
+        H[ms, ia] = H[ia, ms] = u / b
+        H[ms, ib] = H[ib, ms] = -u * a / b ** 2
+        gl = self._dup.T @ Gs.ravel()
+        H[ls, ia] = H[ia, ls] = gl / b
+        H[ls, ib] = H[ib, ls] = -gl * a / b ** 2
+        return value, g, H
+
+    def _obs_terms(self, eta):
+        sp = self._special
+        k, q = self.k, self.q
+        m, lam, a, b = self._unpack(eta)
+        P = np.linalg.inv(lam)
+        e = a / b
+        Q0 = np.zeros((q, q))
+        Q0[:k, :k] = np.outer(m, m) + P
+        Q0[:k, k] = Q0[k, :k] = -m
+        Q0[k, k] = 1.0
+        V = eta.size
+        M = np.zeros((V, q, q))
+        c = np.zeros(V)
+        for i in range(k):
+            dQ = np.zeros((q, q))
+            dQ[i, :k] += m
+            dQ[:k, i] += m
+            dQ[i, k] = dQ[k, i] = -1.0
+            M[self._ms.start + i] = e * dQ
+        for i in range(k):
+            for j in range(i + 1):
+                Eij = np.zeros((k, k))
+                Eij[i, j] = Eij[j, i] = 1.0
+                dQ = np.zeros((q, q))
+                dQ[:k, :k] = -P @ Eij @ P
+                M[self._ls.start + j + i * (i + 1) // 2] = e * dQ
+        M[self._ia] = Q0 / b
+        M[self._ib] = -Q0 * a / b ** 2
+        c[self._ia] = -0.5 * sp.polygamma(1, a)
+        c[self._ib] = 0.5 / b
+        return M, c

@@ -1,0 +1,92 @@
+"""BASELINE.json config 2 on the GPU: MVNParam regression, N = 1e5, k = 21 -> D = 21 + 231 + 2 = 254
+free parameters, dense Hessian on one MI355X.  Oracle: exact AD (torch.func fp64 on the host) of
+the restated -ELBO at the full size, plus small-size cases; tolerance 1e-9 relative (the Hessian
+contains Lambda^-1 products: its condition enters the rounding)."""
+import numpy as np
+import pytest
+import scipy.optimize
+import torch
+
+import torch_ref as tr
+from oracle import packing as opk
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def vb():
+    import lrvb_amd
+    assert lrvb_amd._hip.device_count() >= 1
+    return lrvb_amd
+
+
+def _build(vb, rng, N, k):
+    x = rng.normal(size=(N, k))
+    beta_true = rng.normal(size=k)
+    y = x @ beta_true + rng.normal(size=N) / np.sqrt(2.0)          # tau* = 2
+    par = vb.ModelParamsDict('params')
+    par.push_param(vb.MVNParam('beta', dim=k))
+    par.push_param(vb.GammaParam('tau'))
+    mu0 = np.zeros(k); lam0 = 0.1 * np.eye(k)
+    fun = vb.MVNRegressionObjective(par, x, y, prior_mean=mu0, prior_info=lam0, prior_shape=2.0, prior_rate=1.5)
+    lay = opk.Layout([opk.box_block(k), opk.psd_block(k), opk.box_block(1, lb=0.0), opk.box_block(1, lb=0.0)])
+    ft = tr.mvn_regression_objective(x, y, k, mu0, lam0, 2.0, 1.5, layout=lay)
+    return x, y, par, fun, lay, ft
+
+
+@pytest.mark.parametrize('N,k', [(200, 2), (5000, 6)])
+def test_small_cases_all_derivatives(vb, N, k):
+    rng = np.random.default_rng(N + k)
+    x, y, par, fun, lay, ft = _build(vb, rng, N, k)
+    assert par.free_size() == lay.D == k + k * (k + 1) // 2 + 2
+    objective = vb.Objective(par, fun)
+    w = rng.uniform(0.5, 1.5, N)
+    fun.weights_par.set_vector(w)
+    theta = rng.normal(size=lay.D) * 0.3
+    tt, tw = torch.tensor(theta), torch.tensor(w)
+    H_ad = torch.func.hessian(ft)(tt, tw).numpy()
+    assert abs(objective.fun_free(theta) - ft(tt, tw).item()) < 1e-10 * abs(ft(tt, tw).item())
+    assert rel_err(objective.fun_free_grad(theta), torch.func.grad(ft)(tt, tw).numpy()) < 1e-9
+    assert rel_err(objective.fun_free_hessian(theta), H_ad) < 1e-9
+    v = rng.normal(size=lay.D)
+    assert rel_err(objective.fun_free_hvp(theta, v), H_ad @ v) < 1e-9
+    cross = torch.func.jacrev(torch.func.grad(ft, argnums=0), argnums=1)(tt, tw).numpy()
+    two = vb.TwoParameterObjective(par, fun.weights_par, fun)
+    assert rel_err(two.fun_hessian_free1_vector2(theta, w), cross) < 1e-9
+
+
+def test_config2_full_size(vb):
+    N, k = 100000, 21
+    rng = np.random.default_rng(20242)
+    x, y, par, fun, lay, ft = _build(vb, rng, N, k)
+    D = par.free_size()
+    assert D == 254
+    objective = vb.Objective(par, fun)
+    # start from the closed-form conditional posterior of beta (regression_utils) at tau = 2
+    mean, info = vb.regression_utils.get_posterior_regression_coefficients(y, x, 2.0, np.zeros(k), 0.1 * np.eye(k))
+    par['beta']['mean'].set(mean)
+    par['beta']['info'].set(0.5 * (info + info.T))
+    par['tau']['shape'].set(np.array(2.0 + 0.5 * N)); par['tau']['rate'].set(np.array(1.5 + 0.25 * N))
+    theta0 = par.get_free()
+    opt = scipy.optimize.minimize(objective.fun_free, jac=objective.fun_free_grad, hessp=objective.fun_free_hvp,
+                                  x0=theta0, method='trust-ncg', options={'gtol': 1e-6, 'maxiter': 50})
+    theta_hat = opt.x + 1e-3 * rng.normal(size=D)          # perturbed optimum: third-order terms non-zero
+    w1 = torch.ones(N, dtype=torch.float64)
+    tt = torch.tensor(theta_hat)
+    H = objective.fun_free_hessian(theta_hat)
+    H_ad = torch.func.hessian(ft)(tt, w1).numpy()
+    assert rel_err(H, H_ad) < 1e-9
+    assert np.allclose(H, H.T, rtol=0, atol=1e-9 * np.max(np.abs(H)))
+    assert rel_err(objective.fun_free_grad(theta_hat), torch.func.grad(ft)(tt, w1).numpy()) < 1e-8
+    assert np.min(np.linalg.eigvalsh(0.5 * (H + H.T))) > 0
+    # LRVB covariance of the coefficient means: M H^-1 M^T with M = d mean / d theta, vs the oracle
+    M = vb.Objective(par, vb.LinearMoments(par, B=np.eye(par.vector_size())[:k])).fun_free_jacobian(theta_hat)
+    fun.ctx.chol_factor(H)
+    cov = fun.ctx.lrvb_cov(M)
+    assert rel_err(cov, M @ np.linalg.solve(H_ad, M.T)) < 1e-6        # BASELINE.json's rtol 1e-6
+    # the optimum's posterior covariance of beta is close to the classical (X^T tau X + Lambda0)^-1
+    par.set_free(opt.x)
+    e_tau = par['tau'].e()
+    np.testing.assert_allclose(np.linalg.inv(par['beta']['info'].get()),
+                               np.linalg.inv(e_tau * x.T @ x + 0.1 * np.eye(k)), rtol=1e-4, atol=1e-10)

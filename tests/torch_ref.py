@@ -87,3 +87,31 @@ def example_objective(layout, x, y):
         y_term = -0.5 * torch.einsum('ni,ij,nj,n', r, lam, r, w)
         return -(y_term + 0.5 * torch.sum(w) * torch.logdet(lam))
     return f
+
+
+def mvn_regression_objective(x, y, k, mu0, lam0, a0, b0, layout=None):
+    """Config 2 (-ELBO of the conjugate-normal regression) in torch as f(point, w); `point` is the
+    vector eta = [m (k), tril(Lambda), shape, rate] or, with `layout`, the free vector."""
+    xt, yt = torch.tensor(x), torch.tensor(y).reshape(-1)
+    mu0t, lam0t = torch.tensor(mu0), torch.tensor(lam0)
+    idx = torch.tril_indices(k, k)
+    mm = k * (k + 1) // 2
+
+    def f(point, w):
+        eta = constrain(point, layout) if layout is not None else point
+        m = eta[:k]
+        ll = torch.zeros(k, k, dtype=eta.dtype).index_put((idx[0], idx[1]), eta[k:k + mm])
+        lam = ll + ll.T - torch.diag(torch.diagonal(ll))
+        a, b = eta[k + mm], eta[k + mm + 1]
+        sigma = torch.linalg.inv(lam)
+        e_tau, e_log_tau = a / b, torch.special.digamma(a) - torch.log(b)
+        resid = yt - xt @ m
+        quad = torch.einsum('ni,ij,nj->n', xt, sigma, xt)
+        e_log_lik = torch.sum(w * (-0.5 * e_tau * (resid ** 2 + quad) + 0.5 * e_log_tau))
+        dm = m - mu0t
+        mvn_prior = -0.5 * (dm @ lam0t @ dm + torch.trace(lam0t @ sigma))
+        gamma_prior = (a0 - 1.0) * e_log_tau - b0 * e_tau
+        mvn_entropy = 0.5 * (-torch.logdet(lam) + k + k * math.log(2 * math.pi))
+        gamma_entropy = a - torch.log(b) + torch.lgamma(a) + (1.0 - a) * torch.special.digamma(a)
+        return -(e_log_lik + mvn_prior + gamma_prior + mvn_entropy + gamma_entropy)
+    return f
