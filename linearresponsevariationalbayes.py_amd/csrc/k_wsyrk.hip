@@ -389,6 +389,185 @@ void wsyrk_glds_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
     }
 }
 
+// ---- narrow matrices (P <= 64): the sufficient-statistics shape of configs 2, 4, 5 --------------
+// S = Z^T diag(c) Z with a handful of columns is a streaming problem (HBM-bound up to P ~ 48, balanced
+// at P = 64): no tiling over columns, no LDS staging.  Every wavefront streams its own rows straight
+// into MFMA operand registers -- a k-step is 4 consecutive rows, lane (i = lane & 15, k = lane >> 4)
+// loads the column PAIR (32 m + 2 i, 32 m + 2 i + 1) of row k with one 16-byte load, so one wave
+// instruction reads 4 x 256 contiguous bytes.  The same registers serve as the A operand (after the
+// c_n scaling) and as the B operand.  MFMA tile t = 2 m + p therefore holds columns 32 m + 2 i + p:
+// a fixed column permutation that is undone when the block partial is written.
+template <int NPAIR>      // NPAIR = ceil(P / 32): 1 -> 2 tiles (3 MFMAs per k-step), 2 -> 4 tiles (10)
+__global__ __launch_bounds__(256)
+void gram_small_kernel(const double* __restrict__ Z, i64 ldz, i64 N, int P,
+                       const double* __restrict__ cpad, double* __restrict__ partial /* [grid][64*64] */,
+                       int aligned16)
+{
+    constexpr int NT = 2 * NPAIR;
+    constexpr int NACC = NT * (NT + 1) / 2;
+    constexpr int KS = 4;                       // k-steps (of 4 rows) per stage
+    __shared__ double red[64 * 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+
+    d4 acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) acc[a] = (d4){0.0, 0.0, 0.0, 0.0};
+
+    int colp[NPAIR];                            // first column of this lane's pair, clamped for the load
+    bool in0[NPAIR], in1[NPAIR];
+#pragma unroll
+    for (int m = 0; m < NPAIR; ++m) {
+        const int c0 = 32 * m + 2 * li;
+        in0[m] = c0 < P; in1[m] = c0 + 1 < P;
+        colp[m] = in1[m] ? c0 : (P >= 2 ? P - 2 : 0);
+    }
+
+    auto load_stage = [&](double (&x)[KS][NPAIR][2], double (&cv)[KS], i64 row0) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            i64 n = row0 + ks * 4 + lk;
+            cv[ks] = cpad[n];                                   // zero padding past N
+            if (n > N - 1) n = N - 1;
+            const double* rowp = Z + n * ldz;
+#pragma unroll
+            for (int m = 0; m < NPAIR; ++m) {
+                if (aligned16) {
+                    const double2 t = *reinterpret_cast<const double2*>(rowp + colp[m]);
+                    x[ks][m][0] = t.x; x[ks][m][1] = t.y;
+                } else {
+                    x[ks][m][0] = rowp[colp[m]]; x[ks][m][1] = rowp[colp[m] + (P >= 2 ? 1 : 0)];
+                }
+            }
+        }
+    };
+    auto consume = [&](double (&x)[KS][NPAIR][2], double (&cv)[KS]) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            double b[NT], a[NT];
+#pragma unroll
+            for (int m = 0; m < NPAIR; ++m) {
+                // a clamped pair (P odd or lane past the last column) is re-mapped to zeros
+                const double v0 = in1[m] ? x[ks][m][0] : (in0[m] ? x[ks][m][(P >= 2) ? 1 : 0] : 0.0);
+                const double v1 = in1[m] ? x[ks][m][1] : 0.0;
+                b[2 * m] = v0; b[2 * m + 1] = v1;
+                a[2 * m] = v0 * cv[ks]; a[2 * m + 1] = v1 * cv[ks];
+            }
+            int idx = 0;
+#pragma unroll
+            for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+                for (int tb = 0; tb <= ta; ++tb) {
+                    acc[idx] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ta], b[tb], acc[idx], 0, 0, 0);
+                    ++idx;
+                }
+        }
+    };
+
+    // stages of 16 rows, dealt round-robin to the waves of the whole grid; double-buffered in registers
+    const i64 stage_rows = KS * 4;
+    const i64 nstages = (N + stage_rows - 1) / stage_rows;
+    const i64 gw = (i64)blockIdx.x * 4 + wave, GW = (i64)gridDim.x * 4;
+    i64 st = gw;
+    if (st < nstages) {
+        double xa[KS][NPAIR][2], xb[KS][NPAIR][2], ca[KS], cb[KS];
+        load_stage(xa, ca, st * stage_rows);
+        for (;;) {
+            i64 nx = st + GW;
+            if (nx < nstages) load_stage(xb, cb, nx * stage_rows);
+            consume(xa, ca);
+            if (nx >= nstages) break;
+            st = nx; nx = st + GW;
+            if (nx < nstages) load_stage(xa, ca, nx * stage_rows);
+            consume(xb, cb);
+            if (nx >= nstages) break;
+            st = nx;
+        }
+    }
+
+    // wave partial -> 64 x 64 block in TRUE column order (tile t, lane index i <-> column 32 (t>>1) + 2 i + (t&1)),
+    // waves combined through LDS in a fixed order, both triangles filled
+    auto scatter = [&](double* dst, bool add) {
+        int idx = 0;
+#pragma unroll
+        for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+            for (int tb = 0; tb <= ta; ++tb) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ia = lk + 4 * r;                                 // row index inside tile ta
+                    const int row = 32 * (ta >> 1) + 2 * ia + (ta & 1);
+                    const int col = 32 * (tb >> 1) + 2 * li + (tb & 1);
+                    const double v = acc[idx][r];
+                    if (add) { dst[row * 64 + col] += v; if (ta != tb) dst[col * 64 + row] += v; }
+                    else     { dst[row * 64 + col] = v;  if (ta != tb) dst[col * 64 + row] = v; }
+                }
+                ++idx;
+            }
+    };
+    // the four wave partials are summed in LDS in wave order (deterministic), then the used
+    // 32 NPAIR x 32 NPAIR corner goes to this block's slot
+    if (wave == 0) scatter(red, false);
+    __syncthreads();
+    if (wave == 1) scatter(red, true);
+    __syncthreads();
+    if (wave == 2) scatter(red, true);
+    __syncthreads();
+    if (wave == 3) scatter(red, true);
+    __syncthreads();
+    double* out = partial + (i64)blockIdx.x * (64 * 64);
+    for (int e = tid; e < 64 * 64; e += 256) {
+        const int row = e >> 6, col = e & 63;
+        if (row < 32 * NPAIR && col < 32 * NPAIR) out[e] = red[e];
+    }
+}
+
+// tiles[0] (128 x 128) <- sum_b partial[b] (64 x 64), fixed order
+__global__ __launch_bounds__(256)
+void gram_small_reduce_kernel(const double* __restrict__ partial, int nblk, int P, double* __restrict__ tile0)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 64 * 64) return;
+    const int row = e >> 6, col = e & 63;
+    if (row >= P || col >= P) return;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int b = 0;
+    for (; b + 3 < nblk; b += 4) {
+        s0 += partial[(i64)b * 4096 + e]; s1 += partial[(i64)(b + 1) * 4096 + e];
+        s2 += partial[(i64)(b + 2) * 4096 + e]; s3 += partial[(i64)(b + 3) * 4096 + e];
+    }
+    for (; b < nblk; ++b) s0 += partial[(i64)b * 4096 + e];
+    tile0[row * WS_TILE + col] = (s0 + s1) + (s2 + s3);
+}
+
+static int launch_gram_small(lrvb_ctx* c, const double* cvec_dev, double* tiles_out_dev) {
+    const i64 stages = (c->N + 15) / 16;
+    i64 grid = (stages + 3) / 4;
+    if (grid > 1024) grid = 1024;
+    if (grid < 1) grid = 1;
+    LRVB_TRY(buf_reserve(c, c->tile_part, (size_t)grid * 4096));
+    const int aligned16 = ((c->P % 2) == 0) && ((((uintptr_t)c->X.p) & 15) == 0);
+    if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
+    if (c->P <= 32)
+        hipLaunchKernelGGL(gram_small_kernel<1>, dim3((unsigned)grid), dim3(256), 0, c->stream,
+                           c->X.p, c->P, c->N, (int)c->P, cvec_dev, c->tile_part.p, aligned16);
+    else
+        hipLaunchKernelGGL(gram_small_kernel<2>, dim3((unsigned)grid), dim3(256), 0, c->stream,
+                           c->X.p, c->P, c->N, (int)c->P, cvec_dev, c->tile_part.p, aligned16);
+    HIP_TRY(hipGetLastError());
+    if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
+    HIP_TRY(hipMemsetAsync(tiles_out_dev, 0, sizeof(double) * WS_TILE * WS_TILE, c->stream));   // unused entries stay finite
+    hipLaunchKernelGGL(gram_small_reduce_kernel, dim3(16), dim3(256), 0, c->stream,
+                       c->tile_part.p, (int)grid, (int)c->P, tiles_out_dev);
+    HIP_TRY(hipGetLastError());
+    if (c->prof_on) {
+        c->prof.wsyrk_flops = (double)c->N * (double)c->P * (double)(c->P + 1);
+        c->prof.wsyrk_bytes = 8.0 * ((double)c->N * (double)(c->P + 1)) + 8.0 * 0.5 * (double)c->P * (double)(c->P + 1);
+    }
+    return LRVB_OK;
+}
+
 // Deterministic second stage: tiles[t][e] = sum_s partial[s][t][e]  (fixed order).
 __global__ __launch_bounds__(256)
 void wsyrk_reduce_kernel(const double* __restrict__ partial, int n_splits, i64 tile_elems_total,
@@ -405,6 +584,8 @@ void wsyrk_reduce_kernel(const double* __restrict__ partial, int n_splits, i64 t
 }
 
 int launch_wsyrk(lrvb_ctx* c, const double* cvec_dev, double* tiles_out_dev) {
+    if (c->P <= 64 && !c->force_generic_wsyrk)       // cvec_dev carries zero padding past N (reserve_obs_vec)
+        return launch_gram_small(c, cvec_dev, tiles_out_dev);
     const int T = wsyrk_num_tiles(c->P);
     const int S = wsyrk_auto_splits(c);
     i64 rps = (c->N + S - 1) / S;
