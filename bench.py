@@ -247,6 +247,19 @@ def main():
         ctx.sync()
         t2 = time.perf_counter()
         out['lrvb_solve_ms'] = {'cho_factor': (t1 - t0) * 1e3, 'cov_Q_eq_D': (t2 - t1) * 1e3}
+        # conjugate-gradient route (ConjugateGradientSolver, tol 1e-8) for Q = 16 right-hand sides
+        theta_h = theta.cpu().numpy()
+        rng = np.random.default_rng(5)
+        rhs = rng.normal(size=(16, D))
+        ctx.cg_solve(theta_h, rhs[0])
+        t3 = time.perf_counter()
+        iters = []
+        for q in range(16):
+            _, info, it = ctx.cg_solve(theta_h, rhs[q], tol=1e-8)
+            iters.append(it if info == 0 else -1)
+        t4 = time.perf_counter()
+        out['lrvb_solve_ms']['cg_16_rhs_tol1e-8'] = (t4 - t3) * 1e3
+        out['lrvb_solve_ms']['cg_iterations'] = iters
         if not args.no_cpu_baseline and rank == 0:
             ns = min(args.cpu_sample_rows, n_local)
             xs = X[:ns].cpu().numpy()

@@ -318,3 +318,39 @@ def test_full_size_properties_headline_shape(vb):
     G = torch.empty((P, P), dtype=torch.float64, device=dev)
     ctx.gram_dev(theta.data_ptr(), G.data_ptr(), P); ctx.sync()
     assert torch.equal(G, G.T) and torch.linalg.eigvalsh(G).min().item() > -1e-9 * G.abs().max().item()
+
+
+@pytest.mark.parametrize('N,P', [(1, 1), (3, 2), (15, 7), (16, 16), (17, 33), (100, 64), (129, 65), (1000, 127), (700, 129)])
+def test_edge_shapes(vb, N, P):
+    """Ragged sizes around every internal granule: 16-row stages, 32/64-column narrow kernels, the
+    128-column tile edge, odd P (unaligned rows -> generic register-staged kernel)."""
+    rng = np.random.default_rng(1000 * N + P)
+    par, lay = make_par(vb, [('box', 'b', P, -1.0, np.inf)])
+    x, y, w = glm_data(rng, N, P, om.LOGISTIC)
+    fun = vb.GLMObjective(par, x, y, loss='logistic', prior_info=0.5, weights=w)
+    model = om.DeclaredModel(lay, loss=om.LOGISTIC, x=x, y=y, w=w, quad_A=np.full(P, 0.5))
+    obj = vb.Objective(par, fun)
+    theta = rng.normal(size=P) * 0.3
+    Hw = model.hessian(theta)
+    assert rel_err(obj.fun_free_hessian(theta), Hw) < TOL
+    assert rel_err(obj.fun_free_grad(theta), model.grad(theta)) < TOL
+    v = rng.normal(size=P)
+    assert rel_err(obj.fun_free_hvp(theta, v), Hw @ v) < TOL
+    assert rel_err(fun.gram(theta), model.gram(theta)) < TOL
+    # zero weights on some rows: those observations drop out exactly
+    w2 = w.copy(); w2[::2] = 0.0
+    fun.weights_par.set_vector(w2)
+    model.w = w2
+    assert rel_err(obj.fun_free_hessian(theta), model.hessian(theta)) < TOL
+
+
+def test_wide_pass_unsupported_is_loud(vb):
+    """n_cols > 1024 is outside the register-resident fused pass: the C ABI says so instead of
+    computing something else."""
+    rng = np.random.default_rng(0)
+    P = 1030
+    par, lay = make_par(vb, [('box', 'b', P, -np.inf, np.inf)])
+    x, y, w = glm_data(rng, 8, P, om.GAUSSIAN)
+    fun = vb.GLMObjective(par, x, y)
+    with pytest.raises(NotImplementedError):
+        vb.Objective(par, fun).fun_free_grad(np.zeros(P))
