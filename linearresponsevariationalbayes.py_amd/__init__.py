@@ -24,7 +24,8 @@ from .objectives import (Objective, TwoParameterObjective, ParameterConverter, P
 from .sensitivity import ParametricSensitivityLinearApproximation
 from .cg import ConjugateGradientSolver
 from .models import (DeviceContext, DeviceObjective, GLMObjective, QuadraticObjective, LinearMoments)
-from .quadform import QuadraticDataObjective, NormalRegressionObjective, MVNRegressionObjective
+from .quadform import (QuadraticDataObjective, NormalRegressionObjective, MVNRegressionObjective,
+                       WishartMVNObjective)
 
 # reference-style module aliases
 from . import packing as Parameters

@@ -312,3 +312,146 @@ class MVNRegressionObjective(QuadraticDataObjective):
         c[self._ia] = -0.5 * sp.polygamma(1, a)
         c[self._ib] = 0.5 / b
         return M, c
+
+
+class WishartMVNObjective(QuadraticDataObjective):
+    """BASELINE.json config 5: full-covariance normal model y_n ~ N(mu, Lambda^-1) with
+    q(mu) = MVNParam(d) (mean m, information Lambda_mu) and q(Lambda) = WishartParam(d) (df nu, scale V):
+
+      -ELBO = sum_n w_n [ 1/2 nu ((y_n - m)^T V (y_n - m) + tr(V Sigma_mu)) - 1/2 E log|Lambda| ]
+              - mvn_prior(mu0, Lambda0; m, Sigma_mu) - [1/2 (nu0 - d - 1) E log|Lambda| - 1/2 nu tr(W0 V)]
+              - multivariate_normal_entropy(Lambda_mu) - wishart_entropy(nu, V),
+      E log|Lambda| = psi_d(nu/2) + d log 2 + log|V|,    Sigma_mu = Lambda_mu^-1,
+
+    from the reference's blocks: NormalParams.py:6-23, WishartParams.py:6-35 (with the `size`
+    defect fixed), ExponentialFamilies.py:5-13, 27-31, 72-94, 186-189.  Free size
+    d + d(d+1)/2 + 1 + d(d+1)/2 = (d+1)^2: d = 63 gives D = 4096.  Per observation
+    l_n = 1/2 z^T Q z + c with z = [y; 1], Q = nu [[V, -V m], [-m^T V, m^T V m]]."""
+
+    def __init__(self, par, y, prior_mean=None, prior_info=None, prior_df=None, prior_inv_scale=None,
+                 mu_name='mu', lambda_name='lambda', weights=None, device=0):
+        from scipy import special
+        self._special = special
+        y = _hip.as_f64(y)
+        self.d = d = y.shape[1]
+        mm = d * (d + 1) // 2
+        o = par.vector_indices_dict[mu_name].start
+        sub = par[mu_name]
+        self._ms = range(o + sub.vector_indices_dict['mean'].start, o + sub.vector_indices_dict['mean'].stop)
+        self._ls = range(o + sub.vector_indices_dict['info'].start, o + sub.vector_indices_dict['info'].stop)
+        o = par.vector_indices_dict[lambda_name].start
+        sub = par[lambda_name]
+        self._inu = o + sub.vector_indices_dict['df'].start
+        self._vs = range(o + sub.vector_indices_dict['v'].start, o + sub.vector_indices_dict['v'].stop)
+        if len(self._ms) != d or len(self._ls) != mm or len(self._vs) != mm:
+            raise ValueError('parameter sizes do not match the data dimension {}'.format(d))
+        self.mu0 = np.zeros(d) if prior_mean is None else _hip.as_f64(prior_mean).ravel()
+        self.lam0 = np.eye(d) if prior_info is None else _hip.as_f64(prior_info)
+        self.nu0 = float(d + 2) if prior_df is None else float(prior_df)
+        self.w0 = np.eye(d) if prior_inv_scale is None else _hip.as_f64(prior_inv_scale)
+        self._dup = duplication_matrix(d)
+        super().__init__(par, np.hstack([y, np.ones((y.shape[0], 1))]), weights=weights, device=device)
+
+    def _unpack(self, eta):
+        d = self.d
+        m = eta[self._ms.start:self._ms.stop]
+        lam_mu = (self._dup @ eta[self._ls.start:self._ls.stop]).reshape(d, d)
+        nu = eta[self._inu]
+        v = (self._dup @ eta[self._vs.start:self._vs.stop]).reshape(d, d)
+        return m, lam_mu, nu, v
+
+    def _kappa(self, nu):
+        sp, d = self._special, self.d
+        args = 0.5 * nu - 0.5 * np.arange(d)
+        return (np.sum(sp.digamma(args)), 0.5 * np.sum(sp.polygamma(1, args)), 0.25 * np.sum(sp.polygamma(2, args)),
+                np.sum(sp.gammaln(args)) + 0.25 * np.log(np.pi) * d * (d - 1.0))
+
+    def _terms(self, eta, S, W):
+        d = self.d
+        m, lam_mu, nu, v = self._unpack(eta)
+        Syy, sy = S[:d, :d], S[:d, d]
+        s1, ld_mu = np.linalg.slogdet(lam_mu)
+        s2, ld_v = np.linalg.slogdet(v)
+        if s1 <= 0 or s2 <= 0:
+            raise ValueError('Matrix is not positive definite')
+        P = np.linalg.inv(lam_mu)
+        Vi = np.linalg.inv(v)
+        kap, kap1, kap2, lgam = self._kappa(nu)
+        A = Syy - np.outer(sy, m) - np.outer(m, sy) + W * np.outer(m, m)
+        B = A + self.w0
+        C = W * nu * v + self.lam0
+        alpha = 0.5 * (W + self.nu0 - d - 1.0)
+        gam = alpha + 0.5 * (d + 1.0)
+        dm = m - self.mu0
+        u = W * m - sy
+        e_log_det = kap + d * np.log(2.0) + ld_v
+        value = (0.5 * nu * np.sum(v * B) + 0.5 * np.sum(C * P) - alpha * e_log_det + 0.5 * dm @ self.lam0 @ dm
+                 + 0.5 * ld_mu - 0.5 * d * (1.0 + np.log(2.0 * np.pi))
+                 - 0.5 * (d + 1.0) * ld_v - 0.5 * d * (d + 1.0) * np.log(2.0) - lgam
+                 + 0.5 * (nu - d - 1.0) * kap - 0.5 * nu * d)
+        Vn = eta.size
+        g = np.zeros(Vn)
+        H = np.zeros((Vn, Vn))
+        ms, ls, vs = (slice(r.start, r.stop) for r in (self._ms, self._ls, self._vs))
+        inu = self._inu
+        Dup = self._dup
+        G = P @ C @ P
+        g[ms] = nu * (v @ u) + self.lam0 @ dm
+        g[ls] = Dup.T @ (-0.5 * G + 0.5 * P).ravel()
+        g[inu] = 0.5 * np.sum(v * B) + 0.5 * W * np.sum(v * P) - alpha * kap1 + 0.5 * (nu - d - 1.0) * kap1 - 0.5 * d
+        g[vs] = Dup.T @ (0.5 * nu * B + 0.5 * W * nu * P - gam * Vi).ravel()
+        H[ms, ms] = C
+        H[ms, inu] = H[inu, ms] = v @ u
+        Hmv = nu * np.kron(np.eye(d), u[None, :]) @ Dup
+        H[ms, vs] = Hmv
+        H[vs, ms] = Hmv.T
+        H[ls, ls] = Dup.T @ (0.5 * (np.kron(G, P) + np.kron(P, G)) - 0.5 * np.kron(P, P)) @ Dup
+        hln = Dup.T @ (-0.5 * W * (P @ v @ P)).ravel()
+        H[ls, inu] = H[inu, ls] = hln
+        Hlv = Dup.T @ (-0.5 * W * nu * np.kron(P, P)) @ Dup
+        H[ls, vs] = Hlv
+        H[vs, ls] = Hlv.T
+        H[inu, inu] = 0.5 * kap1 + (0.5 * (nu - d - 1.0) - alpha) * kap2
+        hnv = Dup.T @ (0.5 * B + 0.5 * W * P).ravel()
+        H[inu, vs] = H[vs, inu] = hnv
+        H[vs, vs] = Dup.T @ (gam * np.kron(Vi, Vi)) @ Dup
+        return value, g, H
+
+    def _obs_terms(self, eta):
+        d, q = self.d, self.q
+        m, lam_mu, nu, v = self._unpack(eta)
+        P = np.linalg.inv(lam_mu)
+        Vi = np.linalg.inv(v)
+        _, kap1, _, _ = self._kappa(nu)
+        Vn = eta.size
+        M = np.zeros((Vn, q, q))
+        c = np.zeros(Vn)
+        vm = v @ m
+        for i in range(d):
+            Mi = M[self._ms.start + i]
+            Mi[:d, d] = Mi[d, :d] = -nu * v[:, i]
+            Mi[d, d] = 2.0 * nu * vm[i]
+        PVP = P @ v @ P
+        r, cidx = np.tril_indices(d)
+        fac = np.where(r == cidx, 1.0, 2.0)
+        c[self._ls.start:self._ls.stop] = -0.5 * nu * PVP[r, cidx] * fac
+        Q0 = np.zeros((q, q))
+        Q0[:d, :d] = v
+        Q0[:d, d] = Q0[d, :d] = -vm
+        Q0[d, d] = m @ vm
+        M[self._inu] = Q0
+        c[self._inu] = 0.5 * np.sum(v * P) - 0.5 * kap1
+        cmat = 0.5 * nu * P - 0.5 * Vi
+        c[self._vs.start:self._vs.stop] = cmat[r, cidx] * fac
+        for k, (i, j) in enumerate(zip(r, cidx)):
+            Mk = M[self._vs.start + k]
+            Mk[i, j] += nu
+            if i != j:
+                Mk[j, i] += nu
+            Em = np.zeros(d)
+            Em[i] += m[j]
+            if i != j:
+                Em[j] += m[i]
+            Mk[:d, d] = Mk[d, :d] = -nu * Em
+            Mk[d, d] = nu * (m @ Em)
+        return M, c

@@ -115,3 +115,39 @@ def mvn_regression_objective(x, y, k, mu0, lam0, a0, b0, layout=None):
         gamma_entropy = a - torch.log(b) + torch.lgamma(a) + (1.0 - a) * torch.special.digamma(a)
         return -(e_log_lik + mvn_prior + gamma_prior + mvn_entropy + gamma_entropy)
     return f
+
+
+def wishart_mvn_objective(y, d, mu0, lam0, nu0, w0, layout=None):
+    """Config 5 (-ELBO of the Wishart + MVN full-covariance model) in torch as f(point, w); point =
+    eta = [m (d), tril(Lambda_mu), nu, tril(V)] or the free vector when `layout` is given."""
+    yt = torch.tensor(y)
+    mu0t, lam0t, w0t = torch.tensor(mu0), torch.tensor(lam0), torch.tensor(w0)
+    idx = torch.tril_indices(d, d)
+    mm = d * (d + 1) // 2
+    half_i = 0.5 * torch.arange(d, dtype=torch.float64)
+
+    def sym(vec):
+        ll = torch.zeros(d, d, dtype=vec.dtype).index_put((idx[0], idx[1]), vec)
+        return ll + ll.T - torch.diag(torch.diagonal(ll))
+
+    def f(point, w):
+        eta = constrain(point, layout) if layout is not None else point
+        m = eta[:d]
+        lam_mu = sym(eta[d:d + mm])
+        nu = eta[d + mm]
+        v = sym(eta[d + mm + 1:])
+        sigma_mu = torch.linalg.inv(lam_mu)
+        mdig = torch.sum(torch.special.digamma(0.5 * nu - half_i))
+        mlgam = torch.sum(torch.lgamma(0.5 * nu - half_i)) + 0.25 * math.log(math.pi) * d * (d - 1.0)
+        e_log_det = mdig + d * math.log(2.0) + torch.logdet(v)
+        r = yt - m
+        quad = torch.einsum('ni,ij,nj->n', r, v, r)
+        e_log_lik = torch.sum(w * (-0.5 * nu * (quad + torch.trace(v @ sigma_mu)) + 0.5 * e_log_det))
+        dm = m - mu0t
+        mvn_prior = -0.5 * (dm @ lam0t @ dm + torch.trace(lam0t @ sigma_mu))
+        wishart_prior = 0.5 * (nu0 - d - 1.0) * e_log_det - 0.5 * nu * torch.trace(w0t @ v)
+        mvn_entropy = 0.5 * (-torch.logdet(lam_mu) + d + d * math.log(2 * math.pi))
+        wishart_entropy = (0.5 * (d + 1) * torch.logdet(v) + 0.5 * d * (d + 1) * math.log(2.0) + mlgam
+                           - 0.5 * (nu - d - 1.0) * mdig + 0.5 * nu * d)
+        return -(e_log_lik + mvn_prior + wishart_prior + mvn_entropy + wishart_entropy)
+    return f
