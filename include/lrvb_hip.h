@@ -202,6 +202,13 @@ int lrvb_weighted_gram(lrvb_ctx* ctx, double* S_out, int64_t ld);
 int lrvb_obs_quadform(lrvb_ctx* ctx, const double* M, const double* c, int64_t K,
                       int64_t n0, int64_t n1, double* out);
 
+/* Gram matrix G^T G (D x D, free coordinates) of the per-observation gradients
+ * g_n[k] = 1/2 z_n^T M_k z_n + c_k (K = V matrices, one per vector coordinate): the Kronecker rows
+ * z_n (x) z_n are generated on chip and contracted on the fp64 matrix cores; G (N x D) is never
+ * materialised (BASELINE.json config 5).  n_cols <= 64.                                        */
+int lrvb_quadform_gram(lrvb_ctx* ctx, const double* M, const double* c, int64_t K,
+                       const double* free_in, double* GtG_out, int64_t ld);
+
 /* ---- linear-response solve ------------------------------------------------------------ */
 /* scipy.linalg.cho_factor at LRVB/ModelSensitivity.py:594 / SparseObjectives.py:539.
  * The factor stays on the device inside the context.                                        */
@@ -226,6 +233,12 @@ int lrvb_lrvb_cov   (lrvb_ctx* ctx, const double* M, int64_t Q, int64_t D, doubl
 int lrvb_cg_solve(lrvb_ctx* ctx, const double* free_in, const double* b, const double* x0,
                   const double* Minv, double tol, int64_t maxiter, int64_t D,
                   double* x_out, int* info_out, int64_t* iters_out);
+
+/* The same conjugate-gradient loop on a dense symmetric D x D matrix kept on the device (Hessians
+ * assembled from sufficient statistics).  H == NULL reuses the matrix of the previous call.   */
+int lrvb_cg_solve_matrix(lrvb_ctx* ctx, const double* H, const double* b, const double* x0,
+                         const double* Minv, double tol, int64_t maxiter, int64_t D,
+                         double* x_out, int* info_out, int64_t* iters_out);
 
 /* ---- device-resident / multi-GPU entry points -----------------------------------------
  * Observations shard over ranks (one process, one context per GPU).  A build is

@@ -85,7 +85,8 @@ class ConjugateGradientSolver(object):
             objective, fun = self._device
             fun._push_state()
             minv = None if self.preconditioner is None else np.asarray(self.preconditioner, dtype=np.float64)
-            hinv_vec, cg_info, _ = fun.ctx.cg_solve(self.x0, vec, x0=x0, Minv=minv, tol=self.tol)
+            solve = fun.cg_solve if hasattr(fun, 'cg_solve') else fun.ctx.cg_solve
+            hinv_vec, cg_info, _ = solve(self.x0, vec, x0=x0, Minv=minv, tol=self.tol)
             objective.par.set_free(self.x0)
             return hinv_vec, cg_info
         return scipy.sparse.linalg.cg(self.ObjHessVecProdLO, vec, x0=x0, rtol=self.tol, atol=0.0,

@@ -571,6 +571,222 @@ static int launch_gram_small(lrvb_ctx* c, const double* cvec_dev, double* tiles_
     return LRVB_OK;
 }
 
+__global__ void wsyrk_reduce_kernel(const double* __restrict__ partial, int n_splits, i64 tile_elems_total,
+                                    double* __restrict__ tiles);
+
+// ---- Kronecker-row variant: K4 = sum_n c_n (z_n (x) z_n)(z_n (x) z_n)^T ---------------------------
+// The Gram matrix G^T G of per-observation gradients of an objective that is QUADRATIC IN THE DATA
+// (g_n[k] = 1/2 z_n^T M_k z_n + c_k) is M~^T K4 M~ (+ rank-one terms), where K4 is the weighted SYRK
+// of the VIRTUAL N x 64 q matrix whose row n is z_n (x) z_n (column v = 64 a + b <-> z_na z_nb).
+// The virtual rows are generated on chip and never touch HBM (BASELINE.json config 5: D = 4096,
+// N P (P+1) = 1.7e13 flops from 0.5 GB of data).  Same tiling and queue order as wsyrk_glds_kernel;
+// the stage is just the 16 x 64 block of z (zero-padded past q) plus c, and the MFMA operands are
+// formed at fragment-read time:  A[i][k] = c_k z_k[a_w] z_k[16 m + i],  B[k][j] = z_k[b_w] z_k[16 n + j]
+// -- the four z_k[16 m + i] reads serve both operands.
+constexpr int KR_STRIDE = 80;            // 64 z values + c at [64]; (stride mod 32) == 16 -> conflict-free
+
+__global__ __launch_bounds__(WS_THREADS, 2)
+void wsyrk_kron_kernel(const double* __restrict__ Z, i64 ldz, i64 N, int q,
+                       const double* __restrict__ cpad, int n_splits, int nb, i64 rows_per_split,
+                       double* __restrict__ partial)
+{
+    __shared__ double lds[2 * WS_KC * KR_STRIDE];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7;
+    const int qpos = blockIdx.x >> 3;
+    const int S8 = n_splits >> 3;
+    const int n_off = nb * (nb - 1) / 2;
+    int bi, bj, split_local;
+    if (qpos < n_off * S8) {
+        split_local = qpos / n_off;
+        const int u = qpos - split_local * n_off;
+        bi = (int)((1.f + sqrtf(1.f + 8.f * (float)u)) * 0.5f);
+        while (bi * (bi - 1) / 2 > u) --bi;
+        while ((bi + 1) * bi / 2 <= u) ++bi;
+        bj = u - bi * (bi - 1) / 2;
+    } else {
+        const int qd = qpos - n_off * S8;
+        split_local = qd / nb;
+        bi = bj = qd - split_local * nb;
+    }
+    const bool diag = (bi == bj);
+    const int t = bi * (bi + 1) / 2 + bj;
+    const int T = nb * (nb + 1) / 2;
+    const int split = split_local * 8 + xcd;
+    i64 r0 = (i64)split * rows_per_split;
+    i64 r1 = r0 + rows_per_split;
+    if (r1 > N) r1 = N;
+    if (r0 > N) r0 = N;
+    const int nch = (int)((r1 - r0 + WS_KC - 1) / WS_KC);
+
+    d4 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
+
+    // stage: thread -> (row = tid >> 4, columns 4 seg .. 4 seg + 3), branch-free clamped loads
+    const int srow = tid >> 4, seg = tid & 15;
+    double sv[4], sc;
+    auto load_stage = [&](int ch) {
+        i64 n = r0 + (i64)ch * WS_KC + srow;
+        sc = cpad[n];                                     // zero padding past N
+        if (n > N - 1) n = N - 1;
+        const double* rowp = Z + n * ldz;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int col = 4 * seg + j; sv[j] = rowp[col < q ? col : 0]; }
+    };
+    auto store_stage = [&](int buf) {
+        asm volatile("" : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3]), "+v"(sc));
+        double* dst = lds + buf * (WS_KC * KR_STRIDE) + srow * KR_STRIDE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int col = 4 * seg + j; dst[col] = col < q ? sv[j] : 0.0; }
+        if (seg == 0) dst[64] = sc;
+    };
+
+    if (nch > 0) { load_stage(0); store_stage(0); }
+    __syncthreads();
+
+    const int l15 = lane & 15, l4 = lane >> 4;
+    int buf = 0;
+    if (!diag) {
+        const int wr = wave >> 1, wc = wave & 1;
+        const int a_w = 2 * bi + wr, b_w = 2 * bj + wc;     // the "outer" Kronecker index of this wave's rows / columns
+        for (int ch = 0; ch < nch; ++ch) {
+            const bool more = ch + 1 < nch;
+            if (more) load_stage(ch + 1);
+            const double* zs = lds + buf * (WS_KC * KR_STRIDE);
+            double zv[2][4], za[2], zb[2];
+            auto read_frags = [&](int kk, int set) {
+                const double* rowp = zs + (kk * 4 + l4) * KR_STRIDE;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) zv[set][m] = rowp[16 * m + l15];
+                za[set] = rowp[a_w] * rowp[64];
+                zb[set] = rowp[b_w];
+            };
+            read_frags(0, 0);
+#pragma unroll
+            for (int kk = 0; kk < WS_KC / 4; ++kk) {
+                const int set = kk & 1;
+                double af[4], bf[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) { af[m] = zv[set][m] * za[set]; bf[m] = zv[set][m] * zb[set]; }
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk + 1 < WS_KC / 4) read_frags(kk + 1, set ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        acc[m * 4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m], bf[n], acc[m * 4 + n], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (more) store_stage(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+        double* out = partial + ((i64)split * T + t) * (i64)(WS_TILE * WS_TILE);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    out[(wr * 64 + m * 16 + l4 + 4 * r) * WS_TILE + wc * 64 + n * 16 + l15] = acc[m * 4 + n][r];
+    } else {
+        const int rb0 = wave, rb1 = 7 - wave;
+        const int a0i = 2 * bi + (rb0 >> 2), a1i = 2 * bi + (rb1 >> 2);
+        for (int ch = 0; ch < nch; ++ch) {
+            const bool more = ch + 1 < nch;
+            if (more) load_stage(ch + 1);
+            const double* zs = lds + buf * (WS_KC * KR_STRIDE);
+            double zv[2][4], s0[2], s1[2], zlo[2], zhi[2];
+            auto read_frags = [&](int kk, int set) {
+                const double* rowp = zs + (kk * 4 + l4) * KR_STRIDE;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) zv[set][m] = rowp[16 * m + l15];
+                const double cv = rowp[64];
+                s0[set] = rowp[a0i] * cv;
+                s1[set] = rowp[a1i] * cv;
+                zlo[set] = rowp[2 * bi];
+                zhi[set] = rowp[2 * bi + 1];
+            };
+            read_frags(0, 0);
+#pragma unroll
+            for (int kk = 0; kk < WS_KC / 4; ++kk) {
+                const int set = kk & 1;
+                // A fragments of row blocks rb0 / rb1: z[16 (rb & 3) + i] * (z[a] c); B fragment n: z[16 (n & 3) + j] * z[2 bi + (n >> 2)]
+                double a0 = 0.0, a1 = 0.0, bf[8];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    if ((rb0 & 3) == m) a0 = zv[set][m] * s0[set];
+                    if ((rb1 & 3) == m) a1 = zv[set][m] * s1[set];
+                    bf[m] = zv[set][m] * zlo[set];
+                    bf[4 + m] = zv[set][m] * zhi[set];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk + 1 < WS_KC / 4) read_frags(kk + 1, set ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    if (n <= rb0) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bf[n], acc[n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < 8; ++n)
+                    if (n <= rb1) acc[4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bf[n], acc[4 + n], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (more) store_stage(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+        double* out = partial + ((i64)split * T + t) * (i64)(WS_TILE * WS_TILE);
+#pragma unroll
+        for (int n = 0; n < 8; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double v0 = (n < 4 && n <= rb0) ? acc[n < 4 ? n : 0][r] : 0.0;
+                const double v1 = (n <= rb1) ? acc[4 + n][r] : 0.0;
+                out[(rb0 * 16 + l4 + 4 * r) * WS_TILE + n * 16 + l15] = v0;
+                out[(rb1 * 16 + l4 + 4 * r) * WS_TILE + n * 16 + l15] = v1;
+            }
+    }
+}
+
+// K4 tiles (virtual dimension Pv = 64 q, nb = ceil(q / 2) tile rows) from the context's data matrix.
+int launch_wsyrk_kron(lrvb_ctx* c, const double* cvec_dev, double* tiles_out_dev) {
+    const int q = (int)c->P;
+    if (q > 64) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "Kronecker Gram kernel supports n_cols <= 64 (got %d)", q);
+    const int nb = (q + 1) / 2;
+    const int T = nb * (nb + 1) / 2;
+    i64 S = (4608 + T / 2) / T;
+    S = ((S + 7) / 8) * 8;
+    i64 max_by_rows = (c->N / 256 / 8) * 8;
+    if (S > max_by_rows) S = max_by_rows;
+    if (S > 128) S = 128;
+    if (S < 8) S = 8;
+    i64 rps = (c->N + S - 1) / S;
+    rps = ((rps + WS_KC - 1) / WS_KC) * WS_KC;
+    const i64 tile_elems = (i64)T * WS_TILE * WS_TILE;
+    LRVB_TRY(buf_reserve(c, c->tile_part, (size_t)(tile_elems * S)));
+    if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
+    hipLaunchKernelGGL(wsyrk_kron_kernel, dim3((unsigned)(S * T)), dim3(WS_THREADS), 0, c->stream,
+                       c->X.p, c->P, c->N, q, cvec_dev, (int)S, nb, rps, c->tile_part.p);
+    HIP_TRY(hipGetLastError());
+    if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
+    const i64 nthreads = tile_elems / 2;
+    hipLaunchKernelGGL(wsyrk_reduce_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, c->stream,
+                       c->tile_part.p, (int)S, tile_elems, tiles_out_dev);
+    HIP_TRY(hipGetLastError());
+    if (c->prof_on) {
+        const double pv = 64.0 * q;
+        c->prof.wsyrk_flops = (double)c->N * pv * (pv + 1.0);
+        c->prof.wsyrk_bytes = 8.0 * (double)c->N * (q + 1.0) + 8.0 * 0.5 * pv * (pv + 1.0);
+    }
+    return LRVB_OK;
+}
+
 // Deterministic second stage: tiles[t][e] = sum_s partial[s][t][e]  (fixed order).
 __global__ __launch_bounds__(256)
 void wsyrk_reduce_kernel(const double* __restrict__ partial, int n_splits, i64 tile_elems_total,

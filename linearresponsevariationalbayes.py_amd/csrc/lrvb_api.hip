@@ -169,7 +169,7 @@ extern "C" int lrvb_ctx_destroy(lrvb_ctx* c) {
     DevBuf* all[] = { &c->X, &c->y, &c->w, &c->quadA, &c->quadM, &c->quadB, &c->theta, &c->eta, &c->j1, &c->j2,
                       &c->vtmp, &c->vtmp2, &c->vtmp3, &c->g_eta, &c->g_free, &c->lp, &c->cw, &c->zbuf,
                       &c->part_vec, &c->part_val, &c->stats, &c->tile_part, &c->Heta, &c->Hfree, &c->Jdense,
-                      &c->Tdense, &c->work1, &c->chol, &c->cholW, &c->rhs, &c->cgx, &c->cgr, &c->cgp, &c->cgq, &c->cgz, &c->scal };
+                      &c->Tdense, &c->work1, &c->chol, &c->cholW, &c->cgH, &c->rhs, &c->cgx, &c->cgr, &c->cgp, &c->cgq, &c->cgz, &c->scal };
     for (DevBuf* b : all) buf_free(*b);
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
     for (int k = 0; k < 3; ++k) for (hipEvent_t e : c->ev_pool[k]) (void)hipEventDestroy(e);
@@ -792,6 +792,170 @@ extern "C" int lrvb_obs_quadform(lrvb_ctx* c, const double* M, const double* cve
         HIP_TRY(hipGetLastError());
         LRVB_TRY(d2h(c, out + (a - n0) * K, c->rhs.p, (size_t)rows * (size_t)K));
     }
+    return LRVB_OK;
+}
+
+// Gram matrix of per-observation gradients g_n[k] = 1/2 z_n^T M_k z_n + c_k, in FREE coordinates:
+//   G^T G = J^T ( 1/4 M~^T K4 M~ + 1/2 (t c^T + c t^T) + N c c^T ) J,   t = M~^T s,
+// K4 = sum_n (z_n (x) z_n)(z_n (x) z_n)^T from the Kronecker-row MFMA kernel, s = vec(sum_n z_n z_n^T),
+// M~ (64 q x V) holds vec(M_k) in the virtual index v = 64 a + b.  Everything stays on the device.
+__global__ void mtilde_kernel(const double* __restrict__ M, i64 V, int q, double* __restrict__ Mt /* (64 q) x V */) {
+    const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 v = blockIdx.y;                       // virtual row index 64 a + b
+    if (k >= V) return;
+    const int a = (int)(v >> 6), b = (int)(v & 63);
+    Mt[v * V + k] = (b < q) ? M[k * (i64)q * q + a * q + b] : 0.0;
+}
+__global__ void svec_kernel(const double* __restrict__ S1 /* q x q */, int q, double* __restrict__ sv /* 64 q */) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= 64 * q) return;
+    const int a = v >> 6, b = v & 63;
+    sv[v] = (b < q) ? S1[a * q + b] : 0.0;
+}
+__global__ void rank_terms_kernel(i64 V, double n_obs, const double* __restrict__ t, const double* __restrict__ cvec,
+                                  double* __restrict__ A /* V x V, holds M~^T K4 M~ */) {
+    const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 i = blockIdx.y;
+    if (j >= V) return;
+    A[i * V + j] = 0.25 * A[i * V + j] + 0.5 * (t[i] * cvec[j] + cvec[i] * t[j]) + n_obs * cvec[i] * cvec[j];
+}
+
+extern "C" int lrvb_quadform_gram(lrvb_ctx* c, const double* M, const double* cvec, int64_t K,
+                                  const double* free_in, double* GtG_out, int64_t ld) {
+    LRVB_TRY(ctx_bind(c));
+    if (!M || !cvec || !free_in || !GtG_out) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    if (c->loss == LRVB_LOSS_NONE || !c->have_X) LRVB_FAIL(LRVB_ERR_STATE, "no data matrix: call lrvb_set_data(LRVB_SLOT_X) first");
+    if (K != c->V) LRVB_FAIL(LRVB_ERR_SIZE, "expected one matrix per vector coordinate (%lld), got %lld", (long long)c->V, (long long)K);
+    if (c->P > 64) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "Kronecker Gram kernel supports n_cols <= 64");
+    if (ld < c->D) LRVB_FAIL(LRVB_ERR_SIZE, "leading dimension too small");
+    const int q = (int)c->P;
+    const i64 V = c->V, D = c->D, Pv = 64 * (i64)q;
+    const int nbk = (q + 1) / 2;
+    const i64 Pv_t = (i64)nbk * WS_TILE;                 // tile-padded virtual dimension (>= Pv)
+    // unweighted sums: c_n = 1 (zero padded)
+    LRVB_TRY(reserve_obs_vec(c, c->zbuf));
+    EW(fill_kernel, c->N, 1.0, c->zbuf.p);
+    // s = vec(Z^T Z) through the narrow Gram kernel
+    LRVB_TRY(buf_reserve(c, c->stats, 1 + (size_t)c->P + (size_t)WS_TILE * WS_TILE));
+    double* tile0 = c->stats.p + 1 + c->P;
+    LRVB_TRY(launch_wsyrk(c, c->zbuf.p, tile0));
+    LRVB_TRY(buf_reserve(c, c->vtmp, (size_t)(q * q > V ? q * q : V)));
+    LRVB_TRY(launch_tiles_to_dense(c, tile0, q, c->vtmp.p, q, 0, 0, false));
+    LRVB_TRY(buf_reserve(c, c->vtmp2, (size_t)(Pv_t > V ? Pv_t : V)));
+    HIP_TRY(hipMemsetAsync(c->vtmp2.p, 0, (size_t)Pv_t * sizeof(double), c->stream));
+    hipLaunchKernelGGL(svec_kernel, dim3(nb256(Pv)), dim3(256), 0, c->stream, c->vtmp.p, q, c->vtmp2.p);
+    HIP_TRY(hipGetLastError());
+    // K4 (dense, Pv_t x Pv_t)
+    const size_t tiles_n = (size_t)nbk * (nbk + 1) / 2 * WS_TILE * WS_TILE;
+    LRVB_TRY(buf_reserve(c, c->Tdense, tiles_n));
+    LRVB_TRY(launch_wsyrk_kron(c, c->zbuf.p, c->Tdense.p));
+    LRVB_TRY(buf_reserve(c, c->Heta, (size_t)Pv_t * (size_t)Pv_t));
+    LRVB_TRY(launch_tiles_to_dense(c, c->Tdense.p, Pv_t, c->Heta.p, Pv_t, 0, 0, false));
+    // M~ (Pv_t x V), uploaded through a staging buffer
+    LRVB_TRY(buf_reserve(c, c->work1, (size_t)V * (size_t)q * (size_t)q));
+    LRVB_TRY(h2d(c, c->work1.p, M, (size_t)V * (size_t)q * (size_t)q));
+    LRVB_TRY(buf_reserve(c, c->Jdense, (size_t)Pv_t * (size_t)V > (size_t)V * (size_t)D ? (size_t)Pv_t * (size_t)V : (size_t)V * (size_t)D));
+    DevBuf Mt;                                            // scoped device buffers for this call
+    LRVB_TRY(buf_reserve(c, Mt, (size_t)Pv_t * (size_t)V));
+    HIP_TRY(hipMemsetAsync(Mt.p, 0, (size_t)Pv_t * (size_t)V * sizeof(double), c->stream));
+    {
+        dim3 grid(nb256(V), (unsigned)Pv);
+        hipLaunchKernelGGL(mtilde_kernel, grid, dim3(256), 0, c->stream, c->work1.p, V, q, Mt.p);
+    }
+    int st = (hipGetLastError() == hipSuccess) ? LRVB_OK : LRVB_ERR_HIP;
+    DevBuf T1, Av;
+    if (st == LRVB_OK) st = buf_reserve(c, T1, (size_t)Pv_t * (size_t)V);
+    if (st == LRVB_OK) st = buf_reserve(c, Av, (size_t)V * (size_t)V);
+    // T1 = K4 M~ ;  Av = M~^T T1 ;  t = M~^T s
+    if (st == LRVB_OK) st = launch_gemm(c, false, false, Pv_t, V, Pv_t, 1.0, c->Heta.p, Pv_t, Mt.p, V, 0.0, T1.p, V);
+    if (st == LRVB_OK) st = launch_gemm(c, true, false, V, V, Pv_t, 1.0, Mt.p, V, T1.p, V, 0.0, Av.p, V);
+    if (st == LRVB_OK) st = buf_reserve(c, c->vtmp3, (size_t)(V > D ? V : D));
+    if (st == LRVB_OK) st = launch_gemv(c, true, Pv_t, V, 1.0, Mt.p, V, c->vtmp2.p, 0.0, c->vtmp3.p);
+    if (st == LRVB_OK) st = h2d(c, c->g_eta.p, cvec, (size_t)V);
+    if (st == LRVB_OK) {
+        dim3 grid(nb256(V), (unsigned)V);
+        hipLaunchKernelGGL(rank_terms_kernel, grid, dim3(256), 0, c->stream, V, (double)c->N, c->vtmp3.p, c->g_eta.p, Av.p);
+        if (hipGetLastError() != hipSuccess) st = LRVB_ERR_HIP;
+    }
+    // free coordinates: J^T Av J
+    if (st == LRVB_OK) st = h2d(c, c->theta.p, free_in, (size_t)D);
+    if (st == LRVB_OK) st = launch_dense_jac(c, c->theta.p, c->Jdense.p);
+    if (st == LRVB_OK) st = launch_gemm(c, false, false, V, D, V, 1.0, Av.p, V, c->Jdense.p, D, 0.0, T1.p, D);
+    if (st == LRVB_OK) st = buf_reserve(c, c->Hfree, (size_t)D * (size_t)D);
+    if (st == LRVB_OK) st = launch_gemm(c, true, false, D, D, V, 1.0, c->Jdense.p, D, T1.p, D, 0.0, c->Hfree.p, D);
+    if (st == LRVB_OK) {
+        if (hipMemcpy2DAsync(GtG_out, (size_t)ld * 8, c->Hfree.p, (size_t)D * 8, (size_t)D * 8, (size_t)D, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess) { lrvb_set_error("copy back failed"); st = LRVB_ERR_HIP; }
+    } else {
+        (void)hipStreamSynchronize(c->stream);
+    }
+    buf_free(Mt); buf_free(T1); buf_free(Av);
+    return st;
+}
+
+// Conjugate gradients on a dense symmetric matrix held on the device (objectives whose Hessian is
+// assembled from sufficient statistics: the HVP is a D x D matrix-vector product).  H == NULL reuses
+// the matrix of the previous call.  Same stopping rule as lrvb_cg_solve.
+extern "C" int lrvb_cg_solve_matrix(lrvb_ctx* c, const double* H, const double* b, const double* x0,
+                                    const double* Minv, double tol, int64_t maxiter, int64_t D,
+                                    double* x_out, int* info_out, int64_t* iters_out) {
+    LRVB_TRY(ctx_bind(c));
+    if (!b || !x_out || D <= 0) LRVB_FAIL(LRVB_ERR_INVALID, "bad argument");
+    if (H) {
+        LRVB_TRY(buf_reserve(c, c->cgH, (size_t)D * (size_t)D));
+        LRVB_TRY(h2d(c, c->cgH.p, H, (size_t)D * (size_t)D));
+        c->cgH_n = D;
+    } else if (c->cgH_n != D) {
+        LRVB_FAIL(LRVB_ERR_STATE, "no %lld x %lld matrix resident: pass H once", (long long)D, (long long)D);
+    }
+    if (maxiter <= 0) maxiter = 10 * D;
+    DevBuf* vecs[] = { &c->rhs, &c->cgx, &c->cgr, &c->cgp, &c->cgq, &c->cgz };
+    for (DevBuf* v : vecs) LRVB_TRY(buf_reserve(c, *v, (size_t)D));
+    if (Minv) { LRVB_TRY(buf_reserve(c, c->Hfree, (size_t)D * (size_t)D)); LRVB_TRY(h2d(c, c->Hfree.p, Minv, (size_t)D * (size_t)D)); }
+    LRVB_TRY(h2d(c, c->rhs.p, b, (size_t)D));
+    double* s = c->scal.p;
+    double hs[4];
+    LRVB_TRY(launch_dot(c, c->rhs.p, c->rhs.p, D, s + 0));
+    if (x0) {
+        LRVB_TRY(h2d(c, c->cgx.p, x0, (size_t)D));
+        LRVB_TRY(launch_gemv(c, false, D, D, 1.0, c->cgH.p, D, c->cgx.p, 0.0, c->cgq.p));
+        LRVB_TRY(launch_axpby(c, D, 1.0, c->rhs.p, 0.0, c->cgr.p));
+        LRVB_TRY(launch_axpby(c, D, -1.0, c->cgq.p, 1.0, c->cgr.p));
+    } else {
+        HIP_TRY(hipMemsetAsync(c->cgx.p, 0, (size_t)D * sizeof(double), c->stream));
+        LRVB_TRY(launch_axpby(c, D, 1.0, c->rhs.p, 0.0, c->cgr.p));
+    }
+    LRVB_TRY(d2h(c, hs, s, 1));
+    const double bnorm = sqrt(hs[0]);
+    const double atol = tol * bnorm;
+    int info = 0; i64 it = 0;
+    double rho_prev = 0.0;
+    if (bnorm == 0.0) {
+        HIP_TRY(hipMemsetAsync(c->cgx.p, 0, (size_t)D * sizeof(double), c->stream));
+    } else {
+        info = (int)maxiter;
+        for (it = 0; it < maxiter; ++it) {
+            if (Minv) LRVB_TRY(launch_gemv(c, false, D, D, 1.0, c->Hfree.p, D, c->cgr.p, 0.0, c->cgz.p));
+            const double* z = Minv ? c->cgz.p : c->cgr.p;
+            LRVB_TRY(launch_dot(c, c->cgr.p, c->cgr.p, D, s + 1));
+            LRVB_TRY(launch_dot(c, c->cgr.p, z, D, s + 2));
+            LRVB_TRY(d2h(c, hs + 1, s + 1, 2));
+            if (sqrt(hs[1]) < atol) { info = 0; break; }
+            const double rho = hs[2];
+            if (it > 0) LRVB_TRY(launch_axpby(c, D, 1.0, z, rho / rho_prev, c->cgp.p));
+            else        LRVB_TRY(launch_axpby(c, D, 1.0, z, 0.0, c->cgp.p));
+            LRVB_TRY(launch_gemv(c, false, D, D, 1.0, c->cgH.p, D, c->cgp.p, 0.0, c->cgq.p));
+            LRVB_TRY(launch_dot(c, c->cgp.p, c->cgq.p, D, s + 3));
+            LRVB_TRY(d2h(c, hs + 3, s + 3, 1));
+            const double alpha = rho / hs[3];
+            LRVB_TRY(launch_axpby(c, D, alpha, c->cgp.p, 1.0, c->cgx.p));
+            LRVB_TRY(launch_axpby(c, D, -alpha, c->cgq.p, 1.0, c->cgr.p));
+            rho_prev = rho;
+        }
+    }
+    LRVB_TRY(d2h(c, x_out, c->cgx.p, (size_t)D));
+    if (info_out) *info_out = info;
+    if (iters_out) *iters_out = it;
     return LRVB_OK;
 }
 

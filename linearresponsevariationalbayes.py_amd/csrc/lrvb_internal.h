@@ -59,6 +59,7 @@ struct lrvb_ctx {
     DevBuf stats;                  // [value | g_glm (P) | S tiles]
     DevBuf tile_part;              // weighted-SYRK split partials
     DevBuf Heta, Hfree, Jdense, Tdense, work1;   // dense V x V / D x D scratch
+    DevBuf cgH; i64 cgH_n = 0;     // dense matrix of lrvb_cg_solve_matrix
     DevBuf chol, cholW;            // D x D Cholesky factor (lower); inverses of its 64 x 64 diagonal blocks
     bool chol_valid = false;
     i64 chol_n = 0;
@@ -104,6 +105,7 @@ int launch_obs_grad(lrvb_ctx* c, i64 n0, i64 n1, double* G_dev, int mode, const 
 int  wsyrk_num_tiles(i64 P);
 int  wsyrk_auto_splits(const lrvb_ctx* c);
 int  launch_wsyrk(lrvb_ctx* c, const double* cvec_dev, double* tiles_out_dev /* T*128*128 */);
+int  launch_wsyrk_kron(lrvb_ctx* c, const double* cvec_dev, double* tiles_out_dev /* nb = ceil(q/2) tile rows */);
 int  launch_tiles_to_dense(lrvb_ctx* c, const double* tiles_dev, i64 P, double* dense_dev, i64 ld,
                            i64 row_off, i64 col_off, bool accumulate);
 

@@ -201,6 +201,29 @@ class DeviceContext(object):
         _hip.check(self._lib.lrvb_obs_quadform(self._h, _hip.ptr(M), _hip.ptr(c), K, n0, n1, _hip.ptr(out)))
         return out
 
+    def quadform_gram(self, M, c, free):
+        M, c, f = _hip.as_f64(M), _hip.as_f64(c).ravel(), _hip.as_f64(free).ravel()
+        if M.shape != (self.V, self.n_cols, self.n_cols) or c.size != self.V:
+            raise ValueError('expected M of shape ({0}, {1}, {1}) and c of length {0}'.format(self.V, self.n_cols))
+        out = np.empty((self.D, self.D))
+        _hip.check(self._lib.lrvb_quadform_gram(self._h, _hip.ptr(M), _hip.ptr(c), self.V, _hip.ptr(f),
+                                                _hip.ptr(out), self.D))
+        return out
+
+    def cg_solve_matrix(self, H, b, x0=None, Minv=None, tol=1e-8, maxiter=0):
+        b = _hip.as_f64(b).ravel()
+        D = b.size
+        H = None if H is None else _hip.as_f64(H)
+        x0 = None if x0 is None else _hip.as_f64(x0).ravel()
+        Minv = None if Minv is None else _hip.as_f64(Minv)
+        x = np.empty(D)
+        info = ctypes.c_int(0)
+        iters = ctypes.c_int64(0)
+        _hip.check(self._lib.lrvb_cg_solve_matrix(self._h, _hip.ptr(H), _hip.ptr(b), _hip.ptr(x0), _hip.ptr(Minv),
+                                                  float(tol), int(maxiter), D, _hip.ptr(x),
+                                                  ctypes.byref(info), ctypes.byref(iters)))
+        return x, info.value, iters.value
+
     # -- solves ---------------------------------------------------------------------------
     def chol_factor(self, H):
         H = _hip.as_f64(H)

@@ -100,8 +100,31 @@ class QuadraticDataObjective(object):
             return H
         return self.ctx.free_hessian_from_vector(x, g, H)      # J^T H J + sum_k g_k d2 eta_k, on device
 
+    def _hessian_cached(self, x, is_free):
+        self._push_state()
+        key = (bool(is_free), np.asarray(x, dtype=np.float64).tobytes(), self._w_cache.tobytes())
+        if getattr(self, '_h_key', None) != key:
+            self._h_val = self.hessian(x, is_free)
+            self._h_key = key
+        return self._h_val
+
     def hvp(self, x, v, is_free):
-        return self.hessian(x, is_free) @ _hip.as_f64(v).ravel()
+        return self._hessian_cached(x, is_free) @ _hip.as_f64(v).ravel()
+
+    def gram(self, free_val):
+        """G^T G of the per-observation gradient matrix in free coordinates (Kronecker rows generated
+        on chip, contracted on the fp64 matrix cores)."""
+        M, c = self._obs_terms(self._eta(free_val, True))
+        return self.ctx.quadform_gram(M, c, free_val)
+
+    def cg_solve(self, free_val, b, x0=None, Minv=None, tol=1e-8, maxiter=0):
+        """H(free_val)^-1 b by conjugate gradients on the device; the Hessian is assembled once and
+        stays resident for further right-hand sides at the same point."""
+        H = self._hessian_cached(free_val, True)
+        resident = getattr(self, '_cg_key', None) == self._h_key
+        out = self.ctx.cg_solve_matrix(None if resident else H, b, x0=x0, Minv=Minv, tol=tol, maxiter=maxiter)
+        self._cg_key = self._h_key
+        return out
 
     def hyper_kind(self, hyper_par):
         if hyper_par is self.weights_par:
