@@ -202,6 +202,12 @@ int lrvb_weighted_gram(lrvb_ctx* ctx, double* S_out, int64_t ld);
 int lrvb_obs_quadform(lrvb_ctx* ctx, const double* M, const double* c, int64_t K,
                       int64_t n0, int64_t n1, double* out);
 
+/* Grouped sufficient statistics for hierarchical models (doc/lmm.lyx:105-160): group ids are set
+ * once (0 <= gid < n_groups); lrvb_group_sums returns, with the current weights, an
+ * n_groups x (1 + n_cols) matrix [ sum_g w | sum_g w z ].  n_cols <= 64.                        */
+int lrvb_set_groups(lrvb_ctx* ctx, const int32_t* gid, int64_t n, int64_t n_groups);
+int lrvb_group_sums(lrvb_ctx* ctx, double* out);
+
 /* Gram matrix G^T G (D x D, free coordinates) of the per-observation gradients
  * g_n[k] = 1/2 z_n^T M_k z_n + c_k (K = V matrices, one per vector coordinate): the Kronecker rows
  * z_n (x) z_n are generated on chip and contracted on the fp64 matrix cores; G (N x D) is never

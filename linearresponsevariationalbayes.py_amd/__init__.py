@@ -38,5 +38,6 @@ from . import cg as ConjugateGradient
 from . import optim as OptimizationUtils
 from . import expfam as ExponentialFamilies
 from . import families as NormalParams
+from .hierarchical import LMMObjective
 from . import regression as regression_utils
 from . import distributed

@@ -77,6 +77,8 @@ _SIGNATURES = {
     'lrvb_gram': [_VP, _VP, c_i64, _VP, c_i64],
     'lrvb_weighted_gram': [_VP, _VP, c_i64],
     'lrvb_obs_quadform': [_VP, _VP, _VP, c_i64, c_i64, c_i64, _VP],
+    'lrvb_set_groups': [_VP, _VP, c_i64, c_i64],
+    'lrvb_group_sums': [_VP, _VP],
     'lrvb_quadform_gram': [_VP, _VP, _VP, c_i64, _VP, _VP, c_i64],
     'lrvb_cg_solve_matrix': [_VP, _VP, _VP, _VP, _VP, ctypes.c_double, c_i64, c_i64, _VP,
                              ctypes.POINTER(ctypes.c_int), ctypes.POINTER(c_i64)],

@@ -169,7 +169,7 @@ extern "C" int lrvb_ctx_destroy(lrvb_ctx* c) {
     DevBuf* all[] = { &c->X, &c->y, &c->w, &c->quadA, &c->quadM, &c->quadB, &c->theta, &c->eta, &c->j1, &c->j2,
                       &c->vtmp, &c->vtmp2, &c->vtmp3, &c->g_eta, &c->g_free, &c->lp, &c->cw, &c->zbuf,
                       &c->part_vec, &c->part_val, &c->stats, &c->tile_part, &c->Heta, &c->Hfree, &c->Jdense,
-                      &c->Tdense, &c->work1, &c->chol, &c->cholW, &c->cgH, &c->rhs, &c->cgx, &c->cgr, &c->cgp, &c->cgq, &c->cgz, &c->scal };
+                      &c->Tdense, &c->work1, &c->chol, &c->cholW, &c->cgH, &c->groups, &c->rhs, &c->cgx, &c->cgr, &c->cgp, &c->cgq, &c->cgz, &c->scal };
     for (DevBuf* b : all) buf_free(*b);
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
     for (int k = 0; k < 3; ++k) for (hipEvent_t e : c->ev_pool[k]) (void)hipEventDestroy(e);
@@ -793,6 +793,77 @@ extern "C" int lrvb_obs_quadform(lrvb_ctx* c, const double* M, const double* cve
         LRVB_TRY(d2h(c, out + (a - n0) * K, c->rhs.p, (size_t)rows * (size_t)K));
     }
     return LRVB_OK;
+}
+
+// ---- grouped sufficient statistics (hierarchical models: BASELINE.json config 4) -----------------
+// out[g, 0] = sum_{n in g} w_n,  out[g, 1 + j] = sum_{n in g} w_n z_nj.  One wavefront per group walks
+// the group's rows in a fixed order (counting-sort permutation built once on the host when the group
+// ids are set), lane = column: deterministic, no atomics.  These are the per-group Sigma w, Sigma w y,
+// Sigma w x of doc/lmm.lyx:105-160.
+__global__ __launch_bounds__(256)
+void group_sums_kernel(const double* __restrict__ Z, i64 ldz, int q, const double* __restrict__ w,
+                       const i64* __restrict__ perm, const i64* __restrict__ offs, i64 n_groups,
+                       double* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const i64 g = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= n_groups) return;
+    const i64 b = offs[g], e = offs[g + 1];
+    double sw = 0.0, s0 = 0.0;                  // lane j < q accumulates column j; every lane tracks sum w
+    i64 k = b;
+    for (; k + 1 < e; k += 2) {                 // two rows in flight
+        const i64 n0 = perm[k], n1 = perm[k + 1];
+        const double w0 = w[n0], w1 = w[n1];
+        const double z0 = lane < q ? Z[n0 * ldz + lane] : 0.0;
+        const double z1 = lane < q ? Z[n1 * ldz + lane] : 0.0;
+        sw += w0; s0 += w0 * z0;
+        sw += w1; s0 += w1 * z1;
+    }
+    if (k < e) {
+        const i64 n0 = perm[k];
+        const double w0 = w[n0];
+        sw += w0; s0 += w0 * (lane < q ? Z[n0 * ldz + lane] : 0.0);
+    }
+    double* dst = out + g * (i64)(q + 1);
+    if (lane == 0) dst[0] = sw;
+    if (lane < q) dst[1 + lane] = s0;
+}
+
+extern "C" int lrvb_set_groups(lrvb_ctx* c, const int32_t* gid, int64_t n, int64_t n_groups) {
+    LRVB_TRY(ctx_bind(c));
+    if (!gid || n != c->N || n_groups <= 0) LRVB_FAIL(LRVB_ERR_SIZE, "group ids must have %lld entries and n_groups > 0", (long long)c->N);
+    if (c->P > 64) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "grouped sums support n_cols <= 64");
+    std::vector<i64> offs((size_t)n_groups + 1, 0), perm((size_t)n);
+    for (i64 i = 0; i < n; ++i) {
+        if (gid[i] < 0 || gid[i] >= n_groups) LRVB_FAIL(LRVB_ERR_INVALID, "group id %d of row %lld outside [0, %lld)", gid[i], (long long)i, (long long)n_groups);
+        offs[(size_t)gid[i] + 1]++;
+    }
+    for (i64 g = 0; g < n_groups; ++g) offs[(size_t)g + 1] += offs[(size_t)g];
+    std::vector<i64> cur(offs.begin(), offs.end() - 1);
+    for (i64 i = 0; i < n; ++i) perm[(size_t)cur[(size_t)gid[i]]++] = i;      // stable: rows of a group keep their order
+    const size_t words = (size_t)n + (size_t)n_groups + 1;
+    LRVB_TRY(buf_reserve(c, c->groups, words));          // i64 and double are both 8 bytes
+    i64* dev = reinterpret_cast<i64*>(c->groups.p);
+    HIP_TRY(hipMemcpyAsync(dev, perm.data(), (size_t)n * sizeof(i64), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(dev + n, offs.data(), ((size_t)n_groups + 1) * sizeof(i64), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->n_groups = n_groups;
+    return LRVB_OK;
+}
+
+extern "C" int lrvb_group_sums(lrvb_ctx* c, double* out) {
+    LRVB_TRY(ctx_bind(c));
+    if (!out) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    if (c->n_groups <= 0) LRVB_FAIL(LRVB_ERR_STATE, "no groups: call lrvb_set_groups first");
+    if (!c->have_X) LRVB_FAIL(LRVB_ERR_STATE, "no data matrix");
+    const i64 G = c->n_groups;
+    const size_t n_out = (size_t)G * (size_t)(c->P + 1);
+    LRVB_TRY(buf_reserve(c, c->work1, n_out));
+    const i64* dev = reinterpret_cast<const i64*>(c->groups.p);
+    hipLaunchKernelGGL(group_sums_kernel, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, c->stream,
+                       c->X.p, c->P, (int)c->P, c->w.p, dev, dev + c->N, G, c->work1.p);
+    HIP_TRY(hipGetLastError());
+    return d2h(c, out, c->work1.p, n_out);
 }
 
 // Gram matrix of per-observation gradients g_n[k] = 1/2 z_n^T M_k z_n + c_k, in FREE coordinates:

@@ -59,6 +59,7 @@ struct lrvb_ctx {
     DevBuf stats;                  // [value | g_glm (P) | S tiles]
     DevBuf tile_part;              // weighted-SYRK split partials
     DevBuf Heta, Hfree, Jdense, Tdense, work1;   // dense V x V / D x D scratch
+    DevBuf groups; i64 n_groups = 0;   // [perm (N) | offsets (G+1)] as int64
     DevBuf cgH; i64 cgH_n = 0;     // dense matrix of lrvb_cg_solve_matrix
     DevBuf chol, cholW;            // D x D Cholesky factor (lower); inverses of its 64 x 64 diagonal blocks
     bool chol_valid = false;

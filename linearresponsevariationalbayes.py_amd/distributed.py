@@ -71,6 +71,20 @@ class ShardedHessian(object):
         return self.engine.finish(theta, stats)
 
 
+def allreduce_stats(flat, torch_device=None, group=None):
+    """Sum a flat float64 statistics vector over all ranks (sufficient statistics of the
+    quadratic-in-data and hierarchical objectives: `LMMObjective.local_stats()`), returning a numpy
+    array.  With the `nccl` backend pass the rank's CUDA device; with `gloo` leave it None."""
+    import torch
+    import torch.distributed as dist
+    t = torch.from_numpy(np.ascontiguousarray(flat, dtype=np.float64).copy())
+    if torch_device is not None:
+        t = t.to(torch_device)
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t.cpu().numpy()
+
+
 def stats_layout(n_cols):
     """(offset of value, offset of gradient, offset of tiles, total) in doubles; mirrors
     lrvb_stats_size in csrc/lrvb_api.hip."""

@@ -1,0 +1,295 @@
+"""Hierarchical linear mixed model (BASELINE.json config 4; doc/lmm.lyx:77-160 of the reference):
+
+    y_i ~ N(x_i^T beta + u_{g[i]}, tau_y^-1),   u_g ~ N(mu, tau_mu^-1),   i = 1..N,  g = 1..G
+
+with q(beta) = MVNParam(p), q(mu) = UVNParam, q(tau_y), q(tau_mu) = GammaParam,
+q(u) = UVNParamVector(G) (LRVB/NormalParams.py:6-76, GammaParams.py:4-16).  The -ELBO is a function
+of the weighted sufficient statistics only (doc/lmm.lyx:105-160):
+
+    S = sum_i w_i z_i z_i^T (z = [x; y]),  W = sum_i w_i,   per group: W_g, sum_g w y, sum_g w x
+
+which the GPU produces in two streaming passes per weight vector (`lrvb_weighted_gram`,
+`lrvb_group_sums`); across GPUs they are summed with one all-reduce.
+The Hessian has ARROW structure -- a dense global block (p + p(p+1)/2 + 6 parameters) bordered by G
+diagonal 2 x 2 local blocks -- so besides the dense Hessian the reference would build (used here at
+small sizes for parity) the class exposes the Schur complement onto the global block, which is what
+linear response needs for global moments at G = 1e4.
+"""
+import numpy as np
+from scipy import special
+
+from . import _hip
+from .models import DeviceContext
+from .packing import VectorParam
+from .quadform import duplication_matrix
+
+
+def _gamma_block(a, b, f_t, f_L):
+    """Gradient (2,) and Hessian (2, 2) in (shape, rate) of  f_t * (a/b) + f_L * (psi(a) - log b) - entropy."""
+    p1, p2 = special.polygamma(1, a), special.polygamma(2, a)
+    g = np.array([f_t / b + f_L * p1 - (1.0 + (1.0 - a) * p1),
+                  -f_t * a / b ** 2 - f_L / b + 1.0 / b])
+    H = np.array([[f_L * p2 + p1 - (1.0 - a) * p2, -f_t / b ** 2],
+                  [-f_t / b ** 2, 2.0 * f_t * a / b ** 3 + f_L / b ** 2 - 1.0 / b ** 2]])
+    return g, H
+
+
+def _gamma_entropy(a, b):
+    return a - np.log(b) + special.gammaln(a) + (1.0 - a) * special.digamma(a)
+
+
+class LMMObjective(object):
+    _lrvb_device_functor = True
+
+    def __init__(self, par, x, y, groups, n_groups, beta_prior_mean=None, beta_prior_info=None,
+                 mu_prior_mean=0.0, mu_prior_info=1.0, tau_y_prior=(1.0, 1.0), tau_mu_prior=(1.0, 1.0),
+                 names=('beta', 'mu', 'tau_y', 'tau_mu', 'u'), weights=None, device=0):
+        self.par = par
+        x = _hip.as_f64(x)
+        y = _hip.as_f64(y).reshape(-1, 1)
+        self.n_obs, self.p = x.shape
+        self.G = int(n_groups)
+        p, G = self.p, self.G
+        self._index(par, names)
+        self.beta0 = np.zeros(p) if beta_prior_mean is None else _hip.as_f64(beta_prior_mean).ravel()
+        self.lam0 = np.eye(p) if beta_prior_info is None else _hip.as_f64(beta_prior_info)
+        self.mu0, self.kappa0 = float(mu_prior_mean), float(mu_prior_info)
+        self.a0y, self.b0y = map(float, tau_y_prior)
+        self.a0m, self.b0m = map(float, tau_mu_prior)
+        self.ctx = DeviceContext(par.layout_blocks(), loss='data_only', n_obs=self.n_obs, n_cols=p + 1, device=device)
+        self.ctx.set_data(_hip.SLOT_X, np.hstack([x, y]))
+        self.ctx.set_groups(groups, G)
+        w0 = np.ones(self.n_obs) if weights is None else _hip.as_f64(weights).ravel().copy()
+        self.weights_par = VectorParam('weights', self.n_obs, val=w0)
+        self.tilt_par = None
+        self._w_cache = None
+        self._stats_cache = None
+        self._external_stats = None
+
+    def _index(self, par, names):
+        p, G = self.p, self.G
+        nb, nm, nty, ntm, nu = names
+        vi = par.vector_indices_dict
+        sub = par[nb]
+        self._ms = slice(vi[nb].start + sub.vector_indices_dict['mean'].start, vi[nb].start + sub.vector_indices_dict['mean'].stop)
+        self._ls = slice(vi[nb].start + sub.vector_indices_dict['info'].start, vi[nb].start + sub.vector_indices_dict['info'].stop)
+        sub = par[nm]
+        self._iem = vi[nm].start + sub.vector_indices_dict['mean'].start
+        self._iim = vi[nm].start + sub.vector_indices_dict['info'].start
+        self._iay = vi[nty].start + par[nty].vector_indices_dict['shape'].start
+        self._iby = vi[nty].start + par[nty].vector_indices_dict['rate'].start
+        self._iam = vi[ntm].start + par[ntm].vector_indices_dict['shape'].start
+        self._ibm = vi[ntm].start + par[ntm].vector_indices_dict['rate'].start
+        sub = par[nu]
+        self._es = slice(vi[nu].start + sub.vector_indices_dict['mean'].start, vi[nu].start + sub.vector_indices_dict['mean'].stop)
+        self._is = slice(vi[nu].start + sub.vector_indices_dict['info'].start, vi[nu].start + sub.vector_indices_dict['info'].stop)
+        if self._ms.stop - self._ms.start != p or self._es.stop - self._es.start != G:
+            raise ValueError('parameter sizes do not match the data (p = {}, G = {})'.format(p, G))
+        self.n_global = self._es.start                     # the local block (u) is pushed last
+        if self._is.stop != par.vector_size() or self._is.start != self._es.stop:
+            raise ValueError('the group-effect parameter must be pushed last')
+        self._dup = duplication_matrix(p)
+
+    # ---- sufficient statistics (GPU) ---------------------------------------------------------
+    def _push_state(self):
+        w = np.asarray(self.weights_par.get_vector(), dtype=np.float64)
+        if self._w_cache is None or not np.array_equal(w, self._w_cache):
+            self.ctx.set_weights(w)
+            self._w_cache = w.copy()
+            self._stats_cache = None
+
+    def local_stats(self):
+        """This process's statistics as one flat vector [S (q*q) | group sums (G*(q+1))] -- the
+        buffer that is all-reduced when observations are sharded over GPUs."""
+        self._push_state()
+        if self._stats_cache is None:
+            S = self.ctx.weighted_gram()
+            gs = self.ctx.group_sums()
+            self._stats_cache = np.concatenate([S.ravel(), gs.ravel()])
+        return self._stats_cache
+
+    def set_reduced_stats(self, flat):
+        """Install statistics summed over all shards (None = use this process's own)."""
+        self._external_stats = None if flat is None else np.asarray(flat, dtype=np.float64).copy()
+
+    def _stats(self):
+        flat = self._external_stats if self._external_stats is not None else self.local_stats()
+        q = self.p + 1
+        S = flat[:q * q].reshape(q, q)
+        gs = flat[q * q:].reshape(self.G, q + 1)
+        return S, gs
+
+    # ---- closed forms in vector coordinates ------------------------------------------------------
+    def _pieces(self, eta):
+        p, G = self.p, self.G
+        S, gs = self._stats()
+        Sxx, Sxy, Syy = S[:p, :p], S[:p, p], S[p, p]
+        Wg, sxg, syg = gs[:, 0], gs[:, 1:1 + p], gs[:, 1 + p]
+        W = float(np.sum(Wg))
+        m = eta[self._ms]
+        lam = (self._dup @ eta[self._ls]).reshape(p, p)
+        e_mu, i_mu = eta[self._iem], eta[self._iim]
+        ay, by, am, bm = eta[self._iay], eta[self._iby], eta[self._iam], eta[self._ibm]
+        eg, ig = eta[self._es], eta[self._is]
+        P = np.linalg.inv(lam)
+        return dict(Sxx=Sxx, Sxy=Sxy, Syy=Syy, Wg=Wg, sxg=sxg, syg=syg, W=W, m=m, lam=lam, P=P, e_mu=e_mu, i_mu=i_mu,
+                    ay=ay, by=by, am=am, bm=bm, eg=eg, ig=ig)
+
+    def _scalars(self, q):
+        p, G = self.p, self.G
+        m, P, eg, ig = q['m'], q['P'], q['eg'], q['ig']
+        ty, tm = q['ay'] / q['by'], q['am'] / q['bm']
+        Ly = special.digamma(q['ay']) - np.log(q['by'])
+        Lm = special.digamma(q['am']) - np.log(q['bm'])
+        rg = q['syg'] - q['sxg'] @ m
+        rss = q['Syy'] - 2.0 * m @ q['Sxy'] + m @ q['Sxx'] @ m
+        Ay = rss + np.sum(q['Sxx'] * P) - 2.0 * eg @ rg + np.sum(q['Wg'] * (eg ** 2 + 1.0 / ig))
+        Am = np.sum((eg - q['e_mu']) ** 2 + 1.0 / ig) + G / q['i_mu']
+        return ty, tm, Ly, Lm, rg, Ay, Am
+
+    def value_vec(self, eta):
+        p, G = self.p, self.G
+        q = self._pieces(eta)
+        ty, tm, Ly, Lm, rg, Ay, Am = self._scalars(q)
+        sign, logdet = np.linalg.slogdet(q['lam'])
+        if sign <= 0:
+            raise ValueError('Matrix is not positive definite')
+        dm = q['m'] - self.beta0
+        return float(0.5 * ty * Ay - 0.5 * q['W'] * Ly + 0.5 * tm * Am - 0.5 * G * Lm
+                     + 0.5 * (dm @ self.lam0 @ dm + np.sum(self.lam0 * q['P']))
+                     + 0.5 * self.kappa0 * ((q['e_mu'] - self.mu0) ** 2 + 1.0 / q['i_mu'])
+                     - (self.a0y - 1.0) * Ly + self.b0y * ty - (self.a0m - 1.0) * Lm + self.b0m * tm
+                     + 0.5 * logdet - 0.5 * p * (1.0 + np.log(2.0 * np.pi))
+                     + 0.5 * np.log(q['i_mu']) - 0.5 * (1.0 + np.log(2.0 * np.pi))
+                     + 0.5 * np.sum(np.log(q['ig'])) - 0.5 * G * (1.0 + np.log(2.0 * np.pi))
+                     - _gamma_entropy(q['ay'], q['by']) - _gamma_entropy(q['am'], q['bm']))
+
+    def _arrow(self, eta):
+        """Gradient (V,), global Hessian block (ng, ng), cross block (ng, 2G) and the diagonal of
+        the local block (2G,) in vector coordinates."""
+        p, G, ng = self.p, self.G, self.n_global
+        q = self._pieces(eta)
+        ty, tm, Ly, Lm, rg, Ay, Am = self._scalars(q)
+        m, P, eg, ig, Wg, sxg = q['m'], q['P'], q['eg'], q['ig'], q['Wg'], q['sxg']
+        Dup = self._dup
+        V = eta.size
+        g = np.zeros(V)
+        Hgg = np.zeros((ng, ng))
+        Hgl = np.zeros((ng, 2 * G))
+        um = q['Sxx'] @ m - q['Sxy'] + sxg.T @ eg
+        C = ty * q['Sxx'] + self.lam0
+        Gc = P @ C @ P
+        PSP = P @ q['Sxx'] @ P
+        f_ty, f_tm = 0.5 * Ay + self.b0y, 0.5 * Am + self.b0m
+        f_Ly, f_Lm = -0.5 * q['W'] - (self.a0y - 1.0), -0.5 * G - (self.a0m - 1.0)
+        tay, tby = 1.0 / q['by'], -q['ay'] / q['by'] ** 2
+        tam, tbm = 1.0 / q['bm'], -q['am'] / q['bm'] ** 2
+        ms, ls = self._ms, self._ls
+        iem, iim, iay, iby, iam, ibm = self._iem, self._iim, self._iay, self._iby, self._iam, self._ibm
+        dsum = np.sum(eg - q['e_mu'])
+        # gradient
+        g[ms] = ty * um + self.lam0 @ (m - self.beta0)
+        g[ls] = Dup.T @ (-0.5 * Gc + 0.5 * P).ravel()
+        g[iem] = -tm * dsum + self.kappa0 * (q['e_mu'] - self.mu0)
+        g[iim] = -0.5 * (tm * G + self.kappa0) / q['i_mu'] ** 2 + 0.5 / q['i_mu']
+        gy, Hy = _gamma_block(q['ay'], q['by'], f_ty, f_Ly)
+        gm_, Hm_ = _gamma_block(q['am'], q['bm'], f_tm, f_Lm)
+        g[iay], g[iby] = gy
+        g[iam], g[ibm] = gm_
+        dloc = ty * Wg + tm
+        g[self._es] = ty * (Wg * eg - rg) + tm * (eg - q['e_mu'])
+        g[self._is] = -0.5 * dloc / ig ** 2 + 0.5 / ig
+        # global block
+        Hgg[ms, ms] = C
+        Hgg[ls, ls] = Dup.T @ (0.5 * (np.kron(Gc, P) + np.kron(P, Gc)) - 0.5 * np.kron(P, P)) @ Dup
+        Hgg[ms, iay] = Hgg[iay, ms] = um * tay
+        Hgg[ms, iby] = Hgg[iby, ms] = um * tby
+        gl = Dup.T @ (-0.5 * PSP).ravel()
+        Hgg[ls, iay] = Hgg[iay, ls] = gl * tay
+        Hgg[ls, iby] = Hgg[iby, ls] = gl * tby
+        Hgg[iem, iem] = tm * G + self.kappa0
+        Hgg[iem, iam] = Hgg[iam, iem] = -dsum * tam
+        Hgg[iem, ibm] = Hgg[ibm, iem] = -dsum * tbm
+        Hgg[iim, iim] = (tm * G + self.kappa0) / q['i_mu'] ** 3 - 0.5 / q['i_mu'] ** 2
+        Hgg[iim, iam] = Hgg[iam, iim] = -0.5 * G / q['i_mu'] ** 2 * tam
+        Hgg[iim, ibm] = Hgg[ibm, iim] = -0.5 * G / q['i_mu'] ** 2 * tbm
+        Hgg[np.ix_([iay, iby], [iay, iby])] = Hy
+        Hgg[np.ix_([iam, ibm], [iam, ibm])] = Hm_
+        # cross block: columns [e_1..e_G | i_1..i_G]
+        ce, ci = slice(0, G), slice(G, 2 * G)
+        Hgl[ms, ce] = ty * sxg.T
+        Hgl[iem, ce] = -tm
+        Hgl[iay, ce] = (Wg * eg - rg) * tay
+        Hgl[iby, ce] = (Wg * eg - rg) * tby
+        Hgl[iam, ce] = (eg - q['e_mu']) * tam
+        Hgl[ibm, ce] = (eg - q['e_mu']) * tbm
+        Hgl[iay, ci] = -0.5 * Wg / ig ** 2 * tay
+        Hgl[iby, ci] = -0.5 * Wg / ig ** 2 * tby
+        Hgl[iam, ci] = -0.5 / ig ** 2 * tam
+        Hgl[ibm, ci] = -0.5 / ig ** 2 * tbm
+        dl = np.concatenate([dloc, dloc / ig ** 3 - 0.5 / ig ** 2])
+        return g, Hgg, Hgl, dl
+
+    def _dense_vec(self, eta):
+        g, Hgg, Hgl, dl = self._arrow(eta)
+        ng, V = self.n_global, eta.size
+        H = np.zeros((V, V))
+        H[:ng, :ng] = Hgg
+        H[:ng, ng:] = Hgl
+        H[ng:, :ng] = Hgl.T
+        H[np.arange(ng, V), np.arange(ng, V)] = dl
+        return g, H
+
+    # ---- functor protocol (dense; intended for small G) ---------------------------------------------
+    def _eta(self, x, is_free):
+        x = _hip.as_f64(x).ravel()
+        return self.ctx.constrain(x) if is_free else x
+
+    def __call__(self):
+        return self.value(np.asarray(self.par.get_free(), dtype=np.float64), True)
+
+    def value(self, x, is_free):
+        return self.value_vec(self._eta(x, is_free))
+
+    def grad(self, x, is_free):
+        g = self._arrow(self._eta(x, is_free))[0]
+        return self.ctx.free_to_vector_jac(x).T @ g if is_free else g
+
+    jacobian = grad
+
+    def hessian(self, x, is_free):
+        if self.par.vector_size() > 8192:
+            raise MemoryError('dense Hessian of {} parameters: use global_hessian() (Schur complement)'.format(self.par.vector_size()))
+        g, H = self._dense_vec(self._eta(x, is_free))
+        return self.ctx.free_hessian_from_vector(x, g, H) if is_free else H
+
+    def hvp(self, x, v, is_free):
+        return self.hessian(x, is_free) @ _hip.as_f64(v).ravel()
+
+    # ---- arrow structure: Schur complement onto the global block, free coordinates --------------------
+    def global_hessian(self, free_val):
+        """H_S = H_gg - H_gl diag(H_ll)^-1 H_lg in FREE coordinates (n_global x n_global): the
+        matrix whose inverse is the linear-response covariance block of the global parameters."""
+        free_val = _hip.as_f64(free_val).ravel()
+        eta = self.ctx.constrain(free_val)
+        g, Hgg, Hgl, dl = self._arrow(eta)
+        ng, G = self.n_global, self.G
+        # packing of the global block through a layout that covers only the global parameters
+        if not hasattr(self, '_gctx'):
+            blocks = []
+            size = 0
+            for b in self.par.layout_blocks():
+                if size >= ng:
+                    break
+                blocks.append(b)
+                size += b['vec_size']
+            assert size == ng
+            self._gctx = DeviceContext(blocks, quad_kind=_hip.QUAD_DIAG, device=self.ctx.device)
+        Hgg_free = self._gctx.free_hessian_from_vector(free_val[:ng], g[:ng], Hgg)
+        Jg = self._gctx.free_to_vector_jac(free_val[:ng])
+        # local free coordinates: e_g unconstrained (d eta = 1), i_g = exp(f_g) (d eta = i_g, d2 eta = i_g)
+        ig = eta[self._is]
+        jl = np.concatenate([np.ones(G), ig])
+        dl_free = dl * jl ** 2 + np.concatenate([np.zeros(G), g[self._is] * ig])
+        cross = (Jg.T @ Hgl) * jl[None, :]
+        return Hgg_free - (cross / dl_free[None, :]) @ cross.T

@@ -201,6 +201,16 @@ class DeviceContext(object):
         _hip.check(self._lib.lrvb_obs_quadform(self._h, _hip.ptr(M), _hip.ptr(c), K, n0, n1, _hip.ptr(out)))
         return out
 
+    def set_groups(self, gid, n_groups):
+        g = np.ascontiguousarray(gid, dtype=np.int32).ravel()
+        _hip.check(self._lib.lrvb_set_groups(self._h, g.ctypes.data_as(ctypes.c_void_p), g.size, int(n_groups)))
+        self.n_groups = int(n_groups)
+
+    def group_sums(self):
+        out = np.empty((self.n_groups, self.n_cols + 1))
+        _hip.check(self._lib.lrvb_group_sums(self._h, _hip.ptr(out)))
+        return out
+
     def quadform_gram(self, M, c, free):
         M, c, f = _hip.as_f64(M), _hip.as_f64(c).ravel(), _hip.as_f64(free).ravel()
         if M.shape != (self.V, self.n_cols, self.n_cols) or c.size != self.V:

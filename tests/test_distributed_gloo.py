@@ -118,3 +118,41 @@ def test_two_rank_gloo_build_equals_single_process(tmp_path):
     N, theta, model = _make_problem()
     want = model(slice(0, N)).hessian(theta)
     assert np.max(np.abs(H - want)) < 1e-11 * np.max(np.abs(want))
+
+
+def _lmm_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from lrvb_amd.distributed import shard_rows, allreduce_stats
+    from test_lmm_host_math import make_par, shell, random_eta, host_stats
+    rng = np.random.default_rng(11)
+    N, p, G = 501, 2, 7
+    x = rng.normal(size=(N, p)); y = rng.normal(size=N); w = rng.uniform(0.5, 1.5, N)
+    gid = rng.integers(0, G, size=N); gid[:G] = np.arange(G)
+    eta = random_eta(rng, p, G)
+    r0, r1 = shard_rows(N, rank, world)
+    # whole groups are NOT required per rank: per-group statistics are summed too
+    local = host_stats(x[r0:r1], y[r0:r1], gid[r0:r1], G, w[r0:r1])
+    total = allreduce_stats(local)
+    priors = (np.zeros(p), np.eye(p) * 0.7, 0.2, 0.5, (2.0, 1.5), (1.5, 0.8))
+    f = shell(make_par(p, G), p, G, priors)
+    f._external_stats = None
+    f.set_reduced_stats(total)
+    g, H = f._dense_vec(eta)
+    if rank == 0:
+        f.set_reduced_stats(host_stats(x, y, gid, G, w))
+        g1, H1 = f._dense_vec(eta)
+        np.save(out_path, np.array([np.max(np.abs(H - H1)) / np.max(np.abs(H1)), np.max(np.abs(g - g1)) / np.max(np.abs(g1))]))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sufficient_statistics_allreduce(tmp_path):
+    """Config 4's exchange step: per-rank Gram + per-group sums, one sum all-reduce, identical
+    arrow Hessian on every rank."""
+    out_path = str(tmp_path / 'err.npy')
+    mp.spawn(_lmm_worker, args=(2, _free_port(), out_path), nprocs=2, join=True)
+    err = np.load(out_path)
+    assert err[0] < 1e-12 and err[1] < 1e-12

@@ -1,0 +1,105 @@
+"""BASELINE.json config 4 on the GPU: hierarchical LMM (doc/lmm.lyx:77-160).  Grouped sufficient
+statistics and the weighted Gram come from the device; oracle = exact AD (torch.func fp64) of the
+restated -ELBO at small sizes, the dense arrow Hessian's inverse at a middle size, torch scatter
+sums at N = 1.25e6 (one GPU's shard of the N = 1e7 configuration), p = 43, G = 1e4."""
+import numpy as np
+import pytest
+import torch
+
+import torch_ref as tr
+from oracle import packing as opk
+from helpers import rel_err
+from test_lmm_host_math import make_par, random_eta, host_stats
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def vb():
+    import lrvb_amd
+    assert lrvb_amd._hip.device_count() >= 1
+    return lrvb_amd
+
+
+def _layout(p, G):
+    return opk.Layout([opk.box_block(p), opk.psd_block(p), opk.box_block(1), opk.box_block(1, lb=0.0),
+                       opk.box_block(1, lb=0.0), opk.box_block(1, lb=0.0), opk.box_block(1, lb=0.0), opk.box_block(1, lb=0.0),
+                       opk.box_block(G), opk.box_block(G, lb=0.0)])
+
+
+def _problem(vb, rng, N, p, G):
+    x = rng.normal(size=(N, p))
+    gid = rng.integers(0, G, size=N).astype(np.int32); gid[:G] = np.arange(G)
+    u = rng.normal(size=G) * 0.7 + 0.3
+    y = x @ rng.normal(size=p) + u[gid] + rng.normal(size=N) * 0.5
+    par = make_par(p, G)
+    priors = dict(beta_prior_mean=np.zeros(p), beta_prior_info=0.2 * np.eye(p), mu_prior_mean=0.1, mu_prior_info=0.3,
+                  tau_y_prior=(2.0, 1.0), tau_mu_prior=(1.5, 0.5))
+    fun = vb.LMMObjective(par, x, y, gid, G, **priors)
+    ft = tr.lmm_objective(x, y, gid, G, priors['beta_prior_mean'], priors['beta_prior_info'], 0.1, 0.3, (2.0, 1.0), (1.5, 0.5),
+                          layout=_layout(p, G))
+    return x, y, gid, par, fun, ft
+
+
+def test_small_dense_parity(vb):
+    rng = np.random.default_rng(3)
+    N, p, G = 400, 3, 6
+    x, y, gid, par, fun, ft = _problem(vb, rng, N, p, G)
+    lay = _layout(p, G)
+    assert par.free_size() == lay.D
+    objective = vb.Objective(par, fun)
+    w = rng.uniform(0.5, 1.5, N)
+    fun.weights_par.set_vector(w)
+    # device statistics against numpy
+    assert rel_err(fun.local_stats(), host_stats(x, y, gid, G, w)) < 1e-12
+    theta = lay.unconstrain(random_eta(rng, p, G))
+    tt, tw = torch.tensor(theta), torch.tensor(w)
+    H_ad = torch.func.hessian(ft)(tt, tw).numpy()
+    assert abs(objective.fun_free(theta) - ft(tt, tw).item()) < 1e-10 * abs(ft(tt, tw).item())
+    assert rel_err(objective.fun_free_grad(theta), torch.func.grad(ft)(tt, tw).numpy()) < 1e-9
+    assert rel_err(objective.fun_free_hessian(theta), H_ad) < 1e-9
+    ng = fun.n_global
+    HS = fun.global_hessian(theta)
+    assert rel_err(np.linalg.inv(HS), np.linalg.inv(H_ad)[:ng, :ng]) < 1e-7
+
+
+def test_schur_complement_middle_size(vb):
+    rng = np.random.default_rng(4)
+    N, p, G = 30000, 6, 300
+    x, y, gid, par, fun, ft = _problem(vb, rng, N, p, G)
+    lay = _layout(p, G)
+    theta = lay.unconstrain(random_eta(rng, p, G))
+    H = vb.Objective(par, fun).fun_free_hessian(theta)          # dense 633 x 633 arrow matrix
+    ng = fun.n_global
+    assert ng == p + p * (p + 1) // 2 + 6
+    HS = fun.global_hessian(theta)
+    assert rel_err(np.linalg.inv(HS), np.linalg.inv(H)[:ng, :ng]) < 1e-7
+    # a few AD Hessian-vector products pin the dense matrix itself
+    w1 = torch.ones(N, dtype=torch.float64)
+    grad_fn = torch.func.grad(ft)
+    v = rng.normal(size=lay.D)
+    hv = torch.func.jvp(lambda th: grad_fn(th, w1), (torch.tensor(theta),), (torch.tensor(v),))[1].numpy()
+    assert rel_err(H @ v, hv) < 1e-8
+
+
+def test_config4_shard_scale_statistics(vb):
+    """One GPU's shard of config 4 (N = 1e7 over 8 GPUs -> 1.25e6 rows), p = 43, G = 1e4: the grouped
+    sums and the Gram against torch on the same device; global D = 43 + 946 + 6 = 995."""
+    N, p, G = 1250000, 43, 10000
+    dev = torch.device('cuda', 0)
+    gen = torch.Generator(device=dev); gen.manual_seed(4)
+    Z = torch.randn((N, p + 1), dtype=torch.float64, device=dev, generator=gen)
+    gid = torch.randint(0, G, (N,), device=dev, generator=gen, dtype=torch.int32)
+    w = torch.rand((N,), dtype=torch.float64, device=dev, generator=gen) + 0.5
+    par = make_par(p, G)
+    assert par.free_size() - 2 * G == 995
+    ctx = vb.DeviceContext(par.layout_blocks(), loss='data_only', n_obs=N, n_cols=p + 1)
+    ctx.set_data_dev(0, Z.data_ptr(), N, p + 1)
+    ctx.set_weights_dev(w.data_ptr(), N)
+    ctx.set_groups(gid.cpu().numpy(), G)
+    gs = ctx.group_sums()
+    ref = torch.zeros((G, p + 2), dtype=torch.float64, device=dev)
+    ref.index_add_(0, gid.long(), torch.cat([w[:, None], w[:, None] * Z], dim=1))
+    assert rel_err(gs, ref.cpu().numpy()) < 1e-11
+    S = ctx.weighted_gram()
+    assert rel_err(S, ((Z.T * w) @ Z).cpu().numpy()) < 1e-11

@@ -1,0 +1,67 @@
+"""Config 4: the closed forms of LMMObjective (arrow-structured Hessian in vector coordinates, and its
+Schur complement algebra) against exact AD of a torch restatement of doc/lmm.lyx:77-87."""
+import numpy as np
+import pytest
+import torch
+
+import lrvb_amd as vb
+import torch_ref as tr
+
+
+def make_par(p, G):
+    par = vb.ModelParamsDict('params')
+    par.push_param(vb.MVNParam('beta', dim=p))
+    par.push_param(vb.UVNParam('mu'))
+    par.push_param(vb.GammaParam('tau_y'))
+    par.push_param(vb.GammaParam('tau_mu'))
+    par.push_param(vb.UVNParamVector('u', length=G))
+    return par
+
+
+def shell(par, p, G, priors):
+    f = vb.LMMObjective.__new__(vb.LMMObjective)
+    f.par, f.p, f.G = par, p, G
+    f._index(par, ('beta', 'mu', 'tau_y', 'tau_mu', 'u'))
+    f.beta0, f.lam0, f.mu0, f.kappa0, (f.a0y, f.b0y), (f.a0m, f.b0m) = priors
+    return f
+
+
+def random_eta(rng, p, G):
+    m = rng.normal(size=p)
+    a = rng.normal(size=(p, p)); lam = a @ a.T / p + np.eye(p)
+    return np.concatenate([m, lam[np.tril_indices(p)], [0.3, 1.7, 3.0, 2.2, 2.5, 1.4],
+                           rng.normal(size=G) * 0.5, rng.uniform(0.5, 2.0, G)])
+
+
+def host_stats(x, y, gid, G, w):
+    z = np.hstack([x, y[:, None]])
+    S = z.T @ (w[:, None] * z)
+    gs = np.zeros((G, z.shape[1] + 1))
+    np.add.at(gs[:, 0], gid, w)
+    np.add.at(gs[:, 1:], gid, w[:, None] * z)
+    return np.concatenate([S.ravel(), gs.ravel()])
+
+
+@pytest.mark.parametrize('p,G,N', [(1, 2, 20), (3, 5, 80)])
+def test_arrow_hessian_matches_ad(p, G, N):
+    rng = np.random.default_rng(p * 10 + G)
+    x = rng.normal(size=(N, p)); y = rng.normal(size=N); w = rng.uniform(0.5, 1.5, N)
+    gid = rng.integers(0, G, size=N); gid[:G] = np.arange(G)
+    priors = (rng.normal(size=p), np.eye(p) * 0.7, 0.2, 0.5, (2.0, 1.5), (1.5, 0.8))
+    par = make_par(p, G)
+    f = shell(par, p, G, priors)
+    f._external_stats = host_stats(x, y, gid, G, w)
+    eta = random_eta(rng, p, G)
+    ft = tr.lmm_objective(x, y, gid, G, priors[0], priors[1], priors[2], priors[3], priors[4], priors[5])
+    te, tw = torch.tensor(eta), torch.tensor(w)
+    assert abs(f.value_vec(eta) - ft(te, tw).item()) < 1e-11 * abs(ft(te, tw).item())
+    g, H = f._dense_vec(eta)
+    g_ad = torch.func.grad(ft)(te, tw).numpy()
+    H_ad = torch.func.hessian(ft)(te, tw).numpy()
+    np.testing.assert_allclose(g, g_ad, rtol=0, atol=1e-10 * np.max(np.abs(g_ad)))
+    np.testing.assert_allclose(H, H_ad, rtol=0, atol=1e-10 * np.max(np.abs(H_ad)))
+    # Schur complement algebra in vector coordinates: inverse of H restricted to the global block
+    _, Hgg, Hgl, dl = f._arrow(eta)
+    ng = f.n_global
+    schur = Hgg - (Hgl / dl[None, :]) @ Hgl.T
+    np.testing.assert_allclose(np.linalg.inv(schur), np.linalg.inv(H_ad)[:ng, :ng], rtol=1e-8, atol=1e-10)

@@ -151,3 +151,45 @@ def wishart_mvn_objective(y, d, mu0, lam0, nu0, w0, layout=None):
                            - 0.5 * (nu - d - 1.0) * mdig + 0.5 * nu * d)
         return -(e_log_lik + mvn_prior + wishart_prior + mvn_entropy + wishart_entropy)
     return f
+
+
+def lmm_objective(x, y, gid, G, beta0, lam0, mu0, kappa0, tau_y_prior, tau_mu_prior, layout=None):
+    """Config 4 (-ELBO of the hierarchical LMM, doc/lmm.lyx:77-87) in torch as f(point, w); point =
+    eta = [m (p), tril(Lambda), e_mu, i_mu, a_y, b_y, a_mu, b_mu, e_1..e_G, i_1..i_G] or the free vector."""
+    xt, yt = torch.tensor(x), torch.tensor(y).reshape(-1)
+    gt = torch.tensor(gid, dtype=torch.long)
+    p = x.shape[1]
+    mm = p * (p + 1) // 2
+    b0t, l0t = torch.tensor(beta0), torch.tensor(lam0)
+    idx = torch.tril_indices(p, p)
+    a0y, b0y = tau_y_prior
+    a0m, b0m = tau_mu_prior
+
+    def gam_entropy(a, b):
+        return a - torch.log(b) + torch.lgamma(a) + (1.0 - a) * torch.special.digamma(a)
+
+    def f(point, w):
+        eta = constrain(point, layout) if layout is not None else point
+        m = eta[:p]
+        ll = torch.zeros(p, p, dtype=eta.dtype).index_put((idx[0], idx[1]), eta[p:p + mm])
+        lam = ll + ll.T - torch.diag(torch.diagonal(ll))
+        o = p + mm
+        e_mu, i_mu, ay, by, am, bm = eta[o], eta[o + 1], eta[o + 2], eta[o + 3], eta[o + 4], eta[o + 5]
+        eg, ig = eta[o + 6:o + 6 + G], eta[o + 6 + G:o + 6 + 2 * G]
+        sigma = torch.linalg.inv(lam)
+        ty, tm = ay / by, am / bm
+        Ly, Lm = torch.special.digamma(ay) - torch.log(by), torch.special.digamma(am) - torch.log(bm)
+        resid = yt - xt @ m - eg[gt]
+        e_sq = resid ** 2 + torch.einsum('ni,ij,nj->n', xt, sigma, xt) + 1.0 / ig[gt]
+        e_log_lik = torch.sum(w * (-0.5 * ty * e_sq + 0.5 * Ly))
+        e_log_u = torch.sum(-0.5 * tm * ((eg - e_mu) ** 2 + 1.0 / ig + 1.0 / i_mu) + 0.5 * Lm)
+        dm = m - b0t
+        beta_prior = -0.5 * (dm @ l0t @ dm + torch.trace(l0t @ sigma))
+        mu_prior = -0.5 * kappa0 * ((e_mu - mu0) ** 2 + 1.0 / i_mu)
+        tau_priors = (a0y - 1.0) * Ly - b0y * ty + (a0m - 1.0) * Lm - b0m * tm
+        ent = (0.5 * (-torch.logdet(lam) + p + p * math.log(2 * math.pi))
+               + 0.5 * (-torch.log(i_mu) + 1.0 + math.log(2 * math.pi))
+               + 0.5 * torch.sum(-torch.log(ig) + 1.0 + math.log(2 * math.pi))
+               + gam_entropy(ay, by) + gam_entropy(am, bm))
+        return -(e_log_lik + e_log_u + beta_prior + mu_prior + tau_priors + ent)
+    return f
