@@ -208,6 +208,17 @@ int lrvb_obs_quadform(lrvb_ctx* ctx, const double* M, const double* c, int64_t K
 int lrvb_set_groups(lrvb_ctx* ctx, const int32_t* gid, int64_t n, int64_t n_groups);
 int lrvb_group_sums(lrvb_ctx* ctx, double* out);
 
+/* Mixture models with a SimplexParam row per observation (LRVB/SimplexParams.py:69-175): for every
+ * row, on one wavefront, the simplex map and its closed-form Jacobian / Hessian (:33-63), the local
+ * (K-1) x (K-1) free Hessian block, its Cholesky factor and A_n = J_n H_nn^-1 J_n^T; then the
+ * Schur-complement operand R = sum_n w_n^2 (x~_n (x) x~_n) vec(A_n)^T ((V+1)^2 x K^2) by an MFMA GEMM,
+ * the sufficient statistics S64 = [x~ | z]^T diag(w) [x~ | z] (64 x 64, x~ padded to 32, z to 32),
+ * val2 = [-sum w z.s, sum w z log z] and the free local gradient (N x (K-1); may be NULL, as may
+ * R_out).  s_n = x~_n Lam, Lam = [E log pi; E log phi] ((V+1) x K), x~_n = (1, x_n).
+ * V + 1 <= 32, K in {2, 3, 4, 5, 8, 16, 32}.                                                      */
+int lrvb_mixture_rows(lrvb_ctx* ctx, int32_t K, const double* theta_z, const double* Lam,
+                      double* val2_out, double* gfree_out, double* S64_out, double* R_out);
+
 /* Gram matrix G^T G (D x D, free coordinates) of the per-observation gradients
  * g_n[k] = 1/2 z_n^T M_k z_n + c_k (K = V matrices, one per vector coordinate): the Kronecker rows
  * z_n (x) z_n are generated on chip and contracted on the fp64 matrix cores; G (N x D) is never

@@ -544,35 +544,179 @@ void gram_small_reduce_kernel(const double* __restrict__ partial, int nblk, int 
     tile0[row * WS_TILE + col] = (s0 + s1) + (s2 + s3);
 }
 
-static int launch_gram_small(lrvb_ctx* c, const double* cvec_dev, double* tiles_out_dev) {
-    const i64 stages = (c->N + 15) / 16;
+int launch_gram_small_on(lrvb_ctx* c, const double* Z, i64 N, i64 P, const double* cvec_dev, double* tiles_out_dev) {
+    if (P > 64) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "narrow Gram kernel supports at most 64 columns");
+    const i64 stages = (N + 15) / 16;
     i64 grid = (stages + 3) / 4;
     if (grid > 1024) grid = 1024;
     if (grid < 1) grid = 1;
     LRVB_TRY(buf_reserve(c, c->tile_part, (size_t)grid * 4096));
-    const int aligned16 = ((c->P % 2) == 0) && ((((uintptr_t)c->X.p) & 15) == 0);
+    const int aligned16 = ((P % 2) == 0) && ((((uintptr_t)Z) & 15) == 0);
     if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
-    if (c->P <= 32)
+    if (P <= 32)
         hipLaunchKernelGGL(gram_small_kernel<1>, dim3((unsigned)grid), dim3(256), 0, c->stream,
-                           c->X.p, c->P, c->N, (int)c->P, cvec_dev, c->tile_part.p, aligned16);
+                           Z, P, N, (int)P, cvec_dev, c->tile_part.p, aligned16);
     else
         hipLaunchKernelGGL(gram_small_kernel<2>, dim3((unsigned)grid), dim3(256), 0, c->stream,
-                           c->X.p, c->P, c->N, (int)c->P, cvec_dev, c->tile_part.p, aligned16);
+                           Z, P, N, (int)P, cvec_dev, c->tile_part.p, aligned16);
     HIP_TRY(hipGetLastError());
     if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
     HIP_TRY(hipMemsetAsync(tiles_out_dev, 0, sizeof(double) * WS_TILE * WS_TILE, c->stream));   // unused entries stay finite
     hipLaunchKernelGGL(gram_small_reduce_kernel, dim3(16), dim3(256), 0, c->stream,
-                       c->tile_part.p, (int)grid, (int)c->P, tiles_out_dev);
+                       c->tile_part.p, (int)grid, (int)P, tiles_out_dev);
     HIP_TRY(hipGetLastError());
     if (c->prof_on) {
-        c->prof.wsyrk_flops = (double)c->N * (double)c->P * (double)(c->P + 1);
-        c->prof.wsyrk_bytes = 8.0 * ((double)c->N * (double)(c->P + 1)) + 8.0 * 0.5 * (double)c->P * (double)(c->P + 1);
+        c->prof.wsyrk_flops = (double)N * (double)P * (double)(P + 1);
+        c->prof.wsyrk_bytes = 8.0 * ((double)N * (double)(P + 1)) + 8.0 * 0.5 * (double)P * (double)(P + 1);
     }
     return LRVB_OK;
 }
 
+static int launch_gram_small(lrvb_ctx* c, const double* cvec_dev, double* tiles_out_dev) {
+    return launch_gram_small_on(c, c->X.p, c->N, c->P, cvec_dev, tiles_out_dev);
+}
+
 __global__ void wsyrk_reduce_kernel(const double* __restrict__ partial, int n_splits, i64 tile_elems_total,
                                     double* __restrict__ tiles);
+// ---- two-operand variant: C = A^T diag(c) B over the observation axis -----------------------------
+// A is N x PA, B is N x PB (both row-major, even widths, 16-byte aligned): every 128 x 128 tile of the
+// PA x PB result is an "off-diagonal" tile of the scheme above.  Used for the Schur complement of the
+// mixture model (config 3): sum_n (x~_n (x) x~_n) vec(A_n)^T.  Output: row-major tiles [ta][tb].
+template <int DUMMY>
+__global__ __launch_bounds__(WS_THREADS, 2)
+void atb_glds_kernel(const double* __restrict__ A, i64 lda, int PA, const double* __restrict__ B, i64 ldb, int PB,
+                     i64 N, const double* __restrict__ cpad, int n_splits, int nba, int nbb, i64 rows_per_split,
+                     double* __restrict__ partial)
+{
+    __shared__ double lds[2 * WS_BUF];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7;
+    const int qpos = blockIdx.x >> 3;
+    const int T = nba * nbb;
+    const int split_local = qpos / T;
+    const int t = qpos - split_local * T;
+    const int bi = t / nbb, bj = t - bi * nbb;
+    const int split = split_local * 8 + xcd;
+    i64 r0 = (i64)split * rows_per_split;
+    i64 r1 = r0 + rows_per_split;
+    if (r1 > N) r1 = N;
+    if (r0 > N) r0 = N;
+    const int nch = (int)((r1 - r0 + WS_KC - 1) / WS_KC);
+
+    d4 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
+    int ca = bi * WS_TILE + 2 * lane; if (ca > PA - 2) ca = PA - 2;
+    int cb = bj * WS_TILE + 2 * lane; if (cb > PB - 2) cb = PB - 2;
+
+    auto issue_stage = [&](int ch, int buf) {
+        double* base = lds + buf * WS_BUF;
+        const i64 n0 = r0 + (i64)ch * WS_KC;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wave + 4 * i;
+            i64 n = n0 + row; if (n > N - 1) n = N - 1;
+            WS_GLDS16(A + n * lda + ca, base + row * WS_LDS_STRIDE);
+            WS_GLDS16(B + n * ldb + cb, base + WS_PANEL + row * WS_LDS_STRIDE);
+        }
+        if (wave == 0)
+            WS_GLDS4(reinterpret_cast<const float*>(cpad + n0) + lane, base + 2 * WS_PANEL);
+    };
+    if (nch > 0) issue_stage(0, 0);
+    __syncthreads();
+
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int wr = wave >> 1, wc = wave & 1;
+    int buf = 0;
+    for (int ch = 0; ch < nch; ++ch) {
+        if (ch + 1 < nch) issue_stage(ch + 1, buf ^ 1);
+        const double* As = lds + buf * WS_BUF;
+        const double* Bs = As + WS_PANEL;
+        const double* Cs = As + 2 * WS_PANEL;
+        double af[2][4], bf[2][4], cv[2];
+        auto read_frags = [&](int kk, int set) {
+            const int krow = kk * 4 + l4;
+            cv[set] = Cs[krow];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) af[set][m] = As[krow * WS_LDS_STRIDE + wr * 64 + m * 16 + l15];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) bf[set][n] = Bs[krow * WS_LDS_STRIDE + wc * 64 + n * 16 + l15];
+        };
+        read_frags(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < WS_KC / 4; ++kk) {
+            const int set = kk & 1;
+            double as[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) as[m] = af[set][m] * cv[set];
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk + 1 < WS_KC / 4) read_frags(kk + 1, set ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    acc[m * 4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[m], bf[set][n], acc[m * 4 + n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+    double* out = partial + ((i64)split * T + t) * (i64)(WS_TILE * WS_TILE);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                out[(wr * 64 + m * 16 + l4 + 4 * r) * WS_TILE + wc * 64 + n * 16 + l15] = acc[m * 4 + n][r];
+}
+
+__global__ __launch_bounds__(256)
+void atb_tiles_to_dense_kernel(const double* __restrict__ tiles, int nbb, i64 PA, i64 PB, double* __restrict__ C, i64 ldc)
+{
+    const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 i = blockIdx.y;
+    if (j >= PB || i >= PA) return;
+    const i64 t = (i / WS_TILE) * nbb + (j / WS_TILE);
+    C[i * ldc + j] = tiles[t * (WS_TILE * WS_TILE) + (i % WS_TILE) * WS_TILE + (j % WS_TILE)];
+}
+
+// C (PA x PB, row-major, ld = PB) = A^T diag(c) B;  cvec_dev carries zero padding past N.
+int launch_atb(lrvb_ctx* c, const double* A, i64 PA, const double* B, i64 PB, i64 N,
+               const double* cvec_dev, double* C_dev) {
+    if ((PA % 2) || (PB % 2) || (((uintptr_t)A) & 15) || (((uintptr_t)B) & 15))
+        LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "atb: operands must have even widths and 16-byte aligned rows");
+    const int nba = (int)((PA + WS_TILE - 1) / WS_TILE), nbb = (int)((PB + WS_TILE - 1) / WS_TILE);
+    const int T = nba * nbb;
+    i64 S = (4608 + T / 2) / T;
+    S = ((S + 7) / 8) * 8;
+    i64 max_by_rows = (N / 256 / 8) * 8;
+    if (S > max_by_rows) S = max_by_rows;
+    if (S > 128) S = 128;
+    if (S < 8) S = 8;
+    i64 rps = (N + S - 1) / S;
+    rps = ((rps + WS_KC - 1) / WS_KC) * WS_KC;
+    const i64 tile_elems = (i64)T * WS_TILE * WS_TILE;
+    LRVB_TRY(buf_reserve(c, c->tile_part, (size_t)(tile_elems * (S + 1))));
+    double* part = c->tile_part.p;
+    double* tiles = c->tile_part.p + tile_elems * S;
+    if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
+    hipLaunchKernelGGL(atb_glds_kernel<0>, dim3((unsigned)(S * T)), dim3(WS_THREADS), 0, c->stream,
+                       A, PA, (int)PA, B, PB, (int)PB, N, cvec_dev, (int)S, nba, nbb, rps, part);
+    HIP_TRY(hipGetLastError());
+    if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
+    hipLaunchKernelGGL(wsyrk_reduce_kernel, dim3((unsigned)((tile_elems / 2 + 255) / 256)), dim3(256), 0, c->stream,
+                       part, (int)S, tile_elems, tiles);
+    HIP_TRY(hipGetLastError());
+    dim3 grid((unsigned)((PB + 255) / 256), (unsigned)PA);
+    hipLaunchKernelGGL(atb_tiles_to_dense_kernel, grid, dim3(256), 0, c->stream, tiles, nbb, PA, PB, C_dev, PB);
+    HIP_TRY(hipGetLastError());
+    return LRVB_OK;
+}
+
 
 // ---- Kronecker-row variant: K4 = sum_n c_n (z_n (x) z_n)(z_n (x) z_n)^T ---------------------------
 // The Gram matrix G^T G of per-observation gradients of an objective that is QUADRATIC IN THE DATA

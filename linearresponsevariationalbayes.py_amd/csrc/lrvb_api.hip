@@ -866,6 +866,63 @@ extern "C" int lrvb_group_sums(lrvb_ctx* c, double* out) {
     return d2h(c, out, c->work1.p, n_out);
 }
 
+// ---- mixture model: per-row simplex blocks eliminated on the device (config 3) --------------------
+// Inputs: free local parameters theta_z (N x (K-1)), Lam ((V+1) x K) = [E log pi; E log phi].
+// Outputs: val2 = [-sum w z.s, sum w z log z], the free local gradient (N x (K-1)), the weighted
+// sufficient statistics S64 = U^T diag(w) U with U = [x~ (32) | z (32)], and
+// R ((V+1)^2 x K^2) = sum_n w_n^2 (x~_n (x) x~_n) vec(J_n H_nn^-1 J_n^T)^T  (the Schur-complement term).
+extern "C" int lrvb_mixture_rows(lrvb_ctx* c, int32_t K, const double* theta_z, const double* Lam,
+                                 double* val2_out, double* gfree_out, double* S64_out, double* R_out) {
+    LRVB_TRY(ctx_bind(c));
+    if (!theta_z || !Lam || !val2_out || !S64_out) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    if (c->loss == LRVB_LOSS_NONE || !c->have_X) LRVB_FAIL(LRVB_ERR_STATE, "no data matrix: call lrvb_set_data(LRVB_SLOT_X) first");
+    const i64 N = c->N;
+    const int V = (int)c->P;
+    if (V + 1 > 32 || K > 32 || K < 2) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "mixture kernel supports V + 1 <= 32 and 2 <= K <= 32");
+    const i64 KM = K - 1, KK = (i64)K * K, QQ = (i64)(V + 1) * (V + 1);
+    const i64 lda = KK + (KK & 1), ldk = QQ + (QQ & 1);
+    DevBuf thz, lam, Amat, U, gfr, Xk, Rd;
+    int st = buf_reserve(c, thz, (size_t)(N * KM));
+    if (st == LRVB_OK) st = buf_reserve(c, lam, (size_t)((V + 1) * K));
+    if (st == LRVB_OK) st = buf_reserve(c, Amat, (size_t)(N * lda));
+    if (st == LRVB_OK) st = buf_reserve(c, U, (size_t)(N * 64));
+    if (st == LRVB_OK) st = buf_reserve(c, gfr, (size_t)(N * KM));
+    if (st == LRVB_OK) st = h2d(c, thz.p, theta_z, (size_t)(N * KM));
+    if (st == LRVB_OK) st = h2d(c, lam.p, Lam, (size_t)((V + 1) * K));
+    int* bad = reinterpret_cast<int*>(c->scal.p + 8);
+    if (st == LRVB_OK) st = launch_mixture_rows(c, K, thz.p, lam.p, Amat.p, lda, U.p, gfr.p, c->scal.p, bad);
+    int hbad = 0;
+    if (st == LRVB_OK) {
+        if (hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess) { lrvb_set_error("copy failed"); st = LRVB_ERR_HIP; }
+    }
+    if (st == LRVB_OK) st = d2h(c, val2_out, c->scal.p, 2);
+    if (st == LRVB_OK && gfree_out) st = d2h(c, gfree_out, gfr.p, (size_t)(N * KM));
+    // S64 = U^T diag(w) U
+    if (st == LRVB_OK) st = reserve_obs_vec(c, c->zbuf);
+    if (st == LRVB_OK && hipMemcpyAsync(c->zbuf.p, c->w.p, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, c->stream) != hipSuccess) { lrvb_set_error("copy failed"); st = LRVB_ERR_HIP; }
+    if (st == LRVB_OK) st = buf_reserve(c, c->Tdense, (size_t)WS_TILE * WS_TILE);
+    if (st == LRVB_OK) st = launch_gram_small_on(c, U.p, N, 64, c->zbuf.p, c->Tdense.p);
+    if (st == LRVB_OK) st = buf_reserve(c, c->Hfree, 64 * 64);
+    if (st == LRVB_OK) st = launch_tiles_to_dense(c, c->Tdense.p, 64, c->Hfree.p, 64, 0, 0, false);
+    if (st == LRVB_OK) st = d2h(c, S64_out, c->Hfree.p, 64 * 64);
+    if (st == LRVB_OK && R_out) {
+        if (hbad) { lrvb_set_error("a local (simplex) Hessian block is not positive definite: the Schur complement is undefined at this point"); st = LRVB_ERR_NOT_POSDEF; }
+        if (st == LRVB_OK) st = buf_reserve(c, Xk, (size_t)(N * ldk));
+        if (st == LRVB_OK) st = launch_kron_rows(c, Xk.p, ldk);
+        if (st == LRVB_OK) st = buf_reserve(c, Rd, (size_t)(ldk * lda));
+        if (st == LRVB_OK) { EW(fill_kernel, N, 1.0, c->zbuf.p); }
+        if (st == LRVB_OK) st = launch_atb(c, Xk.p, ldk, Amat.p, lda, N, c->zbuf.p, Rd.p);
+        if (st == LRVB_OK) {
+            if (hipMemcpy2DAsync(R_out, (size_t)KK * 8, Rd.p, (size_t)lda * 8, (size_t)KK * 8, (size_t)QQ, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                hipStreamSynchronize(c->stream) != hipSuccess) { lrvb_set_error("copy failed"); st = LRVB_ERR_HIP; }
+        }
+    }
+    (void)hipStreamSynchronize(c->stream);
+    buf_free(thz); buf_free(lam); buf_free(Amat); buf_free(U); buf_free(gfr); buf_free(Xk); buf_free(Rd);
+    return st;
+}
+
 // Gram matrix of per-observation gradients g_n[k] = 1/2 z_n^T M_k z_n + c_k, in FREE coordinates:
 //   G^T G = J^T ( 1/4 M~^T K4 M~ + 1/2 (t c^T + c t^T) + N c c^T ) J,   t = M~^T s,
 // K4 = sum_n (z_n (x) z_n)(z_n (x) z_n)^T from the Kronecker-row MFMA kernel, s = vec(sum_n z_n z_n^T),

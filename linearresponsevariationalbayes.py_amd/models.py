@@ -201,6 +201,19 @@ class DeviceContext(object):
         _hip.check(self._lib.lrvb_obs_quadform(self._h, _hip.ptr(M), _hip.ptr(c), K, n0, n1, _hip.ptr(out)))
         return out
 
+    def mixture_rows(self, K, theta_z, lam, want_grad=True, want_schur=True):
+        tz, lam = _hip.as_f64(theta_z).ravel(), _hip.as_f64(lam)
+        V = self.n_cols
+        if tz.size != self.n_obs * (K - 1) or lam.shape != (V + 1, K):
+            raise ValueError('expected theta_z with {} entries and Lam of shape {}'.format(self.n_obs * (K - 1), (V + 1, K)))
+        val2 = np.empty(2)
+        gfree = np.empty((self.n_obs, K - 1)) if want_grad else None
+        S64 = np.empty((64, 64))
+        R = np.empty(((V + 1) ** 2, K * K)) if want_schur else None
+        _hip.check(self._lib.lrvb_mixture_rows(self._h, int(K), _hip.ptr(tz), _hip.ptr(lam), _hip.ptr(val2),
+                                               _hip.ptr(gfree), _hip.ptr(S64), _hip.ptr(R)))
+        return val2, gfree, S64, R
+
     def set_groups(self, gid, n_groups):
         g = np.ascontiguousarray(gid, dtype=np.int32).ravel()
         _hip.check(self._lib.lrvb_set_groups(self._h, g.ctypes.data_as(ctypes.c_void_p), g.size, int(n_groups)))
