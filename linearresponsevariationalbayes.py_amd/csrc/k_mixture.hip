@@ -1,0 +1,194 @@
+// k_mixture.hip -- the per-observation ("local") block of a mixture model with simplex-constrained
+// responsibilities (BASELINE.json config 3: Dirichlet-multinomial mixture, K = 32, N = 1e6).
+//
+// Row n has a SimplexParam row z_n = softmax([0, f_n]) (LRVB/SimplexParams.py:11-18) and the local
+// objective  l_n = -w_n sum_k z_nk s_nk + w_n sum_k z_nk log z_nk,  s_nk = sum_j x~_nj Lam_jk
+// (x~ = (1, x_n), Lam = [E log pi; E log phi]).  One WAVEFRONT per row does everything the
+// reference's Python triple loop over COO triplets does for that row (SimplexParams.py:106-155)
+// and the elimination of the row's local block from the global Hessian:
+//
+//   p, s, g = d l / d z                                   (lane k <-> category k)
+//   H_nn  = J^T diag(w / p) J + sum_k g_k d2 p_k          ((K-1) x (K-1), closed forms of
+//                                                          SimplexParams.py:33-63; lane i <-> row i)
+//   L L^T = H_nn   in registers, broadcasts by v_readlane (as the 64 x 64 Cholesky block)
+//   Y = L^-1 J^T   (lane k <-> column k),   A_n = Y^T Y = J H_nn^-1 J^T   (K x K)
+//
+// and writes w_n^2 vec(A_n) (the row of the operand of the Schur-complement GEMM), the row
+// [x~_n | z_n] of the sufficient-statistics matrix, the free local gradient, and value partials.
+#include "lrvb_internal.h"
+#include <math.h>
+
+__device__ __forceinline__ double mx_bcast(double v, int src_lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double mx_wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double mx_wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+template <int K>
+__global__ __launch_bounds__(256)
+void mixture_rows_kernel(const double* __restrict__ theta_z, const double* __restrict__ X, int V,
+                         const double* __restrict__ w, const double* __restrict__ Lam, i64 N,
+                         double* __restrict__ Amat, i64 lda, double* __restrict__ U,
+                         double* __restrict__ gfree, double* __restrict__ part_val, int* __restrict__ bad)
+{
+    constexpr int KM = K - 1;
+    __shared__ double lam_s[32 * 32];
+    __shared__ double vsum[4][2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int e = tid; e < (V + 1) * K; e += 256) lam_s[e] = Lam[e];
+    __syncthreads();
+
+    double v_lin = 0.0, v_ent = 0.0;        // -w sum z s  and  w sum z log z of this wave's rows
+    int flag = 0;
+    for (i64 n = (i64)blockIdx.x * 4 + wave; n < N; n += (i64)gridDim.x * 4) {
+        const double wn = w[n];
+        // logits and probabilities: lane k <-> category k (lane 0 = reference category, logit 0)
+        const double f = (lane < KM) ? theta_z[n * KM + lane] : 0.0;
+        double logit = __shfl_up(f, 1, 64);
+        if (lane == 0) logit = 0.0;
+        const bool cat = lane < K;
+        const double mxl = mx_wave_max(cat ? logit : -INFINITY);
+        const double ex = cat ? exp(logit - mxl) : 0.0;
+        const double den = mx_wave_sum(ex);
+        const double p = ex / den;
+        const double logp = cat ? (logit - mxl - log(den)) : 0.0;
+        // x~ and the scores
+        const double xt = (lane == 0) ? 1.0 : ((lane <= V) ? X[n * V + lane - 1] : 0.0);
+        double s = 0.0;
+        for (int j = 0; j <= V; ++j) s += mx_bcast(xt, j) * (cat ? lam_s[j * K + lane] : 0.0);
+        const double g = cat ? -wn * (s - logp - 1.0) : 0.0;
+        const double gp = g * p;
+        const double gdotp = mx_wave_sum(gp);
+        v_lin += mx_wave_sum(cat ? -wn * p * s : 0.0);
+        v_ent += mx_wave_sum(cat ? wn * p * logp : 0.0);
+        // free local gradient: J^T g, lane j <-> free index j:  p_{j+1} (g_{j+1} - g.p)
+        const double p1 = __shfl_down(p, 1, 64), g1 = __shfl_down(g, 1, 64), gp1 = __shfl_down(gp, 1, 64);
+        if (lane < KM) gfree[n * KM + lane] = p1 * (g1 - gdotp);
+        // sufficient-statistics row [x~ (32) | z (32)]
+        {
+            const double zsh = __shfl(p, lane - 32, 64);
+            U[n * 64 + lane] = (lane < 32) ? xt : ((lane - 32 < K) ? zsh : 0.0);
+        }
+        // local Hessian in free coordinates, lane i <-> row i (identity rows past K-1)
+        double a[KM];
+#pragma unroll
+        for (int j = 0; j < KM; ++j) {
+            const double pj = mx_bcast(p, j + 1), gpj = mx_bcast(gp, j + 1);
+            double h = -wn * p1 * pj - gp1 * pj - p1 * gpj + 2.0 * gdotp * p1 * pj;
+            if (j == lane) h += wn * p1 + gp1 - gdotp * p1;
+            a[j] = (lane < KM) ? h : ((j == lane) ? 1.0 : 0.0);
+        }
+        // Cholesky in registers
+#pragma unroll
+        for (int j = 0; j < KM; ++j) {
+            const double d = mx_bcast(a[j], j);
+            if (!(d > 0.0)) flag = 1;
+            const double r = 1.0 / sqrt(d);
+            a[j] = a[j] * r;
+#pragma unroll
+            for (int k = j + 1; k < KM; ++k) a[k] -= a[j] * mx_bcast(a[j], k);
+        }
+        // Y = L^-1 J^T: lane k solves L y = J[k, :]^T,  J[k][i] = p_k (d_{k,i+1} - p_{i+1})
+        double y[KM];
+#pragma unroll
+        for (int i = 0; i < KM; ++i) {
+            double rhs = p * ((lane == i + 1 ? 1.0 : 0.0) - mx_bcast(p, i + 1));
+#pragma unroll
+            for (int c = 0; c < i; ++c) rhs -= mx_bcast(a[c], i) * y[c];
+            y[i] = rhs / mx_bcast(a[i], i);
+        }
+        // A[k][k'] = y^(k) . y^(k'), scaled by w^2; lane k writes its row
+        const double w2 = wn * wn;
+        double* arow = Amat + n * lda + (i64)lane * K;
+#pragma unroll 4
+        for (int kp = 0; kp < K; ++kp) {
+            double acc = 0.0;
+#pragma unroll
+            for (int i = 0; i < KM; ++i) acc += y[i] * mx_bcast(y[i], kp);
+            if (cat) arow[kp] = w2 * acc;
+        }
+        if (lda > (i64)K * K && lane == 0) Amat[n * lda + (i64)K * K] = 0.0;     // even-width padding column
+    }
+    if (lane == 0) { vsum[wave][0] = v_lin; vsum[wave][1] = v_ent; }
+    if (flag && lane == 0) atomicOr(bad, 1);
+    __syncthreads();
+    if (tid == 0) {
+        part_val[2 * blockIdx.x] = ((vsum[0][0] + vsum[1][0]) + vsum[2][0]) + vsum[3][0];
+        part_val[2 * blockIdx.x + 1] = ((vsum[0][1] + vsum[1][1]) + vsum[2][1]) + vsum[3][1];
+    }
+}
+
+// Xk[n, 32... ] = x~_n (x) x~_n with row length (V+1)^2 (+1 zero column when odd)
+__global__ __launch_bounds__(256)
+void kron_rows_kernel(const double* __restrict__ X, int V, i64 N, double* __restrict__ Xk, i64 ldk)
+{
+    const i64 n = blockIdx.y;
+    const int q = V + 1;
+    for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < ldk; e += (i64)gridDim.x * blockDim.x) {
+        double v = 0.0;
+        if (e < (i64)q * q) {
+            const int a = (int)(e / q), b = (int)(e % q);
+            const double xa = a == 0 ? 1.0 : X[n * V + a - 1];
+            const double xb = b == 0 ? 1.0 : X[n * V + b - 1];
+            v = xa * xb;
+        }
+        Xk[n * ldk + e] = v;
+    }
+}
+
+__global__ void mixture_val_reduce_kernel(const double* __restrict__ part, int nblk, double* __restrict__ out2) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int i = 0; i < nblk; ++i) { a += part[2 * i]; b += part[2 * i + 1]; }
+        out2[0] = a; out2[1] = b;
+    }
+}
+
+int launch_mixture_rows(lrvb_ctx* c, int K, const double* theta_z_dev, const double* lam_dev,
+                        double* Amat_dev, i64 lda, double* U_dev, double* gfree_dev, double* val2_dev, int* bad_dev)
+{
+    const int V = (int)c->P;
+    if (V + 1 > 32 || K > 32 || K < 2) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "mixture kernel supports V + 1 <= 32 and 2 <= K <= 32");
+    i64 grid = (c->N + 3) / 4;
+    if (grid > 2048) grid = 2048;
+    LRVB_TRY(buf_reserve(c, c->part_val, (size_t)(2 * grid)));
+    HIP_TRY(hipMemsetAsync(bad_dev, 0, sizeof(int), c->stream));
+#define MX_LAUNCH(KK) hipLaunchKernelGGL(mixture_rows_kernel<KK>, dim3((unsigned)grid), dim3(256), 0, c->stream, \
+        theta_z_dev, c->X.p, V, c->w.p, lam_dev, c->N, Amat_dev, lda, U_dev, gfree_dev, c->part_val.p, bad_dev)
+    switch (K) {
+    case 2: MX_LAUNCH(2); break;   case 3: MX_LAUNCH(3); break;   case 4: MX_LAUNCH(4); break;
+    case 5: MX_LAUNCH(5); break;   case 8: MX_LAUNCH(8); break;   case 16: MX_LAUNCH(16); break;
+    case 32: MX_LAUNCH(32); break;
+    default: LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "mixture kernel is instantiated for K in {2, 3, 4, 5, 8, 16, 32} (got %d)", K);
+    }
+#undef MX_LAUNCH
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(mixture_val_reduce_kernel, dim3(1), dim3(64), 0, c->stream, c->part_val.p, (int)grid, val2_dev);
+    HIP_TRY(hipGetLastError());
+    return LRVB_OK;
+}
+
+int launch_kron_rows(lrvb_ctx* c, double* Xk_dev, i64 ldk)
+{
+    dim3 grid((unsigned)((ldk + 255) / 256), 1);
+    const i64 chunk = 65535;
+    for (i64 n0 = 0; n0 < c->N; n0 += chunk) {
+        const i64 rows = (c->N - n0 < chunk) ? (c->N - n0) : chunk;
+        grid.y = (unsigned)rows;
+        hipLaunchKernelGGL(kron_rows_kernel, grid, dim3(256), 0, c->stream, c->X.p + n0 * c->P, (int)c->P, rows,
+                           Xk_dev + n0 * ldk, ldk);
+        HIP_TRY(hipGetLastError());
+    }
+    return LRVB_OK;
+}
