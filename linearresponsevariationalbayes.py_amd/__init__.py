@@ -39,5 +39,6 @@ from . import optim as OptimizationUtils
 from . import expfam as ExponentialFamilies
 from . import families as NormalParams
 from .hierarchical import LMMObjective
+from .mixture import MixtureObjective
 from . import regression as regression_utils
 from . import distributed

@@ -10,8 +10,9 @@
 //   p, s, g = d l / d z                                   (lane k <-> category k)
 //   H_nn  = J^T diag(w / p) J + sum_k g_k d2 p_k          ((K-1) x (K-1), closed forms of
 //                                                          SimplexParams.py:33-63; lane i <-> row i)
-//   L L^T = H_nn   in registers, broadcasts by v_readlane (as the 64 x 64 Cholesky block)
-//   Y = L^-1 J^T   (lane k <-> column k),   A_n = Y^T Y = J H_nn^-1 J^T   (K x K)
+//   M = D^-1 H_nn D^-1,  D = diag(sqrt(p_2..p_K))         (scaling: M stays O(w) when p saturates)
+//   L L^T = M   in registers, broadcasts by v_readlane (as the 64 x 64 Cholesky block)
+//   Y = L^-1 (J D^-1)^T  (lane k <-> column k),   A_n = Y^T Y = J H_nn^-1 J^T   (K x K)
 //
 // and writes w_n^2 vec(A_n) (the row of the operand of the Schur-complement GEMM), the row
 // [x~_n | z_n] of the sufficient-statistics matrix, the free local gradient, and value partials.
@@ -73,21 +74,36 @@ void mixture_rows_kernel(const double* __restrict__ theta_z, const double* __res
         v_lin += mx_wave_sum(cat ? -wn * p * s : 0.0);
         v_ent += mx_wave_sum(cat ? wn * p * logp : 0.0);
         // free local gradient: J^T g, lane j <-> free index j:  p_{j+1} (g_{j+1} - g.p)
-        const double p1 = __shfl_down(p, 1, 64), g1 = __shfl_down(g, 1, 64), gp1 = __shfl_down(gp, 1, 64);
-        if (lane < KM) gfree[n * KM + lane] = p1 * (g1 - gdotp);
+        {
+            const double pn = __shfl_down(p, 1, 64), gn = __shfl_down(g, 1, 64);
+            if (lane < KM) gfree[n * KM + lane] = pn * (gn - gdotp);
+        }
         // sufficient-statistics row [x~ (32) | z (32)]
         {
             const double zsh = __shfl(p, lane - 32, 64);
             U[n * 64 + lane] = (lane < 32) ? xt : ((lane - 32 < K) ? zsh : 0.0);
         }
-        // local Hessian in free coordinates, lane i <-> row i (identity rows past K-1)
+        // local Hessian in free coordinates.  Two changes of variables keep it well conditioned when
+        // responsibilities saturate, neither of which changes A_n = J H_nn^-1 J^T:
+        //  (a) the REFERENCE category of the row is its arg-max category m instead of category 0 (a
+        //      linear change of the free coordinates): H_nn has an eigenvalue ~ w p_ref, which
+        //      underflows when p_0 -> 0.  Categories 0 and m are swapped for this part only.
+        //  (b) scaling by D = diag(sqrt(p_{i+1})):  M = D^-1 H_nn D^-1,
+        //      M_ij = r_i r_j (2 g.p - w - g_{i+1} - g_{j+1}) + d_ij (w + g_{i+1} - g.p)
+        // lane i <-> row i (zero rows past K-1, never read)
+        const int m = __builtin_amdgcn_readfirstlane((int)__ffsll((unsigned long long)__ballot(cat && logit == mxl)) - 1);
+        const double p_m = mx_bcast(p, m), g_m = mx_bcast(g, m), p_0 = mx_bcast(p, 0), g_0 = mx_bcast(g, 0);
+        const double ps = (lane == 0) ? p_m : ((lane == m) ? p_0 : p);        // swapped categories
+        const double gs = (lane == 0) ? g_m : ((lane == m) ? g_0 : g);
+        const double p1 = __shfl_down(ps, 1, 64), g1 = __shfl_down(gs, 1, 64);
+        const double r1 = sqrt(p1);
         double a[KM];
 #pragma unroll
         for (int j = 0; j < KM; ++j) {
-            const double pj = mx_bcast(p, j + 1), gpj = mx_bcast(gp, j + 1);
-            double h = -wn * p1 * pj - gp1 * pj - p1 * gpj + 2.0 * gdotp * p1 * pj;
-            if (j == lane) h += wn * p1 + gp1 - gdotp * p1;
-            a[j] = (lane < KM) ? h : ((j == lane) ? 1.0 : 0.0);
+            const double rj = mx_bcast(r1, j), gj = mx_bcast(g1, j);
+            double h = r1 * rj * (2.0 * gdotp - wn - g1 - gj);
+            if (j == lane) h += wn + g1 - gdotp;
+            a[j] = (lane < KM) ? h : 0.0;
         }
         // Cholesky in registers
 #pragma unroll
@@ -99,24 +115,26 @@ void mixture_rows_kernel(const double* __restrict__ theta_z, const double* __res
 #pragma unroll
             for (int k = j + 1; k < KM; ++k) a[k] -= a[j] * mx_bcast(a[j], k);
         }
-        // Y = L^-1 J^T: lane k solves L y = J[k, :]^T,  J[k][i] = p_k (d_{k,i+1} - p_{i+1})
+        // Y = L^-1 (J D^-1)^T: lane k solves L y = Jhat[k, :]^T,  Jhat[k][i] = r_i (d_{k,i+1} - p_k)
         double y[KM];
 #pragma unroll
         for (int i = 0; i < KM; ++i) {
-            double rhs = p * ((lane == i + 1 ? 1.0 : 0.0) - mx_bcast(p, i + 1));
+            double rhs = mx_bcast(r1, i) * ((lane == i + 1 ? 1.0 : 0.0) - ps);
 #pragma unroll
             for (int c = 0; c < i; ++c) rhs -= mx_bcast(a[c], i) * y[c];
             y[i] = rhs / mx_bcast(a[i], i);
         }
-        // A[k][k'] = y^(k) . y^(k'), scaled by w^2; lane k writes its row
+        // A[k][k'] = y^(k) . y^(k'), scaled by w^2; lane k writes its row (undoing the 0 <-> m swap)
         const double w2 = wn * wn;
-        double* arow = Amat + n * lda + (i64)lane * K;
+        const int row = (lane == 0) ? m : ((lane == m) ? 0 : lane);
+        double* arow = Amat + n * lda + (i64)row * K;
 #pragma unroll 4
         for (int kp = 0; kp < K; ++kp) {
             double acc = 0.0;
 #pragma unroll
             for (int i = 0; i < KM; ++i) acc += y[i] * mx_bcast(y[i], kp);
-            if (cat) arow[kp] = w2 * acc;
+            const int col = (kp == 0) ? m : ((kp == m) ? 0 : kp);
+            if (cat) arow[col] = w2 * acc;
         }
         if (lda > (i64)K * K && lane == 0) Amat[n * lda + (i64)K * K] = 0.0;     // even-width padding column
     }

@@ -1,0 +1,233 @@
+"""Dirichlet-multinomial mixture (BASELINE.json config 3): SimplexParam responsibilities per
+observation with DirichletParamArray globals (LRVB/SimplexParams.py:69-175, DirichletParams.py:8-33).
+
+    x_n | c_n = k ~ Multinomial(phi_k),   c_n ~ Categorical(pi),   pi ~ Dir(a0),   phi_k ~ Dir(b0)
+    q(pi) = Dir(alpha) (K,),   q(phi_k) = Dir(beta[:, k]) (V, K),   q(c_n) = z_n  (SimplexParam (N, K))
+
+The -ELBO is
+
+    f = -sum_n w_n z_n^T Lam^T x~_n + sum_n w_n z_n . log z_n - prior(pi) - prior(phi) - H(pi) - sum_k H(phi_k)
+
+with x~_n = (1, x_n) and Lam = [E log pi; E log phi] ((V + 1) x K).  Its Hessian is an ARROW: a dense
+global block (K + V K parameters) bordered by N independent (K - 1) x (K - 1) simplex blocks.  The
+reference would assemble those blocks through the triple Python loop over COO triplets of
+`SimplexParam.free_to_vector_hess` (SimplexParams.py:106-155); here one wavefront per observation
+forms the block from the closed forms (SimplexParams.py:33-63), factors it in registers and emits
+the row of the Schur-complement operand (`lrvb_mixture_rows`, csrc/k_mixture.hip), and an MFMA GEMM
+over the observation axis reduces the operand.  Everything that remains on the host is independent
+of N: digamma chains of the Dirichlet blocks and the (K + V K)^2 Schur assembly.
+
+Parameter order in `par`: the Dirichlet blocks first (any order), the SimplexParam LAST.
+"""
+import numpy as np
+from scipy import special
+
+from . import _hip
+from .models import DeviceContext
+from .packing import VectorParam
+
+
+def _dirichlet_terms(alpha, d):
+    """t(alpha) = -sum_m d_m E log p_m - H(alpha) for ONE Dirichlet (vector alpha) with data/prior
+    coefficients d: value, gradient and Hessian in alpha.  With e = alpha - 1 - d the entropy and the
+    expectation terms collapse to  grad = e psi1(alpha) - sum(e) psi1(alpha_0)."""
+    a0 = np.sum(alpha)
+    M = alpha.size
+    elog = special.digamma(alpha) - special.digamma(a0)
+    ent = (np.sum(special.gammaln(alpha)) - special.gammaln(a0) + (a0 - M) * special.digamma(a0)
+           - np.sum((alpha - 1.0) * special.digamma(alpha)))
+    e = alpha - 1.0 - d
+    p1, p2 = special.polygamma(1, alpha), special.polygamma(2, alpha)
+    p10, p20 = special.polygamma(1, a0), special.polygamma(2, a0)
+    val = -np.sum(d * elog) - ent
+    grad = e * p1 - np.sum(e) * p10
+    hess = np.diag(p1 + e * p2) - p10 - np.sum(e) * p20
+    return val, grad, hess
+
+
+class MixtureObjective(object):
+    _lrvb_device_functor = True
+
+    def __init__(self, par, x, pi_prior=1.0, phi_prior=1.0, names=('pi', 'phi', 'z'), weights=None, device=0):
+        self.par = par
+        x = _hip.as_f64(x)
+        self.n_obs, self.V = x.shape
+        N, V = self.n_obs, self.V
+        npi, nphi, nz = names
+        vi, fi = par.vector_indices_dict, par.free_indices_dict
+        zshape = par[nz].get().shape
+        if zshape[0] != N:
+            raise ValueError('the SimplexParam must have one row per observation')
+        self.K = K = int(zshape[1])
+        if par[nphi]['alpha'].get().shape != (V, K) or par[npi]['alpha'].get().shape != (K,):
+            raise ValueError('expected pi of shape ({0},) and phi of shape ({1}, {0})'.format(K, V))
+        self.n_global = ng = K + V * K
+        if vi[nz].start != ng or vi[nz].stop != par.vector_size() or fi[nz].start != ng:
+            raise ValueError('the SimplexParam must be pushed last, after the two Dirichlet blocks')
+        self._ipi = np.arange(vi[npi].start, vi[npi].stop)                        # (K,)
+        self._iphi = np.arange(vi[nphi].start, vi[nphi].stop).reshape(V, K)      # (V, K)
+        self._lb = np.zeros(ng)
+        self._lb[self._ipi] = par[npi]['alpha']._lb
+        self._lb[self._iphi.ravel()] = par[nphi]['alpha']._lb
+        if np.isfinite(par[npi]['alpha']._ub) or np.isfinite(par[nphi]['alpha']._ub):
+            raise ValueError('the Dirichlet parameters must be bounded below only')
+        self.a0 = np.broadcast_to(_hip.as_f64(pi_prior), (K,)).astype(np.float64)
+        self.b0 = np.broadcast_to(_hip.as_f64(phi_prior), (V, K)).astype(np.float64)
+        # the device context carries the packing of the GLOBAL blocks only: the simplex rows are
+        # constrained inside the row kernel and never materialised on the host
+        blocks, size = [], 0
+        for b in par.layout_blocks():
+            if size >= ng:
+                break
+            blocks.append(b)
+            size += b['vec_size']
+        assert size == ng
+        self.ctx = DeviceContext(blocks, loss='data_only', n_obs=N, n_cols=V, device=device)
+        self.ctx.set_data(_hip.SLOT_X, x)
+        w0 = np.ones(N) if weights is None else _hip.as_f64(weights).ravel().copy()
+        self.weights_par = VectorParam('weights', N, val=w0)
+        self.tilt_par = None
+        self._w_cache = None
+        self._external_stats = None
+
+    def _push_state(self):
+        w = np.asarray(self.weights_par.get_vector(), dtype=np.float64)
+        if self._w_cache is None or not np.array_equal(w, self._w_cache):
+            self.ctx.set_weights(w)
+            self._w_cache = w.copy()
+
+    # ---- pieces ------------------------------------------------------------------------------------
+    def _split(self, free_val):
+        free_val = _hip.as_f64(free_val).ravel()
+        if free_val.size != self.n_global + self.n_obs * (self.K - 1):
+            raise ValueError('Free value is the wrong length')
+        return free_val[:self.n_global], free_val[self.n_global:]
+
+    def _lam(self, eta_g):
+        V, K = self.V, self.K
+        alpha = eta_g[self._ipi]
+        beta = eta_g[self._iphi]
+        lam = np.empty((V + 1, K))
+        lam[0] = special.digamma(alpha) - special.digamma(np.sum(alpha))
+        lam[1:] = special.digamma(beta) - special.digamma(np.sum(beta, axis=0, keepdims=True))
+        return alpha, beta, lam
+
+    def _global_terms(self, alpha, beta, C):
+        """Value, vector-coordinate gradient (ng,) and Hessian (ng, ng) of everything that depends on
+        the Dirichlet parameters, at FIXED responsibilities; C = sum_n w_n x~_n z_n^T."""
+        V, K, ng = self.V, self.K, self.n_global
+        g = np.zeros(ng)
+        H = np.zeros((ng, ng))
+        val, gp, Hp = _dirichlet_terms(alpha, C[0] + self.a0 - 1.0)
+        g[self._ipi] = gp
+        H[np.ix_(self._ipi, self._ipi)] = Hp
+        for k in range(K):
+            vk, gk, Hk = _dirichlet_terms(beta[:, k], C[1:, k] + self.b0[:, k] - 1.0)
+            val += vk
+            g[self._iphi[:, k]] = gk
+            H[np.ix_(self._iphi[:, k], self._iphi[:, k])] = Hk
+        return val, g, H
+
+    def _dlam(self, alpha, beta):
+        """d vec(Lam) / d eta_g  ((V + 1) K x ng), vec index j K + k."""
+        V, K, ng = self.V, self.K, self.n_global
+        DL = np.zeros(((V + 1) * K, ng))
+        DL[np.ix_(np.arange(K), self._ipi)] = np.diag(special.polygamma(1, alpha)) - special.polygamma(1, np.sum(alpha))
+        for k in range(K):
+            rows = (np.arange(V) + 1) * K + k
+            DL[np.ix_(rows, self._iphi[:, k])] = (np.diag(special.polygamma(1, beta[:, k]))
+                                                   - special.polygamma(1, np.sum(beta[:, k])))
+        return DL
+
+    def _rows(self, free_val, want_grad, want_schur):
+        fg, fz = self._split(free_val)
+        eta_g = self._lb + np.exp(fg)                        # lower-bounded box blocks (Parameters.py:24-54)
+        alpha, beta, lam = self._lam(eta_g)
+        gz = None
+        if self._external_stats is None or want_grad:
+            self._push_state()
+            val2, gz, S64, R = self.ctx.mixture_rows(self.K, fz, lam, want_grad=want_grad,
+                                                     want_schur=want_schur and self._external_stats is None)
+        if self._external_stats is not None:
+            val2, S64, R = self._unpack_stats(self._external_stats)
+        C = S64[:self.V + 1, 32:32 + self.K]
+        return fg, eta_g, alpha, beta, val2, gz, C, R
+
+    # ---- statistics that are summed over shards of the observation axis ----------------------------
+    def _unpack_stats(self, flat):
+        q2k2 = (self.V + 1) ** 2 * self.K ** 2
+        if flat.size != 2 + 4096 + q2k2:
+            raise ValueError('expected a statistics vector of length {}'.format(2 + 4096 + q2k2))
+        return flat[:2], flat[2:2 + 4096].reshape(64, 64), flat[2 + 4096:].reshape((self.V + 1) ** 2, self.K ** 2)
+
+    def local_stats(self, free_val):
+        """[val2 (2) | S64 (4096) | R ((V+1)^2 K^2)] of THIS process's rows at free_val: the buffer
+        that is all-reduced when observations (and their simplex rows) are sharded over GPUs."""
+        self._push_state()
+        fg, fz = self._split(free_val)
+        _, _, lam = self._lam(self._lb + np.exp(fg))
+        val2, _, S64, R = self.ctx.mixture_rows(self.K, fz, lam, want_grad=False, want_schur=True)
+        return np.concatenate([val2, S64.ravel(), R.ravel()])
+
+    def set_reduced_stats(self, flat):
+        """Install statistics summed over all shards (None = use this process's own)."""
+        self._external_stats = None if flat is None else np.asarray(flat, dtype=np.float64).copy()
+
+    # ---- functor protocol ------------------------------------------------------------------------------
+    def __call__(self):
+        return self.value(np.asarray(self.par.get_free(), dtype=np.float64), True)
+
+    def value(self, x, is_free=True):
+        if not is_free:
+            raise NotImplementedError('the mixture objective is evaluated in free coordinates')
+        fg, eta_g, alpha, beta, val2, _, C, _ = self._rows(x, False, False)
+        # val2[0] = -tr(Lam^T C) is already inside the Dirichlet terms (d = C + prior - 1)
+        return float(val2[1] + self._global_terms(alpha, beta, C)[0])
+
+    def grad(self, x, is_free=True):
+        if not is_free:
+            raise NotImplementedError('the mixture objective is evaluated in free coordinates')
+        fg, eta_g, alpha, beta, val2, gz, C, _ = self._rows(x, True, False)
+        g_vec = self._global_terms(alpha, beta, C)[1]
+        return np.concatenate([g_vec * (eta_g - self._lb), gz.ravel()])
+
+    jacobian = grad
+
+    def hessian(self, x, is_free=True):
+        raise MemoryError('the dense Hessian of a mixture has N (K - 1) local rows: use global_hessian() '
+                          '(Schur complement onto the Dirichlet block)')
+
+    # ---- arrow structure ---------------------------------------------------------------------------------
+    def global_hessian(self, free_val, return_parts=False):
+        """H_S = H_gg - sum_n H_gn H_nn^-1 H_ng in FREE coordinates ((K + V K) square): the matrix whose
+        inverse is the linear-response covariance of the Dirichlet parameters."""
+        V, K = self.V, self.K
+        fg, eta_g, alpha, beta, val2, gz, C, R = self._rows(free_val, False, True)
+        _, g_vec, Hgg = self._global_terms(alpha, beta, C)
+        q = V + 1
+        Rm = R.reshape(q, q, K, K).transpose(0, 2, 1, 3).reshape(q * K, q * K)
+        Rm = 0.5 * (Rm + Rm.T)
+        DL = self._dlam(alpha, beta)
+        jg = eta_g - self._lb                                 # d alpha / d free (= d2 alpha / d free2)
+        Hgg_free = Hgg * jg[:, None] * jg[None, :] + np.diag(g_vec * jg)
+        DLf = DL * jg[None, :]
+        schur = DLf.T @ Rm @ DLf
+        if return_parts:
+            return Hgg_free - schur, Hgg_free, schur
+        return Hgg_free - schur
+
+    def global_cov(self, free_val, moment_jac=None):
+        """Linear-response covariance  M H_S^-1 M^T  of moments of the Dirichlet parameters whose
+        free Jacobian is M (default: the free parameters themselves), by the device Cholesky path."""
+        HS = self.global_hessian(free_val)
+        self.ctx.chol_factor(HS)
+        M = np.eye(self.n_global) if moment_jac is None else _hip.as_f64(moment_jac)
+        return self.ctx.lrvb_cov(M)
+
+    def e_z(self, free_val):
+        """Responsibilities z = softmax([0, f]) on the host (small N; diagnostics and tests)."""
+        _, fz = self._split(free_val)
+        f = np.hstack([np.zeros((self.n_obs, 1)), fz.reshape(self.n_obs, self.K - 1)])
+        f -= f.max(axis=1, keepdims=True)
+        e = np.exp(f)
+        return e / e.sum(axis=1, keepdims=True)

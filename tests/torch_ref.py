@@ -3,6 +3,7 @@ only so that exact AD (torch.func) can check the oracle's ANALYTIC derivatives. 
 derivatives are unique, so agreement here pins the oracle's Hessians to what autograd (the
 reference's engine, absent from this image) would return for the same function."""
 import math
+import numpy as np
 import torch
 
 torch.set_default_dtype(torch.float64)
@@ -192,4 +193,33 @@ def lmm_objective(x, y, gid, G, beta0, lam0, mu0, kappa0, tau_y_prior, tau_mu_pr
                + 0.5 * torch.sum(-torch.log(ig) + 1.0 + math.log(2 * math.pi))
                + gam_entropy(ay, by) + gam_entropy(am, bm))
         return -(e_log_lik + e_log_u + beta_prior + mu_prior + tau_priors + ent)
+    return f
+
+
+def mixture_objective(x, K, a0, b0, lb=0.0):
+    """-ELBO of the Dirichlet-multinomial mixture as a function of the FREE vector
+    [log(alpha - lb) (K) | log(beta - lb) (V K, row-major) | simplex logits (N (K-1))] and the weights."""
+    xt = torch.as_tensor(x, dtype=torch.float64)
+    N, V = xt.shape
+    a0t = torch.as_tensor(np.broadcast_to(a0, (K,)).copy(), dtype=torch.float64)
+    b0t = torch.as_tensor(np.broadcast_to(b0, (V, K)).copy(), dtype=torch.float64)
+
+    def dir_entropy(al):            # axis 0 is the Dirichlet dimension
+        a_sum = al.sum(0)
+        M = al.shape[0]
+        return (torch.lgamma(al).sum(0) - torch.lgamma(a_sum) + (a_sum - M) * torch.digamma(a_sum)
+                - ((al - 1.0) * torch.digamma(al)).sum(0))
+
+    def f(theta, w):
+        alpha = lb + torch.exp(theta[:K])
+        beta = lb + torch.exp(theta[K:K + V * K]).reshape(V, K)
+        logits = torch.cat([torch.zeros(N, 1, dtype=torch.float64), theta[K + V * K:].reshape(N, K - 1)], 1)
+        z = torch.softmax(logits, 1)
+        elog_pi = torch.digamma(alpha) - torch.digamma(alpha.sum())
+        elog_phi = torch.digamma(beta) - torch.digamma(beta.sum(0, keepdim=True))
+        s = elog_pi[None, :] + xt @ elog_phi
+        lik = (w[:, None] * z * s).sum()
+        ent_z = -(w[:, None] * z * torch.log(z)).sum()
+        prior = ((a0t - 1.0) * elog_pi).sum() + ((b0t - 1.0) * elog_phi).sum()
+        return -(lik + ent_z + prior + dir_entropy(alpha) + dir_entropy(beta).sum())
     return f
