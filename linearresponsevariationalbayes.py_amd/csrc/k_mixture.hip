@@ -40,11 +40,12 @@ __global__ __launch_bounds__(256)
 void mixture_rows_kernel(const double* __restrict__ theta_z, const double* __restrict__ X, int V,
                          const double* __restrict__ w, const double* __restrict__ Lam, i64 N,
                          double* __restrict__ Amat, i64 lda, double* __restrict__ U,
-                         double* __restrict__ gfree, double* __restrict__ part_val, int* __restrict__ bad)
+                         double* __restrict__ gfree, double* __restrict__ part_val, int* __restrict__ bad, int force_dense)
 {
     constexpr int KM = K - 1;
     __shared__ double lam_s[32 * 32];
     __shared__ double vsum[4][2];
+    __shared__ double fstage[4][32 * 4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int e = tid; e < (V + 1) * K; e += 256) lam_s[e] = Lam[e];
@@ -95,46 +96,85 @@ void mixture_rows_kernel(const double* __restrict__ theta_z, const double* __res
         const double p_m = mx_bcast(p, m), g_m = mx_bcast(g, m), p_0 = mx_bcast(p, 0), g_0 = mx_bcast(g, 0);
         const double ps = (lane == 0) ? p_m : ((lane == m) ? p_0 : p);        // swapped categories
         const double gs = (lane == 0) ? g_m : ((lane == m) ? g_0 : g);
-        const double p1 = __shfl_down(ps, 1, 64), g1 = __shfl_down(gs, 1, 64);
-        const double r1 = sqrt(p1);
-        double a[KM];
-#pragma unroll
-        for (int j = 0; j < KM; ++j) {
-            const double rj = mx_bcast(r1, j), gj = mx_bcast(g1, j);
-            double h = r1 * rj * (2.0 * gdotp - wn - g1 - gj);
-            if (j == lane) h += wn + g1 - gdotp;
-            a[j] = (lane < KM) ? h : 0.0;
-        }
-        // Cholesky in registers
-#pragma unroll
-        for (int j = 0; j < KM; ++j) {
-            const double d = mx_bcast(a[j], j);
-            if (!(d > 0.0)) flag = 1;
-            const double r = 1.0 / sqrt(d);
-            a[j] = a[j] * r;
-#pragma unroll
-            for (int k = j + 1; k < KM; ++k) a[k] -= a[j] * mx_bcast(a[j], k);
-        }
-        // Y = L^-1 (J D^-1)^T: lane k solves L y = Jhat[k, :]^T,  Jhat[k][i] = r_i (d_{k,i+1} - p_k)
-        double y[KM];
-#pragma unroll
-        for (int i = 0; i < KM; ++i) {
-            double rhs = mx_bcast(r1, i) * ((lane == i + 1 ? 1.0 : 0.0) - ps);
-#pragma unroll
-            for (int c = 0; c < i; ++c) rhs -= mx_bcast(a[c], i) * y[c];
-            y[i] = rhs / mx_bcast(a[i], i);
-        }
-        // A[k][k'] = y^(k) . y^(k'), scaled by w^2; lane k writes its row (undoing the 0 <-> m swap)
         const double w2 = wn * wn;
-        const int row = (lane == 0) ? m : ((lane == m) ? 0 : lane);
-        double* arow = Amat + n * lda + (i64)row * K;
-#pragma unroll 4
-        for (int kp = 0; kp < K; ++kp) {
-            double acc = 0.0;
-#pragma unroll
-            for (int i = 0; i < KM; ++i) acc += y[i] * mx_bcast(y[i], kp);
-            const int col = (kp == 0) ? m : ((kp == m) ? 0 : kp);
-            if (cat) arow[col] = w2 * acc;
+        const int colp = (lane == 0) ? m : ((lane == m) ? 0 : lane);
+        double* arow = Amat + n * lda + colp;
+        // M = Dg - r s^T - s r^T with Dg = diag(d), d_k = w + g_k - g.p, s = r o (d - w/2): a DIAGONAL plus a
+        // rank-two term, so M^-1 follows from the Woodbury identity in O(K) and
+        //   A = diag(t) - t p^T - p t^T + alpha p p^T - [a1 a2] T^-1 [a1 a2]^T,   t_k = p_k / d_k (k >= 1),
+        //   T = [[alpha, beta - 1], [beta - 1, gamma]],  alpha = sum t,  beta = sum r s / d,  gamma = sum s^2 / d,
+        //   a1 = t - alpha p,  a2 = (p - w t / 2)[k >= 1] - beta p.
+        // With Dg > 0, M is positive definite iff det T < 0 (inertia additivity); det T = -p_ref at the
+        // optimum of the row.  Rows with a small or negative d_k take the dense factorisation below.
+        const bool loc = cat && lane >= 1;
+        const double dk = wn + gs - gdotp;
+        const double dmin = -mx_wave_max(loc ? -dk : -INFINITY);
+        const bool fastp = __builtin_amdgcn_readfirstlane((int)(!force_dense && wn > 0.0 && dmin > 0.05 * wn)) != 0;
+        if (fastp) {
+            const double t = loc ? ps / dk : 0.0;
+            const double alpha = mx_wave_sum(t);
+            const double sumq = mx_wave_sum(loc ? ps : 0.0);
+            const double beta = sumq - 0.5 * wn * alpha;
+            const double gamma = mx_wave_sum(loc ? ps * dk : 0.0) - wn * sumq + 0.25 * wn * wn * alpha;
+            const double det = alpha * gamma - (beta - 1.0) * (beta - 1.0);
+            if (!(det < 0.0)) flag = 1;
+            const double idet = 1.0 / det;
+            const double t11 = gamma * idet, t12 = (1.0 - beta) * idet, t22 = alpha * idet;
+            const double a1 = cat ? t - alpha * ps : 0.0;
+            const double a2 = cat ? (loc ? ps - 0.5 * wn * t : 0.0) - beta * ps : 0.0;
+            const double b1 = a1 * t11 + a2 * t12, b2 = a1 * t12 + a2 * t22;
+            const double c1 = alpha * ps - t;                      // coefficient of p_k'
+            double* fs = fstage[wave];
+            if (lane < 32) { fs[4 * lane] = ps; fs[4 * lane + 1] = t; fs[4 * lane + 2] = a1; fs[4 * lane + 3] = a2; }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll 8
+            for (int kp = 0; kp < K; ++kp) {
+                const double pk = fs[4 * kp], tk = fs[4 * kp + 1], a1k = fs[4 * kp + 2], a2k = fs[4 * kp + 3];
+                double v = c1 * pk - ps * tk - b1 * a1k - b2 * a2k;
+                if (kp == lane) v += t;
+                const int rowp = (kp == 0) ? m : ((kp == m) ? 0 : kp);
+                if (cat) arow[(i64)rowp * K] = w2 * v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            const double p1 = __shfl_down(ps, 1, 64), g1 = __shfl_down(gs, 1, 64);
+            const double r1 = sqrt(p1);
+            double a[KM];
+    #pragma unroll
+            for (int j = 0; j < KM; ++j) {
+                const double rj = mx_bcast(r1, j), gj = mx_bcast(g1, j);
+                double h = r1 * rj * (2.0 * gdotp - wn - g1 - gj);
+                if (j == lane) h += wn + g1 - gdotp;
+                a[j] = (lane < KM) ? h : 0.0;
+            }
+            // Cholesky in registers
+    #pragma unroll
+            for (int j = 0; j < KM; ++j) {
+                const double d = mx_bcast(a[j], j);
+                if (!(d > 0.0)) flag = 1;
+                const double r = 1.0 / sqrt(d);
+                a[j] = a[j] * r;
+    #pragma unroll
+                for (int k = j + 1; k < KM; ++k) a[k] -= a[j] * mx_bcast(a[j], k);
+            }
+            // Y = L^-1 (J D^-1)^T: lane k solves L y = Jhat[k, :]^T,  Jhat[k][i] = r_i (d_{k,i+1} - p_k)
+            double y[KM];
+    #pragma unroll
+            for (int i = 0; i < KM; ++i) {
+                double rhs = mx_bcast(r1, i) * ((lane == i + 1 ? 1.0 : 0.0) - ps);
+    #pragma unroll
+                for (int c = 0; c < i; ++c) rhs -= mx_bcast(a[c], i) * y[c];
+                y[i] = rhs / mx_bcast(a[i], i);
+            }
+            // A[k][k'] = y^(k) . y^(k'), scaled by w^2 (undoing the 0 <-> m swap)
+    #pragma unroll 4
+            for (int kp = 0; kp < K; ++kp) {
+                double acc = 0.0;
+    #pragma unroll
+                for (int i = 0; i < KM; ++i) acc += y[i] * mx_bcast(y[i], kp);
+                const int rowp = (kp == 0) ? m : ((kp == m) ? 0 : kp);
+                if (cat) arow[(i64)rowp * K] = w2 * acc;          // A is symmetric: lane <-> column, coalesced
+            }
         }
         if (lda > (i64)K * K && lane == 0) Amat[n * lda + (i64)K * K] = 0.0;     // even-width padding column
     }
@@ -183,7 +223,8 @@ int launch_mixture_rows(lrvb_ctx* c, int K, const double* theta_z_dev, const dou
     LRVB_TRY(buf_reserve(c, c->part_val, (size_t)(2 * grid)));
     HIP_TRY(hipMemsetAsync(bad_dev, 0, sizeof(int), c->stream));
 #define MX_LAUNCH(KK) hipLaunchKernelGGL(mixture_rows_kernel<KK>, dim3((unsigned)grid), dim3(256), 0, c->stream, \
-        theta_z_dev, c->X.p, V, c->w.p, lam_dev, c->N, Amat_dev, lda, U_dev, gfree_dev, c->part_val.p, bad_dev)
+        theta_z_dev, c->X.p, V, c->w.p, lam_dev, c->N, Amat_dev, lda, U_dev, gfree_dev, c->part_val.p, bad_dev, \
+        c->force_dense_rows)
     switch (K) {
     case 2: MX_LAUNCH(2); break;   case 3: MX_LAUNCH(3); break;   case 4: MX_LAUNCH(4); break;
     case 5: MX_LAUNCH(5); break;   case 8: MX_LAUNCH(8); break;   case 16: MX_LAUNCH(16); break;

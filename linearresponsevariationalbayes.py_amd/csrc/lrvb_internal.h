@@ -71,6 +71,7 @@ struct lrvb_ctx {
     int  stagger_shift = -1;            // timing lab: delay blocks whose queue position has this bit set
     int  dbg_bits = 0;                  // timing-lab variants of the weighted-SYRK kernel (wrong results)
     bool force_generic_wsyrk = false;   // tuning/testing: use the register-staged kernel
+    int  force_dense_rows = 0;          // tuning/testing: mixture rows always take the dense factorisation
     int pass_grid = 0;
 
     // profiling: event pairs are recorded without host synchronisation and summed in

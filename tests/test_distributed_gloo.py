@@ -156,3 +156,41 @@ def test_two_rank_sufficient_statistics_allreduce(tmp_path):
     mp.spawn(_lmm_worker, args=(2, _free_port(), out_path), nprocs=2, join=True)
     err = np.load(out_path)
     assert err[0] < 1e-12 and err[1] < 1e-12
+
+
+def _mixture_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from lrvb_amd.distributed import shard_rows, allreduce_stats
+    from test_mixture_host_math import make_par, shell, near_optimum_problem, oracle_stats
+    N, V, K = 90, 4, 3
+    x, w, theta = near_optimum_problem(N, V, K, seed=5)
+    ng = K + V * K
+    fz = theta[ng:].reshape(N, K - 1)
+    r0, r1 = shard_rows(N, rank, world)
+    # each rank owns a slice of the observations AND the simplex rows that go with them
+    f_loc = shell(make_par(r1 - r0, V, K), x[r0:r1], K, 1.5, 0.8)
+    th_loc = np.concatenate([theta[:ng], fz[r0:r1].ravel()])
+    local, _, _ = oracle_stats(f_loc, x[r0:r1], w[r0:r1], th_loc)
+    total = allreduce_stats(local)
+    f_loc.set_reduced_stats(total)
+    HS = f_loc.global_hessian(th_loc)
+    val = f_loc.value(th_loc)
+    if rank == 0:
+        f = shell(make_par(N, V, K), x, K, 1.5, 0.8)
+        f.set_reduced_stats(oracle_stats(f, x, w, theta)[0])
+        HS1 = f.global_hessian(theta)
+        np.save(out_path, np.array([np.max(np.abs(HS - HS1)) / np.max(np.abs(HS1)), abs(val - f.value(theta)) / abs(val)]))
+    dist.destroy_process_group()
+
+
+def test_two_rank_mixture_statistics_allreduce(tmp_path):
+    """Config 3's exchange step: per-rank [value | S64 | Schur operand R], one sum all-reduce, identical
+    Schur complement of the Dirichlet block on every rank."""
+    out_path = str(tmp_path / 'err.npy')
+    mp.spawn(_mixture_worker, args=(2, _free_port(), out_path), nprocs=2, join=True)
+    err = np.load(out_path)
+    assert err[0] < 1e-11 and err[1] < 1e-12

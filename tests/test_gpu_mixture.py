@@ -40,6 +40,11 @@ def test_rows_match_oracle(vb, N, V, K):
     assert rel_err(gz, o_g) < 1e-11
     assert rel_err(S64, o_S64) < 1e-12
     assert rel_err(R, o_R) < 1e-9                      # includes a (K-1) x (K-1) solve per row
+    # the dense per-row factorisation (taken when a row is far from its optimum) gives the same operand
+    fun.ctx.set_tuning(0, 2)
+    R_dense = fun.ctx.mixture_rows(K, fz, lam)[3]
+    fun.ctx.set_tuning(0, 0)
+    assert rel_err(R_dense, o_R) < 1e-9 and rel_err(R_dense, R) < 1e-9
     # the flat statistics buffer is the same thing
     stats = fun.local_stats(theta)
     assert rel_err(stats, np.concatenate([o_val2, o_S64.ravel(), o_R.ravel()])) < 1e-9
