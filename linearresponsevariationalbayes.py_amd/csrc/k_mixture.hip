@@ -35,12 +35,60 @@ __device__ __forceinline__ double mx_wave_max(double v) {
     return v;
 }
 
+// Shared prelude of one row on one wavefront: lane k <-> category k (lane 0 = reference, logit 0).
+struct MixRow {
+    double wn, p, logp, xt, s, g, gdotp;    // per lane (p, g: category `lane`)
+    double ps, gs;                          // categories 0 and m swapped (m = arg-max category)
+    int m;
+    bool cat;
+};
+
+template <int K>
+__device__ __forceinline__ MixRow mixture_row_prelude(const double* __restrict__ theta_z, const double* __restrict__ X,
+                                                      int V, const double* __restrict__ w, const double* lam_s,
+                                                      i64 n, int lane)
+{
+    constexpr int KM = K - 1;
+    MixRow r;
+    r.wn = w[n];
+    const double f = (lane < KM) ? theta_z[n * KM + lane] : 0.0;
+    double logit = __shfl_up(f, 1, 64);
+    if (lane == 0) logit = 0.0;
+    r.cat = lane < K;
+    const double mxl = mx_wave_max(r.cat ? logit : -INFINITY);
+    const double ex = r.cat ? exp(logit - mxl) : 0.0;
+    const double den = mx_wave_sum(ex);
+    r.p = ex / den;
+    r.logp = r.cat ? (logit - mxl - log(den)) : 0.0;
+    r.xt = (lane == 0) ? 1.0 : ((lane <= V) ? X[n * V + lane - 1] : 0.0);
+    double s = 0.0;
+    for (int j = 0; j <= V; ++j) s += mx_bcast(r.xt, j) * (r.cat ? lam_s[j * K + lane] : 0.0);
+    r.s = s;
+    r.g = r.cat ? -r.wn * (s - r.logp - 1.0) : 0.0;
+    r.gdotp = mx_wave_sum(r.g * r.p);
+    // Two changes of variables keep the local block well conditioned when responsibilities saturate,
+    // neither of which changes A_n = J H_nn^-1 J^T:
+    //  (a) the REFERENCE category of the row is its arg-max category m instead of category 0 (a linear
+    //      change of the free coordinates): H_nn has an eigenvalue ~ w p_ref, which underflows when
+    //      p_0 -> 0.  Categories 0 and m are swapped for the elimination only.
+    //  (b) scaling by D = diag(sqrt(p_{i+1})):  M = D^-1 H_nn D^-1,
+    //      M_ij = r_i r_j (2 g.p - w - g_{i+1} - g_{j+1}) + d_ij (w + g_{i+1} - g.p)
+    r.m = __builtin_amdgcn_readfirstlane((int)__ffsll((unsigned long long)__ballot(r.cat && logit == mxl)) - 1);
+    const double p_m = mx_bcast(r.p, r.m), g_m = mx_bcast(r.g, r.m), p_0 = mx_bcast(r.p, 0), g_0 = mx_bcast(r.g, 0);
+    r.ps = (lane == 0) ? p_m : ((lane == r.m) ? p_0 : r.p);
+    r.gs = (lane == 0) ? g_m : ((lane == r.m) ? g_0 : r.g);
+    return r;
+}
+
+// Pass 1: values, local gradient, statistics row, and A_n by the O(K) diagonal-plus-rank-two formula.
+// Rows that need the dense factorisation (a small or negative d_k, or force_dense) are appended to `todo`.
 template <int K>
 __global__ __launch_bounds__(256)
 void mixture_rows_kernel(const double* __restrict__ theta_z, const double* __restrict__ X, int V,
                          const double* __restrict__ w, const double* __restrict__ Lam, i64 N,
                          double* __restrict__ Amat, i64 lda, double* __restrict__ U,
-                         double* __restrict__ gfree, double* __restrict__ part_val, int* __restrict__ bad, int force_dense)
+                         double* __restrict__ gfree, double* __restrict__ part_val, int* __restrict__ bad,
+                         int force_dense, int* __restrict__ todo, int* __restrict__ todo_count)
 {
     constexpr int KM = K - 1;
     __shared__ double lam_s[32 * 32];
@@ -54,129 +102,66 @@ void mixture_rows_kernel(const double* __restrict__ theta_z, const double* __res
     double v_lin = 0.0, v_ent = 0.0;        // -w sum z s  and  w sum z log z of this wave's rows
     int flag = 0;
     for (i64 n = (i64)blockIdx.x * 4 + wave; n < N; n += (i64)gridDim.x * 4) {
-        const double wn = w[n];
-        // logits and probabilities: lane k <-> category k (lane 0 = reference category, logit 0)
-        const double f = (lane < KM) ? theta_z[n * KM + lane] : 0.0;
-        double logit = __shfl_up(f, 1, 64);
-        if (lane == 0) logit = 0.0;
-        const bool cat = lane < K;
-        const double mxl = mx_wave_max(cat ? logit : -INFINITY);
-        const double ex = cat ? exp(logit - mxl) : 0.0;
-        const double den = mx_wave_sum(ex);
-        const double p = ex / den;
-        const double logp = cat ? (logit - mxl - log(den)) : 0.0;
-        // x~ and the scores
-        const double xt = (lane == 0) ? 1.0 : ((lane <= V) ? X[n * V + lane - 1] : 0.0);
-        double s = 0.0;
-        for (int j = 0; j <= V; ++j) s += mx_bcast(xt, j) * (cat ? lam_s[j * K + lane] : 0.0);
-        const double g = cat ? -wn * (s - logp - 1.0) : 0.0;
-        const double gp = g * p;
-        const double gdotp = mx_wave_sum(gp);
-        v_lin += mx_wave_sum(cat ? -wn * p * s : 0.0);
-        v_ent += mx_wave_sum(cat ? wn * p * logp : 0.0);
+        const MixRow r = mixture_row_prelude<K>(theta_z, X, V, w, lam_s, n, lane);
+        const double wn = r.wn, ps = r.ps;
+        const bool cat = r.cat;
+        const int m = r.m;
+        v_lin += mx_wave_sum(cat ? -wn * r.p * r.s : 0.0);
+        v_ent += mx_wave_sum(cat ? wn * r.p * r.logp : 0.0);
         // free local gradient: J^T g, lane j <-> free index j:  p_{j+1} (g_{j+1} - g.p)
         {
-            const double pn = __shfl_down(p, 1, 64), gn = __shfl_down(g, 1, 64);
-            if (lane < KM) gfree[n * KM + lane] = pn * (gn - gdotp);
+            const double pn = __shfl_down(r.p, 1, 64), gn = __shfl_down(r.g, 1, 64);
+            if (lane < KM) gfree[n * KM + lane] = pn * (gn - r.gdotp);
         }
         // sufficient-statistics row [x~ (32) | z (32)]
         {
-            const double zsh = __shfl(p, lane - 32, 64);
-            U[n * 64 + lane] = (lane < 32) ? xt : ((lane - 32 < K) ? zsh : 0.0);
+            const double zsh = __shfl(r.p, lane - 32, 64);
+            U[n * 64 + lane] = (lane < 32) ? r.xt : ((lane - 32 < K) ? zsh : 0.0);
         }
-        // local Hessian in free coordinates.  Two changes of variables keep it well conditioned when
-        // responsibilities saturate, neither of which changes A_n = J H_nn^-1 J^T:
-        //  (a) the REFERENCE category of the row is its arg-max category m instead of category 0 (a
-        //      linear change of the free coordinates): H_nn has an eigenvalue ~ w p_ref, which
-        //      underflows when p_0 -> 0.  Categories 0 and m are swapped for this part only.
-        //  (b) scaling by D = diag(sqrt(p_{i+1})):  M = D^-1 H_nn D^-1,
-        //      M_ij = r_i r_j (2 g.p - w - g_{i+1} - g_{j+1}) + d_ij (w + g_{i+1} - g.p)
-        // lane i <-> row i (zero rows past K-1, never read)
-        const int m = __builtin_amdgcn_readfirstlane((int)__ffsll((unsigned long long)__ballot(cat && logit == mxl)) - 1);
-        const double p_m = mx_bcast(p, m), g_m = mx_bcast(g, m), p_0 = mx_bcast(p, 0), g_0 = mx_bcast(g, 0);
-        const double ps = (lane == 0) ? p_m : ((lane == m) ? p_0 : p);        // swapped categories
-        const double gs = (lane == 0) ? g_m : ((lane == m) ? g_0 : g);
-        const double w2 = wn * wn;
-        const int colp = (lane == 0) ? m : ((lane == m) ? 0 : lane);
-        double* arow = Amat + n * lda + colp;
+        if (lda > (i64)K * K && lane == 0) Amat[n * lda + (i64)K * K] = 0.0;     // even-width padding column
         // M = Dg - r s^T - s r^T with Dg = diag(d), d_k = w + g_k - g.p, s = r o (d - w/2): a DIAGONAL plus a
         // rank-two term, so M^-1 follows from the Woodbury identity in O(K) and
         //   A = diag(t) - t p^T - p t^T + alpha p p^T - [a1 a2] T^-1 [a1 a2]^T,   t_k = p_k / d_k (k >= 1),
         //   T = [[alpha, beta - 1], [beta - 1, gamma]],  alpha = sum t,  beta = sum r s / d,  gamma = sum s^2 / d,
         //   a1 = t - alpha p,  a2 = (p - w t / 2)[k >= 1] - beta p.
         // With Dg > 0, M is positive definite iff det T < 0 (inertia additivity); det T = -p_ref at the
-        // optimum of the row.  Rows with a small or negative d_k take the dense factorisation below.
+        // optimum of the row.
         const bool loc = cat && lane >= 1;
-        const double dk = wn + gs - gdotp;
+        const double dk = wn + r.gs - r.gdotp;
         const double dmin = -mx_wave_max(loc ? -dk : -INFINITY);
         const bool fastp = __builtin_amdgcn_readfirstlane((int)(!force_dense && wn > 0.0 && dmin > 0.05 * wn)) != 0;
-        if (fastp) {
-            const double t = loc ? ps / dk : 0.0;
-            const double alpha = mx_wave_sum(t);
-            const double sumq = mx_wave_sum(loc ? ps : 0.0);
-            const double beta = sumq - 0.5 * wn * alpha;
-            const double gamma = mx_wave_sum(loc ? ps * dk : 0.0) - wn * sumq + 0.25 * wn * wn * alpha;
-            const double det = alpha * gamma - (beta - 1.0) * (beta - 1.0);
-            if (!(det < 0.0)) flag = 1;
-            const double idet = 1.0 / det;
-            const double t11 = gamma * idet, t12 = (1.0 - beta) * idet, t22 = alpha * idet;
-            const double a1 = cat ? t - alpha * ps : 0.0;
-            const double a2 = cat ? (loc ? ps - 0.5 * wn * t : 0.0) - beta * ps : 0.0;
-            const double b1 = a1 * t11 + a2 * t12, b2 = a1 * t12 + a2 * t22;
-            const double c1 = alpha * ps - t;                      // coefficient of p_k'
-            double* fs = fstage[wave];
-            if (lane < 32) { fs[4 * lane] = ps; fs[4 * lane + 1] = t; fs[4 * lane + 2] = a1; fs[4 * lane + 3] = a2; }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll 8
-            for (int kp = 0; kp < K; ++kp) {
-                const double pk = fs[4 * kp], tk = fs[4 * kp + 1], a1k = fs[4 * kp + 2], a2k = fs[4 * kp + 3];
-                double v = c1 * pk - ps * tk - b1 * a1k - b2 * a2k;
-                if (kp == lane) v += t;
-                const int rowp = (kp == 0) ? m : ((kp == m) ? 0 : kp);
-                if (cat) arow[(i64)rowp * K] = w2 * v;
-            }
-            __builtin_amdgcn_wave_barrier();
-        } else {
-            const double p1 = __shfl_down(ps, 1, 64), g1 = __shfl_down(gs, 1, 64);
-            const double r1 = sqrt(p1);
-            double a[KM];
-    #pragma unroll
-            for (int j = 0; j < KM; ++j) {
-                const double rj = mx_bcast(r1, j), gj = mx_bcast(g1, j);
-                double h = r1 * rj * (2.0 * gdotp - wn - g1 - gj);
-                if (j == lane) h += wn + g1 - gdotp;
-                a[j] = (lane < KM) ? h : 0.0;
-            }
-            // Cholesky in registers
-    #pragma unroll
-            for (int j = 0; j < KM; ++j) {
-                const double d = mx_bcast(a[j], j);
-                if (!(d > 0.0)) flag = 1;
-                const double r = 1.0 / sqrt(d);
-                a[j] = a[j] * r;
-    #pragma unroll
-                for (int k = j + 1; k < KM; ++k) a[k] -= a[j] * mx_bcast(a[j], k);
-            }
-            // Y = L^-1 (J D^-1)^T: lane k solves L y = Jhat[k, :]^T,  Jhat[k][i] = r_i (d_{k,i+1} - p_k)
-            double y[KM];
-    #pragma unroll
-            for (int i = 0; i < KM; ++i) {
-                double rhs = mx_bcast(r1, i) * ((lane == i + 1 ? 1.0 : 0.0) - ps);
-    #pragma unroll
-                for (int c = 0; c < i; ++c) rhs -= mx_bcast(a[c], i) * y[c];
-                y[i] = rhs / mx_bcast(a[i], i);
-            }
-            // A[k][k'] = y^(k) . y^(k'), scaled by w^2 (undoing the 0 <-> m swap)
-    #pragma unroll 4
-            for (int kp = 0; kp < K; ++kp) {
-                double acc = 0.0;
-    #pragma unroll
-                for (int i = 0; i < KM; ++i) acc += y[i] * mx_bcast(y[i], kp);
-                const int rowp = (kp == 0) ? m : ((kp == m) ? 0 : kp);
-                if (cat) arow[(i64)rowp * K] = w2 * acc;          // A is symmetric: lane <-> column, coalesced
-            }
+        if (!fastp) {
+            if (lane == 0) todo[atomicAdd(todo_count, 1)] = (int)n;
+            continue;
         }
-        if (lda > (i64)K * K && lane == 0) Amat[n * lda + (i64)K * K] = 0.0;     // even-width padding column
+        const double t = loc ? ps / dk : 0.0;
+        const double alpha = mx_wave_sum(t);
+        const double sumq = mx_wave_sum(loc ? ps : 0.0);
+        const double beta = sumq - 0.5 * wn * alpha;
+        const double gamma = mx_wave_sum(loc ? ps * dk : 0.0) - wn * sumq + 0.25 * wn * wn * alpha;
+        const double det = alpha * gamma - (beta - 1.0) * (beta - 1.0);
+        if (!(det < 0.0)) flag = 1;
+        const double idet = 1.0 / det;
+        const double t11 = gamma * idet, t12 = (1.0 - beta) * idet, t22 = alpha * idet;
+        const double a1 = cat ? t - alpha * ps : 0.0;
+        const double a2 = cat ? (loc ? ps - 0.5 * wn * t : 0.0) - beta * ps : 0.0;
+        const double w2 = wn * wn;
+        const double b1 = w2 * (a1 * t11 + a2 * t12), b2 = w2 * (a1 * t12 + a2 * t22);
+        const double c1 = w2 * (alpha * ps - t), c2 = w2 * ps, c3 = w2 * t;
+        double* fs = fstage[wave];
+        if (lane < 32) { fs[4 * lane] = ps; fs[4 * lane + 1] = t; fs[4 * lane + 2] = a1; fs[4 * lane + 3] = a2; }
+        __builtin_amdgcn_wave_barrier();
+        const int colp = (lane == 0) ? m : ((lane == m) ? 0 : lane);
+        double* arow = Amat + n * lda + colp;                     // A is symmetric: lane <-> column, coalesced
+#pragma unroll 8
+        for (int kp = 0; kp < K; ++kp) {
+            const double pk = fs[4 * kp], tk = fs[4 * kp + 1], a1k = fs[4 * kp + 2], a2k = fs[4 * kp + 3];
+            double v = c1 * pk - c2 * tk - b1 * a1k - b2 * a2k;
+            if (kp == lane) v += c3;
+            const int rowp = (kp == 0) ? m : ((kp == m) ? 0 : kp);
+            if (cat) arow[(i64)rowp * K] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
     }
     if (lane == 0) { vsum[wave][0] = v_lin; vsum[wave][1] = v_ent; }
     if (flag && lane == 0) atomicOr(bad, 1);
@@ -187,30 +172,98 @@ void mixture_rows_kernel(const double* __restrict__ theta_z, const double* __res
     }
 }
 
+// Pass 2 (rows listed in `todo` only): the dense route.  M = L L^T in registers with v_readlane
+// broadcasts (as the 64 x 64 Cholesky block of k_linalg.hip), Y = L^-1 (J D^-1)^T (lane k <-> column k),
+// A_n = Y^T Y.
+template <int K>
+__global__ __launch_bounds__(256)
+void mixture_rows_dense_kernel(const double* __restrict__ theta_z, const double* __restrict__ X, int V,
+                               const double* __restrict__ w, const double* __restrict__ Lam,
+                               double* __restrict__ Amat, i64 lda, int* __restrict__ bad,
+                               const int* __restrict__ todo, const int* __restrict__ todo_count)
+{
+    constexpr int KM = K - 1;
+    __shared__ double lam_s[32 * 32];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int e = tid; e < (V + 1) * K; e += 256) lam_s[e] = Lam[e];
+    __syncthreads();
+    const int count = *todo_count;
+    int flag = 0;
+    for (int q = blockIdx.x * 4 + wave; q < count; q += gridDim.x * 4) {
+        const i64 n = todo[q];
+        const MixRow r = mixture_row_prelude<K>(theta_z, X, V, w, lam_s, n, lane);
+        const double wn = r.wn, ps = r.ps, gdotp = r.gdotp;
+        const bool cat = r.cat;
+        const int m = r.m;
+        const double p1 = __shfl_down(ps, 1, 64), g1 = __shfl_down(r.gs, 1, 64);
+        const double r1 = sqrt(p1);
+        double a[KM];                                   // lane i <-> row i (zero rows past K-1, never read)
+#pragma unroll
+        for (int j = 0; j < KM; ++j) {
+            const double rj = mx_bcast(r1, j), gj = mx_bcast(g1, j);
+            double h = r1 * rj * (2.0 * gdotp - wn - g1 - gj);
+            if (j == lane) h += wn + g1 - gdotp;
+            a[j] = (lane < KM) ? h : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < KM; ++j) {
+            const double d = mx_bcast(a[j], j);
+            if (!(d > 0.0)) flag = 1;
+            const double rs = 1.0 / sqrt(d);
+            a[j] = a[j] * rs;
+#pragma unroll
+            for (int k = j + 1; k < KM; ++k) a[k] -= a[j] * mx_bcast(a[j], k);
+        }
+        // lane k solves L y = Jhat[k, :]^T,  Jhat[k][i] = r_i (d_{k,i+1} - p_k)
+        double y[KM];
+#pragma unroll
+        for (int i = 0; i < KM; ++i) {
+            double rhs = mx_bcast(r1, i) * ((lane == i + 1 ? 1.0 : 0.0) - ps);
+#pragma unroll
+            for (int c = 0; c < i; ++c) rhs -= mx_bcast(a[c], i) * y[c];
+            y[i] = rhs / mx_bcast(a[i], i);
+        }
+        const double w2 = wn * wn;
+        const int colp = (lane == 0) ? m : ((lane == m) ? 0 : lane);
+        double* arow = Amat + n * lda + colp;
+#pragma unroll 4
+        for (int kp = 0; kp < K; ++kp) {
+            double acc = 0.0;
+#pragma unroll
+            for (int i = 0; i < KM; ++i) acc += y[i] * mx_bcast(y[i], kp);
+            const int rowp = (kp == 0) ? m : ((kp == m) ? 0 : kp);
+            if (cat) arow[(i64)rowp * K] = w2 * acc;
+        }
+    }
+    if (flag && lane == 0) atomicOr(bad, 1);
+}
+
 // Xk[n, 32... ] = x~_n (x) x~_n with row length (V+1)^2 (+1 zero column when odd)
 __global__ __launch_bounds__(256)
 void kron_rows_kernel(const double* __restrict__ X, int V, i64 N, double* __restrict__ Xk, i64 ldk)
 {
-    const i64 n = blockIdx.y;
+    __shared__ double xs[4][32];
     const int q = V + 1;
-    for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < ldk; e += (i64)gridDim.x * blockDim.x) {
-        double v = 0.0;
-        if (e < (i64)q * q) {
-            const int a = (int)(e / q), b = (int)(e % q);
-            const double xa = a == 0 ? 1.0 : X[n * V + a - 1];
-            const double xb = b == 0 ? 1.0 : X[n * V + b - 1];
-            v = xa * xb;
-        }
-        Xk[n * ldk + e] = v;
+    const int sub = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (i64 n0 = (i64)blockIdx.x * 4; n0 < N; n0 += (i64)gridDim.x * 4) {     // one wavefront per row
+        const i64 n = n0 + sub;
+        __syncthreads();
+        if (n < N && lane < q) xs[sub][lane] = lane == 0 ? 1.0 : X[n * V + lane - 1];
+        __syncthreads();
+        if (n < N)
+            for (int e = lane; e < (int)ldk; e += 64) {
+                const int a = e / q, b = e - a * q;
+                Xk[n * ldk + e] = (e < q * q) ? xs[sub][a] * xs[sub][b] : 0.0;
+            }
     }
 }
 
 __global__ void mixture_val_reduce_kernel(const double* __restrict__ part, int nblk, double* __restrict__ out2) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double a = 0.0, b = 0.0;
-        for (int i = 0; i < nblk; ++i) { a += part[2 * i]; b += part[2 * i + 1]; }
-        out2[0] = a; out2[1] = b;
-    }
+    double a = 0.0, b = 0.0;                               // one wavefront, fixed order: deterministic
+    for (int i = threadIdx.x; i < nblk; i += 64) { a += part[2 * i]; b += part[2 * i + 1]; }
+    a = mx_wave_sum(a); b = mx_wave_sum(b);
+    if (threadIdx.x == 0) { out2[0] = a; out2[1] = b; }
 }
 
 int launch_mixture_rows(lrvb_ctx* c, int K, const double* theta_z_dev, const double* lam_dev,
@@ -218,13 +271,24 @@ int launch_mixture_rows(lrvb_ctx* c, int K, const double* theta_z_dev, const dou
 {
     const int V = (int)c->P;
     if (V + 1 > 32 || K > 32 || K < 2) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "mixture kernel supports V + 1 <= 32 and 2 <= K <= 32");
+    if (c->N > 2147483647LL) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "mixture kernel indexes rows with 32 bits");
     i64 grid = (c->N + 3) / 4;
-    if (grid > 2048) grid = 2048;
+    if (grid > 4096) grid = 4096;
     LRVB_TRY(buf_reserve(c, c->part_val, (size_t)(2 * grid)));
+    // todo list of rows for the dense pass: N ints + the counter, in the observation scratch buffer
+    LRVB_TRY(buf_reserve(c, c->lp, (size_t)(c->N / 2 + 2)));
+    int* todo = reinterpret_cast<int*>(c->lp.p) + 2;
+    int* todo_count = reinterpret_cast<int*>(c->lp.p);
     HIP_TRY(hipMemsetAsync(bad_dev, 0, sizeof(int), c->stream));
-#define MX_LAUNCH(KK) hipLaunchKernelGGL(mixture_rows_kernel<KK>, dim3((unsigned)grid), dim3(256), 0, c->stream, \
-        theta_z_dev, c->X.p, V, c->w.p, lam_dev, c->N, Amat_dev, lda, U_dev, gfree_dev, c->part_val.p, bad_dev, \
-        c->force_dense_rows)
+    HIP_TRY(hipMemsetAsync(todo_count, 0, sizeof(int), c->stream));
+    i64 dgrid = (c->N + 3) / 4;
+    if (dgrid > 2048) dgrid = 2048;
+#define MX_LAUNCH(KK) do { \
+        hipLaunchKernelGGL(mixture_rows_kernel<KK>, dim3((unsigned)grid), dim3(256), 0, c->stream, \
+            theta_z_dev, c->X.p, V, c->w.p, lam_dev, c->N, Amat_dev, lda, U_dev, gfree_dev, c->part_val.p, bad_dev, \
+            c->force_dense_rows, todo, todo_count); \
+        hipLaunchKernelGGL(mixture_rows_dense_kernel<KK>, dim3((unsigned)dgrid), dim3(256), 0, c->stream, \
+            theta_z_dev, c->X.p, V, c->w.p, lam_dev, Amat_dev, lda, bad_dev, todo, todo_count); } while (0)
     switch (K) {
     case 2: MX_LAUNCH(2); break;   case 3: MX_LAUNCH(3); break;   case 4: MX_LAUNCH(4); break;
     case 5: MX_LAUNCH(5); break;   case 8: MX_LAUNCH(8); break;   case 16: MX_LAUNCH(16); break;
@@ -240,14 +304,9 @@ int launch_mixture_rows(lrvb_ctx* c, int K, const double* theta_z_dev, const dou
 
 int launch_kron_rows(lrvb_ctx* c, double* Xk_dev, i64 ldk)
 {
-    dim3 grid((unsigned)((ldk + 255) / 256), 1);
-    const i64 chunk = 65535;
-    for (i64 n0 = 0; n0 < c->N; n0 += chunk) {
-        const i64 rows = (c->N - n0 < chunk) ? (c->N - n0) : chunk;
-        grid.y = (unsigned)rows;
-        hipLaunchKernelGGL(kron_rows_kernel, grid, dim3(256), 0, c->stream, c->X.p + n0 * c->P, (int)c->P, rows,
-                           Xk_dev + n0 * ldk, ldk);
-        HIP_TRY(hipGetLastError());
-    }
+    i64 grid = (c->N + 3) / 4;
+    if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL(kron_rows_kernel, dim3((unsigned)grid), dim3(256), 0, c->stream, c->X.p, (int)c->P, c->N, Xk_dev, ldk);
+    HIP_TRY(hipGetLastError());
     return LRVB_OK;
 }
