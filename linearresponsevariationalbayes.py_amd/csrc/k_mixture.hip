@@ -118,7 +118,7 @@ void mixture_rows_kernel(const double* __restrict__ theta_z, const double* __res
             const double zsh = __shfl(r.p, lane - 32, 64);
             U[n * 64 + lane] = (lane < 32) ? r.xt : ((lane - 32 < K) ? zsh : 0.0);
         }
-        if (lda > (i64)K * K && lane == 0) Amat[n * lda + (i64)K * K] = 0.0;     // even-width padding column
+        if (lda > (i64)K * (K + 1) / 2 && lane == 0) Amat[n * lda + (i64)K * (K + 1) / 2] = 0.0;     // even-width padding column
         // M = Dg - r s^T - s r^T with Dg = diag(d), d_k = w + g_k - g.p, s = r o (d - w/2): a DIAGONAL plus a
         // rank-two term, so M^-1 follows from the Woodbury identity in O(K) and
         //   A = diag(t) - t p^T - p t^T + alpha p p^T - [a1 a2] T^-1 [a1 a2]^T,   t_k = p_k / d_k (k >= 1),
@@ -151,15 +151,17 @@ void mixture_rows_kernel(const double* __restrict__ theta_z, const double* __res
         double* fs = fstage[wave];
         if (lane < 32) { fs[4 * lane] = ps; fs[4 * lane + 1] = t; fs[4 * lane + 2] = a1; fs[4 * lane + 3] = a2; }
         __builtin_amdgcn_wave_barrier();
+        // A is symmetric: only its lower triangle is stored, packed (row r, column c <= r at r(r+1)/2 + c);
+        // lane <-> column, so a row is one contiguous store
         const int colp = (lane == 0) ? m : ((lane == m) ? 0 : lane);
-        double* arow = Amat + n * lda + colp;                     // A is symmetric: lane <-> column, coalesced
+        double* arow = Amat + n * lda + colp;
 #pragma unroll 8
         for (int kp = 0; kp < K; ++kp) {
             const double pk = fs[4 * kp], tk = fs[4 * kp + 1], a1k = fs[4 * kp + 2], a2k = fs[4 * kp + 3];
             double v = c1 * pk - c2 * tk - b1 * a1k - b2 * a2k;
             if (kp == lane) v += c3;
             const int rowp = (kp == 0) ? m : ((kp == m) ? 0 : kp);
-            if (cat) arow[(i64)rowp * K] = v;
+            if (cat && rowp >= colp) arow[rowp * (rowp + 1) / 2] = v;
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -233,18 +235,18 @@ void mixture_rows_dense_kernel(const double* __restrict__ theta_z, const double*
 #pragma unroll
             for (int i = 0; i < KM; ++i) acc += y[i] * mx_bcast(y[i], kp);
             const int rowp = (kp == 0) ? m : ((kp == m) ? 0 : kp);
-            if (cat) arow[(i64)rowp * K] = w2 * acc;
+            if (cat && rowp >= colp) arow[rowp * (rowp + 1) / 2] = w2 * acc;      // packed lower triangle
         }
     }
     if (flag && lane == 0) atomicOr(bad, 1);
 }
 
-// Xk[n, 32... ] = x~_n (x) x~_n with row length (V+1)^2 (+1 zero column when odd)
+// Xk[n, :] = packed lower triangle of x~_n x~_n^T, row length q(q+1)/2 (+1 zero column when odd)
 __global__ __launch_bounds__(256)
 void kron_rows_kernel(const double* __restrict__ X, int V, i64 N, double* __restrict__ Xk, i64 ldk)
 {
     __shared__ double xs[4][32];
-    const int q = V + 1;
+    const int q = V + 1, qp = q * (q + 1) / 2;
     const int sub = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (i64 n0 = (i64)blockIdx.x * 4; n0 < N; n0 += (i64)gridDim.x * 4) {     // one wavefront per row
         const i64 n = n0 + sub;
@@ -253,10 +255,37 @@ void kron_rows_kernel(const double* __restrict__ X, int V, i64 N, double* __rest
         __syncthreads();
         if (n < N)
             for (int e = lane; e < (int)ldk; e += 64) {
-                const int a = e / q, b = e - a * q;
-                Xk[n * ldk + e] = (e < q * q) ? xs[sub][a] * xs[sub][b] : 0.0;
+                // packed pair index e = a (a + 1) / 2 + b, b <= a
+                int a = (int)((sqrtf(8.f * (float)e + 1.f) - 1.f) * 0.5f);
+                while (a * (a + 1) / 2 > e) --a;
+                while ((a + 1) * (a + 2) / 2 <= e) ++a;
+                const int b = e - a * (a + 1) / 2;
+                Xk[n * ldk + e] = (e < qp) ? xs[sub][a] * xs[sub][b] : 0.0;
             }
     }
+}
+
+// R (q^2 x K^2, row-major) from the packed result Rs (q(q+1)/2 x lda): both index pairs are symmetric
+__global__ void mixture_expand_kernel(const double* __restrict__ Rs, i64 lda, int q, int K, double* __restrict__ Rfull)
+{
+    const i64 total = (i64)q * q * K * K;
+    for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (i64)gridDim.x * blockDim.x) {
+        const int kk = (int)(e % ((i64)K * K)), jj = (int)(e / ((i64)K * K));
+        int k = kk / K, kp = kk - k * K, j = jj / q, jp = jj - j * q;
+        if (kp > k) { const int t = k; k = kp; kp = t; }
+        if (jp > j) { const int t = j; j = jp; jp = t; }
+        Rfull[e] = Rs[(i64)(j * (j + 1) / 2 + jp) * lda + k * (k + 1) / 2 + kp];
+    }
+}
+
+int launch_mixture_expand(lrvb_ctx* c, const double* Rs, i64 lda, int q, int K, double* Rfull)
+{
+    const i64 total = (i64)q * q * K * K;
+    i64 grid = (total + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(mixture_expand_kernel, dim3((unsigned)grid), dim3(256), 0, c->stream, Rs, lda, q, K, Rfull);
+    HIP_TRY(hipGetLastError());
+    return LRVB_OK;
 }
 
 __global__ void mixture_val_reduce_kernel(const double* __restrict__ part, int nblk, double* __restrict__ out2) {

@@ -169,7 +169,7 @@ extern "C" int lrvb_ctx_destroy(lrvb_ctx* c) {
     DevBuf* all[] = { &c->X, &c->y, &c->w, &c->quadA, &c->quadM, &c->quadB, &c->theta, &c->eta, &c->j1, &c->j2,
                       &c->vtmp, &c->vtmp2, &c->vtmp3, &c->g_eta, &c->g_free, &c->lp, &c->cw, &c->zbuf,
                       &c->part_vec, &c->part_val, &c->stats, &c->tile_part, &c->Heta, &c->Hfree, &c->Jdense,
-                      &c->Tdense, &c->work1, &c->chol, &c->cholW, &c->cgH, &c->groups, &c->rhs, &c->cgx, &c->cgr, &c->cgp, &c->cgq, &c->cgz, &c->scal };
+                      &c->Tdense, &c->work1, &c->chol, &c->cholW, &c->cgH, &c->groups, &c->mx_theta, &c->mx_lam, &c->mx_A, &c->mx_U, &c->mx_g, &c->mx_Xk, &c->mx_R, &c->rhs, &c->cgx, &c->cgr, &c->cgp, &c->cgq, &c->cgz, &c->scal };
     for (DevBuf* b : all) buf_free(*b);
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
     for (int k = 0; k < 3; ++k) for (hipEvent_t e : c->ev_pool[k]) (void)hipEventDestroy(e);
@@ -881,8 +881,10 @@ extern "C" int lrvb_mixture_rows(lrvb_ctx* c, int32_t K, const double* theta_z, 
     const int V = (int)c->P;
     if (V + 1 > 32 || K > 32 || K < 2) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "mixture kernel supports V + 1 <= 32 and 2 <= K <= 32");
     const i64 KM = K - 1, KK = (i64)K * K, QQ = (i64)(V + 1) * (V + 1);
-    const i64 lda = KK + (KK & 1), ldk = QQ + (QQ & 1);
-    DevBuf thz, lam, Amat, U, gfr, Xk, Rd;
+    // both factors of the Schur operand are symmetric matrices: packed lower triangles
+    const i64 KP = (i64)K * (K + 1) / 2, QP = (i64)(V + 1) * (V + 2) / 2;
+    const i64 lda = KP + (KP & 1), ldk = QP + (QP & 1);
+    DevBuf &thz = c->mx_theta, &lam = c->mx_lam, &Amat = c->mx_A, &U = c->mx_U, &gfr = c->mx_g, &Xk = c->mx_Xk, &Rd = c->mx_R;
     int st = buf_reserve(c, thz, (size_t)(N * KM));
     if (st == LRVB_OK) st = buf_reserve(c, lam, (size_t)((V + 1) * K));
     if (st == LRVB_OK) st = buf_reserve(c, Amat, (size_t)(N * lda));
@@ -914,13 +916,11 @@ extern "C" int lrvb_mixture_rows(lrvb_ctx* c, int32_t K, const double* theta_z, 
         if (st == LRVB_OK) st = buf_reserve(c, Rd, (size_t)(ldk * lda));
         if (st == LRVB_OK) { EW(fill_kernel, N, 1.0, c->zbuf.p); }
         if (st == LRVB_OK) st = launch_atb(c, Xk.p, ldk, Amat.p, lda, N, c->zbuf.p, Rd.p);
-        if (st == LRVB_OK) {
-            if (hipMemcpy2DAsync(R_out, (size_t)KK * 8, Rd.p, (size_t)lda * 8, (size_t)KK * 8, (size_t)QQ, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-                hipStreamSynchronize(c->stream) != hipSuccess) { lrvb_set_error("copy failed"); st = LRVB_ERR_HIP; }
-        }
+        // Amat is dead now: reuse it for the expanded (V+1)^2 x K^2 result
+        if (st == LRVB_OK) st = buf_reserve(c, Amat, (size_t)(QQ * KK));
+        if (st == LRVB_OK) st = launch_mixture_expand(c, Rd.p, lda, V + 1, K, Amat.p);
+        if (st == LRVB_OK) st = d2h(c, R_out, Amat.p, (size_t)(QQ * KK));
     }
-    (void)hipStreamSynchronize(c->stream);
-    buf_free(thz); buf_free(lam); buf_free(Amat); buf_free(U); buf_free(gfr); buf_free(Xk); buf_free(Rd);
     return st;
 }
 

@@ -60,6 +60,7 @@ struct lrvb_ctx {
     DevBuf tile_part;              // weighted-SYRK split partials
     DevBuf Heta, Hfree, Jdense, Tdense, work1;   // dense V x V / D x D scratch
     DevBuf groups; i64 n_groups = 0;   // [perm (N) | offsets (G+1)] as int64
+    DevBuf mx_theta, mx_lam, mx_A, mx_U, mx_g, mx_Xk, mx_R;   // mixture rows pipeline (kept between calls)
     DevBuf cgH; i64 cgH_n = 0;     // dense matrix of lrvb_cg_solve_matrix
     DevBuf chol, cholW;            // D x D Cholesky factor (lower); inverses of its 64 x 64 diagonal blocks
     bool chol_valid = false;
@@ -111,6 +112,7 @@ int  launch_gram_small_on(lrvb_ctx* c, const double* Z, i64 N, i64 P, const doub
 int  launch_mixture_rows(lrvb_ctx* c, int K, const double* theta_z_dev, const double* lam_dev,
                          double* Amat_dev, i64 lda, double* U_dev, double* gfree_dev, double* val2_dev, int* bad_dev);
 int  launch_kron_rows(lrvb_ctx* c, double* Xk_dev, i64 ldk);
+int  launch_mixture_expand(lrvb_ctx* c, const double* Rs, i64 lda, int q, int K, double* Rfull);
 int  launch_atb(lrvb_ctx* c, const double* A, i64 PA, const double* B, i64 PB, i64 N,
                 const double* cvec_dev, double* C_dev);
 int  launch_wsyrk_kron(lrvb_ctx* c, const double* cvec_dev, double* tiles_out_dev /* nb = ceil(q/2) tile rows */);
