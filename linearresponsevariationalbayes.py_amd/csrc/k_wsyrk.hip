@@ -25,6 +25,7 @@
 #include <math.h>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
 
 // (stride mod 32 doubles) == 16: the two 16-lane halves of a ds_read_b64 lane group read
 // consecutive observations and land on disjoint banks.
@@ -275,6 +276,7 @@ void wsyrk_glds_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
 
     if (nch > 0) issue_stage(0, 0);
     if (stagger_shift >= 0 && (((blockIdx.x >> 3) >> stagger_shift) & 1)) __builtin_amdgcn_s_sleep(77);
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): LDS-DMA of the stage has landed
     __syncthreads();
 
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -298,10 +300,15 @@ void wsyrk_glds_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
                     return;
                 }
                 cv[set] = Cs[krow];
+                // 16-byte fragment reads: MFMA tile m takes the columns 32 (m >> 1) + 2 i + (m & 1) of the
+                // wave's 64 (i = lane & 15), so one ds_read_b128 feeds two tiles; the store below undoes it
 #pragma unroll
-                for (int m = 0; m < 4; ++m) af[set][m] = As[krow * WS_LDS_STRIDE + wr * 64 + m * 16 + l15];
-#pragma unroll
-                for (int n = 0; n < 4; ++n) bf[set][n] = Bs[krow * WS_LDS_STRIDE + wc * 64 + n * 16 + l15];
+                for (int h = 0; h < 2; ++h) {
+                    const d2 va = *reinterpret_cast<const d2*>(As + krow * WS_LDS_STRIDE + wr * 64 + h * 32 + 2 * l15);
+                    const d2 vb = *reinterpret_cast<const d2*>(Bs + krow * WS_LDS_STRIDE + wc * 64 + h * 32 + 2 * l15);
+                    af[set][2 * h] = va[0]; af[set][2 * h + 1] = va[1];
+                    bf[set][2 * h] = vb[0]; bf[set][2 * h + 1] = vb[1];
+                }
             };
             read_frags(0, 0);
 #pragma unroll
@@ -325,7 +332,7 @@ void wsyrk_glds_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (!(DBG & 2)) __syncthreads();      // with LDS-DMA in flight: s_waitcnt vmcnt(0) + s_barrier
+            if (!(DBG & 2)) { __builtin_amdgcn_s_waitcnt(0x0F70); __syncthreads(); }      // explicit vmcnt(0): the DMA of the next stage must have landed in every wave
             buf ^= 1;
         }
         double* out = partial + ((i64)split * T + t) * (i64)(WS_TILE * WS_TILE);
@@ -335,7 +342,8 @@ void wsyrk_glds_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
             for (int n = 0; n < 4; ++n)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    out[(wr * 64 + m * 16 + l4 + 4 * r) * WS_TILE + wc * 64 + n * 16 + l15] = acc[m * 4 + n][r];
+                    out[(wr * 64 + 32 * (m >> 1) + 2 * (l4 + 4 * r) + (m & 1)) * WS_TILE
+                        + wc * 64 + 32 * (n >> 1) + 2 * l15 + (n & 1)] = acc[m * 4 + n][r];
     } else {
         const int rb0 = wave, rb1 = 7 - wave;        // this wave's two 16-row blocks
         for (int ch = 0; ch < nch; ++ch) {
@@ -374,7 +382,7 @@ void wsyrk_glds_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
                     if (n <= rb1) acc[4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(s1, bf[set][n], acc[4 + n], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (!(DBG & 2)) __syncthreads();
+            if (!(DBG & 2)) { __builtin_amdgcn_s_waitcnt(0x0F70); __syncthreads(); }
             buf ^= 1;
         }
         // lower-triangle blocks get the sums, the rest of the two block rows is zeroed (never read,
@@ -625,6 +633,7 @@ void atb_glds_kernel(const double* __restrict__ A, i64 lda, int PA, const double
             WS_GLDS4(reinterpret_cast<const float*>(cpad + n0) + lane, base + 2 * WS_PANEL);
     };
     if (nch > 0) issue_stage(0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): LDS-DMA of the stage has landed
     __syncthreads();
 
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -661,6 +670,7 @@ void atb_glds_kernel(const double* __restrict__ A, i64 lda, int PA, const double
                     acc[m * 4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[m], bf[set][n], acc[m * 4 + n], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): LDS-DMA of the stage has landed
         __syncthreads();
         buf ^= 1;
     }

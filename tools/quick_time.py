@@ -6,7 +6,7 @@ import lrvb_amd as vb
 N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1000000
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 splits = [int(s) for s in sys.argv[3].split(',')] if len(sys.argv) > 3 else [0]
-flags = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+flag_list = [int(f, 0) for f in sys.argv[4].split(',')] if len(sys.argv) > 4 else [0]
 dev = torch.device('cuda:0')
 g = torch.Generator(device=dev); g.manual_seed(1)
 X = torch.randn((N, P), dtype=torch.float64, device=dev, generator=g) / P ** 0.5
@@ -20,7 +20,7 @@ blocks = [dict(kind=0, free_size=P - P // 4, vec_size=P - P // 4, dim0=P - P // 
 ctx = vb.DeviceContext(blocks, loss='gaussian', n_obs=N, n_cols=P, lik_info=2.0, quad_kind=1)
 ctx.set_data_dev(0, X.data_ptr(), N, P); ctx.set_data_dev(1, y.data_ptr(), N, 1); ctx.set_weights_dev(w.data_ptr(), N)
 ctx.set_data(2, np.ones(P))
-for s in splits:
+for s, flags in [(s, f) for s in splits for f in flag_list]:
     ctx.set_tuning(s, flags)
     ctx.hessian_dev(theta.data_ptr(), H.data_ptr(), P); ctx.sync()
     ctx.profile_enable(True); ctx.profile_reset()
@@ -30,9 +30,12 @@ for s in splits:
     ctx.sync(); t1 = time.time()
     p = ctx.profile_get(); ctx.profile_enable(False)
     ws = p['wsyrk_ms'] / max(p['wsyrk_calls'], 1); ps = p['pass_ms'] / max(p['pass_calls'], 1)
+    print('flags=0x%x ' % flags, end='')
     print('splits=%d build %.3f ms  wsyrk %.3f ms (%.1f TF/s, %.1f%% of 78.6)  pass %.3f ms (%.2f TB/s)' % (
         s, (t1 - t0) / K * 1e3, ws, p['wsyrk_flops'] / ws / 1e9, p['wsyrk_flops'] / ws / 1e9 / 78.6 * 100, ps,
         p['pass_bytes'] / ps / 1e9), flush=True)
+ctx.set_tuning(0, 0)
+ctx.hessian_dev(theta.data_ptr(), H.data_ptr(), P); ctx.sync()
 # hvp timing
 v = torch.randn((P,), dtype=torch.float64, device=dev); out = torch.empty_like(v)
 ctx.hvp_dev(theta.data_ptr(), v.data_ptr(), out.data_ptr()); ctx.sync()
