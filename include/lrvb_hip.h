@@ -183,6 +183,17 @@ int lrvb_obs_grad(lrvb_ctx* ctx, const double* free_in, int64_t D, int64_t n0, i
  * (LRVB/SparseObjectives.py:418-427) with par2 = the weights.                               */
 int lrvb_obs_grad_vec(lrvb_ctx* ctx, const double* vec_in, int64_t V, int64_t n0, int64_t n1,
                       double* G_out);
+/* Weight sensitivity of moments by linear response, streamed over the observations:
+ *   out[n - n0, q] = d m_q / d w_n = -(M H^-1 G^T)[q, n]       ((n1 - n0) x Q, row-major)
+ * -- `moment_jac @ ParametricSensitivityLinearApproximation.get_dinput_dhyper()` with
+ * hyper_par = the observation weights (LRVB/ModelSensitivity.py:596-606, Example.ipynb:425-441),
+ * transposed, without forming the D x N cross Hessian or the D x N sensitivity.  M is Q x D
+ * (free) / Q x V (vector) row-major; H is the factor left by lrvb_chol_factor (same coordinates).
+ * With M = I (Q = D) the result is the whole sensitivity matrix, transposed.                   */
+int lrvb_obs_influence(lrvb_ctx* ctx, const double* free_in, int64_t D, const double* M, int64_t Q,
+                       int64_t n0, int64_t n1, double* out);
+int lrvb_obs_influence_vec(lrvb_ctx* ctx, const double* vec_in, int64_t V, const double* M, int64_t Q,
+                           int64_t n0, int64_t n1, double* out);
 /* D x V cross Hessian w.r.t. the linear tilt b of the quadratic term
  * (the `hyper_param @ theta` term of LRVB/test_model_sensitivity.py:56-66).                 */
 int lrvb_cross_hessian_tilt(lrvb_ctx* ctx, const double* free_in, int64_t D, double* C_out);

@@ -73,6 +73,8 @@ _SIGNATURES = {
     'lrvb_hvp_vec': [_VP, _VP, _VP, c_i64, _VP],
     'lrvb_obs_grad': [_VP, _VP, c_i64, c_i64, c_i64, _VP],
     'lrvb_obs_grad_vec': [_VP, _VP, c_i64, c_i64, c_i64, _VP],
+    'lrvb_obs_influence': [_VP, _VP, c_i64, _VP, c_i64, c_i64, c_i64, _VP],
+    'lrvb_obs_influence_vec': [_VP, _VP, c_i64, _VP, c_i64, c_i64, c_i64, _VP],
     'lrvb_cross_hessian_tilt': [_VP, _VP, c_i64, _VP],
     'lrvb_gram': [_VP, _VP, c_i64, _VP, c_i64],
     'lrvb_weighted_gram': [_VP, _VP, c_i64],

@@ -1158,6 +1158,69 @@ extern "C" int lrvb_lrvb_cov(lrvb_ctx* c, const double* M, int64_t Q, int64_t D,
     return d2h(c, cov_out, c->Heta.p, (size_t)Q * (size_t)Q);
 }
 
+// ---- weight sensitivity of moments, streamed over the observations ------------
+// out[n - n0, q] = -(G H^-1 M^T)[n, q] = d (moment q) / d w_n  by linear response, for rows n0..n1 of G.
+// G = diag(l') X J_glm is never formed: W = H^-1 M^T (D x Q) from the resident Cholesky factor,
+// Z = J_glm W (P x Q), and the rows of X are multiplied by Z in one pass, scaled by -l'_n.
+__global__ void row_scale_rows_kernel(i64 rows, i64 Q, const double* __restrict__ rowscale, double alpha, double* __restrict__ C) {
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < rows * Q) C[e] *= alpha * rowscale[e / Q];
+}
+__global__ void scale_slice_rows_kernel(i64 P, i64 Q, const double* __restrict__ j1, const double* __restrict__ W, double* __restrict__ Z) {
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < P * Q) Z[e] = (j1 ? j1[e / Q] : 1.0) * W[e];
+}
+static int obs_influence_impl(lrvb_ctx* c, const double* point, i64 n_in, bool is_free, const double* M, i64 Q,
+                              i64 n0, i64 n1, double* out) {
+    LRVB_TRY(ctx_bind(c));
+    if (!point || !M || !out || Q <= 0) LRVB_FAIL(LRVB_ERR_INVALID, "bad argument");
+    const i64 width = is_free ? c->D : c->V;
+    LRVB_TRY(check_len(n_in, width, is_free ? "free vector" : "vector"));
+    if (c->loss == LRVB_LOSS_NONE || c->data_only) LRVB_FAIL(LRVB_ERR_STATE, "model has no declared data term");
+    if (n0 < 0 || n1 > c->N || n0 > n1) LRVB_FAIL(LRVB_ERR_INVALID, "row range [%lld, %lld) outside [0, %lld)", (long long)n0, (long long)n1, (long long)c->N);
+    if (!c->chol_valid || c->chol_n != width) LRVB_FAIL(LRVB_ERR_STATE, "no Cholesky factor of size %lld: call lrvb_chol_factor first", (long long)width);
+    LRVB_TRY(data_ready(c));
+    LRVB_TRY(h2d(c, c->theta.p, point, (size_t)width));
+    LRVB_TRY(set_point(c, c->theta.p, is_free));
+    LRVB_TRY(eval_grad_eta(c, c->stats.p, false));                 // leaves l'_n in c->lp
+    // W = H^-1 M^T
+    LRVB_TRY(buf_reserve(c, c->work1, (size_t)Q * (size_t)width));
+    LRVB_TRY(h2d(c, c->work1.p, M, (size_t)Q * (size_t)width));
+    LRVB_TRY(buf_reserve(c, c->rhs, (size_t)width * (size_t)Q));
+    {
+        dim3 grid(nb256(width), (unsigned)Q);
+        hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, c->stream, Q, width, c->work1.p, c->rhs.p);
+        HIP_TRY(hipGetLastError());
+    }
+    LRVB_TRY(launch_potrs_lower(c, c->chol.p, width, width, c->rhs.p, Q, Q));
+    // Z = J_glm W  (P x Q)
+    LRVB_TRY(buf_reserve(c, c->Heta, (size_t)c->P * (size_t)Q));
+    if (!is_free || c->all_box) {
+        EW(scale_slice_rows_kernel, c->P * Q, Q, is_free ? c->j1.p + c->glm_off : nullptr, c->rhs.p + c->glm_off * Q, c->Heta.p);
+    } else {
+        LRVB_TRY(ensure_dense_J(c, c->theta.p));
+        LRVB_TRY(launch_gemm(c, false, false, c->P, Q, c->D, 1.0, c->Jdense.p + c->glm_off * c->D, c->D, c->rhs.p, Q, 0.0, c->Heta.p, Q));
+    }
+    const i64 chunk = 65536;
+    for (i64 a = n0; a < n1; a += chunk) {
+        const i64 b = (a + chunk < n1) ? a + chunk : n1;
+        const i64 rows = b - a;
+        LRVB_TRY(buf_reserve(c, c->work1, (size_t)rows * (size_t)Q));
+        LRVB_TRY(launch_gemm(c, false, false, rows, Q, c->P, 1.0, c->X.p + a * c->P, c->P, c->Heta.p, Q, 0.0, c->work1.p, Q));
+        EW(row_scale_rows_kernel, rows * Q, Q, c->lp.p + a, -1.0, c->work1.p);
+        LRVB_TRY(d2h(c, out + (a - n0) * Q, c->work1.p, (size_t)rows * (size_t)Q));
+    }
+    return LRVB_OK;
+}
+extern "C" int lrvb_obs_influence(lrvb_ctx* c, const double* free_in, int64_t D, const double* M, int64_t Q,
+                                  int64_t n0, int64_t n1, double* out) {
+    return obs_influence_impl(c, free_in, D, true, M, Q, n0, n1, out);
+}
+extern "C" int lrvb_obs_influence_vec(lrvb_ctx* c, const double* vec_in, int64_t V, const double* M, int64_t Q,
+                                      int64_t n0, int64_t n1, double* out) {
+    return obs_influence_impl(c, vec_in, V, false, M, Q, n0, n1, out);
+}
+
 // ---- conjugate gradient ----------------------------------------------------------------------
 extern "C" int lrvb_cg_solve(lrvb_ctx* c, const double* free_in, const double* b, const double* x0,
                              const double* Minv, double tol, int64_t maxiter, int64_t D,

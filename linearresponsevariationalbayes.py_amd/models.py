@@ -52,6 +52,7 @@ class DeviceContext(object):
         desc.lik_info = float(lik_info)
         desc.quad_kind = int(quad_kind)
         self._h = ctypes.c_void_p()
+        self.chol_token = 0            # bumped by every factorisation: lets holders of a factor notice a replacement
         _hip.check(self._lib.lrvb_ctx_create(ctypes.byref(self._h), int(device), ctypes.byref(desc)))
         self.n_obs, self.n_cols = int(n_obs), int(n_cols)
         self.device = int(device)
@@ -172,6 +173,18 @@ class DeviceContext(object):
         _hip.check(fn(self._h, _hip.ptr(x), x.size, n0, n1, _hip.ptr(G)))
         return G
 
+    def obs_influence(self, x, moment_jac, n0=0, n1=None, is_free=True):
+        """d moments / d weights for observations n0..n1 ((n1 - n0) x Q), from the resident factor."""
+        x = _hip.as_f64(x).ravel()
+        M = _hip.as_f64(moment_jac)
+        if M.ndim != 2 or M.shape[1] != self._n(is_free):
+            raise ValueError('moment Jacobian must have {} columns'.format(self._n(is_free)))
+        n1 = self.n_obs if n1 is None else n1
+        out = np.empty((max(n1 - n0, 0), M.shape[0]))
+        fn = self._lib.lrvb_obs_influence if is_free else self._lib.lrvb_obs_influence_vec
+        _hip.check(fn(self._h, _hip.ptr(x), x.size, _hip.ptr(M), M.shape[0], n0, n1, _hip.ptr(out)))
+        return out
+
     def cross_hessian_tilt(self, free):
         f = _hip.as_f64(free).ravel()
         C = np.empty((self.D, self.V))
@@ -253,9 +266,11 @@ class DeviceContext(object):
         if H.ndim != 2 or H.shape[0] != H.shape[1]:
             raise ValueError('expected a square matrix')
         _hip.check(self._lib.lrvb_chol_factor(self._h, _hip.ptr(H), H.shape[0]))
+        self.chol_token += 1
 
     def chol_factor_last(self):
         _hip.check(self._lib.lrvb_chol_factor_last(self._h))
+        self.chol_token += 1
 
     def chol_solve(self, B):
         B = _hip.as_f64(B)
@@ -308,6 +323,7 @@ class DeviceContext(object):
         _hip.check(self._lib.lrvb_gram_dev(self._h, ctypes.c_void_p(free_ptr), ctypes.c_void_p(G_ptr), ld))
 
     def chol_factor_dev(self, H_ptr, D, ld):
+        self.chol_token += 1
         _hip.check(self._lib.lrvb_chol_factor_dev(self._h, ctypes.c_void_p(H_ptr), D, ld))
 
     def chol_solve_dev(self, B_ptr, D, nrhs):

@@ -32,12 +32,23 @@ class DeviceCholesky(object):
     def __init__(self, ctx, hess):
         self.ctx = ctx
         self.dim = int(np.shape(hess)[0])
+        self._hess = hess
         ctx.chol_factor(hess)
+        self._token = ctx.chol_token
+
+    def ensure_resident(self, ctx=None):
+        """Re-factor if another factorisation has replaced this one in the context since."""
+        ctx = self.ctx if ctx is None else ctx
+        if ctx is not self.ctx or ctx.chol_token != self._token:
+            ctx.chol_factor(self._hess)
+            self.ctx, self._token = ctx, ctx.chol_token
 
     def solve(self, rhs):
+        self.ensure_resident()
         return self.ctx.chol_solve(rhs)
 
     def lrvb_cov(self, moment_jac):
+        self.ensure_resident()
         return self.ctx.lrvb_cov(moment_jac)
 
 
@@ -51,7 +62,12 @@ def _factor_and_solve(functor, hess, rhs):
 
 class ParametricSensitivityLinearApproximation(object):
     def __init__(self, objective_functor, input_par, hyper_par, input_val0, hyper_val0,
-                 input_is_free=True, hyper_is_free=False, hess0=None, hyper_par_objective_functor=None):
+                 input_is_free=True, hyper_is_free=False, hess0=None, hyper_par_objective_functor=None,
+                 stream_hyper=False):
+        # stream_hyper=True (extension): do not form the D x P cross Hessian and the D x P sensitivity
+        # at construction -- with hyper_par = N observation weights they are D x N -- but keep the
+        # factor resident and serve `get_doutput_dhyper_rows` from the device, row block by row block
+        self.stream_hyper = bool(stream_hyper)
         self.objective_functor = objective_functor
         self.input_par = input_par
         self.hyper_par = hyper_par
@@ -81,6 +97,14 @@ class ParametricSensitivityLinearApproximation(object):
                 self.hess0 = self.objective.fun_vector_hessian(self.input_val0)
         else:
             self.hess0 = hess0
+        if self.stream_hyper:
+            ctx = getattr(self.objective_functor, 'ctx', None)
+            if ctx is None:
+                raise NotImplementedError('the objective functor exposes no device context for the solve')
+            self.hess0_chol = DeviceCholesky(ctx, self.hess0)
+            self.hyper_par_cross_hessian0 = None
+            self.hyper_par_sensitivity = None
+            return
         self.hyper_par_cross_hessian0 = self.joint_objective._cross12(
             self.input_val0, self.hyper_val0, self.input_is_free, self.hyper_is_free)
         self.hess0_chol, solved = _factor_and_solve(
@@ -88,7 +112,23 @@ class ParametricSensitivityLinearApproximation(object):
         self.hyper_par_sensitivity = -1 * solved
 
     def get_dinput_dhyper(self):
+        if self.hyper_par_sensitivity is None:
+            raise RuntimeError('constructed with stream_hyper=True: use get_doutput_dhyper_rows')
         return self.hyper_par_sensitivity
+
+    def get_doutput_dhyper_rows(self, moment_jac, n0=0, n1=None):
+        """(moment_jac @ get_dinput_dhyper())[:, n0:n1] TRANSPOSED, shape (n1 - n0, Q), for
+        hyper_par = the observation weights (Example.ipynb:425-441): the sensitivity of Q moments
+        to each observation's weight.  Streams over the observations on the device from the
+        resident factor; nothing of size D x N is formed."""
+        fun = self.hyper_par_objective_functor
+        kind = fun.hyper_kind(self.hyper_par) if hasattr(fun, 'hyper_kind') else None
+        if kind != 'weights' or self.hyper_is_free or not hasattr(fun, 'ctx'):
+            raise NotImplementedError('row streaming is defined for hyper_par = observation weights of a declared objective')
+        self.set_par_to_base_values()
+        fun._push_state()
+        self.hess0_chol.ensure_resident(fun.ctx)
+        return fun.ctx.obs_influence(self.input_val0, moment_jac, n0=n0, n1=n1, is_free=self.input_is_free)
 
     def predict_input_par_from_hyperparameters(self, new_hyper_par_value):
         hyper_par_diff = new_hyper_par_value - self.hyper_val0

@@ -153,6 +153,16 @@ class DeclaredModel(object):
         Jg = self.layout.jac(theta)[self.glm_off:self.glm_off + self.P, :]
         return (l1[:, None] * self.x[n0:n1]) @ Jg
 
+    def obs_grad_vec(self, eta, n0=0, n1=None):
+        """Rows of G in vector coordinates ((n1 - n0) x V): loss' x_n^T in the coefficient slice."""
+        n1 = self.N if n1 is None else n1
+        eta = np.asarray(eta, dtype=np.float64)
+        z = self.x[n0:n1] @ self._beta(eta)
+        l1 = loss_terms(self.loss, self.y[n0:n1], z, self.lik_info)[1]
+        G = np.zeros((n1 - n0, self.layout.V))
+        G[:, self.glm_off:self.glm_off + self.P] = l1[:, None] * self.x[n0:n1]
+        return G
+
     def gram(self, theta):
         G = self.obs_grad(theta)
         return G.T @ G
