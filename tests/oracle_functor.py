@@ -18,9 +18,11 @@ class OracleCtx(object):
         self.D = functor.model.layout.D
         self.V = functor.model.layout.V
         self._chol = None
+        self.chol_token = 0
 
     def chol_factor(self, H):
         self._chol = scipy.linalg.cho_factor(np.asarray(H))
+        self.chol_token += 1
 
     def chol_solve(self, B):
         return scipy.linalg.cho_solve(self._chol, np.asarray(B))
