@@ -258,8 +258,15 @@ def main():
             _, info, it = ctx.cg_solve(theta_h, rhs[q], tol=1e-8)
             iters.append(it if info == 0 else -1)
         t4 = time.perf_counter()
-        out['lrvb_solve_ms']['cg_16_rhs_tol1e-8'] = (t4 - t3) * 1e3
-        out['lrvb_solve_ms']['cg_iterations'] = iters
+        out['lrvb_solve_ms']['cg_16_rhs_one_by_one'] = (t4 - t3) * 1e3
+        # the same 16 systems in lockstep: one pair of passes over X per iteration for all of them
+        ctx.cg_solve_multi(theta_h, rhs[:2], tol=1e-8)
+        t5 = time.perf_counter()
+        _, infos, its = ctx.cg_solve_multi(theta_h, rhs, tol=1e-8)
+        t6 = time.perf_counter()
+        out['lrvb_solve_ms']['cg_16_rhs_tol1e-8'] = (t6 - t5) * 1e3
+        out['lrvb_solve_ms']['cg_iterations'] = [int(i) if f == 0 else -1 for i, f in zip(its, infos)]
+        out['lrvb_solve_ms']['cg_iterations_one_by_one'] = iters
         if not args.no_cpu_baseline and rank == 0:
             ns = min(args.cpu_sample_rows, n_local)
             xs = X[:ns].cpu().numpy()

@@ -261,6 +261,13 @@ int lrvb_lrvb_cov   (lrvb_ctx* ctx, const double* M, int64_t Q, int64_t D, doubl
 int lrvb_cg_solve(lrvb_ctx* ctx, const double* free_in, const double* b, const double* x0,
                   const double* Minv, double tol, int64_t maxiter, int64_t D,
                   double* x_out, int* info_out, int64_t* iters_out);
+/* Blocked variant: Q right-hand sides (rows of B, Q x D row-major) advance in lockstep -- the loop over
+ * masks of ConjugateGradientSolver.get_hinv_vec_subsets (LRVB/ConjugateGradient.py:87-105) -- so that the
+ * Q Hessian-vector products of an iteration share one pair of passes over the observations.  Each row
+ * follows exactly the recurrence and stopping rule of lrvb_cg_solve; info_out / iters_out have Q entries. */
+int lrvb_cg_solve_multi(lrvb_ctx* ctx, const double* free_in, const double* B, const double* X0 /*nullable*/,
+                        const double* Minv /*nullable D x D*/, double tol, int64_t maxiter, int64_t D, int64_t Q,
+                        double* X_out, int* info_out, int64_t* iters_out);
 
 /* The same conjugate-gradient loop on a dense symmetric D x D matrix kept on the device (Hessians
  * assembled from sufficient statistics).  H == NULL reuses the matrix of the previous call.   */

@@ -94,6 +94,7 @@ _SIGNATURES = {
     'lrvb_lrvb_cov_dev': [_VP, _VP, c_i64, c_i64, _VP],
     'lrvb_cg_solve': [_VP, _VP, _VP, _VP, _VP, ctypes.c_double, c_i64, c_i64, _VP,
                       ctypes.POINTER(ctypes.c_int), ctypes.POINTER(c_i64)],
+    'lrvb_cg_solve_multi': [_VP, _VP, _VP, _VP, _VP, ctypes.c_double, c_i64, c_i64, c_i64, _VP, _VP, _VP],
     'lrvb_stats_size': [_VP, ctypes.POINTER(c_i64)],
     'lrvb_hessian_partial_dev': [_VP, _VP, _VP],
     'lrvb_hessian_finish_dev': [_VP, _VP, _VP, _VP, c_i64],

@@ -94,6 +94,29 @@ class ConjugateGradientSolver(object):
 
     def get_hinv_vec_subsets(self, vec, masks, verbose=False, print_every=10):
         num_masks = len(masks)
+        fun = self._device[1] if self._device is not None else None
+        if fun is not None and not hasattr(fun, 'cg_solve') and hasattr(fun.ctx, 'cg_solve_multi') and num_masks > 1:
+            # all masked right-hand sides advance together on the device: every CG iteration makes ONE
+            # pair of passes over the observations for the whole batch (`lrvb_cg_solve_multi`); each
+            # system still follows its own recurrence and stopping rule, so the results are those of the loop
+            objective = self._device[0]
+            fun._push_state()
+            minv = None if self.preconditioner is None else np.asarray(self.preconditioner, dtype=np.float64)
+            vec = np.asarray(vec, dtype=np.float64)
+            B = np.zeros((num_masks, len(vec)))
+            for i, mask in enumerate(masks):
+                B[i, mask] = vec[mask]
+            cg_time = time.time()
+            X, infos, _ = fun.ctx.cg_solve_multi(self.x0, B, Minv=minv, tol=self.tol)
+            elapsed = (time.time() - cg_time) / num_masks
+            objective.par.set_free(self.x0)
+            for i, mask in enumerate(masks):
+                self.times.append(elapsed)
+                self.vecs.append(B[i].copy())
+                self.masks.append(mask)
+                self.hinv_vecs.append(X[i].copy())
+                self.cg_infos.append(int(infos[i]))
+            return
         for ind, mask in enumerate(masks, start=1):
             if verbose and ind % print_every == 0:
                 print('{} of {}\n'.format(ind, num_masks))

@@ -1,6 +1,7 @@
 // lrvb_api.hip -- the C ABI declared in include/lrvb_hip.h (context, orchestration, host<->device
 // staging).  Kernels live in the k_*.hip files.
 #include "lrvb_internal.h"
+#include <vector>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -169,7 +170,7 @@ extern "C" int lrvb_ctx_destroy(lrvb_ctx* c) {
     DevBuf* all[] = { &c->X, &c->y, &c->w, &c->quadA, &c->quadM, &c->quadB, &c->theta, &c->eta, &c->j1, &c->j2,
                       &c->vtmp, &c->vtmp2, &c->vtmp3, &c->g_eta, &c->g_free, &c->lp, &c->cw, &c->zbuf,
                       &c->part_vec, &c->part_val, &c->stats, &c->tile_part, &c->Heta, &c->Hfree, &c->Jdense,
-                      &c->Tdense, &c->work1, &c->chol, &c->cholW, &c->cgH, &c->groups, &c->mx_theta, &c->mx_lam, &c->mx_A, &c->mx_U, &c->mx_g, &c->mx_Xk, &c->mx_R, &c->rhs, &c->cgx, &c->cgr, &c->cgp, &c->cgq, &c->cgz, &c->scal };
+                      &c->Tdense, &c->work1, &c->chol, &c->cholW, &c->cgH, &c->groups, &c->mx_theta, &c->mx_lam, &c->mx_A, &c->mx_U, &c->mx_g, &c->mx_Xk, &c->mx_R, &c->cgT, &c->cgm[0], &c->cgm[1], &c->cgm[2], &c->cgm[3], &c->cgm[4], &c->cgm[5], &c->cgm[6], &c->cgm[7], &c->cgm[8], &c->rhs, &c->cgx, &c->cgr, &c->cgp, &c->cgq, &c->cgz, &c->scal };
     for (DevBuf* b : all) buf_free(*b);
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
     for (int k = 0; k < 3; ++k) for (hipEvent_t e : c->ev_pool[k]) (void)hipEventDestroy(e);
@@ -1283,6 +1284,173 @@ extern "C" int lrvb_cg_solve(lrvb_ctx* c, const double* free_in, const double* b
     LRVB_TRY(d2h(c, x_out, c->cgx.p, (size_t)D));
     if (info_out) *info_out = info;
     if (iters_out) *iters_out = it;
+    return LRVB_OK;
+}
+
+// ---- blocked conjugate gradients: Q right-hand sides share every pass over the observations ------------
+// Q independent CG recurrences (the ones `ConjugateGradientSolver.get_hinv_vec_subsets` runs one after the
+// other, LRVB/ConjugateGradient.py:87-105) advance in lockstep, so that the Hessian-vector products of an
+// iteration become ONE pair of skinny MFMA GEMMs over X -- T = X U_glm^T (N x Q), then X^T diag(c) T (P x Q)
+// -- instead of Q fused passes.  Block vectors are Q x D row-major (one right-hand side per row).
+__global__ void mul_rows_kernel(i64 n, i64 D, const double* __restrict__ a, const double* __restrict__ v, double* __restrict__ o) {
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) o[e] = a[e % D] * v[e];
+}
+__global__ void fma3_rows_kernel(i64 n, i64 D, const double* __restrict__ g, const double* __restrict__ j2, const double* __restrict__ v,
+                                 const double* __restrict__ j1, const double* __restrict__ he, double* __restrict__ o) {
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) { const i64 d = e % D; o[e] = j1[d] * he[e] + g[d] * j2[d] * v[e]; }
+}
+__global__ void diag_mul_add_rows_kernel(i64 n, i64 V, double scale, const double* __restrict__ a, const double* __restrict__ u, double* __restrict__ out) {
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) out[e] += scale * a[e % V] * u[e];
+}
+__global__ void scatter_rows_T_kernel(i64 n, i64 Q, i64 V, i64 P, i64 off, const double* __restrict__ Rt, i64 ldr, double* __restrict__ out) {
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;        // e over Q x P
+    if (e < n) { const i64 q = e / P, p = e - q * P; out[q * V + off + p] = Rt[p * ldr + q]; }
+}
+// per-row scalars of the block recurrences
+__global__ void rows_dot_kernel(i64 Q, i64 D, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out) {
+    __shared__ double sh[256];
+    const i64 q = blockIdx.x;
+    double s = 0.0;
+    for (i64 d = threadIdx.x; d < D; d += 256) s += a[q * D + d] * b[q * D + d];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) { if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off]; __syncthreads(); }
+    if (threadIdx.x == 0) out[q] = sh[0];
+}
+__global__ void rows_axpby_kernel(i64 n, i64 D, const double* __restrict__ alpha, const double* __restrict__ x,
+                                  const double* __restrict__ beta, double* __restrict__ y) {
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;        // y = alpha[q] x + beta[q] y
+    if (e < n) { const i64 q = e / D; y[e] = alpha[q] * x[e] + beta[q] * y[e]; }
+}
+
+static int heta_apply_multi(lrvb_ctx* c, i64 Q, const double* U /* Q x V */, double* Out /* Q x V */) {
+    const i64 V = c->V, P = c->P, N = c->N;
+    HIP_TRY(hipMemsetAsync(Out, 0, (size_t)(Q * V) * sizeof(double), c->stream));
+    if (c->loss != LRVB_LOSS_NONE) {
+        const i64 Qp = Q + (Q & 1);
+        const bool mfma_ok = (P % 2 == 0) && ((((uintptr_t)c->X.p) & 15) == 0) && P >= 2;
+        if (mfma_ok) {
+            LRVB_TRY(launch_gemm(c, false, true, N, Q, P, 1.0, c->X.p, P, U + c->glm_off, V, 0.0, c->cgT.p, Qp));
+            LRVB_TRY(launch_atb(c, c->X.p, P, c->cgT.p, Qp, N, c->cw.p, c->cgm[8].p));
+            EW(scatter_rows_T_kernel, Q * P, Q, V, P, c->glm_off, c->cgm[8].p, Qp, Out);
+        } else {                                  // odd row length: one fused pass per right-hand side
+            LRVB_TRY(buf_reserve(c, c->vtmp3, (size_t)(V > P ? V : P)));
+            for (i64 q = 0; q < Q; ++q) {
+                LRVB_TRY(launch_glm_pass(c, PASS_HVP_C, nullptr, U + q * V + c->glm_off, c->vtmp3.p, nullptr, false));
+                HIP_TRY(hipMemcpyAsync(Out + q * V + c->glm_off, c->vtmp3.p, (size_t)P * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+            }
+        }
+    }
+    if (c->quad_kind == LRVB_QUAD_DIAG) {
+        EW(diag_mul_add_rows_kernel, Q * V, V, c->quad_scale, c->quadA.p, U, Out);
+    } else if (c->quad_kind == LRVB_QUAD_DENSE) {
+        LRVB_TRY(launch_gemm(c, false, true, Q, V, V, c->quad_scale, U, V, c->quadA.p, V, 1.0, Out, V));
+    }
+    return LRVB_OK;
+}
+
+// Out (Q x D) = H_free Vb^T row by row.  Requires set_point + eval_grad_eta (+ prepare_general_hvp) done.
+static int hvp_apply_multi(lrvb_ctx* c, i64 Q, const double* Vb, double* Out) {
+    const i64 D = c->D, V = c->V;
+    double* U = c->cgm[6].p; double* W = c->cgm[7].p;
+    if (c->all_box) {
+        EW(mul_rows_kernel, Q * D, D, c->j1.p, Vb, U);
+        LRVB_TRY(heta_apply_multi(c, Q, U, W));
+        EW(fma3_rows_kernel, Q * D, D, c->g_eta.p, c->j2.p, Vb, c->j1.p, W, Out);
+        return LRVB_OK;
+    }
+    LRVB_TRY(launch_gemm(c, false, true, Q, V, D, 1.0, Vb, D, c->Jdense.p, D, 0.0, U, V));       // U = Vb J^T
+    LRVB_TRY(heta_apply_multi(c, Q, U, W));
+    LRVB_TRY(launch_gemm(c, false, false, Q, D, V, 1.0, W, V, c->Jdense.p, D, 0.0, Out, D));     // W J
+    return launch_gemm(c, false, false, Q, D, D, 1.0, Vb, D, c->Tdense.p, D, 1.0, Out, D);        // + Vb T (T symmetric)
+}
+
+extern "C" int lrvb_cg_solve_multi(lrvb_ctx* c, const double* free_in, const double* B, const double* X0,
+                                   const double* Minv, double tol, int64_t maxiter, int64_t D, int64_t Q,
+                                   double* X_out, int* info_out, int64_t* iters_out) {
+    LRVB_TRY(ctx_bind(c));
+    if (!free_in || !B || !X_out || Q <= 0) LRVB_FAIL(LRVB_ERR_INVALID, "bad argument");
+    LRVB_TRY(check_len(D, c->D, "free vector"));
+    LRVB_TRY(data_ready(c));
+    if (maxiter <= 0) maxiter = 10 * D;
+    const i64 V = c->V, Qp = Q + (Q & 1);
+    const size_t qd = (size_t)Q * (size_t)D, qv = (size_t)Q * (size_t)V;
+    for (int k = 0; k < 6; ++k) LRVB_TRY(buf_reserve(c, c->cgm[k], qd));
+    LRVB_TRY(buf_reserve(c, c->cgm[6], qv));
+    LRVB_TRY(buf_reserve(c, c->cgm[7], qv));
+    LRVB_TRY(buf_reserve(c, c->cgm[8], (size_t)((c->P > 0 ? c->P : 1) * Qp)));
+    if (c->loss != LRVB_LOSS_NONE) {
+        LRVB_TRY(buf_reserve(c, c->cgT, (size_t)(c->N * Qp)));
+        HIP_TRY(hipMemsetAsync(c->cgT.p, 0, (size_t)(c->N * Qp) * sizeof(double), c->stream));     // keeps the padding column zero
+    }
+    double *Bd = c->cgm[0].p, *Xd = c->cgm[1].p, *Rd = c->cgm[2].p, *Pd = c->cgm[3].p, *Qd = c->cgm[4].p, *Zd = c->cgm[5].p;
+    if (Minv) { LRVB_TRY(buf_reserve(c, c->Hfree, (size_t)D * (size_t)D)); LRVB_TRY(h2d(c, c->Hfree.p, Minv, (size_t)D * (size_t)D)); }
+    LRVB_TRY(h2d(c, c->theta.p, free_in, (size_t)D));
+    LRVB_TRY(h2d(c, Bd, B, qd));
+    LRVB_TRY(set_point(c, c->theta.p, true));
+    LRVB_TRY(eval_grad_eta(c, c->stats.p, true));
+    LRVB_TRY(prepare_general_hvp(c, c->theta.p));
+    // scalars: s[0..Q) = ||b||^2 | rr | rz | pq | alpha | beta | minus_alpha | one
+    LRVB_TRY(buf_reserve(c, c->scal, (size_t)(8 * Q + 16)));
+    double* s = c->scal.p;
+    std::vector<double> hs((size_t)(4 * Q)), coef((size_t)(4 * Q));
+    std::vector<double> bnorm((size_t)Q), rho_prev((size_t)Q, 0.0);
+    std::vector<int> info((size_t)Q, 0); std::vector<int64_t> iters((size_t)Q, 0); std::vector<char> active((size_t)Q, 1);
+    hipLaunchKernelGGL(rows_dot_kernel, dim3((unsigned)Q), dim3(256), 0, c->stream, Q, D, Bd, Bd, s);
+    HIP_TRY(hipGetLastError());
+    if (X0) {
+        LRVB_TRY(h2d(c, Xd, X0, qd));
+        LRVB_TRY(hvp_apply_multi(c, Q, Xd, Qd));
+        HIP_TRY(hipMemcpyAsync(Rd, Bd, qd * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        LRVB_TRY(launch_axpby(c, (i64)qd, -1.0, Qd, 1.0, Rd));
+    } else {
+        HIP_TRY(hipMemsetAsync(Xd, 0, qd * sizeof(double), c->stream));
+        HIP_TRY(hipMemcpyAsync(Rd, Bd, qd * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIP_TRY(hipMemsetAsync(Pd, 0, qd * sizeof(double), c->stream));
+    LRVB_TRY(d2h(c, hs.data(), s, (size_t)Q));
+    i64 n_active = 0;
+    for (i64 q = 0; q < Q; ++q) {
+        bnorm[q] = sqrt(hs[q]);
+        if (bnorm[q] == 0.0) { active[q] = 0; HIP_TRY(hipMemsetAsync(Xd + q * D, 0, (size_t)D * sizeof(double), c->stream)); }
+        else { info[q] = (int)maxiter; ++n_active; }
+    }
+    for (i64 it = 0; it < maxiter && n_active > 0; ++it) {
+        if (Minv) LRVB_TRY(launch_gemm(c, false, true, Q, D, D, 1.0, Rd, D, c->Hfree.p, D, 0.0, Zd, D));   // Z = R Minv^T
+        const double* Z = Minv ? Zd : Rd;
+        hipLaunchKernelGGL(rows_dot_kernel, dim3((unsigned)Q), dim3(256), 0, c->stream, Q, D, Rd, Rd, s + Q);
+        hipLaunchKernelGGL(rows_dot_kernel, dim3((unsigned)Q), dim3(256), 0, c->stream, Q, D, Rd, Z, s + 2 * Q);
+        HIP_TRY(hipGetLastError());
+        LRVB_TRY(d2h(c, hs.data(), s + Q, (size_t)(2 * Q)));
+        for (i64 q = 0; q < Q; ++q) {
+            if (!active[q]) { coef[q] = 0.0; coef[Q + q] = 1.0; continue; }          // p frozen
+            if (sqrt(hs[q]) < tol * bnorm[q]) { active[q] = 0; info[q] = 0; iters[q] = it; --n_active; coef[q] = 0.0; coef[Q + q] = 1.0; continue; }
+            const double rho = hs[Q + q];
+            coef[q] = 1.0;                                    // p = 1 * z + beta p
+            coef[Q + q] = (it > 0 && rho_prev[q] != 0.0) ? rho / rho_prev[q] : 0.0;
+            rho_prev[q] = rho;
+        }
+        if (n_active == 0) break;
+        LRVB_TRY(h2d(c, s + 4 * Q, coef.data(), (size_t)(2 * Q)));
+        EW(rows_axpby_kernel, (i64)qd, D, s + 4 * Q, Z, s + 5 * Q, Pd);
+        LRVB_TRY(hvp_apply_multi(c, Q, Pd, Qd));
+        hipLaunchKernelGGL(rows_dot_kernel, dim3((unsigned)Q), dim3(256), 0, c->stream, Q, D, Pd, Qd, s + 3 * Q);
+        HIP_TRY(hipGetLastError());
+        LRVB_TRY(d2h(c, hs.data() + 2 * Q, s + 3 * Q, (size_t)Q));
+        for (i64 q = 0; q < Q; ++q) {
+            const double alpha = active[q] ? rho_prev[q] / hs[2 * Q + q] : 0.0;
+            coef[q] = alpha; coef[Q + q] = 1.0; coef[2 * Q + q] = -alpha; coef[3 * Q + q] = 1.0;
+            if (active[q]) iters[q] = it + 1;
+        }
+        LRVB_TRY(h2d(c, s + 4 * Q, coef.data(), (size_t)(4 * Q)));
+        EW(rows_axpby_kernel, (i64)qd, D, s + 4 * Q, Pd, s + 5 * Q, Xd);          // x += alpha p
+        EW(rows_axpby_kernel, (i64)qd, D, s + 6 * Q, Qd, s + 7 * Q, Rd);          // r -= alpha q
+    }
+    LRVB_TRY(d2h(c, X_out, Xd, qd));
+    for (i64 q = 0; q < Q; ++q) { if (info_out) info_out[q] = info[q]; if (iters_out) iters_out[q] = iters[q]; }
     return LRVB_OK;
 }
 

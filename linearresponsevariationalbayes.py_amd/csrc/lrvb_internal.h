@@ -66,6 +66,8 @@ struct lrvb_ctx {
     bool chol_valid = false;
     i64 chol_n = 0;
     DevBuf rhs, cgx, cgr, cgp, cgq, cgz, scal;
+    DevBuf cgm[9];                 // blocked CG: B, X, R, P, Q, Z (Q x D), U, W (Q x V), R^T (P x Q)
+    DevBuf cgT;                    // N x Q products X U^T of the blocked HVP
     double* host_pinned = nullptr; size_t host_pinned_n = 0;
 
     int n_splits_user = 0;

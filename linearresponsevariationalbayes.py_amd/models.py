@@ -300,6 +300,22 @@ class DeviceContext(object):
                                            ctypes.byref(info), ctypes.byref(iters)))
         return x, info.value, iters.value
 
+    def cg_solve_multi(self, free, B, X0=None, Minv=None, tol=1e-8, maxiter=0):
+        """Rows of B are right-hand sides; returns (X (Q x D), info (Q,), iterations (Q,))."""
+        f, B = _hip.as_f64(free).ravel(), _hip.as_f64(B)
+        if B.ndim != 2 or B.shape[1] != self.D:
+            raise ValueError('Wrong size for the right-hand sides.  Expected (Q, {}), got {}'.format(self.D, B.shape))
+        Q = B.shape[0]
+        X0 = None if X0 is None else _hip.as_f64(X0).reshape(Q, self.D)
+        Minv = None if Minv is None else _hip.as_f64(Minv)
+        X = np.empty((Q, self.D))
+        info = np.zeros(Q, dtype=np.int32)
+        iters = np.zeros(Q, dtype=np.int64)
+        _hip.check(self._lib.lrvb_cg_solve_multi(self._h, _hip.ptr(f), _hip.ptr(B), _hip.ptr(X0), _hip.ptr(Minv),
+                                                 float(tol), int(maxiter), f.size, Q, _hip.ptr(X),
+                                                 info.ctypes.data_as(ctypes.c_void_p), iters.ctypes.data_as(ctypes.c_void_p)))
+        return X, info, iters
+
     # -- device-resident / multi-GPU -------------------------------------------------------
     def stats_size(self):
         n = ctypes.c_int64(0)

@@ -1,0 +1,109 @@
+"""Blocked conjugate gradients (`lrvb_cg_solve_multi`): the masked right-hand sides of
+ConjugateGradientSolver.get_hinv_vec_subsets (LRVB/ConjugateGradient.py:87-105) solved in lockstep.
+Each row must reproduce the single-system solver (same recurrence, same stopping rule) and the
+reference's own criterion against a direct solve (< 1e-8, LRVB/test_objectives.py:552-554)."""
+import numpy as np
+import pytest
+
+from oracle import models as om
+from helpers import make_par, glm_data, rel_err, LOSS_NAME
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def vb():
+    import lrvb_amd
+    assert lrvb_amd._hip.device_count() >= 1
+    return lrvb_amd
+
+
+@pytest.mark.parametrize('loss,N,P,Q', [(om.GAUSSIAN, 2000, 64, 5), (om.POISSON, 3000, 200, 16), (om.LOGISTIC, 1500, 33, 3),
+                                        (om.GAUSSIAN, 700, 130, 1)])
+def test_rows_match_single_solver_and_direct_solve(vb, loss, N, P, Q):
+    rng = np.random.default_rng(N + Q)
+    par, lay = make_par(vb, [('box', 'a', P // 2, -np.inf, np.inf), ('box', 'b', P - P // 2, 0.0, np.inf)])
+    x, y, w = glm_data(rng, N, P, loss)
+    fun = vb.DeviceObjective(par, x=x, y=y, loss=LOSS_NAME[loss], quad_A=np.full(P, 1.0), weights=w)
+    model = om.DeclaredModel(lay, loss=loss, x=x, y=y, w=w, quad_A=np.full(P, 1.0))
+    theta = rng.normal(size=P) * 0.1
+    fun._push_state()
+    H = model.hessian(theta)
+    assert np.min(np.linalg.eigvalsh(H)) > 0
+    B = rng.normal(size=(Q, P))
+    if Q > 2:
+        B[1] = 0.0                                           # a zero right-hand side: solution 0, no iterations
+    X, info, iters = fun.ctx.cg_solve_multi(theta, B)
+    assert np.all(info == 0)
+    want = np.linalg.solve(H, B.T).T
+    assert np.max(np.abs(X - want)) < 1e-8 * max(1.0, np.max(np.abs(want)))
+    for q in range(Q):
+        xq, iq, itq = fun.ctx.cg_solve(theta, B[q])
+        assert iq == 0 and itq == iters[q]
+        assert rel_err(X[q], xq) < 1e-9 or np.max(np.abs(xq)) == 0.0
+    if Q > 2:
+        assert iters[1] == 0 and np.all(X[1] == 0.0)
+    # preconditioner and warm start
+    Minv = np.diag(1.0 / np.diag(H))
+    X2, info2, iters2 = fun.ctx.cg_solve_multi(theta, B, X0=0.5 * want, Minv=Minv, tol=1e-10)
+    assert np.all(info2 == 0) and np.max(np.abs(X2 - want)) < 1e-8 * max(1.0, np.max(np.abs(want)))
+    # iteration cap is reported per row
+    X3, info3, iters3 = fun.ctx.cg_solve_multi(theta, B, maxiter=2)
+    nz = np.flatnonzero(np.abs(B).sum(axis=1) > 0)
+    assert np.all(info3[nz] == 2) and np.all(iters3[nz] == 2)
+
+
+def test_general_layout(vb):
+    rng = np.random.default_rng(7)
+    spec = [('box', 'pre', 2, -np.inf, np.inf), ('box', 'beta', 6, -1.0, np.inf), ('psd', 'm', 3, 0.2), ('simplex', 's', 2, 3)]
+    par, lay = make_par(vb, spec)
+    N, P, Q = 500, 6, 4
+    x, y, w = glm_data(rng, N, P, om.LOGISTIC)
+    A = rng.normal(size=(lay.V, lay.V)); A = A @ A.T / lay.V + 3.0 * np.eye(lay.V)
+    fun = vb.DeviceObjective(par, x=x, y=y, loss='logistic', glm_param='beta', quad_A=A, weights=w)
+    model = om.DeclaredModel(lay, loss=om.LOGISTIC, x=x, y=y, w=w, glm_off=2, quad_A=A)
+    theta = rng.normal(size=lay.D) * 0.05
+    H = model.hessian(theta)
+    if np.min(np.linalg.eigvalsh(H)) <= 0:
+        pytest.skip('Hessian not positive definite at this point')
+    fun._push_state()
+    B = rng.normal(size=(Q, lay.D))
+    X, info, iters = fun.ctx.cg_solve_multi(theta, B)
+    assert np.all(info == 0)
+    assert np.max(np.abs(X - np.linalg.solve(H, B.T).T)) < 1e-8
+
+
+def test_solver_class_batches_masks(vb):
+    rng = np.random.default_rng(3)
+    N, P = 4000, 256
+    par, lay = make_par(vb, [('box', 'beta', P, 0.0, np.inf)])
+    x, y, w = glm_data(rng, N, P, om.POISSON)
+    fun = vb.GLMObjective(par, x, y, loss='poisson', prior_info=1.0, weights=w)
+    model = om.DeclaredModel(lay, loss=om.POISSON, x=x, y=y, w=w, quad_A=np.ones(P))
+    obj = vb.Objective(par, fun)
+    theta = rng.normal(size=P) * 0.2
+    H = model.hessian(theta)
+    solver = vb.ConjugateGradientSolver(obj.fun_free_hvp, theta)
+    masks = vb.ConjugateGradient.get_masks(P, 16)
+    vec = rng.normal(size=P)
+    solver.get_hinv_vec_subsets(vec, masks)
+    assert len(solver.hinv_vecs) == len(masks) == 16 and len(solver.times) == 16
+    total = np.zeros(P)
+    for rhs, sol, info, mask in zip(solver.vecs, solver.hinv_vecs, solver.cg_infos, solver.masks):
+        assert info == 0 and np.array_equal(rhs[mask], vec[mask]) and np.all(rhs[~mask] == 0)
+        assert np.max(np.abs(sol - np.linalg.solve(H, rhs))) < 1e-8
+        total += sol
+    assert np.max(np.abs(total - np.linalg.solve(H, vec))) < 1e-7          # the masks partition vec
+    assert np.max(np.abs(par.get_free() - theta)) < 1e-12
+
+
+def test_errors(vb):
+    rng = np.random.default_rng(1)
+    par, lay = make_par(vb, [('box', 'beta', 4, -np.inf, np.inf)])
+    x, y, w = glm_data(rng, 50, 4, om.GAUSSIAN)
+    fun = vb.DeviceObjective(par, x=x, y=y, loss='gaussian', quad_A=np.ones(4))
+    fun._push_state()
+    with pytest.raises(ValueError):
+        fun.ctx.cg_solve_multi(np.zeros(4), np.zeros((3, 5)))
+    with pytest.raises(ValueError):
+        fun.ctx.cg_solve_multi(np.zeros(3), np.zeros((3, 4)))
