@@ -170,7 +170,7 @@ extern "C" int lrvb_ctx_destroy(lrvb_ctx* c) {
     DevBuf* all[] = { &c->X, &c->y, &c->w, &c->quadA, &c->quadM, &c->quadB, &c->theta, &c->eta, &c->j1, &c->j2,
                       &c->vtmp, &c->vtmp2, &c->vtmp3, &c->g_eta, &c->g_free, &c->lp, &c->cw, &c->zbuf,
                       &c->part_vec, &c->part_val, &c->stats, &c->tile_part, &c->Heta, &c->Hfree, &c->Jdense,
-                      &c->Tdense, &c->work1, &c->chol, &c->cholW, &c->cgH, &c->groups, &c->mx_theta, &c->mx_lam, &c->mx_A, &c->mx_U, &c->mx_g, &c->mx_Xk, &c->mx_R, &c->cgT, &c->cgm[0], &c->cgm[1], &c->cgm[2], &c->cgm[3], &c->cgm[4], &c->cgm[5], &c->cgm[6], &c->cgm[7], &c->cgm[8], &c->rhs, &c->cgx, &c->cgr, &c->cgp, &c->cgq, &c->cgz, &c->scal };
+                      &c->Tdense, &c->work1, &c->chol, &c->cholW, &c->cgH, &c->groups, &c->mx_theta, &c->mx_lam, &c->mx_A, &c->mx_U, &c->mx_g, &c->mx_Xk, &c->mx_R, &c->cgT, &c->ones, &c->cgm[0], &c->cgm[1], &c->cgm[2], &c->cgm[3], &c->cgm[4], &c->cgm[5], &c->cgm[6], &c->cgm[7], &c->cgm[8], &c->rhs, &c->cgx, &c->cgr, &c->cgp, &c->cgq, &c->cgz, &c->scal };
     for (DevBuf* b : all) buf_free(*b);
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
     for (int k = 0; k < 3; ++k) for (hipEvent_t e : c->ev_pool[k]) (void)hipEventDestroy(e);
@@ -928,6 +928,21 @@ extern "C" int lrvb_mixture_rows(lrvb_ctx* c, int32_t K, const double* theta_z, 
 // Gram matrix of per-observation gradients g_n[k] = 1/2 z_n^T M_k z_n + c_k, in FREE coordinates:
 //   G^T G = J^T ( 1/4 M~^T K4 M~ + 1/2 (t c^T + c t^T) + N c c^T ) J,   t = M~^T s,
 // K4 = sum_n (z_n (x) z_n)(z_n (x) z_n)^T from the Kronecker-row MFMA kernel, s = vec(sum_n z_n z_n^T),
+// C (PA x PB) = A^T B for row-major A (K x PA), B (K x PB): the two-operand LDS-DMA MFMA kernel with unit
+// contraction weights (~66 TFLOP/s at 4096^3) when the operands are even-width and 16-byte aligned,
+// the generic 64 x 64 tile GEMM otherwise.
+static int gemm_tn(lrvb_ctx* c, i64 K, i64 PA, i64 PB, const double* A, const double* B, double* C) {
+    const bool fast = !(PA % 2) && !(PB % 2) && !(((uintptr_t)A) & 15) && !(((uintptr_t)B) & 15) && K >= 2048 && PA >= 128 && PB >= 128;
+    if (!fast) return launch_gemm(c, true, false, PA, PB, K, 1.0, A, PA, B, PB, 0.0, C, PB);
+    if (c->ones_n != K) {                      // the kernel reads up to 32 weights past K: they must be zero
+        LRVB_TRY(buf_reserve(c, c->ones, (size_t)(K + 64)));
+        EW(fill_kernel, K, 1.0, c->ones.p);
+        HIP_TRY(hipMemsetAsync(c->ones.p + K, 0, 64 * sizeof(double), c->stream));
+        c->ones_n = K;
+    }
+    return launch_atb(c, A, PA, B, PB, K, c->ones.p, C);
+}
+
 // M~ (64 q x V) holds vec(M_k) in the virtual index v = 64 a + b.  Everything stays on the device.
 __global__ void mtilde_kernel(const double* __restrict__ M, i64 V, int q, double* __restrict__ Mt /* (64 q) x V */) {
     const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -997,8 +1012,8 @@ extern "C" int lrvb_quadform_gram(lrvb_ctx* c, const double* M, const double* cv
     if (st == LRVB_OK) st = buf_reserve(c, T1, (size_t)Pv_t * (size_t)V);
     if (st == LRVB_OK) st = buf_reserve(c, Av, (size_t)V * (size_t)V);
     // T1 = K4 M~ ;  Av = M~^T T1 ;  t = M~^T s
-    if (st == LRVB_OK) st = launch_gemm(c, false, false, Pv_t, V, Pv_t, 1.0, c->Heta.p, Pv_t, Mt.p, V, 0.0, T1.p, V);
-    if (st == LRVB_OK) st = launch_gemm(c, true, false, V, V, Pv_t, 1.0, Mt.p, V, T1.p, V, 0.0, Av.p, V);
+    if (st == LRVB_OK) st = gemm_tn(c, Pv_t, Pv_t, V, c->Heta.p, Mt.p, T1.p);        // K4 is symmetric: K4 M~ = K4^T M~
+    if (st == LRVB_OK) st = gemm_tn(c, Pv_t, V, V, Mt.p, T1.p, Av.p);
     if (st == LRVB_OK) st = buf_reserve(c, c->vtmp3, (size_t)(V > D ? V : D));
     if (st == LRVB_OK) st = launch_gemv(c, true, Pv_t, V, 1.0, Mt.p, V, c->vtmp2.p, 0.0, c->vtmp3.p);
     if (st == LRVB_OK) st = h2d(c, c->g_eta.p, cvec, (size_t)V);
@@ -1010,9 +1025,9 @@ extern "C" int lrvb_quadform_gram(lrvb_ctx* c, const double* M, const double* cv
     // free coordinates: J^T Av J
     if (st == LRVB_OK) st = h2d(c, c->theta.p, free_in, (size_t)D);
     if (st == LRVB_OK) st = launch_dense_jac(c, c->theta.p, c->Jdense.p);
-    if (st == LRVB_OK) st = launch_gemm(c, false, false, V, D, V, 1.0, Av.p, V, c->Jdense.p, D, 0.0, T1.p, D);
+    if (st == LRVB_OK) st = gemm_tn(c, V, V, D, Av.p, c->Jdense.p, T1.p);             // Av is symmetric
     if (st == LRVB_OK) st = buf_reserve(c, c->Hfree, (size_t)D * (size_t)D);
-    if (st == LRVB_OK) st = launch_gemm(c, true, false, D, D, V, 1.0, c->Jdense.p, D, T1.p, D, 0.0, c->Hfree.p, D);
+    if (st == LRVB_OK) st = gemm_tn(c, V, D, D, c->Jdense.p, T1.p, c->Hfree.p);
     if (st == LRVB_OK) {
         if (hipMemcpy2DAsync(GtG_out, (size_t)ld * 8, c->Hfree.p, (size_t)D * 8, (size_t)D * 8, (size_t)D, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
             hipStreamSynchronize(c->stream) != hipSuccess) { lrvb_set_error("copy back failed"); st = LRVB_ERR_HIP; }

@@ -68,6 +68,7 @@ struct lrvb_ctx {
     DevBuf rhs, cgx, cgr, cgp, cgq, cgz, scal;
     DevBuf cgm[9];                 // blocked CG: B, X, R, P, Q, Z (Q x D), U, W (Q x V), R^T (P x Q)
     DevBuf cgT;                    // N x Q products X U^T of the blocked HVP
+    DevBuf ones; i64 ones_n = 0;   // [1 x n | 0 x 64] contraction weights of the plain TN GEMM
     double* host_pinned = nullptr; size_t host_pinned_n = 0;
 
     int n_splits_user = 0;
