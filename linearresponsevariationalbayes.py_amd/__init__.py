@@ -15,7 +15,8 @@ Reference module names are importable as attributes for drop-in code
 """
 __version__ = '0.1.0'
 
-from .packing import (ScalarParam, VectorParam, ArrayParam, PosDefMatrixParam, SimplexParam,
+from .packing import (ScalarParam, VectorParam, ArrayParam, PosDefMatrixParam, PosDefMatrixParamVector,
+                      PosDefMatrixParamArray, SimplexParam,
                       ModelParamsDict, ModelParamsDictValues, convert_vector_to_free_hessian)
 from .families import (UVNParam, UVNParamVector, UVNParamArray, UVNMomentParamArray, MVNParam,
                        MVNArray, GammaParam, WishartParam, DirichletParamArray)

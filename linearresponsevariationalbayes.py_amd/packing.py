@@ -458,7 +458,132 @@ class PosDefMatrixParam(object):
         return self._vec_size
 
 
-# ------------------------------------------------------------------------------ simplex maps
+class PosDefMatrixParamArray(object):
+    """An array of positive definite matrices; the last two indices are the matrix indices
+    (LRVB/MatrixParameters.py:311-481).  Free and vector forms are the per-matrix forms of
+    PosDefMatrixParam stacked in C order of the array index, so the packing Jacobian / Hessians are
+    block diagonal; on the device every matrix is one log-Cholesky block."""
+
+    def __init__(self, name='', array_shape=(1,), matrix_size=2, diag_lb=0.0, val=None):
+        self.name = name
+        self._matrix_size = int(matrix_size)
+        self._array_shape = tuple(int(t) for t in np.atleast_1d(array_shape))
+        self._array_ranges = [range(0, t) for t in self._array_shape]
+        self._array_length = int(np.prod(self._array_shape))
+        self._shape = self._array_shape + (self._matrix_size, self._matrix_size)
+        self._vec_size = self._matrix_size * (self._matrix_size + 1) // 2
+        self._diag_lb = diag_lb
+        assert diag_lb >= 0
+        if val is None:
+            default_val = np.diag(np.full(self._matrix_size, diag_lb + 1.0))
+            self._val = np.broadcast_to(default_val, self._shape)
+        else:
+            self.set(val)
+
+    def layout_blocks(self):
+        return [dict(kind=_hip.BLOCK_PSD, free_size=self._vec_size, vec_size=self._vec_size,
+                     dim0=self._matrix_size, dim1=0, lb=self._diag_lb, ub=_INF)
+                for _ in range(self._array_length)]
+
+    def __str__(self):
+        return self.name + ':\n' + str(self._val)
+
+    def names(self):
+        return [self.name]
+
+    def dictval(self):
+        return np.asarray(self._val).tolist()
+
+    def set(self, val):
+        # (the reference only rejects a value whose EVERY dimension differs, :349-354; any mismatch is rejected here)
+        if tuple(np.shape(val)) != self._shape:
+            raise ValueError('Array is the wrong size')
+        self._val = val
+
+    def get(self):
+        return self._val
+
+    def stacked_obs_slice(self, obs):
+        """Positions in the free / vector form of the matrix at array index `obs` (a tuple)."""
+        assert len(obs) == len(self._array_shape)
+        start = int(np.ravel_multi_index(obs, self._array_shape)) * self._vec_size
+        return slice(start, start + self._vec_size)
+
+    def _matrices(self):
+        return np.reshape(np.asarray(self._val), (self._array_length, self._matrix_size, self._matrix_size))
+
+    def set_free(self, free_val):
+        free_val = np.asarray(free_val)
+        if free_val.size != self.free_size():
+            raise ValueError('Free value is the wrong length')
+        blocks = np.reshape(free_val, (self._array_length, self._vec_size))
+        self._val = np.reshape(np.array([unpack_posdef_matrix(b, diag_lb=self._diag_lb) for b in blocks]), self._shape)
+
+    def get_free(self):
+        return np.hstack([pack_posdef_matrix(m, diag_lb=self._diag_lb) for m in self._matrices()])
+
+    def set_vector(self, vec_val):
+        vec_val = np.asarray(vec_val)
+        if vec_val.size != self.vector_size():
+            raise ValueError('Vector value is the wrong length')
+        blocks = np.reshape(vec_val, (self._array_length, self._vec_size))
+        self._val = np.reshape(np.array([unvectorize_symmetric_matrix(b) for b in blocks]), self._shape)
+
+    def get_vector(self):
+        return np.hstack([vectorize_ld_matrix(m) for m in self._matrices()])
+
+    def apply_matrix_function(self, mat_func):
+        out = np.array([mat_func(m) for m in self._matrices()])
+        return np.reshape(out, self._array_shape + out.shape[1:])
+
+    def free_to_vector(self, free_val):
+        self.set_free(free_val)
+        return self.get_vector()
+
+    def free_to_vector_jac(self, free_val):
+        blocks = np.reshape(np.asarray(free_val, dtype=np.float64), (self._array_length, self._vec_size))
+        return block_diag([_psd_jac_dense(b, self._matrix_size) for b in blocks], format='coo')
+
+    def free_to_vector_hess(self, free_val):
+        blocks = np.reshape(np.asarray(free_val, dtype=np.float64), (self._array_length, self._vec_size))
+        n, v = self.free_size(), self._vec_size
+        hessians = []
+        for a, b in enumerate(blocks):
+            H = _psd_hess_dense(b, self._matrix_size)
+            rows, cols = np.meshgrid(np.arange(a * v, (a + 1) * v), np.arange(a * v, (a + 1) * v), indexing='ij')
+            for k in range(v):
+                hessians.append(coo_matrix((H[k].ravel(), (rows.ravel(), cols.ravel())), (n, n)))
+        return hessians
+
+    def matrix_size(self):
+        return self._matrix_size
+
+    def length(self):
+        return self._array_length
+
+    def get_array_ranges(self):
+        return self._array_ranges
+
+    def free_size(self):
+        return self._vec_size * self._array_length
+
+    def vector_size(self):
+        return self._vec_size * self._array_length
+
+
+class PosDefMatrixParamVector(PosDefMatrixParamArray):
+    """A vector of positive definite matrices, first index = which matrix
+    (LRVB/MatrixParameters.py:201-307)."""
+
+    def __init__(self, name='', length=1, matrix_size=2, diag_lb=0.0, val=None):
+        super().__init__(name=name, array_shape=(int(length),), matrix_size=matrix_size, diag_lb=diag_lb, val=val)
+
+    def free_obs_slice(self, obs):
+        assert obs < self._array_length
+        return slice(self._vec_size * obs, self._vec_size * (obs + 1))
+
+
+# ---------------------------------------------------------------------------------- simplex
 def constrain_simplex_matrix(free_mat):
     """LRVB/SimplexParams.py:11-18."""
     free_mat = np.asarray(free_mat, dtype=np.float64)

@@ -62,6 +62,36 @@ def test_packing_maps(vb):
         ctx.unconstrain(bad)
 
 
+def test_packing_maps_matrix_arrays(vb):
+    """PosDefMatrixParamVector / PosDefMatrixParamArray (LRVB/MatrixParameters.py:201-481): one
+    log-Cholesky block per matrix on the device, block-diagonal sparse derivatives on the host."""
+    from oracle import packing as opk
+    rng = np.random.default_rng(2)
+    par = vb.ModelParamsDict('par')
+    par.push_param(vb.VectorParam('v', 3, lb=0.0))
+    par.push_param(vb.PosDefMatrixParamVector('pv', length=3, matrix_size=3, diag_lb=0.2))
+    par.push_param(vb.PosDefMatrixParamArray('pa', array_shape=(2, 2), matrix_size=2))
+    lay = opk.Layout([opk.box_block(3, 0.0, np.inf)] + [opk.psd_block(3, 0.2) for _ in range(3)]
+                     + [opk.psd_block(2, 0.0) for _ in range(4)])
+    assert par.free_size() == lay.D and par.vector_size() == lay.V
+    ctx = vb.DeviceContext(par.layout_blocks(), quad_kind=1)
+    theta = rng.normal(size=lay.D) * 0.5
+    eta = lay.constrain(theta)
+    par.set_free(theta)
+    assert rel_err(par.get_vector(), eta) < 1e-14
+    assert rel_err(ctx.constrain(theta), eta) < 1e-14
+    assert np.max(np.abs(ctx.unconstrain(eta) - theta)) < 1e-12
+    assert rel_err(ctx.free_to_vector_jac(theta), lay.jac(theta)) < 1e-14
+    assert rel_err(np.asarray(par.free_to_vector_jac(theta).todense()), lay.jac(theta)) < 1e-14
+    g = rng.normal(size=lay.V)
+    Hv = rng.normal(size=(lay.V, lay.V)); Hv = Hv + Hv.T
+    want = opk.convert_vector_to_free_hessian(lay, theta, g, Hv)
+    assert rel_err(ctx.free_hessian_from_vector(theta, g, Hv), want) < 1e-13
+    assert rel_err(np.asarray(vb.convert_vector_to_free_hessian(par, theta, g, Hv)), want) < 1e-13
+    # the matrices themselves
+    np.testing.assert_allclose(par['pv'].get()[1], opk.psd_matrix_from_vector(eta[3 + 6:3 + 12], 3), atol=1e-14)
+
+
 @pytest.mark.parametrize('loss', [om.GAUSSIAN, om.LOGISTIC, om.POISSON])
 @pytest.mark.parametrize('N,P', [(1, 3), (37, 5), (1000, 130), (4099, 254), (3000, 256), (2500, 300)])
 def test_glm_box_layout(vb, loss, N, P):

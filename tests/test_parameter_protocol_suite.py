@@ -96,6 +96,58 @@ def test_pos_def_matrix_and_simplex_methods():
     required_methods(vb.SimplexParam(shape=(3, 4)))
 
 
+def test_pos_def_matrix_vector_and_array():
+    """LRVB/test_variational_bayes.py:124-173."""
+    rng = np.random.default_rng(8)
+    k, length = 3, 4
+    mats = np.array([(lambda a: a @ a.T + 0.5 * np.eye(k))(rng.normal(size=(k, k))) for _ in range(length)])
+    pv = vb.PosDefMatrixParamVector('pv', length=length, matrix_size=k, diag_lb=0.1)
+    required_methods(pv)
+    pv.set(mats)
+    np.testing.assert_allclose(pv.get(), mats)
+    free = pv.get_free()
+    assert free.size == length * k * (k + 1) // 2
+    for obs in range(length):
+        np.testing.assert_allclose(free[pv.free_obs_slice(obs)],
+                                   vb.MatrixParameters.pack_posdef_matrix(mats[obs], diag_lb=0.1))
+    pv.set_free(rng.normal(size=free.size))
+    pv.set_free(free)
+    np.testing.assert_allclose(pv.get(), mats, atol=1e-12)
+    vec = pv.get_vector()
+    pv.set_free(rng.normal(size=free.size))
+    pv.set_vector(vec)
+    np.testing.assert_allclose(pv.get(), mats, atol=1e-14)
+    with pytest.raises(ValueError):
+        pv.set_free(free[:-1])
+    with pytest.raises(ValueError):
+        pv.set_vector(vec[:-1])
+    with pytest.raises(ValueError):
+        pv.set(mats[:-1])
+    assert pv.length() == length and pv.matrix_size() == k
+    shape = (2, 3)
+    amats = np.array([[(lambda a: a @ a.T + np.eye(2))(rng.normal(size=(2, 2))) for _ in range(3)] for _ in range(2)])
+    pa = vb.PosDefMatrixParamArray('pa', array_shape=shape, matrix_size=2, diag_lb=0.0)
+    required_methods(pa)
+    pa.set(amats)
+    free = pa.get_free()
+    for obs in [(0, 0), (1, 2), (0, 1)]:
+        np.testing.assert_allclose(free[pa.stacked_obs_slice(obs)], vb.MatrixParameters.pack_posdef_matrix(amats[obs]))
+    pa.set_free(np.zeros(free.size))
+    pa.set_free(free)
+    np.testing.assert_allclose(pa.get(), amats, atol=1e-12)
+    dets = pa.apply_matrix_function(np.linalg.det)
+    assert dets.shape == shape
+    np.testing.assert_allclose(dets, np.linalg.det(amats))
+    invs = pa.apply_matrix_function(np.linalg.inv)
+    assert invs.shape == shape + (2, 2)
+    # inside a dictionary the blocks keep their offsets
+    mp = vb.ModelParamsDict('d')
+    mp.push_param(vb.VectorParam('v', 2, lb=0.0))
+    mp.push_param(pa)
+    check_sparse_transforms(mp)
+    assert len(mp.layout_blocks()) == 1 + 6
+
+
 def test_mvn_methods_and_moments():
     par = vb.MVNParam(dim=3)
     required_methods(par)
