@@ -17,6 +17,7 @@ linear response needs for global moments at G = 1e4.
 """
 import numpy as np
 from scipy import special
+from scipy import sparse as sp_sparse
 
 from . import _hip
 from .models import DeviceContext
@@ -265,6 +266,28 @@ class LMMObjective(object):
 
     def hvp(self, x, v, is_free):
         return self.hessian(x, is_free) @ _hip.as_f64(v).ravel()
+
+    # ---- arrow structure: sparse export (SparseObjectives.get_sparse_sub_hessian, :587-594) ------------
+    def sparse_hessian(self, free_val):
+        """The full free-coordinate Hessian as a scipy CSR matrix: dense global block, the cross block
+        and the 2G diagonal local entries placed with `get_sparse_sub_matrix` -- the format in which the
+        reference hands arrow-structured Hessians to sparse solvers."""
+        from .objectives import get_sparse_sub_hessian, get_sparse_sub_matrix
+        free_val = _hip.as_f64(free_val).ravel()
+        eta = self.ctx.constrain(free_val)
+        g, Hgg, Hgl, dl = self._arrow(eta)
+        ng, G, D = self.n_global, self.G, free_val.size
+        self.global_hessian(free_val)                       # builds the global-block packing context
+        Hgg_free = self._gctx.free_hessian_from_vector(free_val[:ng], g[:ng], Hgg)
+        Jg = self._gctx.free_to_vector_jac(free_val[:ng])
+        ig = eta[self._is]
+        jl = np.concatenate([np.ones(G), ig])
+        dl_free = dl * jl ** 2 + np.concatenate([np.zeros(G), g[self._is] * ig])
+        cross = (Jg.T @ Hgl) * jl[None, :]
+        gi, li = np.arange(ng), np.arange(ng, D)
+        H = get_sparse_sub_hessian(Hgg_free, gi, D)
+        H = H + get_sparse_sub_matrix(cross, gi, li, D, D) + get_sparse_sub_matrix(cross.T, li, gi, D, D)
+        return (H + sp_sparse.diags(np.concatenate([np.zeros(ng), dl_free]), format='csr')).tocsr()
 
     # ---- arrow structure: Schur complement onto the global block, free coordinates --------------------
     def global_hessian(self, free_val):

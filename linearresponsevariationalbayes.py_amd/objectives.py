@@ -449,3 +449,20 @@ def pack_csr_matrix(sp_mat):
 def unpack_csr_matrix(sp_mat_dict):
     return sp.sparse.csr_matrix((sp_mat_dict['data'], sp_mat_dict['indices'], sp_mat_dict['indptr']),
                                 shape=sp_mat_dict['shape'])
+
+
+def json_pack_csr_matrix(sp_mat):
+    """JSON-serialisable form of a CSR matrix (LRVB/SparseObjectives.py:631-639; the reference encodes
+    the three arrays with json_tricks, absent here -- plain lists carry the same content)."""
+    assert sp.sparse.isspmatrix_csr(sp_mat)
+    sp_mat = sp.sparse.csr_matrix(sp_mat)
+    return {'data': sp_mat.data.tolist(), 'indices': sp_mat.indices.tolist(), 'indptr': sp_mat.indptr.tolist(),
+            'shape': [int(t) for t in sp_mat.shape], 'type': 'csr_matrix'}
+
+
+def json_unpack_csr_matrix(sp_mat_dict):
+    assert sp_mat_dict['type'] == 'csr_matrix'
+    return sp.sparse.csr_matrix((np.asarray(sp_mat_dict['data'], dtype=np.float64),
+                                 np.asarray(sp_mat_dict['indices'], dtype=np.int64),
+                                 np.asarray(sp_mat_dict['indptr'], dtype=np.int64)),
+                                shape=tuple(sp_mat_dict['shape']))

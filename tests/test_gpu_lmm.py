@@ -74,6 +74,20 @@ def test_schur_complement_middle_size(vb):
     assert ng == p + p * (p + 1) // 2 + 6
     HS = fun.global_hessian(theta)
     assert rel_err(np.linalg.inv(HS), np.linalg.inv(H)[:ng, :ng]) < 1e-7
+    # sparse export of the same arrow matrix (SparseObjectives.get_sparse_sub_hessian placement) and its
+    # JSON round trip; a sparse solve agrees with the dense one
+    import scipy.sparse
+    import scipy.sparse.linalg
+    Hs = fun.sparse_hessian(theta)
+    assert scipy.sparse.isspmatrix_csr(Hs) and Hs.shape == H.shape
+    assert Hs.nnz <= ng * ng + 2 * ng * 2 * G + 2 * G            # dense global block, borders, diagonal
+    assert rel_err(Hs.toarray(), H) < 1e-12
+    packed = vb.SparseObjectives.json_pack_csr_matrix(Hs)
+    import json
+    back = vb.SparseObjectives.json_unpack_csr_matrix(json.loads(json.dumps(packed)))
+    assert (back != Hs).nnz == 0
+    b = rng.normal(size=H.shape[0])
+    assert rel_err(scipy.sparse.linalg.spsolve(Hs.tocsc(), b), np.linalg.solve(H, b)) < 1e-8
     # a few AD Hessian-vector products pin the dense matrix itself
     w1 = torch.ones(N, dtype=torch.float64)
     grad_fn = torch.func.grad(ft)

