@@ -117,42 +117,59 @@ __device__ __forceinline__ double lane_bcast(double v, int src_lane) {
     return __hiloint2double(hi, lo);
 }
 
+constexpr int CH_LS = CH_NB + 2;          // LDS row stride of the diagonal block (even: 16-byte pair reads)
+
 __global__ __launch_bounds__(64)
 void potrf_inv_diag_kernel(double* __restrict__ A, i64 lda, int nb, double* __restrict__ W /* 64 x 64 */,
                            int* __restrict__ info, int col0)
 {
+    // One wavefront, lane i <-> row i of the 64 x 64 block.  The cross-lane traffic of the factorisation
+    // (step j needs L[k][j] of every later row k in every lane) goes through LDS: the lanes deposit
+    // column j once and read it back with wave-uniform 16-byte reads -- (63 - j) / 2 broadcast reads per
+    // step instead of 2 (63 - j) v_readlane, which is what made this kernel two thirds of the D = 1024
+    // factorisation time.
+    __shared__ double Ls[CH_NB * CH_LS];
+    __shared__ double colbuf[CH_NB];
     const int lane = threadIdx.x;
+    // coalesced load of the block (row r, column lane), identity padding past nb
+    for (int r = 0; r < CH_NB; ++r)
+        Ls[r * CH_LS + lane] = (r < nb && lane < nb) ? ((lane <= r) ? A[(i64)r * lda + lane] : 0.0) : ((r == lane) ? 1.0 : 0.0);
+    __syncthreads();
     double a[CH_NB];
-    // rows/columns past nb are padded with the identity, so partial blocks need no special code
 #pragma unroll
-    for (int k = 0; k < CH_NB; ++k)
-        a[k] = (lane < nb && k < nb) ? ((k <= lane) ? A[(i64)lane * lda + k] : 0.0) : ((k == lane) ? 1.0 : 0.0);
-    // symmetric fill of the upper part is not needed: the update below only ever reads a[j] of
-    // lanes >= j and a[k] (k > j) of lanes >= k
+    for (int k = 0; k < CH_NB; ++k) a[k] = Ls[lane * CH_LS + k];
     int bad = 0;
 #pragma unroll
     for (int j = 0; j < CH_NB; ++j) {
-        const double d = lane_bcast(a[j], j);
+        __syncthreads();
+        colbuf[lane] = a[j];                     // column j of the current trailing matrix
+        __syncthreads();
+        const double d = colbuf[j];
         if (!(d > 0.0) && bad == 0) bad = j + 1;
-        const double r = 1.0 / sqrt(d);
-        a[j] = a[j] * r;                         // lane j now holds sqrt(d); lanes > j hold L[i][j]
+        const double t = a[j] / d;               // L[i][j] / sqrt(d)
+        a[j] = a[j] / sqrt(d);                   // L[i][j]  (lane j: sqrt(d))
 #pragma unroll
-        for (int k = j + 1; k < CH_NB; ++k)
-            a[k] -= a[j] * lane_bcast(a[j], k);  // A[i][k] -= L[i][j] L[k][j]
+        for (int k = j + 1; k < CH_NB; ++k) a[k] -= t * colbuf[k];      // A[i][k] -= L[i][j] L[k][j]
     }
     if (lane == 0 && bad != 0 && *info == 0) *info = col0 + bad;
-    // store L (lower part of the real block)
+    // L through LDS: coalesced store of the lower part, and the source of the broadcasts below
+    __syncthreads();
 #pragma unroll
-    for (int k = 0; k < CH_NB; ++k)
-        if (lane < nb && k <= lane) A[(i64)lane * lda + k] = a[k];
-    // W = L^-1: lane c solves L w = e_c by forward substitution; L[i][k] is a[k] of lane i
+    for (int k = 0; k < CH_NB; ++k) Ls[lane * CH_LS + k] = (k <= lane) ? a[k] : 0.0;
+    __syncthreads();
+    for (int r = 0; r < nb; ++r)
+        if (lane <= r && lane < nb) A[(i64)r * lda + lane] = Ls[r * CH_LS + lane];
+    // W = L^-1: lane c solves L w = e_c by forward substitution; row i of L is read wave-uniformly
     double w[CH_NB];
 #pragma unroll
     for (int i = 0; i < CH_NB; ++i) {
-        double s = (i == lane) ? 1.0 : 0.0;
+        const double* Li = Ls + i * CH_LS;
+        double s0 = (i == lane) ? 1.0 : 0.0, s1 = 0.0;       // two interleaved chains halve the dependent-FMA latency
 #pragma unroll
-        for (int k = 0; k < i; ++k) s -= lane_bcast(a[k], i) * w[k];
-        w[i] = s / lane_bcast(a[i], i);
+        for (int k = 0; k < i; ++k) {
+            if (k & 1) s1 = fma(-Li[k], w[k], s1); else s0 = fma(-Li[k], w[k], s0);
+        }
+        w[i] = (s0 + s1) / Li[i];
     }
 #pragma unroll
     for (int i = 0; i < CH_NB; ++i) W[i * CH_NB + lane] = w[i];    // W[i][c], coalesced over c
