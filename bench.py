@@ -109,7 +109,13 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29531')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        # LRVB_BENCH_REHEARSE_ONE_GPU=1: every rank uses GPU 0 and the exchange goes over gloo -- a
+        # correctness rehearsal of the multi-rank path on a one-GPU box (RCCL refuses two ranks on one
+        # device); the numbers it prints are not a measurement
+        rehearse = os.environ.get('LRVB_BENCH_REHEARSE_ONE_GPU', '0') == '1'
+        dist.init_process_group('gloo' if rehearse else 'nccl', rank=rank, world_size=world)
+        if rehearse:
+            local_rank = 0
     if args.gpus != world and rank == 0:
         print('warning: --gpus {} but WORLD_SIZE {}'.format(args.gpus, world), file=sys.stderr)
     torch.cuda.set_device(local_rank)
