@@ -1,0 +1,176 @@
+// k_hvp_multi.hip -- R = X^T diag(c) X U for up to 16 vectors at once, X read ONCE.
+//
+// The blocked conjugate-gradient solver (lrvb_cg_solve_multi; the loop over masks of
+// LRVB/ConjugateGradient.py:87-105) needs Q Hessian-vector products per iteration.  One after the other
+// they cost Q fused passes over X; as two skinny GEMMs (T = X U, then X^T diag(c) T) two passes on
+// generic kernels.  Here both contractions happen on a row chunk while it sits in LDS:
+//
+//   chunk = 8 observations x P columns, staged by LDS-DMA (double buffered, 2 x 64 KiB at P = 1024)
+//   step A:  T (8 x 16)   = X_chunk U          contraction over COLUMNS:  A[i = row][k = col], B = U slice
+//   step B:  R (P x 16)  += X_chunk^T (c o T)  contraction over ROWS:     A[i = col][k = row], B = c o T
+//
+// The two steps want the chunk in transposed register layouts -- LDS is the transposer: both read the same
+// staged rows with different address patterns (16-byte reads, conflict-free with a row stride of P + 2).
+// Wave w owns the column quarter [w P/4, (w+1) P/4): its slice of U stays in registers for the whole kernel
+// (the B operand of step A), and so do its 16-row tiles of R (the accumulators of step B); the four partial
+// T tiles meet in LDS once per chunk, and the sum comes back in exactly the register layout step B needs
+// as its B operand (D register r <-> row (lane >> 4) + 4 r).  P <= 1024, P % 128 == 0, Q <= 16.
+#include "lrvb_internal.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+#define HM_GLDS16(gp, lp) __builtin_amdgcn_global_load_lds( \
+    (const __attribute__((address_space(1))) void*)(gp), (__attribute__((address_space(3))) void*)(lp), 16, 0, 0)
+
+constexpr int HM_ROWS = 8;               // observations per chunk
+
+template <int NB>                        // NB = P / 128: column blocks of 32 per wave = NB
+__global__ __launch_bounds__(256, 1)
+void hvp_multi_kernel(const double* __restrict__ X, i64 N, const double* __restrict__ cw,
+                      const double* __restrict__ U, i64 ldu, int Q, double* __restrict__ Rpart)
+{
+    constexpr int P = NB * 128;
+    constexpr int PW = P / 4;             // columns per wave
+    constexpr int STRIDE = P + 2;         // doubles; (STRIDE / 2) odd -> rows land on distinct 16-byte bank groups
+    constexpr int NT = PW / 16;           // 16-column tiles of R per wave
+    extern __shared__ double lds[];       // [2][HM_ROWS][STRIDE] chunk buffers | [4][2][64] partial T tiles
+    double* Tpart = lds + 2 * HM_ROWS * STRIDE;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int pc0 = wave * PW;
+
+    // this wave's slice of U as MFMA B operands: block b (32 columns), sub-step t: k = pc0 + 32 b + 8 l4 + t, q = l15
+    double uf[NB][8];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            uf[b][t] = (l15 < Q) ? U[(i64)l15 * ldu + pc0 + 32 * b + 8 * l4 + t] : 0.0;
+
+    d4 acc[NT];
+#pragma unroll
+    for (int m = 0; m < NT; ++m) acc[m] = (d4){0.0, 0.0, 0.0, 0.0};
+
+    const i64 nchunks = (N + HM_ROWS - 1) / HM_ROWS;
+    auto issue = [&](i64 ch, int buf) {
+        // wave w stages rows {2 w, 2 w + 1} of the chunk: P / 128 instructions of 1 KiB per row
+        double* base = lds + buf * (HM_ROWS * STRIDE);
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int row = 2 * wave + rr;
+            i64 n = ch * HM_ROWS + row; if (n > N - 1) n = N - 1;       // rows past N carry weight zero
+            const double* rowp = X + n * (i64)P;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) HM_GLDS16(rowp + 128 * j + 2 * lane, base + row * STRIDE + 128 * j);
+        }
+    };
+
+    i64 ch = blockIdx.x;
+    int buf = 0;
+    if (ch < nchunks) issue(ch, 0);
+    for (; ch < nchunks; ch += gridDim.x) {
+        // weights of this chunk's rows in the D-register layout of T: reg s <-> row l4 + 4 s
+        const double c0 = cw[ch * HM_ROWS + l4], c1 = cw[ch * HM_ROWS + 4 + l4];
+        __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): this wave's part of the stage has landed
+        __syncthreads();                                      // ... and everybody's; the other buffer is free again
+        const i64 nxt = ch + gridDim.x;
+        if (nxt < nchunks) issue(nxt, buf ^ 1);
+        const double* Xs = lds + buf * (HM_ROWS * STRIDE);
+
+        // ---- step A: partial T over this wave's columns ------------------------------------------------
+        d4 tp = (d4){0.0, 0.0, 0.0, 0.0};
+        const double* arow = Xs + (l15 & 7) * STRIDE + pc0 + 8 * l4;
+        // (MFMA rows 8..15 are padding: lanes with l15 >= 8 re-read rows 0..7, which only feeds the unused half of T)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const d2 v0 = *reinterpret_cast<const d2*>(arow + 32 * b);
+            const d2 v1 = *reinterpret_cast<const d2*>(arow + 32 * b + 2);
+            const d2 v2 = *reinterpret_cast<const d2*>(arow + 32 * b + 4);
+            const d2 v3 = *reinterpret_cast<const d2*>(arow + 32 * b + 6);
+            const double af[8] = {v0[0], v0[1], v1[0], v1[1], v2[0], v2[1], v3[0], v3[1]};
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                tp = __builtin_amdgcn_mfma_f64_16x16x4f64(af[t], uf[b][t], tp, 0, 0, 0);
+        }
+        // ---- the four partial tiles meet in LDS; every wave leaves with the full T, scaled by c ----------
+        Tpart[(wave * 2 + 0) * 64 + lane] = tp[0];             // rows l4       (register 0)
+        Tpart[(wave * 2 + 1) * 64 + lane] = tp[1];             // rows l4 + 4   (register 1)
+        __syncthreads();
+        double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { t0 += Tpart[(w * 2 + 0) * 64 + lane]; t1 += Tpart[(w * 2 + 1) * 64 + lane]; }
+        t0 *= c0; t1 *= c1;
+
+        // ---- step B: R tiles of this wave's columns += X_chunk^T (c o T) ---------------------------------
+        // one 16-byte read feeds two tiles: tile m takes the columns pc0 + 32 (m >> 1) + 2 i + (m & 1)
+        const double* brow0 = Xs + l4 * STRIDE + pc0 + 2 * l15;
+        const double* brow1 = brow0 + 4 * STRIDE;
+#pragma unroll
+        for (int h = 0; h < NT / 2; ++h) {
+            const d2 x0 = *reinterpret_cast<const d2*>(brow0 + 32 * h);
+            const d2 x1 = *reinterpret_cast<const d2*>(brow1 + 32 * h);
+            acc[2 * h]     = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[0], t0, acc[2 * h], 0, 0, 0);
+            acc[2 * h + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[1], t0, acc[2 * h + 1], 0, 0, 0);
+            acc[2 * h]     = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[0], t1, acc[2 * h], 0, 0, 0);
+            acc[2 * h + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[1], t1, acc[2 * h + 1], 0, 0, 0);
+        }
+        buf ^= 1;
+    }
+    // partial R of this workgroup: [P][16]
+    double* out = Rpart + (i64)blockIdx.x * P * 16;
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int p = pc0 + 32 * (m >> 1) + 2 * (l4 + 4 * r) + (m & 1);
+            out[p * 16 + l15] = acc[m][r];
+        }
+}
+
+// Out[q][off + p] = sum over workgroups of Rpart[g][p][q], fixed order (deterministic)
+__global__ void hvp_multi_reduce_kernel(const double* __restrict__ Rpart, int G, int P, int Q, i64 ldo, i64 off,
+                                        double* __restrict__ Out)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;       // e = p * 16 + q
+    if (e >= P * 16) return;
+    const int p = e >> 4, q = e & 15;
+    if (q >= Q) return;
+    double s = 0.0;
+    for (int g = 0; g < G; ++g) s += Rpart[(i64)g * P * 16 + e];
+    Out[(i64)q * ldo + off + p] = s;
+}
+
+bool hvp_multi_supported(const lrvb_ctx* c, i64 Q) {
+    return Q >= 1 && Q <= 16 && c->P % 128 == 0 && c->P >= 128 && c->P <= 1024 && c->N >= 1 &&
+           ((((uintptr_t)c->X.p) & 15) == 0);
+}
+
+// Out (Q x ldo, row q) [off .. off + P) = X^T diag(cw) X U[q, off .. off + P);  U is Q x ldu row-major.
+int launch_hvp_multi(lrvb_ctx* c, i64 Q, const double* U_dev, i64 ldu, double* Out_dev, i64 ldo)
+{
+    if (!hvp_multi_supported(c, Q)) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "fused multi-vector pass: n_cols %% 128 == 0, n_cols <= 1024, at most 16 vectors");
+    const int P = (int)c->P;
+    const i64 nchunks = (c->N + HM_ROWS - 1) / HM_ROWS;
+    int grid = 256;                                           // one workgroup per CU (64+ KiB of LDS each)
+    if (grid > nchunks) grid = (int)nchunks;
+    LRVB_TRY(buf_reserve(c, c->part_vec, (size_t)grid * (size_t)P * 16));
+    const size_t lds_bytes = (size_t)(2 * HM_ROWS * (P + 2) + 4 * 2 * 64) * sizeof(double);
+    const double* Uoff = U_dev + c->glm_off;
+#define HM_LAUNCH(NB) do { \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&hvp_multi_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+        hipLaunchKernelGGL(hvp_multi_kernel<NB>, dim3((unsigned)grid), dim3(256), lds_bytes, c->stream, \
+                           c->X.p, c->N, c->cw.p, Uoff, ldu, (int)Q, c->part_vec.p); } while (0)
+    switch (P / 128) {
+    case 1: HM_LAUNCH(1); break; case 2: HM_LAUNCH(2); break; case 3: HM_LAUNCH(3); break; case 4: HM_LAUNCH(4); break;
+    case 5: HM_LAUNCH(5); break; case 6: HM_LAUNCH(6); break; case 7: HM_LAUNCH(7); break; default: HM_LAUNCH(8); break;
+    }
+#undef HM_LAUNCH
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(hvp_multi_reduce_kernel, dim3((unsigned)((P * 16 + 255) / 256)), dim3(256), 0, c->stream,
+                       c->part_vec.p, grid, P, (int)Q, ldo, c->glm_off, Out_dev);
+    HIP_TRY(hipGetLastError());
+    return LRVB_OK;
+}

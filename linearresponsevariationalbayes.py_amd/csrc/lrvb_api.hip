@@ -1347,7 +1347,13 @@ static int heta_apply_multi(lrvb_ctx* c, i64 Q, const double* U /* Q x V */, dou
     if (c->loss != LRVB_LOSS_NONE) {
         const i64 Qp = Q + (Q & 1);
         const bool mfma_ok = (P % 2 == 0) && ((((uintptr_t)c->X.p) & 15) == 0) && P >= 2;
-        if (mfma_ok) {
+        if (hvp_multi_supported(c, 1) && !c->force_generic_wsyrk) {
+            // both contractions on each row chunk while it sits in LDS: X is read once per 16 vectors
+            for (i64 q0 = 0; q0 < Q; q0 += 16) {
+                const i64 qn = (Q - q0 < 16) ? Q - q0 : 16;
+                LRVB_TRY(launch_hvp_multi(c, qn, U + q0 * V, V, Out + q0 * V, V));
+            }
+        } else if (mfma_ok) {
             LRVB_TRY(launch_gemm(c, false, true, N, Q, P, 1.0, c->X.p, P, U + c->glm_off, V, 0.0, c->cgT.p, Qp));
             LRVB_TRY(launch_atb(c, c->X.p, P, c->cgT.p, Qp, N, c->cw.p, c->cgm[8].p));
             EW(scatter_rows_T_kernel, Q * P, Q, V, P, c->glm_off, c->cgm[8].p, Qp, Out);

@@ -105,6 +105,8 @@ enum PassMode { PASS_GRAD = 0, PASS_HVP = 1, PASS_HVP_C = 2 };
 int launch_glm_pass(lrvb_ctx* c, PassMode mode, const double* beta_dev, const double* u_dev,
                     double* out_vec_P /* reduced */, double* value_out_dev /* nullable */,
                     bool store_obs);
+bool hvp_multi_supported(const lrvb_ctx* c, i64 Q);
+int  launch_hvp_multi(lrvb_ctx* c, i64 Q, const double* U_dev, i64 ldu, double* Out_dev, i64 ldo);
 int launch_obs_grad(lrvb_ctx* c, i64 n0, i64 n1, double* G_dev, int mode, const double* scale_vec);
 
 // k_wsyrk.hip

@@ -19,7 +19,10 @@ def vb():
 
 
 @pytest.mark.parametrize('loss,N,P,Q', [(om.GAUSSIAN, 2000, 64, 5), (om.POISSON, 3000, 200, 16), (om.LOGISTIC, 1500, 33, 3),
-                                        (om.GAUSSIAN, 700, 130, 1)])
+                                        (om.GAUSSIAN, 700, 130, 1),
+                                        # n_cols % 128 == 0: the fused multi-vector pass (X read once per iteration)
+                                        (om.GAUSSIAN, 1003, 128, 16), (om.POISSON, 4099, 384, 7), (om.LOGISTIC, 2001, 1024, 16),
+                                        (om.GAUSSIAN, 5, 256, 20)])
 def test_rows_match_single_solver_and_direct_solve(vb, loss, N, P, Q):
     rng = np.random.default_rng(N + Q)
     par, lay = make_par(vb, [('box', 'a', P // 2, -np.inf, np.inf), ('box', 'b', P - P // 2, 0.0, np.inf)])
@@ -36,7 +39,8 @@ def test_rows_match_single_solver_and_direct_solve(vb, loss, N, P, Q):
     X, info, iters = fun.ctx.cg_solve_multi(theta, B)
     assert np.all(info == 0)
     want = np.linalg.solve(H, B.T).T
-    assert np.max(np.abs(X - want)) < 1e-8 * max(1.0, np.max(np.abs(want)))
+    # residual rule ||r|| < 1e-8 ||b||: the error is that times the conditioning of H
+    assert np.max(np.abs(X - want)) < 1e-7 * max(1.0, np.max(np.abs(want)))
     for q in range(Q):
         xq, iq, itq = fun.ctx.cg_solve(theta, B[q])
         assert iq == 0 and itq == iters[q]
@@ -46,11 +50,30 @@ def test_rows_match_single_solver_and_direct_solve(vb, loss, N, P, Q):
     # preconditioner and warm start
     Minv = np.diag(1.0 / np.diag(H))
     X2, info2, iters2 = fun.ctx.cg_solve_multi(theta, B, X0=0.5 * want, Minv=Minv, tol=1e-10)
-    assert np.all(info2 == 0) and np.max(np.abs(X2 - want)) < 1e-8 * max(1.0, np.max(np.abs(want)))
+    assert np.all(info2 == 0) and np.max(np.abs(X2 - want)) < 1e-7 * max(1.0, np.max(np.abs(want)))
     # iteration cap is reported per row
     X3, info3, iters3 = fun.ctx.cg_solve_multi(theta, B, maxiter=2)
     nz = np.flatnonzero(np.abs(B).sum(axis=1) > 0)
     assert np.all(info3[nz] == 2) and np.all(iters3[nz] == 2)
+
+
+def test_fused_pass_equals_two_gemm_route(vb):
+    """The same blocked solve with the fused kernel switched off (tuning flag bit 0) must agree."""
+    rng = np.random.default_rng(9)
+    N, P, Q = 3001, 512, 11
+    par, lay = make_par(vb, [('box', 'a', P, 0.0, np.inf)])
+    x, y, w = glm_data(rng, N, P, om.POISSON)
+    fun = vb.DeviceObjective(par, x=x, y=y, loss='poisson', quad_A=np.full(P, 1.0), weights=w)
+    theta = rng.normal(size=P) * 0.1
+    fun._push_state()
+    B = rng.normal(size=(Q, P))
+    X1, info1, it1 = fun.ctx.cg_solve_multi(theta, B)
+    fun.ctx.set_tuning(0, 1)
+    X2, info2, it2 = fun.ctx.cg_solve_multi(theta, B)
+    fun.ctx.set_tuning(0, 0)
+    # ~65 iterations here: the two routes round differently, so a system may stop one iteration apart
+    assert np.all(info1 == 0) and np.all(info2 == 0) and np.max(np.abs(it1 - it2)) <= 1
+    assert rel_err(X1, X2) < 1e-7
 
 
 def test_general_layout(vb):
