@@ -66,11 +66,34 @@ class QuadraticDataObjective(object):
             self._S = None
 
     def _stats(self):
+        ext = getattr(self, '_external_stats', None)
+        if ext is not None:
+            return ext[:-1].reshape(self.q, self.q), float(ext[-1])
         self._push_state()
         if self._S is None:
             self._S = self.ctx.weighted_gram()           # GPU: sum_n w_n z_n z_n^T
             self._W = float(np.sum(self._w_cache))
         return self._S, self._W
+
+    # ---- observations sharded over GPUs: the statistics are sums over rows ---------------------------
+    def local_stats(self):
+        """[S (q*q) | W] of THIS process's rows: the buffer of the one sum all-reduce per evaluation
+        (SURVEY.md section 8(e)); value, gradient and Hessian are then replicated host closed forms.
+        G^T G (`gram`) is additive over shards as well: all-reduce the matrices the ranks return."""
+        self._external_stats = None
+        S, W = self._stats()
+        return np.concatenate([np.asarray(S, dtype=np.float64).ravel(), [W]])
+
+    def set_reduced_stats(self, flat):
+        """Install statistics summed over all shards (None = use this process's own)."""
+        if flat is None:
+            self._external_stats = None
+            return
+        flat = np.asarray(flat, dtype=np.float64).ravel()
+        if flat.size != self.q * self.q + 1:
+            raise ValueError('expected {} statistics'.format(self.q * self.q + 1))
+        self._external_stats = flat.copy()
+        self._h_key = None
 
     def _eta(self, x, is_free):
         x = _hip.as_f64(x).ravel()

@@ -194,3 +194,38 @@ def test_two_rank_mixture_statistics_allreduce(tmp_path):
     mp.spawn(_mixture_worker, args=(2, _free_port(), out_path), nprocs=2, join=True)
     err = np.load(out_path)
     assert err[0] < 1e-11 and err[1] < 1e-12
+
+
+def _mvn_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from lrvb_amd.distributed import shard_rows, allreduce_stats
+    from test_mvn_regression_host_math import _shell
+    rng = np.random.default_rng(4)
+    N, k = 333, 4
+    x = rng.normal(size=(N, k)); y = rng.normal(size=N); w = rng.uniform(0.5, 1.5, N)
+    a = rng.normal(size=(k, k)); lam0 = a @ a.T / k + np.eye(k)
+    c = rng.normal(size=(k, k)); lam = c @ c.T + np.eye(k)
+    eta = np.concatenate([rng.normal(size=k), lam[np.tril_indices(k)], [3.1, 1.7]])
+    f = _shell(k, rng.normal(size=k), lam0, 2.5, 1.3)
+    z = np.hstack([x, y[:, None]])
+    r0, r1 = shard_rows(N, rank, world)
+    local = np.concatenate([(z[r0:r1].T @ (w[r0:r1, None] * z[r0:r1])).ravel(), [w[r0:r1].sum()]])
+    f.set_reduced_stats(allreduce_stats(local))
+    S, W = f._stats()
+    val, g, H = f._terms(eta, S, W)
+    if rank == 0:
+        v1, g1, H1 = f._terms(eta, z.T @ (w[:, None] * z), float(w.sum()))
+        np.save(out_path, np.array([abs(val - v1) / abs(v1), np.max(np.abs(g - g1)) / np.max(np.abs(g1)),
+                                    np.max(np.abs(H - H1)) / np.max(np.abs(H1))]))
+    dist.destroy_process_group()
+
+
+def test_two_rank_quadratic_data_statistics_allreduce(tmp_path):
+    """Configs 1, 2, 5: S = sum w z z^T and W are the whole exchange."""
+    out_path = str(tmp_path / 'err.npy')
+    mp.spawn(_mvn_worker, args=(2, _free_port(), out_path), nprocs=2, join=True)
+    assert np.all(np.load(out_path) < 1e-12)
