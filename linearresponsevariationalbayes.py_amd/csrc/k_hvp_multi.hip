@@ -25,10 +25,13 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 
 constexpr int HM_ROWS = 8;               // observations per chunk
 
-template <int NB>                        // NB = P / 128: column blocks of 32 per wave = NB
+// TONLY = true stops after step A and writes the scaled rows of T instead (out[n][q] = c_n (X U)[n][q]):
+// the streamed weight-sensitivity product of lrvb_obs_influence.
+template <int NB, bool TONLY>            // NB = P / 128: column blocks of 32 per wave = NB
 __global__ __launch_bounds__(256, 1)
 void hvp_multi_kernel(const double* __restrict__ X, i64 N, const double* __restrict__ cw,
-                      const double* __restrict__ U, i64 ldu, int Q, double* __restrict__ Rpart)
+                      const double* __restrict__ U, i64 ldu, int Q, double* __restrict__ Rpart,
+                      double* __restrict__ Tout, i64 ldt)
 {
     constexpr int P = NB * 128;
     constexpr int PW = P / 4;             // columns per wave
@@ -103,6 +106,15 @@ void hvp_multi_kernel(const double* __restrict__ X, i64 N, const double* __restr
 #pragma unroll
         for (int w = 0; w < 4; ++w) { t0 += Tpart[(w * 2 + 0) * 64 + lane]; t1 += Tpart[(w * 2 + 1) * 64 + lane]; }
         t0 *= c0; t1 *= c1;
+        if (TONLY) {
+            if (wave == 0 && l15 < Q) {
+                const i64 n = ch * HM_ROWS + l4;
+                if (n < N) Tout[n * ldt + l15] = t0;
+                if (n + 4 < N) Tout[(n + 4) * ldt + l15] = t1;
+            }
+            buf ^= 1;
+            continue;
+        }
 
         // ---- step B: R tiles of this wave's columns += X_chunk^T (c o T) ---------------------------------
         // one 16-byte read feeds two tiles: tile m takes the columns pc0 + 32 (m >> 1) + 2 i + (m & 1)
@@ -119,6 +131,7 @@ void hvp_multi_kernel(const double* __restrict__ X, i64 N, const double* __restr
         }
         buf ^= 1;
     }
+    if (TONLY) return;
     // partial R of this workgroup: [P][16]
     double* out = Rpart + (i64)blockIdx.x * P * 16;
 #pragma unroll
@@ -160,9 +173,9 @@ int launch_hvp_multi(lrvb_ctx* c, i64 Q, const double* U_dev, i64 ldu, double* O
     const size_t lds_bytes = (size_t)(2 * HM_ROWS * (P + 2) + 4 * 2 * 64) * sizeof(double);
     const double* Uoff = U_dev + c->glm_off;
 #define HM_LAUNCH(NB) do { \
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&hvp_multi_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
-        hipLaunchKernelGGL(hvp_multi_kernel<NB>, dim3((unsigned)grid), dim3(256), lds_bytes, c->stream, \
-                           c->X.p, c->N, c->cw.p, Uoff, ldu, (int)Q, c->part_vec.p); } while (0)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&hvp_multi_kernel<NB, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+        hipLaunchKernelGGL((hvp_multi_kernel<NB, false>), dim3((unsigned)grid), dim3(256), lds_bytes, c->stream, \
+                           c->X.p, c->N, c->cw.p, Uoff, ldu, (int)Q, c->part_vec.p, (double*)nullptr, (i64)0); } while (0)
     switch (P / 128) {
     case 1: HM_LAUNCH(1); break; case 2: HM_LAUNCH(2); break; case 3: HM_LAUNCH(3); break; case 4: HM_LAUNCH(4); break;
     case 5: HM_LAUNCH(5); break; case 6: HM_LAUNCH(6); break; case 7: HM_LAUNCH(7); break; default: HM_LAUNCH(8); break;
@@ -171,6 +184,32 @@ int launch_hvp_multi(lrvb_ctx* c, i64 Q, const double* U_dev, i64 ldu, double* O
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(hvp_multi_reduce_kernel, dim3((unsigned)((P * 16 + 255) / 256)), dim3(256), 0, c->stream,
                        c->part_vec.p, grid, P, (int)Q, ldo, c->glm_off, Out_dev);
+    HIP_TRY(hipGetLastError());
+    return LRVB_OK;
+}
+
+// Tout[n - n0][q] = rowscale[n] * sum_p X[n][p] Zt[q][p]  for rows n0 <= n < n1 and q < Q <= 16 (Zt is Q x ldz row-major).
+// rowscale must be followed by at least 8 zeros past n1 - 1 when n1 == N (reserve_obs_vec provides 64).
+int launch_rows_times_matrix(lrvb_ctx* c, i64 n0, i64 n1, i64 Q, const double* Zt_dev, i64 ldz,
+                             const double* rowscale_dev, double* Tout_dev, i64 ldt)
+{
+    if (!hvp_multi_supported(c, Q)) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "fused multi-vector pass: n_cols %% 128 == 0, n_cols <= 1024, at most 16 vectors");
+    const int P = (int)c->P;
+    const i64 rows = n1 - n0;
+    if (rows <= 0) return LRVB_OK;
+    const i64 nchunks = (rows + HM_ROWS - 1) / HM_ROWS;
+    int grid = 256;
+    if (grid > nchunks) grid = (int)nchunks;
+    const size_t lds_bytes = (size_t)(2 * HM_ROWS * (P + 2) + 4 * 2 * 64) * sizeof(double);
+#define HM_LAUNCH_T(NB) do { \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&hvp_multi_kernel<NB, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+        hipLaunchKernelGGL((hvp_multi_kernel<NB, true>), dim3((unsigned)grid), dim3(256), lds_bytes, c->stream, \
+                           c->X.p + n0 * (i64)P, rows, rowscale_dev + n0, Zt_dev, ldz, (int)Q, (double*)nullptr, Tout_dev, ldt); } while (0)
+    switch (P / 128) {
+    case 1: HM_LAUNCH_T(1); break; case 2: HM_LAUNCH_T(2); break; case 3: HM_LAUNCH_T(3); break; case 4: HM_LAUNCH_T(4); break;
+    case 5: HM_LAUNCH_T(5); break; case 6: HM_LAUNCH_T(6); break; case 7: HM_LAUNCH_T(7); break; default: HM_LAUNCH_T(8); break;
+    }
+#undef HM_LAUNCH_T
     HIP_TRY(hipGetLastError());
     return LRVB_OK;
 }

@@ -1217,6 +1217,25 @@ static int obs_influence_impl(lrvb_ctx* c, const double* point, i64 n_in, bool i
         LRVB_TRY(ensure_dense_J(c, c->theta.p));
         LRVB_TRY(launch_gemm(c, false, false, c->P, Q, c->D, 1.0, c->Jdense.p + c->glm_off * c->D, c->D, c->rhs.p, Q, 0.0, c->Heta.p, Q));
     }
+    if (hvp_multi_supported(c, 1) && !c->force_generic_wsyrk && n1 > n0) {
+        // streamed: 8-row chunks of X through LDS, 16 moments at a time on the matrix cores (k_hvp_multi.hip)
+        const i64 rows = n1 - n0;
+        LRVB_TRY(reserve_obs_vec(c, c->zbuf));                                   // -l'_n with zero padding past N
+        HIP_TRY(hipMemcpyAsync(c->zbuf.p, c->lp.p, (size_t)c->N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        LRVB_TRY(launch_axpby(c, c->N, 0.0, c->zbuf.p, -1.0, c->zbuf.p));
+        LRVB_TRY(buf_reserve(c, c->vtmp3, (size_t)Q * (size_t)c->P));             // Z^T (Q x P)
+        {
+            dim3 grid(nb256(Q), (unsigned)c->P);
+            hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, c->stream, c->P, Q, c->Heta.p, c->vtmp3.p);
+            HIP_TRY(hipGetLastError());
+        }
+        LRVB_TRY(buf_reserve(c, c->work1, (size_t)rows * (size_t)Q));
+        for (i64 q0 = 0; q0 < Q; q0 += 16) {
+            const i64 qn = (Q - q0 < 16) ? Q - q0 : 16;
+            LRVB_TRY(launch_rows_times_matrix(c, n0, n1, qn, c->vtmp3.p + q0 * c->P, c->P, c->zbuf.p, c->work1.p + q0, Q));
+        }
+        return d2h(c, out, c->work1.p, (size_t)rows * (size_t)Q);
+    }
     const i64 chunk = 65536;
     for (i64 a = n0; a < n1; a += chunk) {
         const i64 b = (a + chunk < n1) ? a + chunk : n1;

@@ -107,6 +107,8 @@ int launch_glm_pass(lrvb_ctx* c, PassMode mode, const double* beta_dev, const do
                     bool store_obs);
 bool hvp_multi_supported(const lrvb_ctx* c, i64 Q);
 int  launch_hvp_multi(lrvb_ctx* c, i64 Q, const double* U_dev, i64 ldu, double* Out_dev, i64 ldo);
+int  launch_rows_times_matrix(lrvb_ctx* c, i64 n0, i64 n1, i64 Q, const double* Zt_dev, i64 ldz,
+                              const double* rowscale_dev, double* Tout_dev, i64 ldt);
 int launch_obs_grad(lrvb_ctx* c, i64 n0, i64 n1, double* G_dev, int mode, const double* scale_vec);
 
 // k_wsyrk.hip

@@ -21,7 +21,9 @@ def vb():
 
 
 @pytest.mark.parametrize('loss', [om.GAUSSIAN, om.LOGISTIC, om.POISSON])
-@pytest.mark.parametrize('N,P,Q', [(1, 3, 2), (37, 5, 5), (1000, 130, 7), (70001, 64, 16)])
+@pytest.mark.parametrize('N,P,Q', [(1, 3, 2), (37, 5, 5), (1000, 130, 7), (70001, 64, 16),
+                                   # n_cols % 128 == 0: the streamed kernel (8-row chunks through LDS)
+                                   (1003, 128, 5), (4099, 384, 33), (5, 256, 16)])
 def test_box_layout_matches_dense_formula(vb, loss, N, P, Q):
     rng = np.random.default_rng(N + P + loss)
     p1 = P // 3
