@@ -14,7 +14,8 @@
 // Wave w owns the column quarter [w P/4, (w+1) P/4): its slice of U stays in registers for the whole kernel
 // (the B operand of step A), and so do its 16-row tiles of R (the accumulators of step B); the four partial
 // T tiles meet in LDS once per chunk, and the sum comes back in exactly the register layout step B needs
-// as its B operand (D register r <-> row (lane >> 4) + 4 r).  P <= 1024, P % 128 == 0, Q <= 16.
+// as its B operand (D register r <-> row (lane >> 4) + 4 r).  Even P <= 1024 (columns are padded to whole
+// 128-column DMA instructions inside LDS; the padding meets zeros of U), Q <= 16.
 #include "lrvb_internal.h"
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -29,11 +30,11 @@ constexpr int HM_ROWS = 8;               // observations per chunk
 // the streamed weight-sensitivity product of lrvb_obs_influence.
 template <int NB, bool TONLY>            // NB = P / 128: column blocks of 32 per wave = NB
 __global__ __launch_bounds__(256, 1)
-void hvp_multi_kernel(const double* __restrict__ X, i64 N, const double* __restrict__ cw,
+void hvp_multi_kernel(const double* __restrict__ X, int Preal, i64 N, const double* __restrict__ cw,
                       const double* __restrict__ U, i64 ldu, int Q, double* __restrict__ Rpart,
                       double* __restrict__ Tout, i64 ldt)
 {
-    constexpr int P = NB * 128;
+    constexpr int P = NB * 128;           // columns rounded up to whole 128-column DMA instructions (Preal is even)
     constexpr int PW = P / 4;             // columns per wave
     constexpr int STRIDE = P + 2;         // doubles; (STRIDE / 2) odd -> rows land on distinct 16-byte bank groups
     constexpr int NT = PW / 16;           // 16-column tiles of R per wave
@@ -50,8 +51,10 @@ void hvp_multi_kernel(const double* __restrict__ X, i64 N, const double* __restr
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
-        for (int t = 0; t < 8; ++t)
-            uf[b][t] = (l15 < Q) ? U[(i64)l15 * ldu + pc0 + 32 * b + 8 * l4 + t] : 0.0;
+        for (int t = 0; t < 8; ++t) {
+            const int k = pc0 + 32 * b + 8 * l4 + t;
+            uf[b][t] = (l15 < Q && k < Preal) ? U[(i64)l15 * ldu + k] : 0.0;        // padding columns carry a zero vector
+        }
 
     d4 acc[NT];
 #pragma unroll
@@ -65,9 +68,12 @@ void hvp_multi_kernel(const double* __restrict__ X, i64 N, const double* __restr
         for (int rr = 0; rr < 2; ++rr) {
             const int row = 2 * wave + rr;
             i64 n = ch * HM_ROWS + row; if (n > N - 1) n = N - 1;       // rows past N carry weight zero
-            const double* rowp = X + n * (i64)P;
+            const double* rowp = X + n * (i64)Preal;
 #pragma unroll
-            for (int j = 0; j < NB; ++j) HM_GLDS16(rowp + 128 * j + 2 * lane, base + row * STRIDE + 128 * j);
+            for (int j = 0; j < NB; ++j) {
+                int col = 128 * j + 2 * lane; if (col > Preal - 2) col = Preal - 2;     // stay inside the row; the duplicates meet zeros of U
+                HM_GLDS16(rowp + col, base + row * STRIDE + 128 * j);
+            }
         }
     };
 
@@ -144,7 +150,7 @@ void hvp_multi_kernel(const double* __restrict__ X, i64 N, const double* __restr
 }
 
 // Out[q][off + p] = sum over workgroups of Rpart[g][p][q], fixed order (deterministic)
-__global__ void hvp_multi_reduce_kernel(const double* __restrict__ Rpart, int G, int P, int Q, i64 ldo, i64 off,
+__global__ void hvp_multi_reduce_kernel(const double* __restrict__ Rpart, int G, int P, int Ppad, int Q, i64 ldo, i64 off,
                                         double* __restrict__ Out)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;       // e = p * 16 + q
@@ -152,20 +158,21 @@ __global__ void hvp_multi_reduce_kernel(const double* __restrict__ Rpart, int G,
     const int p = e >> 4, q = e & 15;
     if (q >= Q) return;
     double s = 0.0;
-    for (int g = 0; g < G; ++g) s += Rpart[(i64)g * P * 16 + e];
+    for (int g = 0; g < G; ++g) s += Rpart[(i64)g * Ppad * 16 + e];
     Out[(i64)q * ldo + off + p] = s;
 }
 
 bool hvp_multi_supported(const lrvb_ctx* c, i64 Q) {
-    return Q >= 1 && Q <= 16 && c->P % 128 == 0 && c->P >= 128 && c->P <= 1024 && c->N >= 1 &&
+    return Q >= 1 && Q <= 16 && c->P % 2 == 0 && c->P >= 2 && c->P <= 1024 && c->N >= 1 &&
            ((((uintptr_t)c->X.p) & 15) == 0);
 }
 
 // Out (Q x ldo, row q) [off .. off + P) = X^T diag(cw) X U[q, off .. off + P);  U is Q x ldu row-major.
 int launch_hvp_multi(lrvb_ctx* c, i64 Q, const double* U_dev, i64 ldu, double* Out_dev, i64 ldo)
 {
-    if (!hvp_multi_supported(c, Q)) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "fused multi-vector pass: n_cols %% 128 == 0, n_cols <= 1024, at most 16 vectors");
-    const int P = (int)c->P;
+    if (!hvp_multi_supported(c, Q)) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "fused multi-vector pass: even n_cols <= 1024, 16-byte aligned rows, at most 16 vectors");
+    const int Preal = (int)c->P;
+    const int P = ((Preal + 127) / 128) * 128;
     const i64 nchunks = (c->N + HM_ROWS - 1) / HM_ROWS;
     int grid = 256;                                           // one workgroup per CU (64+ KiB of LDS each)
     if (grid > nchunks) grid = (int)nchunks;
@@ -175,15 +182,15 @@ int launch_hvp_multi(lrvb_ctx* c, i64 Q, const double* U_dev, i64 ldu, double* O
 #define HM_LAUNCH(NB) do { \
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&hvp_multi_kernel<NB, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
         hipLaunchKernelGGL((hvp_multi_kernel<NB, false>), dim3((unsigned)grid), dim3(256), lds_bytes, c->stream, \
-                           c->X.p, c->N, c->cw.p, Uoff, ldu, (int)Q, c->part_vec.p, (double*)nullptr, (i64)0); } while (0)
+                           c->X.p, Preal, c->N, c->cw.p, Uoff, ldu, (int)Q, c->part_vec.p, (double*)nullptr, (i64)0); } while (0)
     switch (P / 128) {
     case 1: HM_LAUNCH(1); break; case 2: HM_LAUNCH(2); break; case 3: HM_LAUNCH(3); break; case 4: HM_LAUNCH(4); break;
     case 5: HM_LAUNCH(5); break; case 6: HM_LAUNCH(6); break; case 7: HM_LAUNCH(7); break; default: HM_LAUNCH(8); break;
     }
 #undef HM_LAUNCH
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(hvp_multi_reduce_kernel, dim3((unsigned)((P * 16 + 255) / 256)), dim3(256), 0, c->stream,
-                       c->part_vec.p, grid, P, (int)Q, ldo, c->glm_off, Out_dev);
+    hipLaunchKernelGGL(hvp_multi_reduce_kernel, dim3((unsigned)((Preal * 16 + 255) / 256)), dim3(256), 0, c->stream,
+                       c->part_vec.p, grid, Preal, P, (int)Q, ldo, c->glm_off, Out_dev);
     HIP_TRY(hipGetLastError());
     return LRVB_OK;
 }
@@ -193,8 +200,9 @@ int launch_hvp_multi(lrvb_ctx* c, i64 Q, const double* U_dev, i64 ldu, double* O
 int launch_rows_times_matrix(lrvb_ctx* c, i64 n0, i64 n1, i64 Q, const double* Zt_dev, i64 ldz,
                              const double* rowscale_dev, double* Tout_dev, i64 ldt)
 {
-    if (!hvp_multi_supported(c, Q)) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "fused multi-vector pass: n_cols %% 128 == 0, n_cols <= 1024, at most 16 vectors");
-    const int P = (int)c->P;
+    if (!hvp_multi_supported(c, Q)) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "fused multi-vector pass: even n_cols <= 1024, 16-byte aligned rows, at most 16 vectors");
+    const int Preal = (int)c->P;
+    const int P = ((Preal + 127) / 128) * 128;
     const i64 rows = n1 - n0;
     if (rows <= 0) return LRVB_OK;
     const i64 nchunks = (rows + HM_ROWS - 1) / HM_ROWS;
@@ -204,7 +212,7 @@ int launch_rows_times_matrix(lrvb_ctx* c, i64 n0, i64 n1, i64 Q, const double* Z
 #define HM_LAUNCH_T(NB) do { \
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&hvp_multi_kernel<NB, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
         hipLaunchKernelGGL((hvp_multi_kernel<NB, true>), dim3((unsigned)grid), dim3(256), lds_bytes, c->stream, \
-                           c->X.p + n0 * (i64)P, rows, rowscale_dev + n0, Zt_dev, ldz, (int)Q, (double*)nullptr, Tout_dev, ldt); } while (0)
+                           c->X.p + n0 * (i64)Preal, Preal, rows, rowscale_dev + n0, Zt_dev, ldz, (int)Q, (double*)nullptr, Tout_dev, ldt); } while (0)
     switch (P / 128) {
     case 1: HM_LAUNCH_T(1); break; case 2: HM_LAUNCH_T(2); break; case 3: HM_LAUNCH_T(3); break; case 4: HM_LAUNCH_T(4); break;
     case 5: HM_LAUNCH_T(5); break; case 6: HM_LAUNCH_T(6); break; case 7: HM_LAUNCH_T(7); break; default: HM_LAUNCH_T(8); break;
