@@ -146,8 +146,9 @@ void potrf_inv_diag_kernel(double* __restrict__ A, i64 lda, int nb, double* __re
         __syncthreads();
         const double d = colbuf[j];
         if (!(d > 0.0) && bad == 0) bad = j + 1;
-        const double t = a[j] / d;               // L[i][j] / sqrt(d)
-        a[j] = a[j] / sqrt(d);                   // L[i][j]  (lane j: sqrt(d))
+        const double rs = rsqrt(d);              // one reciprocal square root instead of a division and a square root
+        a[j] = a[j] * rs;                        // L[i][j]  (lane j: sqrt(d))
+        const double t = a[j] * rs;              // L[i][j] / sqrt(d)
 #pragma unroll
         for (int k = j + 1; k < CH_NB; ++k) a[k] -= t * colbuf[k];      // A[i][k] -= L[i][j] L[k][j]
     }
