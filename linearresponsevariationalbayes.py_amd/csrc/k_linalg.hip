@@ -199,6 +199,20 @@ int launch_potrf_lower(lrvb_ctx* c, double* A, i64 n, i64 lda, int* info_dev) {
     return LRVB_OK;
 }
 
+// forward substitution only: B <- L^-1 B
+int launch_trsm_lower_forward(lrvb_ctx* c, const double* L, i64 n, i64 ldl, double* B, i64 nrhs, i64 ldb) {
+    for (i64 j0 = 0, jb = 0; j0 < n; j0 += CH_NB, ++jb) {
+        const int nb = (int)((n - j0 < CH_NB) ? (n - j0) : CH_NB);
+        const double* Wj = c->cholW.p + jb * CH_NB * CH_NB;
+        LRVB_TRY(launch_gemm(c, false, false, nb, nrhs, nb, 1.0, Wj, CH_NB, B + j0 * ldb, ldb, 0.0, B + j0 * ldb, ldb));
+        const i64 rows = n - j0 - nb;
+        if (rows > 0)
+            LRVB_TRY(launch_gemm(c, false, false, rows, nrhs, nb, -1.0, L + (j0 + nb) * ldl + j0, ldl,
+                                 B + j0 * ldb, ldb, 1.0, B + (j0 + nb) * ldb, ldb));
+    }
+    return LRVB_OK;
+}
+
 int launch_potrs_lower(lrvb_ctx* c, const double* L, i64 n, i64 ldl, double* B, i64 nrhs, i64 ldb) {
     // forward: L Y = B
     for (i64 j0 = 0, jb = 0; j0 < n; j0 += CH_NB, ++jb) {

@@ -932,7 +932,7 @@ extern "C" int lrvb_mixture_rows(lrvb_ctx* c, int32_t K, const double* theta_z, 
 // contraction weights (~66 TFLOP/s at 4096^3) when the operands are even-width and 16-byte aligned,
 // the generic 64 x 64 tile GEMM otherwise.
 static int gemm_tn(lrvb_ctx* c, i64 K, i64 PA, i64 PB, const double* A, const double* B, double* C) {
-    const bool fast = !(PA % 2) && !(PB % 2) && !(((uintptr_t)A) & 15) && !(((uintptr_t)B) & 15) && K >= 2048 && PA >= 128 && PB >= 128;
+    const bool fast = !(PA % 2) && !(PB % 2) && !(((uintptr_t)A) & 15) && !(((uintptr_t)B) & 15) && K >= 512 && PA >= 128 && PB >= 128;
     if (!fast) return launch_gemm(c, true, false, PA, PB, K, 1.0, A, PA, B, PB, 0.0, C, PB);
     if (c->ones_n != K) {                      // the kernel reads up to 32 weights past K: they must be zero
         LRVB_TRY(buf_reserve(c, c->ones, (size_t)(K + 64)));
@@ -1150,14 +1150,17 @@ extern "C" int lrvb_chol_solve(lrvb_ctx* c, const double* B, int64_t D, int64_t 
     LRVB_TRY(launch_potrs_lower(c, c->chol.p, D, D, c->rhs.p, nrhs, nrhs));
     return d2h(c, X_out, c->rhs.p, (size_t)D * (size_t)nrhs);
 }
+static int gemm_tn(lrvb_ctx* c, i64 K, i64 PA, i64 PB, const double* A, const double* B, double* C);
 static int lrvb_cov_dev_impl(lrvb_ctx* c, const double* M_dev, i64 Q, i64 D, double* cov_dev) {
     if (!c->chol_valid || c->chol_n != D) LRVB_FAIL(LRVB_ERR_STATE, "no Cholesky factor of size %lld: call lrvb_chol_factor first", (long long)D);
     LRVB_TRY(buf_reserve(c, c->rhs, (size_t)D * (size_t)Q));
     dim3 grid(nb256(D), (unsigned)Q);
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, c->stream, Q, D, M_dev, c->rhs.p);   // rhs = M^T (D x Q)
     HIP_TRY(hipGetLastError());
-    LRVB_TRY(launch_potrs_lower(c, c->chol.p, D, D, c->rhs.p, Q, Q));
-    return launch_gemm(c, false, false, Q, Q, D, 1.0, M_dev, D, c->rhs.p, Q, 0.0, cov_dev, Q);
+    // M H^-1 M^T = Y^T Y with Y = L^-1 M^T: one forward substitution and a TN product -- half the
+    // triangular work of solve-then-multiply, and the result is symmetric by construction
+    LRVB_TRY(launch_trsm_lower_forward(c, c->chol.p, D, D, c->rhs.p, Q, Q));
+    return gemm_tn(c, D, Q, Q, c->rhs.p, c->rhs.p, cov_dev);
 }
 extern "C" int lrvb_lrvb_cov_dev(lrvb_ctx* c, const double* M_dev, int64_t Q, int64_t D, double* cov_dev) {
     LRVB_TRY(ctx_bind(c));

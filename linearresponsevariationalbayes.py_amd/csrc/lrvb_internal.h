@@ -133,6 +133,7 @@ int launch_gemm_lower(lrvb_ctx* c, i64 M, i64 K, double alpha, const double* A, 
                       double beta, double* C, i64 ldc);
 int launch_potrf_lower(lrvb_ctx* c, double* A, i64 n, i64 lda, int* info_dev);
 int launch_potrs_lower(lrvb_ctx* c, const double* L, i64 n, i64 ldl, double* B, i64 nrhs, i64 ldb);
+int launch_trsm_lower_forward(lrvb_ctx* c, const double* L, i64 n, i64 ldl, double* B, i64 nrhs, i64 ldb);
 int launch_dot(lrvb_ctx* c, const double* a, const double* b, i64 n, double* out_dev);
 int launch_axpby(lrvb_ctx* c, i64 n, double alpha, const double* x, double beta, double* y);
 int launch_gemv(lrvb_ctx* c, bool trans, i64 M, i64 Nn, double alpha, const double* A, i64 lda,
