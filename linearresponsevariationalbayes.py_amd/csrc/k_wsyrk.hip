@@ -45,7 +45,10 @@ int wsyrk_auto_splits(const lrvb_ctx* c) {
     // keep >= 256 observations per split
     i64 s = (4608 + T / 2) / T;
     s = ((s + 7) / 8) * 8;
-    i64 max_by_rows = c->N / 256;
+    // every split writes a full set of partial tiles (128 KiB each): keep >= ~2000 observations per split so that
+    // the partial traffic stays small beside the staged rows (a 125k-row shard of the 8-GPU run: 64 splits, 2.40 ms
+    // per build against 2.48 ms with 128)
+    i64 max_by_rows = c->N / 1900;
     max_by_rows = (max_by_rows / 8) * 8;
     if (s > max_by_rows) s = max_by_rows;
     if (s > 128) s = 128;
