@@ -77,11 +77,15 @@ void glm_pass_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
     // Branch-free raw loads from clamped addresses (rows past N re-read row N-1 and get a zero
     // coefficient; columns past P meet zero entries of beta / u and are never written back), so
     // every load of a stage is in flight before anything waits.
-    auto load_stage = [&](double (&x)[R][NIT][2], i64 base) {
+    // the per-row scalars (y, w or the cached curvature) travel with the stage, so that their latency
+    // is hidden behind the previous stage like that of the row itself
+    auto load_stage = [&](double (&x)[R][NIT][2], double (&sc)[R][2], i64 base) {
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
             i64 n = base + rr; if (n > N - 1) n = N - 1;
             const double* rowp = X + n * ldx;
+            if (MODE == PASS_HVP_C) { sc[rr][0] = cw_io[n]; sc[rr][1] = 0.0; }
+            else { sc[rr][0] = y[n]; sc[rr][1] = w[n]; }
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 if (vec_ok) {
@@ -94,7 +98,7 @@ void glm_pass_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
             }
         }
     };
-    auto consume = [&](double (&x)[R][NIT][2], i64 base) {
+    auto consume = [&](double (&x)[R][NIT][2], double (&sc)[R][2], i64 base) {
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
             const i64 n = base + rr;
@@ -110,11 +114,11 @@ void glm_pass_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
             if (MODE != PASS_GRAD)  tt = wave_sum(tt);
             double coef;
             if (MODE == PASS_HVP_C) {
-                coef = cw_io[ne] * tt;
+                coef = sc[rr][0] * tt;
             } else {
                 double l0, l1, l2;
-                loss_eval(loss, lik_info, y[ne], z, l0, l1, l2);
-                const double wn = w[ne];
+                loss_eval(loss, lik_info, sc[rr][0], z, l0, l1, l2);
+                const double wn = sc[rr][1];
                 if (MODE == PASS_GRAD) {
                     coef = wn * l1;
                     if (live) val += wn * l0;
@@ -137,16 +141,16 @@ void glm_pass_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
     const i64 step = (i64)gridDim.x * 4 * R;
     i64 base = ((i64)blockIdx.x * 4 + wave) * R;
     if (base < N) {
-        double xa[R][NIT][2], xb[R][NIT][2];
-        load_stage(xa, base);
+        double xa[R][NIT][2], xb[R][NIT][2], sa[R][2], sb[R][2];
+        load_stage(xa, sa, base);
         for (;;) {
             i64 nxt = base + step;
-            if (nxt < N) load_stage(xb, nxt);
-            consume(xa, base);
+            if (nxt < N) load_stage(xb, sb, nxt);
+            consume(xa, sa, base);
             if (nxt >= N) break;
             base = nxt; nxt = base + step;
-            if (nxt < N) load_stage(xa, nxt);
-            consume(xb, base);
+            if (nxt < N) load_stage(xa, sa, nxt);
+            consume(xb, sb, base);
             if (nxt >= N) break;
             base = nxt;
         }
