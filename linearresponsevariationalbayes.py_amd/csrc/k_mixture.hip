@@ -43,15 +43,27 @@ struct MixRow {
     bool cat;
 };
 
+// the three global inputs of a row, loaded one row ahead of their use
+struct MixIn { double wn, f, x; };
 template <int K>
-__device__ __forceinline__ MixRow mixture_row_prelude(const double* __restrict__ theta_z, const double* __restrict__ X,
-                                                      int V, const double* __restrict__ w, const double* lam_s,
-                                                      i64 n, int lane)
+__device__ __forceinline__ MixIn mixture_row_load(const double* __restrict__ theta_z, const double* __restrict__ X,
+                                                  int V, const double* __restrict__ w, i64 n, int lane)
+{
+    constexpr int KM = K - 1;
+    MixIn in;
+    in.wn = w[n];
+    in.f = (lane < KM) ? theta_z[n * KM + lane] : 0.0;
+    in.x = (lane >= 1 && lane <= V) ? X[n * V + lane - 1] : 0.0;
+    return in;
+}
+
+template <int K>
+__device__ __forceinline__ MixRow mixture_row_prelude(const MixIn& in, int V, const double* lam_s, int lane)
 {
     constexpr int KM = K - 1;
     MixRow r;
-    r.wn = w[n];
-    const double f = (lane < KM) ? theta_z[n * KM + lane] : 0.0;
+    r.wn = in.wn;
+    const double f = in.f;
     double logit = __shfl_up(f, 1, 64);
     if (lane == 0) logit = 0.0;
     r.cat = lane < K;
@@ -60,7 +72,7 @@ __device__ __forceinline__ MixRow mixture_row_prelude(const double* __restrict__
     const double den = mx_wave_sum(ex);
     r.p = ex / den;
     r.logp = r.cat ? (logit - mxl - log(den)) : 0.0;
-    r.xt = (lane == 0) ? 1.0 : ((lane <= V) ? X[n * V + lane - 1] : 0.0);
+    r.xt = (lane == 0) ? 1.0 : in.x;
     double s = 0.0;
     for (int j = 0; j <= V; ++j) s += mx_bcast(r.xt, j) * (r.cat ? lam_s[j * K + lane] : 0.0);
     r.s = s;
@@ -101,8 +113,13 @@ void mixture_rows_kernel(const double* __restrict__ theta_z, const double* __res
 
     double v_lin = 0.0, v_ent = 0.0;        // -w sum z s  and  w sum z log z of this wave's rows
     int flag = 0;
-    for (i64 n = (i64)blockIdx.x * 4 + wave; n < N; n += (i64)gridDim.x * 4) {
-        const MixRow r = mixture_row_prelude<K>(theta_z, X, V, w, lam_s, n, lane);
+    const i64 nstep = (i64)gridDim.x * 4;
+    i64 n = (i64)blockIdx.x * 4 + wave;
+    MixIn nxt_in = mixture_row_load<K>(theta_z, X, V, w, n < N ? n : N - 1, lane);
+    for (; n < N; n += nstep) {
+        const MixIn in = nxt_in;
+        nxt_in = mixture_row_load<K>(theta_z, X, V, w, (n + nstep < N) ? n + nstep : N - 1, lane);   // next row in flight
+        const MixRow r = mixture_row_prelude<K>(in, V, lam_s, lane);
         const double wn = r.wn, ps = r.ps;
         const bool cat = r.cat;
         const int m = r.m;
@@ -194,7 +211,7 @@ void mixture_rows_dense_kernel(const double* __restrict__ theta_z, const double*
     int flag = 0;
     for (int q = blockIdx.x * 4 + wave; q < count; q += gridDim.x * 4) {
         const i64 n = todo[q];
-        const MixRow r = mixture_row_prelude<K>(theta_z, X, V, w, lam_s, n, lane);
+        const MixRow r = mixture_row_prelude<K>(mixture_row_load<K>(theta_z, X, V, w, n, lane), V, lam_s, lane);
         const double wn = r.wn, ps = r.ps, gdotp = r.gdotp;
         const bool cat = r.cat;
         const int m = r.m;
