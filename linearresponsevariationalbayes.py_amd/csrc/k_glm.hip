@@ -248,10 +248,125 @@ static int launch_pass_nit(lrvb_ctx* c, PassMode mode, const double* beta, const
     return LRVB_OK;
 }
 
+
+// ---- wide designs (n_cols > PASS_MAX_COLS): the row no longer fits in the registers of one wavefront ----
+// Two passes over X instead of one: (1) one wavefront per row streams the row in 128-column chunks and
+// reduces the dot product(s), evaluates the loss terms and leaves the rank-one coefficient of the row in
+// coef[n]; (2) one workgroup per (row block, 128-column tile) accumulates sum_n coef_n x_n over its rows.
+// Same outputs, same fixed-order reductions as the fused kernel; twice its traffic.
+constexpr int WIDE_ROWS = 2048;          // rows per block of the accumulation pass
+
+template <int MODE>
+__global__ __launch_bounds__(256)
+void glm_wide_rows_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
+                          const double* __restrict__ y, const double* __restrict__ w,
+                          const double* __restrict__ beta, const double* __restrict__ u,
+                          int loss, double lik_info, double* __restrict__ lp_out, double* __restrict__ cw_io,
+                          double* __restrict__ coef_out, double* __restrict__ part_val, int store_obs)
+{
+    __shared__ double redv[4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    double val = 0.0;
+    for (i64 n = (i64)blockIdx.x * 4 + wave; n < N; n += (i64)gridDim.x * 4) {
+        const double* rowp = X + n * ldx;
+        double z = 0.0, tt = 0.0;
+        for (int c0 = 0; c0 < P; c0 += 128) {
+            const int col = c0 + 2 * lane;
+            const double x0 = (col < P) ? rowp[col] : 0.0, x1 = (col + 1 < P) ? rowp[col + 1] : 0.0;
+            if (MODE != PASS_HVP_C) z += x0 * ((col < P) ? beta[col] : 0.0) + x1 * ((col + 1 < P) ? beta[col + 1] : 0.0);
+            if (MODE != PASS_GRAD)  tt += x0 * ((col < P) ? u[col] : 0.0) + x1 * ((col + 1 < P) ? u[col + 1] : 0.0);
+        }
+        if (MODE != PASS_HVP_C) z = wave_sum(z);
+        if (MODE != PASS_GRAD)  tt = wave_sum(tt);
+        double coef;
+        if (MODE == PASS_HVP_C) {
+            coef = cw_io[n] * tt;
+        } else {
+            double l0, l1, l2;
+            loss_eval(loss, lik_info, y[n], z, l0, l1, l2);
+            const double wn = w[n];
+            if (MODE == PASS_GRAD) {
+                coef = wn * l1;
+                val += wn * l0;
+                if (store_obs && lane == 0) { lp_out[n] = l1; cw_io[n] = wn * l2; }
+            } else {
+                coef = wn * l2 * tt;
+            }
+        }
+        if (lane == 0) coef_out[n] = coef;
+    }
+    if (lane == 0) redv[wave] = val;
+    __syncthreads();
+    if (tid == 0 && MODE == PASS_GRAD) part_val[blockIdx.x] = ((redv[0] + redv[1]) + redv[2]) + redv[3];
+}
+
+// part_vec[row block][P] (+)= sum over the block's rows of coef_n x_n, one 128-column tile per workgroup
+__global__ __launch_bounds__(256)
+void glm_wide_accum_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P, const double* __restrict__ coef,
+                           double* __restrict__ part_vec)
+{
+    __shared__ double red[3][128];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int col = blockIdx.x * 128 + 2 * lane;
+    const i64 r0 = (i64)blockIdx.y * WIDE_ROWS;
+    i64 r1 = r0 + WIDE_ROWS; if (r1 > N) r1 = N;
+    double a0 = 0.0, a1 = 0.0;
+    for (i64 n = r0 + wave; n < r1; n += 4) {
+        const double cf = coef[n];
+        const double* rowp = X + n * ldx;
+        a0 += cf * ((col < P) ? rowp[col] : 0.0);
+        a1 += cf * ((col + 1 < P) ? rowp[col + 1] : 0.0);
+    }
+    if (wave > 0) { red[wave - 1][2 * lane] = a0; red[wave - 1][2 * lane + 1] = a1; }
+    __syncthreads();
+    if (wave == 0) {
+        double* dst = part_vec + (i64)blockIdx.y * P;
+        const double s0 = ((a0 + red[0][2 * lane]) + red[1][2 * lane]) + red[2][2 * lane];
+        const double s1 = ((a1 + red[0][2 * lane + 1]) + red[1][2 * lane + 1]) + red[2][2 * lane + 1];
+        if (col < P) dst[col] = s0;
+        if (col + 1 < P) dst[col + 1] = s1;
+    }
+}
+
+static int launch_glm_pass_wide(lrvb_ctx* c, PassMode mode, const double* beta, const double* u,
+                                double* out_vec_P, double* value_out_dev, bool store_obs) {
+    i64 grid1 = (c->N + 3) / 4;
+    if (grid1 > 4096) grid1 = 4096;
+    const i64 nblk = (c->N + WIDE_ROWS - 1) / WIDE_ROWS;
+    LRVB_TRY(buf_reserve(c, c->part_vec, (size_t)(nblk * c->P)));
+    LRVB_TRY(buf_reserve(c, c->part_val, (size_t)grid1));
+    LRVB_TRY(buf_reserve(c, c->lp, (size_t)c->N));
+    LRVB_TRY(reserve_obs_vec(c, c->cw));
+    LRVB_TRY(reserve_obs_vec(c, c->zbuf));                  // coef
+    if (c->prof_on && mode == PASS_GRAD) LRVB_TRY(prof_mark(c, PROF_PASS));
+    const int so = store_obs ? 1 : 0;
+    dim3 g1((unsigned)grid1), b(256);
+#define WIDE_ROWS_LAUNCH(M) hipLaunchKernelGGL((glm_wide_rows_kernel<M>), g1, b, 0, c->stream, c->X.p, c->P, c->N, (int)c->P, \
+        c->y.p, c->w.p, beta, u, c->loss, c->lik_info, c->lp.p, c->cw.p, c->zbuf.p, c->part_val.p, so)
+    if (mode == PASS_GRAD) WIDE_ROWS_LAUNCH(PASS_GRAD); else if (mode == PASS_HVP) WIDE_ROWS_LAUNCH(PASS_HVP); else WIDE_ROWS_LAUNCH(PASS_HVP_C);
+#undef WIDE_ROWS_LAUNCH
+    HIP_TRY(hipGetLastError());
+    dim3 g2((unsigned)((c->P + 127) / 128), (unsigned)nblk);
+    hipLaunchKernelGGL(glm_wide_accum_kernel, g2, b, 0, c->stream, c->X.p, c->P, c->N, (int)c->P, c->zbuf.p, c->part_vec.p);
+    HIP_TRY(hipGetLastError());
+    if (c->prof_on && mode == PASS_GRAD) LRVB_TRY(prof_mark(c, PROF_PASS));
+    // the value partials are per block of the FIRST kernel, the vector partials per row block of the second:
+    // two calls of the fixed-order reduction
+    hipLaunchKernelGGL(pass_reduce_kernel, dim3((unsigned)((c->P + 63) / 64)), dim3(512), 0, c->stream,
+                       c->part_vec.p, c->part_val.p, (int)nblk, (int)c->P, out_vec_P, (double*)nullptr);
+    HIP_TRY(hipGetLastError());
+    if (mode == PASS_GRAD && value_out_dev) {
+        hipLaunchKernelGGL(pass_reduce_kernel, dim3(1), dim3(512), 0, c->stream,
+                           c->part_vec.p, c->part_val.p, (int)grid1, 0, out_vec_P, value_out_dev);
+        HIP_TRY(hipGetLastError());
+    }
+    if (c->prof_on && mode == PASS_GRAD) c->prof.pass_bytes = 2.0 * 8.0 * (double)c->N * (double)(c->P + 3);
+    return LRVB_OK;
+}
+
 int launch_glm_pass(lrvb_ctx* c, PassMode mode, const double* beta_dev, const double* u_dev,
                     double* out_vec_P, double* value_out_dev, bool store_obs) {
-    if (c->P > PASS_MAX_COLS)
-        LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "fused pass supports n_cols <= %d (got %lld)", PASS_MAX_COLS, (long long)c->P);
+    if (c->P > PASS_MAX_COLS) return launch_glm_pass_wide(c, mode, beta_dev, u_dev, out_vec_P, value_out_dev, store_obs);
     // 8 blocks per CU worth of row pairs, capped by the work available
     const i64 rows_per_stage = (mode == PASS_HVP) ? 1 : 2;
     i64 pairs = (c->N + rows_per_stage - 1) / rows_per_stage;

@@ -374,13 +374,28 @@ def test_edge_shapes(vb, N, P):
     assert rel_err(obj.fun_free_hessian(theta), model.hessian(theta)) < TOL
 
 
-def test_wide_pass_unsupported_is_loud(vb):
-    """n_cols > 1024 is outside the register-resident fused pass: the C ABI says so instead of
-    computing something else."""
-    rng = np.random.default_rng(0)
-    P = 1030
-    par, lay = make_par(vb, [('box', 'b', P, -np.inf, np.inf)])
-    x, y, w = glm_data(rng, 8, P, om.GAUSSIAN)
-    fun = vb.GLMObjective(par, x, y)
-    with pytest.raises(NotImplementedError):
-        vb.Objective(par, fun).fun_free_grad(np.zeros(P))
+@pytest.mark.parametrize('loss,N,P', [(om.GAUSSIAN, 300, 1030), (om.POISSON, 2051, 1153), (om.LOGISTIC, 1000, 2048)])
+def test_wide_designs(vb, loss, N, P):
+    """n_cols > 1024: the row no longer fits in one wavefront's registers; the two-pass route
+    (row dots, then column accumulation) must give the same value, gradient, Hessian, HVP and CG."""
+    rng = np.random.default_rng(P)
+    p1 = P // 2
+    par, lay = make_par(vb, [('box', 'u', p1, -np.inf, np.inf), ('box', 'pos', P - p1, 0.0, np.inf)])
+    x, y, w = glm_data(rng, N, P, loss)
+    fun = vb.DeviceObjective(par, x=x, y=y, loss=LOSS_NAME[loss], lik_info=1.3, quad_A=np.full(P, 0.7), weights=w)
+    model = om.DeclaredModel(lay, loss=loss, x=x, y=y, w=w, lik_info=1.3, quad_A=np.full(P, 0.7))
+    obj = vb.Objective(par, fun)
+    theta = rng.normal(size=P) * 0.1
+    v = rng.normal(size=P)
+    assert abs(obj.fun_free(theta) - model.value(theta)) <= 1e-12 * max(1.0, abs(model.value(theta)))
+    assert rel_err(obj.fun_free_grad(theta), model.grad(theta)) < TOL
+    Hw = model.hessian(theta)
+    assert rel_err(obj.fun_free_hessian(theta), Hw) < TOL
+    assert rel_err(obj.fun_free_hvp(theta, v), Hw @ v) < TOL
+    eta = lay.constrain(theta)
+    assert rel_err(obj.fun_vector_hvp(eta, v), model.hessian_vec(eta) @ v) < TOL
+    assert rel_err(fun.ctx.obs_grad(theta, 0, min(N, 50)), model.obs_grad(theta, 0, min(N, 50))) < TOL
+    if np.min(np.linalg.eigvalsh(Hw)) > 0:
+        B = rng.normal(size=(3, P))
+        X, info, _ = fun.ctx.cg_solve_multi(theta, B)
+        assert np.all(info == 0) and rel_err(X, np.linalg.solve(Hw, B.T).T) < 1e-6
