@@ -1,9 +1,23 @@
 #!/bin/bash
 # Builds liblrvb_hip.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
+# Translation units are compiled in parallel (the per-row mixture kernels are instantiated for
+# K = 2 .. 32, split over four units), then linked into one shared library.
 set -euo pipefail
 cd "$(dirname "$0")"
 OUT=../liblrvb_hip.so
-SRCS="lrvb_api.hip k_wsyrk.hip k_glm.hip k_pack.hip k_linalg.hip k_finish.hip k_mixture.hip k_hvp_multi.hip"
-exec hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared \
-     -Wall -Wno-unused-function -Wno-unused-variable \
-     ${LRVB_HIPCC_EXTRA:-} $SRCS -o "$OUT"
+SRCS="lrvb_api.hip k_wsyrk.hip k_glm.hip k_pack.hip k_linalg.hip k_finish.hip k_mixture.hip k_hvp_multi.hip \
+      k_mixture_inst0.hip k_mixture_inst1.hip k_mixture_inst2.hip k_mixture_inst3.hip"
+OBJDIR=.obj
+mkdir -p "$OBJDIR"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable ${LRVB_HIPCC_EXTRA:-}"
+pids=()
+for f in $SRCS; do
+    hipcc $FLAGS -c "$f" -o "$OBJDIR/${f%.hip}.o" &
+    pids+=($!)
+done
+fail=0
+for p in "${pids[@]}"; do wait "$p" || fail=1; done
+[ "$fail" -eq 0 ] || { echo "compilation failed" >&2; exit 1; }
+OBJS=""
+for f in $SRCS; do OBJS="$OBJS $OBJDIR/${f%.hip}.o"; done
+exec hipcc --offload-arch=gfx950 -fPIC -shared $OBJS -o "$OUT"

@@ -1,0 +1,28 @@
+// k_mixture_inst1.hip -- instantiations of the per-row mixture kernels for K = 13 .. 20
+// (split over four translation units so that they compile in parallel).
+#include "k_mixture_rows.h"
+
+int mixture_rows_launch_1(lrvb_ctx* c, int K, unsigned grid, unsigned dgrid, const double* theta_z_dev, int V,
+                             const double* lam_dev, double* Amat_dev, i64 lda, double* U_dev, double* gfree_dev,
+                             int* bad_dev, int* todo, int* todo_count)
+{
+#define MX_LAUNCH(KK) do { \
+        hipLaunchKernelGGL(mixture_rows_kernel<KK>, dim3(grid), dim3(256), 0, c->stream, \
+            theta_z_dev, c->X.p, V, c->w.p, lam_dev, c->N, Amat_dev, lda, U_dev, gfree_dev, c->part_val.p, bad_dev, \
+            c->force_dense_rows, todo, todo_count); \
+        hipLaunchKernelGGL(mixture_rows_dense_kernel<KK>, dim3(dgrid), dim3(256), 0, c->stream, \
+            theta_z_dev, c->X.p, V, c->w.p, lam_dev, Amat_dev, lda, bad_dev, todo, todo_count); } while (0)
+    switch (K) {
+    case 13: MX_LAUNCH(13); break;
+    case 14: MX_LAUNCH(14); break;
+    case 15: MX_LAUNCH(15); break;
+    case 16: MX_LAUNCH(16); break;
+    case 17: MX_LAUNCH(17); break;
+    case 18: MX_LAUNCH(18); break;
+    case 19: MX_LAUNCH(19); break;
+    case 20: MX_LAUNCH(20); break;
+    default: return 0;
+    }
+#undef MX_LAUNCH
+    return 1;
+}

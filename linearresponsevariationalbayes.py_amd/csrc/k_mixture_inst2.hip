@@ -1,0 +1,27 @@
+// k_mixture_inst2.hip -- instantiations of the per-row mixture kernels for K = 21 .. 27
+// (split over four translation units so that they compile in parallel).
+#include "k_mixture_rows.h"
+
+int mixture_rows_launch_2(lrvb_ctx* c, int K, unsigned grid, unsigned dgrid, const double* theta_z_dev, int V,
+                             const double* lam_dev, double* Amat_dev, i64 lda, double* U_dev, double* gfree_dev,
+                             int* bad_dev, int* todo, int* todo_count)
+{
+#define MX_LAUNCH(KK) do { \
+        hipLaunchKernelGGL(mixture_rows_kernel<KK>, dim3(grid), dim3(256), 0, c->stream, \
+            theta_z_dev, c->X.p, V, c->w.p, lam_dev, c->N, Amat_dev, lda, U_dev, gfree_dev, c->part_val.p, bad_dev, \
+            c->force_dense_rows, todo, todo_count); \
+        hipLaunchKernelGGL(mixture_rows_dense_kernel<KK>, dim3(dgrid), dim3(256), 0, c->stream, \
+            theta_z_dev, c->X.p, V, c->w.p, lam_dev, Amat_dev, lda, bad_dev, todo, todo_count); } while (0)
+    switch (K) {
+    case 21: MX_LAUNCH(21); break;
+    case 22: MX_LAUNCH(22); break;
+    case 23: MX_LAUNCH(23); break;
+    case 24: MX_LAUNCH(24); break;
+    case 25: MX_LAUNCH(25); break;
+    case 26: MX_LAUNCH(26); break;
+    case 27: MX_LAUNCH(27); break;
+    default: return 0;
+    }
+#undef MX_LAUNCH
+    return 1;
+}

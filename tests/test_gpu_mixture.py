@@ -24,8 +24,8 @@ def vb():
     return lrvb_amd
 
 
-@pytest.mark.parametrize('N,V,K', [(1, 2, 2), (37, 3, 2), (50, 4, 3), (61, 5, 4), (40, 7, 5), (45, 9, 8),
-                                   (130, 12, 16), (150, 31, 32)])
+@pytest.mark.parametrize('N,V,K', [(1, 2, 2), (37, 3, 2), (50, 4, 3), (61, 5, 4), (40, 7, 5), (33, 6, 6), (45, 9, 8),
+                                   (38, 8, 11), (130, 12, 16), (64, 20, 23), (150, 31, 32)])
 def test_rows_match_oracle(vb, N, V, K):
     x, w, theta = problem(N, V, K, seed=100 + K)
     par = make_par(N, V, K)
@@ -112,9 +112,11 @@ def test_indefinite_local_block_is_reported(vb):
 
 
 def test_unsupported_shapes_fail_loudly(vb):
-    N, V, K = 10, 3, 6                                  # K = 6 is not instantiated
-    x, w, theta = problem(N, V, K, seed=1)
+    N, V, K = 10, 3, 33                                 # one wavefront holds at most 32 categories (and V + 1 <= 32)
+    rng = np.random.default_rng(1)
+    x = rng.poisson(2.0, size=(N, V)).astype(np.float64)
     fun = vb.MixtureObjective(make_par(N, V, K), x)
+    theta = np.concatenate([np.ones(K + V * K), rng.normal(size=N * (K - 1))])
     with pytest.raises(NotImplementedError):
         fun.value(theta)
 
