@@ -230,7 +230,7 @@ def main():
                    'parallelism': 'observation shards x{} + 1 sum all-reduce per build'.format(world)},
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP64_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': achieved / PEAK_FP64_MFMA_TFLOPS, 'traffic': traffic,
-                     'kernel': 'wsyrk_kernel (v_mfma_f64_16x16x4_f64)', 'kernel_ms': ws_ms,
+                     'kernel': 'wsyrk_glds_kernel (v_mfma_f64_16x16x4_f64)', 'kernel_ms': ws_ms,
                      'flops_per_launch': ws_flops,
                      'pass_kernel_ms': prof['pass_ms'] / max(prof['pass_calls'], 1),
                      'pass_kernel_GBs': (8.0 * n_local * (D + 3)) / (prof['pass_ms'] / max(prof['pass_calls'], 1) * 1e-3) / 1e9
