@@ -46,11 +46,10 @@ struct MixRow {
 
 // the three global inputs of a row, loaded one row ahead of their use
 struct MixIn { double wn, f, x; };
-template <int K>
-__device__ __forceinline__ MixIn mixture_row_load(const double* __restrict__ theta_z, const double* __restrict__ X,
+__device__ __forceinline__ MixIn mixture_row_load(int K, const double* __restrict__ theta_z, const double* __restrict__ X,
                                                   int V, const double* __restrict__ w, i64 n, int lane)
 {
-    constexpr int KM = K - 1;
+    const int KM = K - 1;
     MixIn in;
     in.wn = w[n];
     in.f = (lane < KM) ? theta_z[n * KM + lane] : 0.0;
@@ -58,10 +57,9 @@ __device__ __forceinline__ MixIn mixture_row_load(const double* __restrict__ the
     return in;
 }
 
-template <int K>
-__device__ __forceinline__ MixRow mixture_row_prelude(const MixIn& in, int V, const double* lam_s, int lane)
+__device__ __forceinline__ MixRow mixture_row_prelude(int K, const MixIn& in, int V, const double* lam_s, int lane)
 {
-    constexpr int KM = K - 1;
+    const int KM = K - 1;
     MixRow r;
     r.wn = in.wn;
     const double f = in.f;
@@ -116,11 +114,11 @@ void mixture_rows_kernel(const double* __restrict__ theta_z, const double* __res
     int flag = 0;
     const i64 nstep = (i64)gridDim.x * 4;
     i64 n = (i64)blockIdx.x * 4 + wave;
-    MixIn nxt_in = mixture_row_load<K>(theta_z, X, V, w, n < N ? n : N - 1, lane);
+    MixIn nxt_in = mixture_row_load(K, theta_z, X, V, w, n < N ? n : N - 1, lane);
     for (; n < N; n += nstep) {
         const MixIn in = nxt_in;
-        nxt_in = mixture_row_load<K>(theta_z, X, V, w, (n + nstep < N) ? n + nstep : N - 1, lane);   // next row in flight
-        const MixRow r = mixture_row_prelude<K>(in, V, lam_s, lane);
+        nxt_in = mixture_row_load(K, theta_z, X, V, w, (n + nstep < N) ? n + nstep : N - 1, lane);   // next row in flight
+        const MixRow r = mixture_row_prelude(K, in, V, lam_s, lane);
         const double wn = r.wn, ps = r.ps;
         const bool cat = r.cat;
         const int m = r.m;
@@ -195,14 +193,15 @@ void mixture_rows_kernel(const double* __restrict__ theta_z, const double* __res
 // Pass 2 (rows listed in `todo` only): the dense route.  M = L L^T in registers with v_readlane
 // broadcasts (as the 64 x 64 Cholesky block of k_linalg.hip), Y = L^-1 (J D^-1)^T (lane k <-> column k),
 // A_n = Y^T Y.
-template <int K>
+template <int KT>                        // size class: K <= KT; rows/columns past K - 1 are identity padding
 __global__ __launch_bounds__(256)
-void mixture_rows_dense_kernel(const double* __restrict__ theta_z, const double* __restrict__ X, int V,
+void mixture_rows_dense_kernel(int K, const double* __restrict__ theta_z, const double* __restrict__ X, int V,
                                const double* __restrict__ w, const double* __restrict__ Lam,
                                double* __restrict__ Amat, i64 lda, int* __restrict__ bad,
                                const int* __restrict__ todo, const int* __restrict__ todo_count)
 {
-    constexpr int KM = K - 1;
+    constexpr int KMT = KT - 1;
+    const int KM = K - 1;
     __shared__ double lam_s[32 * 32];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -212,34 +211,34 @@ void mixture_rows_dense_kernel(const double* __restrict__ theta_z, const double*
     int flag = 0;
     for (int q = blockIdx.x * 4 + wave; q < count; q += gridDim.x * 4) {
         const i64 n = todo[q];
-        const MixRow r = mixture_row_prelude<K>(mixture_row_load<K>(theta_z, X, V, w, n, lane), V, lam_s, lane);
+        const MixRow r = mixture_row_prelude(K, mixture_row_load(K, theta_z, X, V, w, n, lane), V, lam_s, lane);
         const double wn = r.wn, ps = r.ps, gdotp = r.gdotp;
         const bool cat = r.cat;
         const int m = r.m;
         const double p1 = __shfl_down(ps, 1, 64), g1 = __shfl_down(r.gs, 1, 64);
         const double r1 = sqrt(p1);
-        double a[KM];                                   // lane i <-> row i (zero rows past K-1, never read)
+        double a[KMT];                                  // lane i <-> row i
 #pragma unroll
-        for (int j = 0; j < KM; ++j) {
+        for (int j = 0; j < KMT; ++j) {
             const double rj = mx_bcast(r1, j), gj = mx_bcast(g1, j);
             double h = r1 * rj * (2.0 * gdotp - wn - g1 - gj);
             if (j == lane) h += wn + g1 - gdotp;
-            a[j] = (lane < KM) ? h : 0.0;
+            a[j] = (lane < KM && j < KM) ? h : ((j == lane) ? 1.0 : 0.0);
         }
 #pragma unroll
-        for (int j = 0; j < KM; ++j) {
+        for (int j = 0; j < KMT; ++j) {
             const double d = mx_bcast(a[j], j);
             if (!(d > 0.0)) flag = 1;
             const double rs = 1.0 / sqrt(d);
             a[j] = a[j] * rs;
 #pragma unroll
-            for (int k = j + 1; k < KM; ++k) a[k] -= a[j] * mx_bcast(a[j], k);
+            for (int k = j + 1; k < KMT; ++k) a[k] -= a[j] * mx_bcast(a[j], k);
         }
-        // lane k solves L y = Jhat[k, :]^T,  Jhat[k][i] = r_i (d_{k,i+1} - p_k)
-        double y[KM];
+        // lane k solves L y = Jhat[k, :]^T,  Jhat[k][i] = r_i (d_{k,i+1} - p_k)   (r_i = 0 past K - 1)
+        double y[KMT];
 #pragma unroll
-        for (int i = 0; i < KM; ++i) {
-            double rhs = mx_bcast(r1, i) * ((lane == i + 1 ? 1.0 : 0.0) - ps);
+        for (int i = 0; i < KMT; ++i) {
+            double rhs = (i < KM) ? mx_bcast(r1, i) * ((lane == i + 1 ? 1.0 : 0.0) - ps) : 0.0;
 #pragma unroll
             for (int c = 0; c < i; ++c) rhs -= mx_bcast(a[c], i) * y[c];
             y[i] = rhs / mx_bcast(a[i], i);
@@ -247,15 +246,13 @@ void mixture_rows_dense_kernel(const double* __restrict__ theta_z, const double*
         const double w2 = wn * wn;
         const int colp = (lane == 0) ? m : ((lane == m) ? 0 : lane);
         double* arow = Amat + n * lda + colp;
-#pragma unroll 4
         for (int kp = 0; kp < K; ++kp) {
             double acc = 0.0;
 #pragma unroll
-            for (int i = 0; i < KM; ++i) acc += y[i] * mx_bcast(y[i], kp);
+            for (int i = 0; i < KMT; ++i) acc += y[i] * mx_bcast(y[i], kp);
             const int rowp = (kp == 0) ? m : ((kp == m) ? 0 : kp);
             if (cat && rowp >= colp) arow[rowp * (rowp + 1) / 2] = w2 * acc;      // packed lower triangle
         }
     }
     if (flag && lane == 0) atomicOr(bad, 1);
 }
-
