@@ -115,13 +115,24 @@ class Objective(object):
     # ---- values: plain plumbing, any callable -------------------------------------------
     def fun_free(self, free_val, *argv, verbose=False, **argk):
         self.par.set_free(free_val)
-        val = self.fun(*argv, **argk)
+        if getattr(self.fun, '_lrvb_device_functor', False) and hasattr(self.fun, 'value'):
+            # a declared objective is evaluated AT free_val (not at get_free() of the state just set: that
+            # round trip through the bounds-checked unconstraining map would turn a nan probe of an
+            # optimiser into a ValueError, where the reference's closure simply returns nan)
+            val = self.fun.value(np.asarray(free_val, dtype=np.float64), True, *argv, **argk)
+        else:
+            val = self.fun(*argv, **argk)
         if verbose:
             self.logger.log(val, free_val)
         return val
 
     def fun_vector(self, vec_val, *argv, **argk):
         self.par.set_vector(vec_val)
+        if getattr(self.fun, '_lrvb_device_functor', False) and hasattr(self.fun, 'value'):
+            try:
+                return self.fun.value(np.asarray(vec_val, dtype=np.float64), False, *argv, **argk)
+            except NotImplementedError:
+                pass                               # objectives that are evaluated in free coordinates only
         return self.fun(*argv, **argk)
 
     # ---- derivatives: one device call each, then restore `par` (reference :142-150) -------

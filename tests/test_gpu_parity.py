@@ -399,3 +399,30 @@ def test_wide_designs(vb, loss, N, P):
         B = rng.normal(size=(3, P))
         X, info, _ = fun.ctx.cg_solve_multi(theta, B)
         assert np.all(info == 0) and rel_err(X, np.linalg.solve(Hw, B.T).T) < 1e-6
+
+
+def test_nan_and_overflow_inputs_do_not_fault(vb):
+    """An optimiser's stray probe: nan / overflowing free values give nan results (as the reference's numpy
+    closure does) or the documented exceptions -- never a device fault or a hang."""
+    rng = np.random.default_rng(0)
+    N, P = 1000, 256
+    par, lay = make_par(vb, [('box', 'b', P, 0.0, np.inf)])
+    x, y, w = glm_data(rng, N, P, om.POISSON)
+    fun = vb.DeviceObjective(par, x=x, y=y, loss='poisson', quad_A=np.ones(P), weights=w)
+    obj = vb.Objective(par, fun)
+    th = rng.normal(size=P) * 0.1
+    th[3] = np.nan
+    assert np.isnan(obj.fun_free(th))
+    assert np.isnan(obj.fun_free_grad(th)).any()
+    H = obj.fun_free_hessian(th)
+    assert np.isnan(H).any()
+    with pytest.raises(np.linalg.LinAlgError):
+        fun.ctx.chol_factor(H)
+    X, info, it = fun.ctx.cg_solve_multi(th, rng.normal(size=(3, P)), maxiter=5)
+    assert np.all(info == 5)                                 # not converged is reported, not raised (ConjugateGradient.py:82-85)
+    th2 = rng.normal(size=P) * 0.1
+    th2[5] = 800.0                                           # exp overflows in the box map
+    with np.errstate(over='ignore', invalid='ignore'):
+        assert not np.isfinite(obj.fun_free(th2))
+    good = rng.normal(size=P) * 0.1                          # the context is still usable afterwards
+    assert np.isfinite(obj.fun_free(good)) and np.all(np.isfinite(obj.fun_free_hessian(good)))
