@@ -173,6 +173,22 @@ int lrvb_grad_vec   (lrvb_ctx* ctx, const double* vec_in, int64_t V, double* val
 int lrvb_hessian_vec(lrvb_ctx* ctx, const double* vec_in, int64_t V, double* H_out, int64_t ld);
 int lrvb_hvp_vec    (lrvb_ctx* ctx, const double* vec_in, const double* v, int64_t V, double* out);
 
+/* Vector-coordinate Hessian assembled ON THE DEVICE from small host blocks, then converted to free
+ * coordinates (convert_vector_to_free_hessian, LRVB/Parameters.py:397-424) without a V x V host matrix:
+ * the N-independent closed forms of the normal-family ELBOs (LRVB/NormalParams.py, WishartParams.py,
+ * ExponentialFamilies.py) are sums of blocks  coef * D^T (A (x) B) D  with k x k matrices A, B and the
+ * duplication matrix D of the symmetric-matrix vector form (MatrixParameters.py:16-41), plus small dense
+ * blocks.  begin -> add_* ... -> finish.  `mirror` also adds the transposed block at the mirrored position
+ * (off-diagonal blocks of a symmetric matrix).  finish: is_free = 1 returns J^T H J + sum_k g_k d2 eta_k
+ * (H_out may be NULL: the result stays resident for lrvb_chol_factor_last), is_free = 0 returns H itself. */
+int lrvb_hvec_begin(lrvb_ctx* ctx);
+int lrvb_hvec_add_block(lrvb_ctx* ctx, const double* block, int64_t rows, int64_t cols, int64_t row_off,
+                        int64_t col_off, int mirror);
+int lrvb_hvec_add_symkron(lrvb_ctx* ctx, const double* A, const double* B, int64_t k, double coef,
+                          int64_t row_off, int64_t col_off, int mirror);
+int lrvb_hvec_finish(lrvb_ctx* ctx, const double* point, int64_t n_in, int is_free, const double* g_vec,
+                     double* H_out);
+
 /* ---- cross Hessians: TwoParameterObjective.fun_hessian_free1_vector2
  * (LRVB/SparseObjectives.py:429-438) for the two hyper-parameters a declared model has ---- */
 /* Rows n0..n1 of G (shape (n1-n0) x D): G[n,:] = d/dtheta of d f/d w_n, i.e. the transpose

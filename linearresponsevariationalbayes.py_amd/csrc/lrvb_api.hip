@@ -625,6 +625,106 @@ extern "C" int lrvb_free_hessian_from_vector(lrvb_ctx* c, const double* free_in,
     return d2h(c, H_free_out, c->Hfree.p, (size_t)D * (size_t)D);
 }
 
+static int gemm_tn(lrvb_ctx* c, i64 K, i64 PA, i64 PB, const double* A, const double* B, double* C);
+
+// ---- vector-coordinate Hessian assembled on the device from small host blocks ------------------------------
+// The N-independent closed forms of the quadratic-in-data objectives are Kronecker products of k x k
+// matrices sandwiched between duplication matrices: D^T (A (x) B) D is a k(k+1)/2-square block (4 M entries
+// at k = 63) that is cheap to WRITE but expensive to form with dense host algebra.  The host sends A and B.
+__global__ void hvec_symkron_kernel(i64 total, i64 m, int k, const double* __restrict__ A, const double* __restrict__ B, double coef,
+                                    double* __restrict__ H, i64 ld, i64 row_off, i64 col_off, int mirror)
+{
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;                                  // total = m * m (the EW launcher passes the element count first)
+    const i64 r = e / m, cidx = e - r * m;
+    // vech index -> (i, j), j <= i, row-major lower triangle (SymIndex of LRVB/MatrixParameters.py:16-23)
+    int i = (int)((sqrt(8.0 * (double)r + 1.0) - 1.0) * 0.5);
+    while ((i64)i * (i + 1) / 2 > r) --i;
+    while ((i64)(i + 1) * (i + 2) / 2 <= r) ++i;
+    const int j = (int)(r - (i64)i * (i + 1) / 2);
+    int p = (int)((sqrt(8.0 * (double)cidx + 1.0) - 1.0) * 0.5);
+    while ((i64)p * (p + 1) / 2 > cidx) --p;
+    while ((i64)(p + 1) * (p + 2) / 2 <= cidx) ++p;
+    const int q = (int)(cidx - (i64)p * (p + 1) / 2);
+    double v = A[i * k + p] * B[j * k + q];
+    if (i != j) v += A[j * k + p] * B[i * k + q];
+    if (p != q) v += A[i * k + q] * B[j * k + p];
+    if (i != j && p != q) v += A[j * k + q] * B[i * k + p];
+    v *= coef;
+    H[(row_off + r) * ld + col_off + cidx] += v;
+    if (mirror) H[(col_off + cidx) * ld + row_off + r] += v;
+}
+__global__ void hvec_add_block_kernel(i64 total, i64 cols, const double* __restrict__ Bk, double* __restrict__ H, i64 ld,
+                                      i64 row_off, i64 col_off, int mirror)
+{
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;                                  // total = rows * cols
+    const i64 r = e / cols, cidx = e - r * cols;
+    H[(row_off + r) * ld + col_off + cidx] += Bk[e];
+    if (mirror) H[(col_off + cidx) * ld + row_off + r] += Bk[e];
+}
+extern "C" int lrvb_hvec_begin(lrvb_ctx* c) {
+    LRVB_TRY(ctx_bind(c));
+    LRVB_TRY(buf_reserve(c, c->Heta, (size_t)c->V * (size_t)c->V));
+    HIP_TRY(hipMemsetAsync(c->Heta.p, 0, (size_t)c->V * (size_t)c->V * sizeof(double), c->stream));
+    c->hvec_open = true;
+    return LRVB_OK;
+}
+extern "C" int lrvb_hvec_add_block(lrvb_ctx* c, const double* block, int64_t rows, int64_t cols, int64_t row_off,
+                                   int64_t col_off, int mirror) {
+    LRVB_TRY(ctx_bind(c));
+    if (!c->hvec_open) LRVB_FAIL(LRVB_ERR_STATE, "call lrvb_hvec_begin first");
+    if (!block || rows <= 0 || cols <= 0 || row_off < 0 || col_off < 0 || row_off + rows > c->V || col_off + cols > c->V)
+        LRVB_FAIL(LRVB_ERR_INVALID, "block [%lld+%lld, %lld+%lld) outside the %lld x %lld matrix", (long long)row_off, (long long)rows,
+                  (long long)col_off, (long long)cols, (long long)c->V, (long long)c->V);
+    if (mirror && row_off == col_off) LRVB_FAIL(LRVB_ERR_INVALID, "a mirrored block cannot sit on the diagonal");
+    LRVB_TRY(buf_reserve(c, c->work1, (size_t)(rows * cols)));
+    LRVB_TRY(h2d(c, c->work1.p, block, (size_t)(rows * cols)));
+    EW(hvec_add_block_kernel, rows * cols, cols, c->work1.p, c->Heta.p, c->V, row_off, col_off, mirror);
+    return LRVB_OK;
+}
+extern "C" int lrvb_hvec_add_symkron(lrvb_ctx* c, const double* A, const double* B, int64_t k, double coef,
+                                     int64_t row_off, int64_t col_off, int mirror) {
+    LRVB_TRY(ctx_bind(c));
+    if (!c->hvec_open) LRVB_FAIL(LRVB_ERR_STATE, "call lrvb_hvec_begin first");
+    const i64 m = k * (k + 1) / 2;
+    if (!A || !B || k <= 0 || k > 2048 || row_off < 0 || col_off < 0 || row_off + m > c->V || col_off + m > c->V)
+        LRVB_FAIL(LRVB_ERR_INVALID, "Kronecker block of order %lld at (%lld, %lld) outside the %lld x %lld matrix", (long long)m,
+                  (long long)row_off, (long long)col_off, (long long)c->V, (long long)c->V);
+    if (mirror && row_off == col_off) LRVB_FAIL(LRVB_ERR_INVALID, "a mirrored block cannot sit on the diagonal");
+    LRVB_TRY(buf_reserve(c, c->vtmp3, (size_t)(2 * k * k)));
+    LRVB_TRY(h2d(c, c->vtmp3.p, A, (size_t)(k * k)));
+    LRVB_TRY(h2d(c, c->vtmp3.p + k * k, B, (size_t)(k * k)));
+    EW(hvec_symkron_kernel, m * m, m, (int)k, c->vtmp3.p, c->vtmp3.p + k * k, coef, c->Heta.p, c->V, row_off, col_off, mirror);
+    return LRVB_OK;
+}
+// H_free = J^T H_vec J + sum_k g_k d2 eta_k with H_vec the matrix assembled by the lrvb_hvec_* calls.  The result
+// stays on the device (lrvb_chol_factor_last factors it); H_free_out may be NULL.  is_free = 0 returns H_vec itself.
+extern "C" int lrvb_hvec_finish(lrvb_ctx* c, const double* point, int64_t n_in, int is_free, const double* g_vec, double* H_out) {
+    LRVB_TRY(ctx_bind(c));
+    if (!c->hvec_open) LRVB_FAIL(LRVB_ERR_STATE, "call lrvb_hvec_begin first");
+    c->hvec_open = false;
+    const i64 D = c->D, V = c->V;
+    if (!is_free) {
+        LRVB_TRY(check_len(n_in, V, "vector"));
+        return H_out ? d2h(c, H_out, c->Heta.p, (size_t)V * (size_t)V) : LRVB_OK;
+    }
+    if (!point || !g_vec) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    LRVB_TRY(check_len(n_in, D, "free vector"));
+    LRVB_TRY(h2d(c, c->theta.p, point, (size_t)D));
+    LRVB_TRY(h2d(c, c->g_eta.p, g_vec, (size_t)V));
+    LRVB_TRY(buf_reserve(c, c->work1, (size_t)V * (size_t)D));
+    LRVB_TRY(buf_reserve(c, c->Hfree, (size_t)D * (size_t)D));
+    LRVB_TRY(buf_reserve(c, c->Tdense, (size_t)D * (size_t)D));
+    LRVB_TRY(ensure_dense_J(c, c->theta.p));
+    LRVB_TRY(gemm_tn(c, V, V, D, c->Heta.p, c->Jdense.p, c->work1.p));          // H_vec is symmetric: H J = H^T J
+    LRVB_TRY(gemm_tn(c, V, D, D, c->Jdense.p, c->work1.p, c->Tdense.p));        // J^T (H J)
+    HIP_TRY(hipMemsetAsync(c->Hfree.p, 0, (size_t)D * (size_t)D * sizeof(double), c->stream));
+    LRVB_TRY(launch_third_order(c, c->theta.p, c->g_eta.p, c->Hfree.p));
+    LRVB_TRY(launch_axpby(c, D * D, 1.0, c->Tdense.p, 1.0, c->Hfree.p));
+    return H_out ? d2h(c, H_out, c->Hfree.p, (size_t)D * (size_t)D) : LRVB_OK;
+}
+
 // ---- cross Hessians ----------------------------------------------------------------------
 __global__ void fill_kernel(i64 n, double v, double* __restrict__ o) {
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1181,13 +1281,13 @@ extern "C" int lrvb_lrvb_cov(lrvb_ctx* c, const double* M, int64_t Q, int64_t D,
 // out[n - n0, q] = -(G H^-1 M^T)[n, q] = d (moment q) / d w_n  by linear response, for rows n0..n1 of G.
 // G = diag(l') X J_glm is never formed: W = H^-1 M^T (D x Q) from the resident Cholesky factor,
 // Z = J_glm W (P x Q), and the rows of X are multiplied by Z in one pass, scaled by -l'_n.
-__global__ void row_scale_rows_kernel(i64 rows, i64 Q, const double* __restrict__ rowscale, double alpha, double* __restrict__ C) {
-    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < rows * Q) C[e] *= alpha * rowscale[e / Q];
+__global__ void row_scale_rows_kernel(i64 total, i64 Q, const double* __restrict__ rowscale, double alpha, double* __restrict__ C) {
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;      // total = rows * Q (the EW launcher passes the element count first)
+    if (e < total) C[e] *= alpha * rowscale[e / Q];
 }
-__global__ void scale_slice_rows_kernel(i64 P, i64 Q, const double* __restrict__ j1, const double* __restrict__ W, double* __restrict__ Z) {
-    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < P * Q) Z[e] = (j1 ? j1[e / Q] : 1.0) * W[e];
+__global__ void scale_slice_rows_kernel(i64 total, i64 Q, const double* __restrict__ j1, const double* __restrict__ W, double* __restrict__ Z) {
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;      // total = P * Q
+    if (e < total) Z[e] = (j1 ? j1[e / Q] : 1.0) * W[e];
 }
 static int obs_influence_impl(lrvb_ctx* c, const double* point, i64 n_in, bool is_free, const double* M, i64 Q,
                               i64 n0, i64 n1, double* out) {

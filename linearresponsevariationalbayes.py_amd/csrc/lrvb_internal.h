@@ -64,6 +64,7 @@ struct lrvb_ctx {
     DevBuf cgH; i64 cgH_n = 0;     // dense matrix of lrvb_cg_solve_matrix
     DevBuf chol, cholW;            // D x D Cholesky factor (lower); inverses of its 64 x 64 diagonal blocks
     bool chol_valid = false;
+    bool hvec_open = false;        // between lrvb_hvec_begin and lrvb_hvec_finish
     i64 chol_n = 0;
     DevBuf rhs, cgx, cgr, cgp, cgq, cgz, scal;
     DevBuf cgm[9];                 // blocked CG: B, X, R, P, Q, Z (Q x D), U, W (Q x V), R^T (P x Q)

@@ -185,6 +185,32 @@ class DeviceContext(object):
         _hip.check(fn(self._h, _hip.ptr(x), x.size, _hip.ptr(M), M.shape[0], n0, n1, _hip.ptr(out)))
         return out
 
+    # -- vector-coordinate Hessian assembled on the device from small host blocks ---------------------
+    def hvec_begin(self):
+        _hip.check(self._lib.lrvb_hvec_begin(self._h))
+
+    def hvec_add_block(self, block, row_off, col_off, mirror=False):
+        B = _hip.as_f64(block)
+        B = B.reshape(B.shape[0], -1) if B.ndim > 1 else B.reshape(-1, 1)
+        _hip.check(self._lib.lrvb_hvec_add_block(self._h, _hip.ptr(B), B.shape[0], B.shape[1], int(row_off), int(col_off), int(bool(mirror))))
+
+    def hvec_add_symkron(self, A, B, coef, row_off, col_off, mirror=False):
+        A, B = _hip.as_f64(A), _hip.as_f64(B)
+        if A.ndim != 2 or A.shape[0] != A.shape[1] or A.shape != B.shape:
+            raise ValueError('expected two square matrices of the same order')
+        _hip.check(self._lib.lrvb_hvec_add_symkron(self._h, _hip.ptr(A), _hip.ptr(B), A.shape[0], float(coef),
+                                                   int(row_off), int(col_off), int(bool(mirror))))
+
+    def hvec_finish(self, x, g_vec, is_free=True, want_host=True):
+        x = _hip.as_f64(x).ravel()
+        g = _hip.as_f64(g_vec).ravel()
+        n = self._n(is_free)
+        out = np.empty((n, n)) if want_host else None
+        _hip.check(self._lib.lrvb_hvec_finish(self._h, _hip.ptr(x), x.size, int(bool(is_free)), _hip.ptr(g), _hip.ptr(out)))
+        if is_free:
+            self.chol_token += 0          # (the resident free Hessian is what chol_factor_last factors)
+        return out
+
     def cross_hessian_tilt(self, free):
         f = _hip.as_f64(free).ravel()
         C = np.empty((self.D, self.V))

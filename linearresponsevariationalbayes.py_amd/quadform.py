@@ -103,13 +103,17 @@ class QuadraticDataObjective(object):
     def __call__(self):
         return self.value(np.asarray(self.par.get_free(), dtype=np.float64), True)
 
+    def _terms_vg(self, eta, S, W):
+        """(value, gradient) only; subclasses whose Hessian blocks are expensive override this."""
+        return self._terms(eta, S, W)[:2]
+
     def value(self, x, is_free):
         S, W = self._stats()
-        return float(self._terms(self._eta(x, is_free), S, W)[0])
+        return float(self._terms_vg(self._eta(x, is_free), S, W)[0])
 
     def grad(self, x, is_free):
         S, W = self._stats()
-        g = self._terms(self._eta(x, is_free), S, W)[1]
+        g = self._terms_vg(self._eta(x, is_free), S, W)[1]
         if not is_free:
             return g
         return self.ctx.free_to_vector_jac(x).T @ g
@@ -412,7 +416,7 @@ class WishartMVNObjective(QuadraticDataObjective):
         return (np.sum(sp.digamma(args)), 0.5 * np.sum(sp.polygamma(1, args)), 0.25 * np.sum(sp.polygamma(2, args)),
                 np.sum(sp.gammaln(args)) + 0.25 * np.log(np.pi) * d * (d - 1.0))
 
-    def _terms(self, eta, S, W):
+    def _terms(self, eta, S, W, want_hess=True):
         d = self.d
         m, lam_mu, nu, v = self._unpack(eta)
         Syy, sy = S[:d, :d], S[:d, d]
@@ -437,7 +441,6 @@ class WishartMVNObjective(QuadraticDataObjective):
                  + 0.5 * (nu - d - 1.0) * kap - 0.5 * nu * d)
         Vn = eta.size
         g = np.zeros(Vn)
-        H = np.zeros((Vn, Vn))
         ms, ls, vs = (slice(r.start, r.stop) for r in (self._ms, self._ls, self._vs))
         inu = self._inu
         Dup = self._dup
@@ -446,22 +449,69 @@ class WishartMVNObjective(QuadraticDataObjective):
         g[ls] = Dup.T @ (-0.5 * G + 0.5 * P).ravel()
         g[inu] = 0.5 * np.sum(v * B) + 0.5 * W * np.sum(v * P) - alpha * kap1 + 0.5 * (nu - d - 1.0) * kap1 - 0.5 * d
         g[vs] = Dup.T @ (0.5 * nu * B + 0.5 * W * nu * P - gam * Vi).ravel()
-        H[ms, ms] = C
-        H[ms, inu] = H[inu, ms] = v @ u
-        Hmv = nu * np.kron(np.eye(d), u[None, :]) @ Dup
-        H[ms, vs] = Hmv
-        H[vs, ms] = Hmv.T
-        H[ls, ls] = Dup.T @ (0.5 * (np.kron(G, P) + np.kron(P, G)) - 0.5 * np.kron(P, P)) @ Dup
-        hln = Dup.T @ (-0.5 * W * (P @ v @ P)).ravel()
-        H[ls, inu] = H[inu, ls] = hln
-        Hlv = Dup.T @ (-0.5 * W * nu * np.kron(P, P)) @ Dup
-        H[ls, vs] = Hlv
-        H[vs, ls] = Hlv.T
-        H[inu, inu] = 0.5 * kap1 + (0.5 * (nu - d - 1.0) - alpha) * kap2
-        hnv = Dup.T @ (0.5 * B + 0.5 * W * P).ravel()
-        H[inu, vs] = H[vs, inu] = hnv
-        H[vs, vs] = Dup.T @ (gam * np.kron(Vi, Vi)) @ Dup
-        return value, g, H
+        if not want_hess:
+            return value, g, None
+        # The Hessian as a list of blocks: ('dense', block, row, col, mirror) and ('symkron', A, B, coef, row,
+        # col, mirror) = coef * Dup^T (A (x) B) Dup.  The same list feeds the host assembler (small d, tests)
+        # and the device assembler (`lrvb_hvec_*`), which never forms a V x V matrix on the host.
+        r, cidx = np.tril_indices(d)
+        Hmv = np.zeros((d, r.size))                         # nu * kron(I, u^T) Dup, written directly
+        cols = np.arange(r.size)
+        np.add.at(Hmv, (r, cols), nu * u[cidx])
+        off = r != cidx
+        np.add.at(Hmv, (cidx[off], cols[off]), nu * u[r[off]])
+        blocks = [
+            ('dense', C, ms.start, ms.start, False),
+            ('dense', (v @ u)[:, None], ms.start, inu, True),
+            ('dense', Hmv, ms.start, vs.start, True),
+            ('symkron', G, P, 0.5, ls.start, ls.start, False),
+            ('symkron', P, G, 0.5, ls.start, ls.start, False),
+            ('symkron', P, P, -0.5, ls.start, ls.start, False),
+            ('dense', (Dup.T @ (-0.5 * W * (P @ v @ P)).ravel())[:, None], ls.start, inu, True),
+            ('symkron', P, P, -0.5 * W * nu, ls.start, vs.start, True),
+            ('dense', np.array([[0.5 * kap1 + (0.5 * (nu - d - 1.0) - alpha) * kap2]]), inu, inu, False),
+            ('dense', (Dup.T @ (0.5 * B + 0.5 * W * P).ravel())[None, :], inu, vs.start, True),
+            ('symkron', Vi, Vi, gam, vs.start, vs.start, False),
+        ]
+        if want_hess == 'blocks':
+            return value, g, blocks
+        return value, g, self._assemble_host(blocks, Vn)
+
+    def _terms_vg(self, eta, S, W):
+        return self._terms(eta, S, W, want_hess=False)[:2]
+
+    def _assemble_host(self, blocks, Vn):
+        H = np.zeros((Vn, Vn))
+        Dup = self._dup
+        for blk in blocks:
+            if blk[0] == 'dense':
+                _, Bk, ro, co, mirror = blk
+                H[ro:ro + Bk.shape[0], co:co + Bk.shape[1]] += Bk
+                if mirror:
+                    H[co:co + Bk.shape[1], ro:ro + Bk.shape[0]] += Bk.T
+            else:
+                _, A, Bm, coef, ro, co, mirror = blk
+                Bk = coef * (Dup.T @ np.kron(A, Bm) @ Dup)
+                H[ro:ro + Bk.shape[0], co:co + Bk.shape[1]] += Bk
+                if mirror:
+                    H[co:co + Bk.shape[1], ro:ro + Bk.shape[0]] += Bk.T
+        return H
+
+    def hessian(self, x, is_free):
+        """Dense Hessian.  From d = 16 upwards the Kronecker blocks are written by the device
+        (`lrvb_hvec_add_symkron`) and the free-coordinate conversion runs on the resident matrix."""
+        if self.d < 16:
+            return super().hessian(x, is_free)
+        S, W = self._stats()
+        x = _hip.as_f64(x).ravel()
+        _, g, blocks = self._terms(self._eta(x, is_free), S, W, want_hess='blocks')
+        self.ctx.hvec_begin()
+        for blk in blocks:
+            if blk[0] == 'dense':
+                self.ctx.hvec_add_block(blk[1], blk[2], blk[3], blk[4])
+            else:
+                self.ctx.hvec_add_symkron(blk[1], blk[2], blk[3], blk[4], blk[5], blk[6])
+        return self.ctx.hvec_finish(x, g, is_free)
 
     def _obs_terms(self, eta):
         d, q = self.d, self.q
