@@ -165,7 +165,7 @@ class LMMObjective(object):
                      + 0.5 * np.sum(np.log(q['ig'])) - 0.5 * G * (1.0 + np.log(2.0 * np.pi))
                      - _gamma_entropy(q['ay'], q['by']) - _gamma_entropy(q['am'], q['bm']))
 
-    def _arrow(self, eta):
+    def _arrow(self, eta, kron_block=True):
         """Gradient (V,), global Hessian block (ng, ng), cross block (ng, 2G) and the diagonal of
         the local block (2G,) in vector coordinates."""
         p, G, ng = self.p, self.G, self.n_global
@@ -202,7 +202,10 @@ class LMMObjective(object):
         g[self._is] = -0.5 * dloc / ig ** 2 + 0.5 / ig
         # global block
         Hgg[ms, ms] = C
-        Hgg[ls, ls] = Dup.T @ (0.5 * (np.kron(Gc, P) + np.kron(P, Gc)) - 0.5 * np.kron(P, P)) @ Dup
+        if kron_block:                    # (p(p+1)/2)^2 block through dense duplication-matrix algebra: small p only
+            Hgg[ls, ls] = Dup.T @ (0.5 * (np.kron(Gc, P) + np.kron(P, Gc)) - 0.5 * np.kron(P, P)) @ Dup
+        else:
+            self._kron_factors = (Gc, P)
         Hgg[ms, iay] = Hgg[iay, ms] = um * tay
         Hgg[ms, iby] = Hgg[iby, ms] = um * tby
         gl = Dup.T @ (-0.5 * PSP).ravel()
@@ -295,7 +298,8 @@ class LMMObjective(object):
         matrix whose inverse is the linear-response covariance block of the global parameters."""
         free_val = _hip.as_f64(free_val).ravel()
         eta = self.ctx.constrain(free_val)
-        g, Hgg, Hgl, dl = self._arrow(eta)
+        g, Hgg, Hgl, dl = self._arrow(eta, kron_block=False)
+        Gc, P = self._kron_factors
         ng, G = self.n_global, self.G
         # packing of the global block through a layout that covers only the global parameters
         if not hasattr(self, '_gctx'):
@@ -308,11 +312,26 @@ class LMMObjective(object):
                 size += b['vec_size']
             assert size == ng
             self._gctx = DeviceContext(blocks, quad_kind=_hip.QUAD_DIAG, device=self.ctx.device)
-        Hgg_free = self._gctx.free_hessian_from_vector(free_val[:ng], g[:ng], Hgg)
-        Jg = self._gctx.free_to_vector_jac(free_val[:ng])
+        # global block: the dense part from the host, the Kronecker block of q(beta)'s information matrix written
+        # by the device (lrvb_hvec_add_symkron), conversion to free coordinates on the resident matrix
+        gc = self._gctx
+        gc.hvec_begin()
+        gc.hvec_add_block(Hgg, 0, 0)
+        ls0 = self._ls.start
+        gc.hvec_add_symkron(Gc, P, 0.5, ls0, ls0)
+        gc.hvec_add_symkron(P, Gc, 0.5, ls0, ls0)
+        gc.hvec_add_symkron(P, P, -0.5, ls0, ls0)
+        Hgg_free = gc.hvec_finish(free_val[:ng], g[:ng], True)
         # local free coordinates: e_g unconstrained (d eta = 1), i_g = exp(f_g) (d eta = i_g, d2 eta = i_g)
         ig = eta[self._is]
         jl = np.concatenate([np.ones(G), ig])
         dl_free = dl * jl ** 2 + np.concatenate([np.zeros(G), g[self._is] * ig])
-        cross = (Jg.T @ Hgl) * jl[None, :]
-        return Hgg_free - (cross / dl_free[None, :]) @ cross.T
+        # only the mean of q(beta) and the five scalar parameters couple to the group effects; their packing
+        # maps are element-wise (identity / exp), so the free cross block is a row scaling of those rows
+        rows = np.flatnonzero(np.any(Hgl != 0.0, axis=1))
+        assert not np.any((rows >= self._ls.start) & (rows < self._ls.stop))
+        jrow = np.diag(gc.free_to_vector_jac(free_val[:ng]))[rows]      # those rows of J are diagonal
+        cross = (jrow[:, None] * Hgl[rows]) * jl[None, :]
+        HS = Hgg_free
+        HS[np.ix_(rows, rows)] -= (cross / dl_free[None, :]) @ cross.T
+        return HS

@@ -53,3 +53,18 @@ M5 = rng.normal(size=(16, H5.shape[0]))
 ms, _ = timeit(lambda: fun5.ctx.lrvb_cov(M5), reps=2); print('C5  lrvb_cov(Q=16) %.1f ms' % ms)
 b5 = rng.normal(size=H5.shape[0])
 ms, out = timeit(lambda: fun5.ctx.cg_solve_matrix(Hs, b5, tol=1e-8), reps=2); print('C5  CG on the resident dense Hessian: %.1f ms, %d iterations' % (ms, out[2]))
+
+# config 4: one GPU's shard of the hierarchical LMM (N = 1.25e6, p = 43, G = 1e4)
+from test_lmm_host_math import make_par as lmm_par, random_eta
+from oracle import packing as opk
+N4, p4, G4 = 1_250_000, 43, 10_000
+x4 = rng.normal(size=(N4, p4)); gid4 = rng.integers(0, G4, size=N4).astype(np.int32); gid4[:G4] = np.arange(G4)
+y4 = x4 @ rng.normal(size=p4) + rng.normal(size=G4)[gid4] * 0.7 + rng.normal(size=N4) * 0.5
+par4 = lmm_par(p4, G4)
+fun4 = vb.LMMObjective(par4, x4, y4, gid4, G4)
+th4 = par4.get_free()
+def stats4():
+    fun4._w_cache = None; fun4._stats_cache = None
+    return fun4.local_stats()
+ms, _ = timeit(stats4); print('C4  shard N=1.25e6 p=43 G=1e4: sufficient statistics (host weights in) %.2f ms' % ms)
+ms, HS4 = timeit(lambda: fun4.global_hessian(th4), reps=2); print('C4  Schur complement onto the %d global parameters %.1f ms' % (HS4.shape[0], ms))
