@@ -426,3 +426,58 @@ def test_nan_and_overflow_inputs_do_not_fault(vb):
         assert not np.isfinite(obj.fun_free(th2))
     good = rng.normal(size=P) * 0.1                          # the context is still usable afterwards
     assert np.isfinite(obj.fun_free(good)) and np.all(np.isfinite(obj.fun_free_hessian(good)))
+
+
+def test_device_hessian_assembly_from_kronecker_blocks(vb):
+    """lrvb_hvec_*: coef * D^T (A (x) B) D blocks written by the device against dense duplication-matrix
+    algebra, mirrored off-diagonal blocks, and the free-coordinate conversion of the assembled matrix."""
+    from lrvb_amd.quadform import duplication_matrix
+    from oracle import packing as opk
+    rng = np.random.default_rng(4)
+    k1, k2 = 5, 5
+    par = vb.ModelParamsDict('p')
+    par.push_param(vb.VectorParam('v', 3, lb=0.0))
+    par.push_param(vb.PosDefMatrixParam('a', k1))
+    par.push_param(vb.PosDefMatrixParam('b', k2, diag_lb=0.1))
+    lay = opk.Layout([opk.box_block(3, 0.0, np.inf), opk.psd_block(k1), opk.psd_block(k2, 0.1)])
+    ctx = vb.DeviceContext(par.layout_blocks(), quad_kind=1)
+    V = lay.V
+    m1 = k1 * (k1 + 1) // 2
+    A, B, C = (rng.normal(size=(k1, k1)) for _ in range(3))
+    Dm = duplication_matrix(k1)
+    dense = rng.normal(size=(3, 3)); dense = dense + dense.T
+    col = rng.normal(size=(3, m1))
+    want = np.zeros((V, V))
+    want[:3, :3] += dense
+    want[:3, 3:3 + m1] += col; want[3:3 + m1, :3] += col.T
+    blk_aa = 0.7 * Dm.T @ np.kron(A, A.T) @ Dm
+    want[3:3 + m1, 3:3 + m1] += blk_aa
+    blk_ab = -1.3 * Dm.T @ np.kron(B, C) @ Dm
+    want[3:3 + m1, 3 + m1:] += blk_ab; want[3 + m1:, 3:3 + m1] += blk_ab.T
+    ctx.hvec_begin()
+    ctx.hvec_add_block(dense, 0, 0)
+    ctx.hvec_add_block(col, 0, 3, mirror=True)
+    ctx.hvec_add_symkron(A, A.T, 0.7, 3, 3)
+    ctx.hvec_add_symkron(B, C, -1.3, 3, 3 + m1, mirror=True)
+    theta = rng.normal(size=lay.D) * 0.4
+    Hv = ctx.hvec_finish(lay.constrain(theta), np.zeros(V), is_free=False)
+    assert rel_err(Hv, want) < 1e-13
+    # same blocks again, free coordinates (the assembled matrix must be symmetric for the conversion)
+    S = rng.normal(size=(k1, k1)); S = S + S.T
+    g = rng.normal(size=V)
+    wantS = np.zeros((V, V)); wantS[:3, :3] = dense
+    wantS[3:3 + m1, 3:3 + m1] = Dm.T @ np.kron(S, S) @ Dm
+    ctx.hvec_begin()
+    ctx.hvec_add_block(dense, 0, 0)
+    ctx.hvec_add_symkron(S, S, 1.0, 3, 3)
+    Hf = ctx.hvec_finish(theta, g, is_free=True)
+    assert rel_err(Hf, opk.convert_vector_to_free_hessian(lay, theta, g, wantS)) < 1e-12
+    # misuse is reported
+    with pytest.raises(RuntimeError):
+        ctx.hvec_add_block(dense, 0, 0)                      # no begin
+    ctx.hvec_begin()
+    with pytest.raises(ValueError):
+        ctx.hvec_add_symkron(A, A, 1.0, V - 2, 0)            # does not fit
+    with pytest.raises(ValueError):
+        ctx.hvec_add_block(col, 3, 3, mirror=True)           # mirrored block on the diagonal
+    ctx.hvec_finish(theta, g, is_free=True, want_host=False)
