@@ -31,24 +31,36 @@ void gemm_f64_kernel(int transA, int transB, i64 M, i64 N, i64 K, double alpha,
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
 
-    for (i64 k0 = 0; k0 < K; k0 += GM_KC) {
+    // the next K-chunk is fetched into registers while the current one is on the MFMA pipe
+    double ar[4], br[4];
+    auto fetch = [&](i64 k0) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int idx = it * 256 + tid;
             int kk, mm;
             if (transA) { mm = idx & 63; kk = idx >> 6; } else { kk = idx & 15; mm = idx >> 4; }
             const i64 gm = m0 + mm, gk = k0 + kk;
-            double v = 0.0;
-            if (gm < M && gk < K) v = transA ? A[gk * lda + gm] : A[gm * lda + gk];
-            As[kk][mm] = v;
+            ar[it] = (gm < M && gk < K) ? (transA ? A[gk * lda + gm] : A[gm * lda + gk]) : 0.0;
             int kb, nn;
             if (transB) { kb = idx & 15; nn = idx >> 4; } else { nn = idx & 63; kb = idx >> 6; }
             const i64 gn = n0 + nn, gkb = k0 + kb;
-            double u = 0.0;
-            if (gn < N && gkb < K) u = transB ? B[gn * ldb + gkb] : B[gkb * ldb + gn];
-            Bs[kb][nn] = u;
+            br[it] = (gn < N && gkb < K) ? (transB ? B[gn * ldb + gkb] : B[gkb * ldb + gn]) : 0.0;
+        }
+    };
+    fetch(0);
+    for (i64 k0 = 0; k0 < K; k0 += GM_KC) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = it * 256 + tid;
+            int kk, mm;
+            if (transA) { mm = idx & 63; kk = idx >> 6; } else { kk = idx & 15; mm = idx >> 4; }
+            As[kk][mm] = ar[it];
+            int kb, nn;
+            if (transB) { kb = idx & 15; nn = idx >> 4; } else { nn = idx & 63; kb = idx >> 6; }
+            Bs[kb][nn] = br[it];
         }
         __syncthreads();
+        if (k0 + GM_KC < K) fetch(k0 + GM_KC);
 #pragma unroll
         for (int ks = 0; ks < GM_KC / 4; ++ks) {
             const int krow = ks * 4 + (lane >> 4);
@@ -105,7 +117,7 @@ int launch_gemm(lrvb_ctx* c, bool transA, bool transB, i64 M, i64 Nn, i64 K, dou
 // ---- Cholesky ------------------------------------------------------------------------
 // Right-looking blocked factorisation, block size 64:
 //   (1) one wavefront factors the 64 x 64 diagonal block held in registers (lane i = row i,
-//       broadcasts by v_readlane) and also forms W = L_jj^-1 (lane c = column c of W);
+//       broadcasts by v_readlane) and also forms W = L_jj^-1 (four waves, blocked 16 -> 32 -> 64 on MFMA);
 //   (2) panel  P <- P W^T           (MFMA GEMM, in place: one 64-column tile per row tile);
 //   (3) trailing A22 -= P P^T       (MFMA GEMM, lower tiles only).
 // The solves use the stored W blocks: X_j = W_j B_j / W_j^T B_j are GEMMs too.
@@ -119,61 +131,127 @@ __device__ __forceinline__ double lane_bcast(double v, int src_lane) {
 
 constexpr int CH_LS = CH_NB + 2;          // LDS row stride of the diagonal block (even: 16-byte pair reads)
 
-__global__ __launch_bounds__(64)
+constexpr int CH_WS = CH_NB + 1;          // LDS row stride of W
+
+// 16 x 16 x 16 tile product on one wave, acc += X Y: X(i, k) = xs[i * ldx + k], Y(k, j) = ys[k * ldy + j]
+__device__ __forceinline__ d4 tile16_mm(const double* xs, int ldx, const double* ys, int ldy, d4 acc, int lane) {
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+        const double av = xs[(lane & 15) * ldx + 4 * kc + (lane >> 4)];
+        const double bv = ys[(4 * kc + (lane >> 4)) * ldy + (lane & 15)];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+    return acc;
+}
+// acc += X T with T held in MFMA result layout (register r = rows 4 r + (lane >> 4), which is exactly
+// the B operand of K-chunk r)
+__device__ __forceinline__ d4 tile16_mm_reg(const double* xs, int ldx, d4 t, d4 acc, int lane) {
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+        const double av = xs[(lane & 15) * ldx + 4 * kc + (lane >> 4)];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, t[kc], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(256)
 void potrf_inv_diag_kernel(double* __restrict__ A, i64 lda, int nb, double* __restrict__ W /* 64 x 64 */,
                            int* __restrict__ info, int col0)
 {
-    // One wavefront, lane i <-> row i of the 64 x 64 block.  The cross-lane traffic of the factorisation
-    // (step j needs L[k][j] of every later row k in every lane) goes through LDS: the lanes deposit
-    // column j once and read it back with wave-uniform 16-byte reads -- (63 - j) / 2 broadcast reads per
-    // step instead of 2 (63 - j) v_readlane, which is what made this kernel two thirds of the D = 1024
-    // factorisation time.
+    // Wave 0 factors the block, lane i <-> row i.  The cross-lane traffic of the factorisation (step j
+    // needs L[k][j] of every later row k in every lane) goes through LDS: the lanes deposit column j once
+    // and read it back with wave-uniform 16-byte reads -- (63 - j) / 2 broadcast reads per step instead of
+    // 2 (63 - j) v_readlane.  LDS operations of one wave execute in order, so the loop needs no barrier.
+    // W = L^-1 is then formed by all four waves, blocked 16 -> 32 -> 64 with MFMA products:
+    //   inv [[P, 0], [Q, R]] = [[P^-1, 0], [-R^-1 Q P^-1, R^-1]].
     __shared__ double Ls[CH_NB * CH_LS];
+    __shared__ double Ws[CH_NB * CH_WS];
     __shared__ double colbuf[CH_NB];
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // coalesced load of the block (row r, column lane), identity padding past nb
-    for (int r = 0; r < CH_NB; ++r)
+    for (int r = wave; r < CH_NB; r += 4) {
         Ls[r * CH_LS + lane] = (r < nb && lane < nb) ? ((lane <= r) ? A[(i64)r * lda + lane] : 0.0) : ((r == lane) ? 1.0 : 0.0);
-    __syncthreads();
-    double a[CH_NB];
-#pragma unroll
-    for (int k = 0; k < CH_NB; ++k) a[k] = Ls[lane * CH_LS + k];
-    int bad = 0;
-#pragma unroll
-    for (int j = 0; j < CH_NB; ++j) {
-        __syncthreads();
-        colbuf[lane] = a[j];                     // column j of the current trailing matrix
-        __syncthreads();
-        const double d = colbuf[j];
-        if (!(d > 0.0) && bad == 0) bad = j + 1;
-        const double rs = rsqrt(d);              // one reciprocal square root instead of a division and a square root
-        a[j] = a[j] * rs;                        // L[i][j]  (lane j: sqrt(d))
-        const double t = a[j] * rs;              // L[i][j] / sqrt(d)
-#pragma unroll
-        for (int k = j + 1; k < CH_NB; ++k) a[k] -= t * colbuf[k];      // A[i][k] -= L[i][j] L[k][j]
+        Ws[r * CH_WS + lane] = 0.0;
     }
-    if (lane == 0 && bad != 0 && *info == 0) *info = col0 + bad;
-    // L through LDS: coalesced store of the lower part, and the source of the broadcasts below
     __syncthreads();
+    if (wave == 0) {
+        double a[CH_NB];
 #pragma unroll
-    for (int k = 0; k < CH_NB; ++k) Ls[lane * CH_LS + k] = (k <= lane) ? a[k] : 0.0;
-    __syncthreads();
-    for (int r = 0; r < nb; ++r)
-        if (lane <= r && lane < nb) A[(i64)r * lda + lane] = Ls[r * CH_LS + lane];
-    // W = L^-1: lane c solves L w = e_c by forward substitution; row i of L is read wave-uniformly
-    double w[CH_NB];
+        for (int k = 0; k < CH_NB; ++k) a[k] = Ls[lane * CH_LS + k];
+        int bad = 0;
 #pragma unroll
-    for (int i = 0; i < CH_NB; ++i) {
-        const double* Li = Ls + i * CH_LS;
-        double s0 = (i == lane) ? 1.0 : 0.0, s1 = 0.0;       // two interleaved chains halve the dependent-FMA latency
+        for (int j = 0; j < CH_NB; ++j) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            colbuf[lane] = a[j];                     // column j of the current trailing matrix
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            const double d = colbuf[j];
+            if (!(d > 0.0) && bad == 0) bad = j + 1;
+            const double rs = rsqrt(d);              // one reciprocal square root instead of a division and a square root
+            a[j] = a[j] * rs;                        // L[i][j]  (lane j: sqrt(d))
+            const double t = a[j] * rs;              // L[i][j] / sqrt(d)
 #pragma unroll
-        for (int k = 0; k < i; ++k) {
-            if (k & 1) s1 = fma(-Li[k], w[k], s1); else s0 = fma(-Li[k], w[k], s0);
+            for (int k = j + 1; k < CH_NB; ++k) a[k] -= t * colbuf[k];      // A[i][k] -= L[i][j] L[k][j]
         }
-        w[i] = (s0 + s1) / Li[i];
-    }
+        if (lane == 0 && bad != 0 && *info == 0) *info = col0 + bad;
 #pragma unroll
-    for (int i = 0; i < CH_NB; ++i) W[i * CH_NB + lane] = w[i];    // W[i][c], coalesced over c
+        for (int k = 0; k < CH_NB; ++k) Ls[lane * CH_LS + k] = (k <= lane) ? a[k] : 0.0;
+    }
+    __syncthreads();
+    for (int r = wave; r < nb; r += 4)
+        if (lane <= r && lane < nb) A[(i64)r * lda + lane] = Ls[r * CH_LS + lane];
+
+    // level 1: wave w inverts the 16 x 16 diagonal block w; lane c solves L_ww x = e_c
+    {
+        const double* Lw = Ls + (16 * wave) * CH_LS + 16 * wave;
+        const int cc = lane & 15;
+        double x[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            double s = (i == cc) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < i; ++k) s = fma(-Lw[i * CH_LS + k], x[k], s);
+            x[i] = s / Lw[i * CH_LS + i];
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) Ws[(16 * wave + i) * CH_WS + 16 * wave + cc] = x[i];
+        }
+    }
+    __syncthreads();
+    const d4 zero4 = (d4){0.0, 0.0, 0.0, 0.0};
+    // level 2: waves 0 and 1 complete the two 32 x 32 diagonal inverses, W[d1][d0] = -W[d1][d1] L[d1][d0] W[d0][d0]
+    if (wave < 2) {
+        const int d0 = 2 * wave, d1 = d0 + 1;
+        const d4 t = tile16_mm(Ls + (16 * d1) * CH_LS + 16 * d0, CH_LS, Ws + (16 * d0) * CH_WS + 16 * d0, CH_WS, zero4, lane);
+        const d4 o = tile16_mm_reg(Ws + (16 * d1) * CH_WS + 16 * d1, CH_WS, t, zero4, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            Ws[(16 * d1 + (lane >> 4) + 4 * r) * CH_WS + 16 * d0 + (lane & 15)] = -o[r];
+    }
+    __syncthreads();
+    // level 3: wave (a, b) forms tile (2 + a, b) of -W[2:4][2:4] L[2:4][0:2] W[0:2][0:2]
+    {
+        const int ta = wave >> 1, tb = wave & 1;
+        d4 t[2];
+#pragma unroll
+        for (int cq = 0; cq < 2; ++cq) {
+            d4 acc = zero4;
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                acc = tile16_mm(Ls + (16 * (2 + cq)) * CH_LS + 16 * e, CH_LS, Ws + (16 * e) * CH_WS + 16 * tb, CH_WS, acc, lane);
+            t[cq] = acc;
+        }
+        d4 o = zero4;
+#pragma unroll
+        for (int cq = 0; cq < 2; ++cq)
+            o = tile16_mm_reg(Ws + (16 * (2 + ta)) * CH_WS + 16 * (2 + cq), CH_WS, t[cq], o, lane);
+        __syncthreads();       // every wave has read the 32 x 32 diagonal inverses before the corner is written
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            Ws[(16 * (2 + ta) + (lane >> 4) + 4 * r) * CH_WS + 16 * tb + (lane & 15)] = -o[r];
+    }
+    __syncthreads();
+    for (int r = wave; r < CH_NB; r += 4) W[r * CH_NB + lane] = Ws[r * CH_WS + lane];
 }
 
 int launch_potrf_lower(lrvb_ctx* c, double* A, i64 n, i64 lda, int* info_dev) {
@@ -184,7 +262,7 @@ int launch_potrf_lower(lrvb_ctx* c, double* A, i64 n, i64 lda, int* info_dev) {
         const int nb = (int)((n - j0 < CH_NB) ? (n - j0) : CH_NB);
         double* Ajj = A + j0 * lda + j0;
         double* Wj = c->cholW.p + jb * CH_NB * CH_NB;
-        hipLaunchKernelGGL(potrf_inv_diag_kernel, dim3(1), dim3(64), 0, c->stream, Ajj, lda, nb, Wj, info_dev, (int)j0);
+        hipLaunchKernelGGL(potrf_inv_diag_kernel, dim3(1), dim3(256), 0, c->stream, Ajj, lda, nb, Wj, info_dev, (int)j0);
         HIP_TRY(hipGetLastError());
         const i64 rows = n - j0 - nb;
         if (rows > 0) {
