@@ -16,7 +16,7 @@ Reference module names are importable as attributes for drop-in code
 __version__ = '0.1.0'
 
 from .packing import (ScalarParam, VectorParam, ArrayParam, PosDefMatrixParam, PosDefMatrixParamVector,
-                      PosDefMatrixParamArray, SimplexParam,
+                      PosDefMatrixParamArray, SimplexParam, SubspaceVectorParam,
                       ModelParamsDict, ModelParamsDictValues, convert_vector_to_free_hessian)
 from .families import (UVNParam, UVNParamVector, UVNParamArray, UVNMomentParamArray, MVNParam,
                        MVNArray, GammaParam, WishartParam, DirichletParamArray)
@@ -42,4 +42,18 @@ from . import families as NormalParams
 from .hierarchical import LMMObjective
 from .mixture import MixtureObjective
 from . import regression as regression_utils
+from . import packing as ProjectionParams
+from . import families as GammaParams
+from . import families as WishartParams
+from . import families as DirichletParams
+from . import modeling as Modeling
 from . import distributed
+
+# `import lrvb_amd.SparseObjectives as obj_lib` (the reference's usual import style) resolves too
+import sys as _sys
+for _alias in ('Parameters', 'MatrixParameters', 'SimplexParams', 'ParameterDictionary', 'ProjectionParams',
+               'SparseObjectives', 'ModelSensitivity', 'ConjugateGradient', 'OptimizationUtils',
+               'ExponentialFamilies', 'NormalParams', 'GammaParams', 'WishartParams', 'DirichletParams',
+               'Modeling', 'regression_utils'):
+    _sys.modules.setdefault(__name__ + '.' + _alias, globals()[_alias])
+del _sys, _alias

@@ -3,7 +3,8 @@ the N-independent scalars of an ELBO (host-side)
 
 Same names and argument meaning as LRVB/ExponentialFamilies.py (multivariate_digamma/gammaln
 :5-13; entropies :20-82; e_log_det_wishart :88-94; e_log_inv_wishart_diag :97-102; lognormal
-moments :104-109; get_e_log_gamma :111-112; Dirichlet moments :114-120; priors :186-212).
+moments :104-109; get_e_log_gamma :111-112; Dirichlet moments :114-120; Gauss-Hermite expectations
+:126-168; get_uvn_from_natural_parameters :176-179; priors :186-221).
 """
 import math
 
@@ -123,3 +124,50 @@ def dirichlet_prior(alpha, log_e_obs):
 def expected_ljk_prior(lkj_param, df, v):
     e_log_r = -1 * e_log_det_wishart(df, v) - np.sum(e_log_inv_wishart_diag(df, v))
     return (lkj_param - 1) * e_log_r
+
+
+# ---- Gauss-Hermite expectations under arrays of univariate normals --------------------------
+def get_e_fun_normal(means, infos, gh_loc, gh_weights, fun):
+    """E[fun(X)] elementwise for X ~ N(means, 1 / infos), by Gauss-Hermite quadrature with nodes
+    gh_loc and weights gh_weights (numpy.polynomial.hermite.hermgauss convention: weight exp(-x^2)).
+    The node axis is appended last and summed out.  LRVB/ExponentialFamilies.py:126-143."""
+    means = np.asarray(means, dtype=np.float64)
+    infos = np.asarray(infos, dtype=np.float64)
+    assert means.shape == infos.shape
+    nodes = means[..., None] + math.sqrt(2.0) * np.asarray(gh_loc) / np.sqrt(infos[..., None])
+    return np.sum(np.asarray(gh_weights) * fun(nodes), axis=means.ndim) / math.sqrt(math.pi)
+
+
+def get_e_logitnormal(lognorm_means, lognorm_infos, gh_loc, gh_weights):
+    """E[expit(X)].  LRVB/ExponentialFamilies.py:145-150."""
+    return get_e_fun_normal(lognorm_means, lognorm_infos, gh_loc, gh_weights, special.expit)
+
+
+def _log_expit(x):
+    # log(expit(x)) without overflow: -log1p(exp(-x)) where that is finite, x itself far in the left tail
+    # (the reference switches branches at x = -100 and floors the first at -1e16, :156-157)
+    x = np.asarray(x, dtype=np.float64)
+    with np.errstate(over='ignore'):
+        right = np.maximum(-np.log1p(np.exp(-x)), -1e16)
+    return np.where(x > -1e2, right, x)
+
+
+def get_e_log_logitnormal(lognorm_means, lognorm_infos, gh_loc, gh_weights):
+    """(E[log V], E[log(1 - V)]) for V = expit(X); the second follows from log(1 - v) = log v - x.
+    LRVB/ExponentialFamilies.py:152-168."""
+    e_log_v = get_e_fun_normal(lognorm_means, lognorm_infos, gh_loc, gh_weights, _log_expit)
+    return e_log_v, e_log_v - np.asarray(lognorm_means, dtype=np.float64)
+
+
+def get_uvn_from_natural_parameters(e_term, e2_term):
+    """(mean, info) of the normal whose log density is e_term x + e2_term x^2 + const.
+    LRVB/ExponentialFamilies.py:176-179."""
+    x_info = -2.0 * e2_term
+    return e_term / x_info, x_info
+
+
+def get_e_dp_prior_logitnorm_approx(alpha, lognorm_means, lognorm_infos, gh_loc, gh_weights):
+    """Expected Beta(1, alpha) stick prior under logit-normal sticks: (alpha - 1) E[log(1 - V)],
+    elementwise.  LRVB/ExponentialFamilies.py:214-221."""
+    _, e_log_1mv = get_e_log_logitnormal(lognorm_means, lognorm_infos, gh_loc, gh_weights)
+    return (alpha - 1) * e_log_1mv

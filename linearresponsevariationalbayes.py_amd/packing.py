@@ -15,6 +15,7 @@ element, LRVB/Parameters.py:200-218) this module uses the closed forms; the O(N)
 an objective never runs here -- it runs in liblrvb_hip.so, which receives the layout through
 `layout_blocks()`.
 """
+import copy
 import math
 import numbers
 from collections import OrderedDict
@@ -346,6 +347,24 @@ def unpack_posdef_matrix(free_vec, diag_lb=0.0):
     """MatrixParameters.py:108-112."""
     chol = exp_matrix_diagonal(unvectorize_ld_matrix(free_vec))
     return chol @ chol.T + diag_lb * np.eye(chol.shape[0])
+
+
+def pos_def_matrix_free_to_vector(free_val, diag_lb=0.0):
+    """Lower triangle of the matrix a free vector encodes.  LRVB/MatrixParameters.py:126-128."""
+    return vectorize_ld_matrix(unpack_posdef_matrix(free_val, diag_lb=diag_lb))
+
+
+def pos_def_matrix_free_to_vector_jac(free_val, diag_lb=0.0):
+    """Closed-form Jacobian of `pos_def_matrix_free_to_vector` (the reference differentiates it with
+    autograd, LRVB/MatrixParameters.py:130-131); diag_lb only shifts the diagonal."""
+    free_val = np.asarray(free_val, dtype=np.float64)
+    return _psd_jac_dense(free_val, _ld_size_to_dim(free_val.size))
+
+
+def pos_def_matrix_free_to_vector_hess(free_val, diag_lb=0.0):
+    """Closed-form Hessian, indexed [vec, free, free].  LRVB/MatrixParameters.py:132-133."""
+    free_val = np.asarray(free_val, dtype=np.float64)
+    return _psd_hess_dense(free_val, _ld_size_to_dim(free_val.size))
 
 
 def _psd_jac_dense(free_val, k):
@@ -717,6 +736,97 @@ class SimplexParam(object):
 
 
 # ------------------------------------------------------------------------------ offsets
+def get_perpendicular_subspace(x):
+    """Orthonormal basis (as columns) of the orthogonal complement of the row space of x.
+    LRVB/ProjectionParams.py:13-26: eigenvectors of I - x^T (x x^T)^-1 x with non-zero eigenvalue;
+    asserts that exactly x.shape[1] - x.shape[0] of them survive (full row rank)."""
+    x = np.asarray(x, dtype=np.float64)
+    n_con, dim = x.shape
+    complement = np.eye(dim) - x.T @ np.linalg.solve(x @ x.T, x)
+    evals, evecs = np.linalg.eigh(complement)
+    keep = np.abs(evals) > 1e-8
+    assert np.sum(keep) == dim - n_con
+    return evecs[:, keep]
+
+
+class SubspaceVectorParam(object):
+    """A vector confined to the subspace orthogonal to the rows of `perp_subspace` (default: one row of
+    ones, i.e. zero-mean vectors).  LRVB/ProjectionParams.py:30-100.  The free <-> vector map is linear
+    (vector = basis @ free), the Hessians of the map are empty, and `set` only checks the size -- like
+    the reference it does not project or reject an off-subspace value."""
+
+    def __init__(self, name='', dim=3, val=None, perp_subspace=None):
+        self.name = name
+        self._dim = int(dim)
+        if perp_subspace is None:
+            self._perp = np.full((1, self._dim), 1.0)
+        else:
+            self._perp = copy.deepcopy(perp_subspace)
+        if self._perp.shape[1] != self._dim:
+            raise ValueError('The rows of <perp_subspace> must be of length <dim>')
+        if self._perp.shape[0] >= self._dim:
+            raise ValueError('<perp_subspace> must have strictly fewer rows than <dim>')
+        self._basis = get_perpendicular_subspace(self._perp)
+        self._free_dim = self._dim - self._perp.shape[0]
+        self.set(val if val is not None else np.full(self._dim, 0.))
+
+    def layout_blocks(self):
+        raise NotImplementedError(
+            'SubspaceVectorParam ' + self.name + ' has no device packing block: the map is linear, so keep the '
+            'full vector as a VectorParam in the device objective and apply the basis on the host '
+            '(H_free = B^T H_vec B, g_free = B^T g_vec)')
+
+    def __str__(self):
+        return self.name + ':\n' + str(self._val)
+
+    def names(self):
+        return [self.name + '_' + str(k) for k in range(self.vector_size())]
+
+    def dictval(self):
+        return self._val.tolist()
+
+    def set(self, val):
+        if val.size != self.dim():
+            raise ValueError('Wrong size for vector ' + self.name)
+        self._val = val
+
+    def get(self):
+        return self._val
+
+    def set_free(self, free_val):
+        if free_val.size != self.free_size():
+            raise ValueError('Wrong free size for vector ' + self.name)
+        self.set(self._basis @ free_val)
+
+    def get_free(self):
+        return self._basis.T @ self._val
+
+    def free_to_vector(self, free_val):
+        self.set_free(free_val)
+        return self.get_vector()
+
+    def free_to_vector_jac(self, free_val):
+        return coo_matrix(self._basis)
+
+    def free_to_vector_hess(self, free_val):
+        return [coo_matrix((self._free_dim, self._free_dim)) for _ in range(self.vector_size())]
+
+    def set_vector(self, val):
+        self.set(val)
+
+    def get_vector(self):
+        return self._val
+
+    def dim(self):
+        return self._dim
+
+    def free_size(self):
+        return self._free_dim
+
+    def vector_size(self):
+        return self._dim
+
+
 def set_free_offset(param, free_vec, offset):
     param.set_free(free_vec[offset:(offset + param.free_size())])
     return offset + param.free_size()
