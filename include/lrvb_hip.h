@@ -246,6 +246,17 @@ int lrvb_group_sums(lrvb_ctx* ctx, double* out);
 int lrvb_mixture_rows(lrvb_ctx* ctx, int32_t K, const double* theta_z, const double* Lam,
                       double* val2_out, double* gfree_out, double* S64_out, double* R_out);
 
+/* Schur complement of the mixture's global (Dirichlet) block onto itself, assembled on the device:
+ *   H_out = diag(scale) Hgg diag(scale) + diag(diag_add) - sym(Jlam^T Rm Jlam),
+ * Rm[(j K + k), (j' K + k')] = R[(j q + j'), (k K + k')], n = q K.  R is the (q^2 x K^2) operand of
+ * lrvb_mixture_rows (after the all-reduce over shards when there is one); NULL = the result of the last
+ * lrvb_mixture_rows call on this context, still resident.  Jlam (n x n) = d vec(Lam) / d free with rows
+ * ordered (j, k); Hgg (n x n) the global block without the Schur term; scale / diag_add (n, nullable)
+ * the free-coordinate chain rule of a box block (LRVB/Parameters.py:397-424).  Two n^3 MFMA GEMMs
+ * replace the host contraction the reference would do with sparse Jacobian lists.  All host pointers. */
+int lrvb_mixture_schur(lrvb_ctx* ctx, int32_t K, int32_t q, const double* R, const double* Jlam,
+                       const double* Hgg, const double* scale, const double* diag_add, double* H_out);
+
 /* Gram matrix G^T G (D x D, free coordinates) of the per-observation gradients
  * g_n[k] = 1/2 z_n^T M_k z_n + c_k (K = V matrices, one per vector coordinate): the Kronecker rows
  * z_n (x) z_n are generated on chip and contracted on the fp64 matrix cores; G (N x D) is never

@@ -986,6 +986,7 @@ extern "C" int lrvb_mixture_rows(lrvb_ctx* c, int32_t K, const double* theta_z, 
     const i64 KP = (i64)K * (K + 1) / 2, QP = (i64)(V + 1) * (V + 2) / 2;
     const i64 lda = KP + (KP & 1), ldk = QP + (QP & 1);
     DevBuf &thz = c->mx_theta, &lam = c->mx_lam, &Amat = c->mx_A, &U = c->mx_U, &gfr = c->mx_g, &Xk = c->mx_Xk, &Rd = c->mx_R;
+    c->mx_res_K = c->mx_res_q = 0;
     int st = buf_reserve(c, thz, (size_t)(N * KM));
     if (st == LRVB_OK) st = buf_reserve(c, lam, (size_t)((V + 1) * K));
     if (st == LRVB_OK) st = buf_reserve(c, Amat, (size_t)(N * lda));
@@ -1021,8 +1022,67 @@ extern "C" int lrvb_mixture_rows(lrvb_ctx* c, int32_t K, const double* theta_z, 
         if (st == LRVB_OK) st = buf_reserve(c, Amat, (size_t)(QQ * KK));
         if (st == LRVB_OK) st = launch_mixture_expand(c, Rd.p, lda, V + 1, K, Amat.p);
         if (st == LRVB_OK) st = d2h(c, R_out, Amat.p, (size_t)(QQ * KK));
+        if (st == LRVB_OK) { c->mx_res_K = K; c->mx_res_q = V + 1; }
     }
     return st;
+}
+
+// ---- Schur complement of the mixture's global block, assembled on the device -------------------------
+// Rm[(j K + k), (j' K + k')] = R[(j q + j'), (k K + k')]: the (q^2 x K^2) operand re-indexed as the square
+// matrix that sits between d vec(Lam) / d free and its transpose
+__global__ void mixture_permute_kernel(i64 total, int q, int K, const double* __restrict__ R, double* __restrict__ Rm)
+{
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const i64 n = (i64)q * K;
+    const i64 r = e / n, cc = e - r * n;
+    const int j = (int)(r / K), k = (int)(r - (i64)j * K), jp = (int)(cc / K), kp = (int)(cc - (i64)jp * K);
+    Rm[e] = R[((i64)j * q + jp) * ((i64)K * K) + (i64)k * K + kp];
+}
+// H = diag(s) Hgg diag(s) + diag(d) - 1/2 (S + S^T)
+__global__ void mixture_schur_finish_kernel(i64 total, i64 n, const double* __restrict__ Hgg, const double* __restrict__ sc,
+                                            const double* __restrict__ dg, const double* __restrict__ S, double* __restrict__ H)
+{
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const i64 r = e / n, cc = e - r * n;
+    double v = Hgg[e];
+    if (sc) v *= sc[r] * sc[cc];
+    if (dg && r == cc) v += dg[r];
+    H[e] = v - 0.5 * (S[e] + S[cc * n + r]);
+}
+
+extern "C" int lrvb_mixture_schur(lrvb_ctx* c, int32_t K, int32_t q, const double* R, const double* Jlam, const double* Hgg,
+                                  const double* scale, const double* diag_add, double* H_out) {
+    LRVB_TRY(ctx_bind(c));
+    if (!Jlam || !Hgg || !H_out) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    if (K < 1 || q < 1 || (i64)K * q > 8192) LRVB_FAIL(LRVB_ERR_INVALID, "K, q out of range");
+    const i64 n = (i64)K * q, nn = n * n;
+    DevBuf &Rfull = c->mx_A, &Rm = c->mx_Xk, &Jd = c->mx_U, &T = c->mx_R, &Hd = c->mx_g;
+    if (R) {
+        LRVB_TRY(buf_reserve(c, Rfull, (size_t)nn));
+        LRVB_TRY(h2d(c, Rfull.p, R, (size_t)nn));
+        c->mx_res_K = K; c->mx_res_q = q;
+    } else if (c->mx_res_K != K || c->mx_res_q != q) {
+        LRVB_FAIL(LRVB_ERR_STATE, "R is NULL and no lrvb_mixture_rows result of this shape is resident");
+    }
+    LRVB_TRY(buf_reserve(c, Rm, (size_t)nn));
+    EW(mixture_permute_kernel, nn, (int)q, (int)K, Rfull.p, Rm.p);
+    LRVB_TRY(buf_reserve(c, Jd, (size_t)nn));
+    LRVB_TRY(h2d(c, Jd.p, Jlam, (size_t)nn));
+    LRVB_TRY(buf_reserve(c, T, (size_t)nn));
+    LRVB_TRY(gemm_tn(c, n, n, n, Rm.p, Jd.p, T.p));              // T = Rm^T J (Rm is symmetric up to rounding)
+    LRVB_TRY(gemm_tn(c, n, n, n, Jd.p, T.p, Rm.p));              // S = J^T T, into the dead Rm
+    // Hgg, scale and diag go through the Hessian scratch
+    LRVB_TRY(buf_reserve(c, Hd, (size_t)(nn)));
+    LRVB_TRY(buf_reserve(c, c->Hfree, (size_t)(nn + 2 * n)));
+    LRVB_TRY(h2d(c, Hd.p, Hgg, (size_t)nn));
+    double* sc = nullptr; double* dg = nullptr;
+    if (scale) { sc = c->Hfree.p + nn; LRVB_TRY(h2d(c, sc, scale, (size_t)n)); }
+    if (diag_add) { dg = c->Hfree.p + nn + n; LRVB_TRY(h2d(c, dg, diag_add, (size_t)n)); }
+    EW(mixture_schur_finish_kernel, nn, n, (const double*)Hd.p, (const double*)sc, (const double*)dg, (const double*)Rm.p, c->Hfree.p);
+    LRVB_TRY(d2h(c, H_out, c->Hfree.p, (size_t)nn));
+    return LRVB_OK;
 }
 
 // Gram matrix of per-observation gradients g_n[k] = 1/2 z_n^T M_k z_n + c_k, in FREE coordinates:

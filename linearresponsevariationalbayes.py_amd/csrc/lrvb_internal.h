@@ -76,6 +76,7 @@ struct lrvb_ctx {
     int  stagger_shift = -1;            // timing lab: delay blocks whose queue position has this bit set
     int  dbg_bits = 0;                  // timing-lab variants of the weighted-SYRK kernel (wrong results)
     bool force_generic_wsyrk = false;   // tuning/testing: use the register-staged kernel
+    int  mx_res_K = 0, mx_res_q = 0;    // shape of the expanded mixture operand R resident in mx_A (0 = none)
     int  force_dense_rows = 0;          // tuning/testing: mixture rows always take the dense factorisation
     int pass_grid = 0;
 

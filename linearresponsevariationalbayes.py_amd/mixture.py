@@ -206,31 +206,16 @@ class MixtureObjective(object):
         _, g_vec, Hgg = self._global_terms(alpha, beta, C)
         q = V + 1
         jg = eta_g - self._lb                                 # d alpha / d free (= d2 alpha / d free2)
-        Hgg_free = Hgg * jg[:, None] * jg[None, :] + np.diag(g_vec * jg)
-        # Schur term  DLam^T Rm DLam  with  Rm[(j,k),(j',k')] = R[(j,j'),(k,k')].  d vec(Lam) / d free is block
-        # sparse -- row (0, k) depends on pi only, row (j >= 1, k) on column k of phi only -- so the product is
-        # three small contractions (~3e7 flops at K = 32, V = 31) instead of two dense (K (V+1))^3 GEMMs
-        # R[(j,j'),(k,k')] is symmetric in both index pairs (it is expanded from packed triangles), so
-        # Rm is symmetric as it stands.  Work on Rb[k, k', j, j']: every step is a batched BLAS matmul.
-        Rb = np.ascontiguousarray(R.T).reshape(K, K, q, q)
-        p1a, p1b = special.polygamma(1, alpha), special.polygamma(1, beta)
-        Dpi = (np.diag(p1a) - special.polygamma(1, np.sum(alpha))) * jg[self._ipi][None, :]            # [k, a]
-        Dphi = np.empty((K, V, V))                                                                    # [k, j, v]
-        for k in range(K):
-            Dphi[k] = (np.diag(p1b[:, k]) - special.polygamma(1, np.sum(beta[:, k]))) * jg[self._iphi[:, k]][None, :]
-        schur = np.zeros((self.n_global, self.n_global))
-        ipi, cols = self._ipi, self._iphi.ravel()                             # cols: (v, k) in C order
-        schur[np.ix_(ipi, ipi)] = Dpi.T @ Rb[:, :, 0, 0] @ Dpi
-        T1 = np.matmul(Rb[:, :, 0, 1:].transpose(1, 0, 2), Dphi)              # [k', k, v'] = sum_j' R[0,j',k,k'] Dphi[k'][j',v']
-        Spf = np.matmul(Dpi.T[None, :, :], T1).transpose(1, 2, 0).reshape(K, V * K)     # [a, (v', k')]
-        schur[np.ix_(ipi, cols)] = Spf
-        schur[np.ix_(cols, ipi)] = Spf.T
-        A2 = np.matmul(np.matmul(Dphi.transpose(0, 2, 1)[:, None], Rb[:, :, 1:, 1:]), Dphi[None, :])   # [k, k', v, v']
-        schur[np.ix_(cols, cols)] = A2.transpose(2, 0, 3, 1).reshape(V * K, V * K)
-        schur = 0.5 * (schur + schur.T)
+        # Schur term  DLam^T Rm DLam  with  Rm[(j,k),(j',k')] = R[(j,j'),(k,k')], and the free-coordinate chain
+        # rule of the lower-bounded boxes, on the device: two (K q)^3 MFMA GEMMs (lrvb_mixture_schur).  R is
+        # taken from the device when this process's own rows produced it, from the host after an all-reduce.
+        own = self._external_stats is None
+        HS = self.ctx.mixture_schur(K, q, None if own else R, self._dlam(alpha, beta) * jg[None, :], Hgg,
+                                    scale=jg, diag_add=g_vec * jg)
         if return_parts:
-            return Hgg_free - schur, Hgg_free, schur
-        return Hgg_free - schur
+            Hgg_free = Hgg * jg[:, None] * jg[None, :] + np.diag(g_vec * jg)
+            return HS, Hgg_free, Hgg_free - HS
+        return HS
 
     def global_cov(self, free_val, moment_jac=None):
         """Linear-response covariance  M H_S^-1 M^T  of moments of the Dirichlet parameters whose

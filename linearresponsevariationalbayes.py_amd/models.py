@@ -253,6 +253,27 @@ class DeviceContext(object):
                                                _hip.ptr(gfree), _hip.ptr(S64), _hip.ptr(R)))
         return val2, gfree, S64, R
 
+    def mixture_schur(self, K, q, R, jlam, hgg, scale=None, diag_add=None):
+        """H = diag(scale) hgg diag(scale) + diag(diag_add) - sym(jlam^T Rm jlam) on the device (lrvb_mixture_schur);
+        R=None uses the operand the last mixture_rows call left on the device."""
+        n = int(K) * int(q)
+        jlam, hgg = _hip.as_f64(jlam), _hip.as_f64(hgg)
+        if jlam.shape != (n, n) or hgg.shape != (n, n):
+            raise ValueError('expected {0} x {0} matrices'.format(n))
+        if R is not None:
+            R = _hip.as_f64(R)
+            if R.shape != (q * q, K * K):
+                raise ValueError('expected R of shape {}'.format((q * q, K * K)))
+        scale = None if scale is None else _hip.as_f64(scale).ravel()
+        diag_add = None if diag_add is None else _hip.as_f64(diag_add).ravel()
+        for v in (scale, diag_add):
+            if v is not None and v.size != n:
+                raise ValueError('expected vectors of length {}'.format(n))
+        out = np.empty((n, n))
+        _hip.check(self._lib.lrvb_mixture_schur(self._h, int(K), int(q), _hip.ptr(R), _hip.ptr(jlam), _hip.ptr(hgg),
+                                                _hip.ptr(scale), _hip.ptr(diag_add), _hip.ptr(out)))
+        return out
+
     def set_groups(self, gid, n_groups):
         g = np.ascontiguousarray(gid, dtype=np.int32).ravel()
         _hip.check(self._lib.lrvb_set_groups(self._h, g.ctypes.data_as(ctypes.c_void_p), g.size, int(n_groups)))

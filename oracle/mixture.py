@@ -40,3 +40,21 @@ def mixture_rows(theta_z, X, w, Lam):
     U[:, 32:32 + K] = Z
     S64 = U.T @ (w[:, None] * U)
     return val2, gfree, Hloc, S64, R
+
+
+def mixture_schur(K, q, R, jlam, hgg, scale=None, diag_add=None):
+    """Schur complement of the global block: diag(scale) hgg diag(scale) + diag(diag_add) - sym(jlam^T Rm jlam)
+    with Rm[(j K + k), (j' K + k')] = R[(j q + j'), (k K + k')].  This is the reference's
+    H_free = J^T H_vec J + sum_k (df/d eta_k) d2 eta_k (LRVB/Parameters.py:397-424) applied to the
+    block that remains after eliminating the per-observation simplex rows (doc/sensitivity.lyx)."""
+    n = K * q
+    R = np.asarray(R, dtype=np.float64).reshape(q, q, K, K)
+    Rm = R.transpose(0, 2, 1, 3).reshape(n, n)
+    jlam = np.asarray(jlam, dtype=np.float64)
+    S = jlam.T @ Rm @ jlam
+    H = np.array(hgg, dtype=np.float64)
+    if scale is not None:
+        H = H * np.asarray(scale)[:, None] * np.asarray(scale)[None, :]
+    if diag_add is not None:
+        H = H + np.diag(np.asarray(diag_add))
+    return H - 0.5 * (S + S.T)

@@ -75,6 +75,38 @@ def test_schur_complement_matches_ad(vb, N, V, K):
     assert rel_err(fun.global_cov(theta, M), M @ np.linalg.inv(HS_ad) @ M.T) < 1e-6
 
 
+@pytest.mark.parametrize('K,q', [(2, 3), (3, 5), (5, 4), (8, 16), (32, 32)])
+def test_device_schur_assembly_matches_oracle(vb, K, q):
+    """lrvb_mixture_schur against oracle.mixture_schur: odd sizes take the generic GEMM, (8, 16) and (32, 32)
+    the LDS-DMA MFMA kernel; R from the host and R left on the device by lrvb_mixture_rows."""
+    rng = np.random.default_rng(K * 100 + q)
+    n = K * q
+    B = rng.normal(size=(q * q, 7)); C = rng.normal(size=(K * K, 7))
+    R = B @ C.T
+    R4 = R.reshape(q, q, K, K)
+    R = (R4 + R4.transpose(1, 0, 2, 3) + R4.transpose(0, 1, 3, 2) + R4.transpose(1, 0, 3, 2)).reshape(q * q, K * K)
+    J = rng.normal(size=(n, n)) * (rng.random((n, n)) < 0.3)
+    Hgg = rng.normal(size=(n, n)); Hgg = Hgg + Hgg.T
+    sc, dg = rng.uniform(0.5, 2.0, n), rng.normal(size=n)
+    ctx = vb.DeviceContext([dict(kind=0, free_size=n, vec_size=n, dim0=n, dim1=0, lb=-np.inf, ub=np.inf)], quad_kind=1)
+    for scale, diag in ((sc, dg), (None, None), (sc, None)):
+        got = ctx.mixture_schur(K, q, R, J, Hgg, scale=scale, diag_add=diag)
+        want = om.mixture_schur(K, q, R, J, Hgg, scale, diag)
+        assert rel_err(got, want) < 1e-13
+        assert np.array_equal(got, got.T)                  # symmetrised on the device, exactly
+    # R uploaded once stays resident: NULL reuses it
+    assert np.array_equal(ctx.mixture_schur(K, q, None, J, Hgg, scale=sc, diag_add=dg),
+                          ctx.mixture_schur(K, q, R, J, Hgg, scale=sc, diag_add=dg))
+    # a fresh context has nothing resident, and a resident operand of another shape is refused
+    ctx2 = vb.DeviceContext([dict(kind=0, free_size=n, vec_size=n, dim0=n, dim1=0, lb=-np.inf, ub=np.inf)], quad_kind=1)
+    with pytest.raises(RuntimeError):
+        ctx2.mixture_schur(K, q, None, J, Hgg)
+    with pytest.raises(RuntimeError):
+        ctx.mixture_schur(q, K, None, J, Hgg) if K != q else ctx2.mixture_schur(q, K, None, J, Hgg)
+    with pytest.raises(ValueError):
+        ctx.mixture_schur(K, q, R, J[:-1], Hgg)
+
+
 def test_saturated_responsibilities(vb):
     """Rows whose responsibilities sit at a vertex (p ~ 1e-12 here; the unscaled H_nn of the reference
     is then singular to rounding).  The oracle follows the reference's unscaled algebra, so agreement

@@ -17,9 +17,18 @@ def make_par(N, V, K, lb=0.0):
     return par
 
 
+class OracleSchurCtx(object):
+    """Stands in for DeviceContext.mixture_schur (the CPU suite has no device): the oracle's restatement."""
+
+    def mixture_schur(self, K, q, R, jlam, hgg, scale=None, diag_add=None):
+        assert R is not None, 'the shell always installs reduced statistics'
+        return om.mixture_schur(K, q, R, jlam, hgg, scale, diag_add)
+
+
 def shell(par, x, K, a0, b0):
-    """A MixtureObjective without a device context: statistics come from the oracle."""
+    """A MixtureObjective without a device context: statistics and the Schur assembly come from the oracle."""
     f = vb.MixtureObjective.__new__(vb.MixtureObjective)
+    f.ctx = OracleSchurCtx()
     N, V = x.shape
     f.par, f.n_obs, f.V, f.K, f.n_global = par, N, V, K, K + V * K
     vi = par.vector_indices_dict

@@ -19,6 +19,6 @@ for rep in range(3):
     t0 = time.perf_counter(); stats = fun.local_stats(theta); t1 = time.perf_counter()
     print('local_stats (rows + kron + GEMM + Gram, host in/out): %.1f ms' % ((t1 - t0) * 1e3), flush=True)
 t0 = time.perf_counter(); HS = fun.global_hessian(theta); t1 = time.perf_counter()
-print('global_hessian (device pipeline + host Schur assembly, D_g = %d): %.1f ms' % (fun.n_global, (t1 - t0) * 1e3))
+print('global_hessian (device rows + device Schur assembly, D_g = %d): %.1f ms' % (fun.n_global, (t1 - t0) * 1e3))
 t0 = time.perf_counter(); cov = fun.global_cov(theta); t1 = time.perf_counter()
 print('global_cov: %.1f ms; min eig H_S %.3e' % ((t1 - t0) * 1e3, np.linalg.eigvalsh(HS).min()))
