@@ -166,8 +166,10 @@ class LMMObjective(object):
                      - _gamma_entropy(q['ay'], q['by']) - _gamma_entropy(q['am'], q['bm']))
 
     def _arrow(self, eta, kron_block=True):
-        """Gradient (V,), global Hessian block (ng, ng), cross block (ng, 2G) and the diagonal of
-        the local block (2G,) in vector coordinates."""
+        """Gradient (V,), global Hessian block (ng, ng), cross block and the diagonal of the local block
+        (2G,) in vector coordinates.  Only the mean of q(beta) and the five scalar parameters couple to the
+        group effects, so the cross block is returned row-sparse: (rows (p + 5,), values (p + 5, 2G)) --
+        the dense (ng, 2G) matrix would be 160 MB of zeros at G = 1e4."""
         p, G, ng = self.p, self.G, self.n_global
         q = self._pieces(eta)
         ty, tm, Ly, Lm, rg, Ay, Am = self._scalars(q)
@@ -176,7 +178,9 @@ class LMMObjective(object):
         V = eta.size
         g = np.zeros(V)
         Hgg = np.zeros((ng, ng))
-        Hgl = np.zeros((ng, 2 * G))
+        xrows = np.concatenate([np.arange(self._ms.start, self._ms.stop),
+                                [self._iem, self._iay, self._iby, self._iam, self._ibm]])
+        Hx = np.zeros((p + 5, 2 * G))
         um = q['Sxx'] @ m - q['Sxy'] + sxg.T @ eg
         C = ty * q['Sxx'] + self.lam0
         Gc = P @ C @ P
@@ -221,26 +225,27 @@ class LMMObjective(object):
         Hgg[np.ix_([iam, ibm], [iam, ibm])] = Hm_
         # cross block: columns [e_1..e_G | i_1..i_G]
         ce, ci = slice(0, G), slice(G, 2 * G)
-        Hgl[ms, ce] = ty * sxg.T
-        Hgl[iem, ce] = -tm
-        Hgl[iay, ce] = (Wg * eg - rg) * tay
-        Hgl[iby, ce] = (Wg * eg - rg) * tby
-        Hgl[iam, ce] = (eg - q['e_mu']) * tam
-        Hgl[ibm, ce] = (eg - q['e_mu']) * tbm
-        Hgl[iay, ci] = -0.5 * Wg / ig ** 2 * tay
-        Hgl[iby, ci] = -0.5 * Wg / ig ** 2 * tby
-        Hgl[iam, ci] = -0.5 / ig ** 2 * tam
-        Hgl[ibm, ci] = -0.5 / ig ** 2 * tbm
+        rem, ray, rby, ram, rbm = p, p + 1, p + 2, p + 3, p + 4
+        Hx[:p, ce] = ty * sxg.T
+        Hx[rem, ce] = -tm
+        Hx[ray, ce] = (Wg * eg - rg) * tay
+        Hx[rby, ce] = (Wg * eg - rg) * tby
+        Hx[ram, ce] = (eg - q['e_mu']) * tam
+        Hx[rbm, ce] = (eg - q['e_mu']) * tbm
+        Hx[ray, ci] = -0.5 * Wg / ig ** 2 * tay
+        Hx[rby, ci] = -0.5 * Wg / ig ** 2 * tby
+        Hx[ram, ci] = -0.5 / ig ** 2 * tam
+        Hx[rbm, ci] = -0.5 / ig ** 2 * tbm
         dl = np.concatenate([dloc, dloc / ig ** 3 - 0.5 / ig ** 2])
-        return g, Hgg, Hgl, dl
+        return g, Hgg, (xrows, Hx), dl
 
     def _dense_vec(self, eta):
-        g, Hgg, Hgl, dl = self._arrow(eta)
+        g, Hgg, (xrows, Hx), dl = self._arrow(eta)
         ng, V = self.n_global, eta.size
         H = np.zeros((V, V))
         H[:ng, :ng] = Hgg
-        H[:ng, ng:] = Hgl
-        H[ng:, :ng] = Hgl.T
+        H[xrows, ng:] = Hx
+        H[ng:, xrows] = Hx.T
         H[np.arange(ng, V), np.arange(ng, V)] = dl
         return g, H
 
@@ -278,19 +283,24 @@ class LMMObjective(object):
         from .objectives import get_sparse_sub_hessian, get_sparse_sub_matrix
         free_val = _hip.as_f64(free_val).ravel()
         eta = self.ctx.constrain(free_val)
-        g, Hgg, Hgl, dl = self._arrow(eta)
+        g, Hgg, (xrows, Hx), dl = self._arrow(eta)
         ng, G, D = self.n_global, self.G, free_val.size
         self.global_hessian(free_val)                       # builds the global-block packing context
         Hgg_free = self._gctx.free_hessian_from_vector(free_val[:ng], g[:ng], Hgg)
-        Jg = self._gctx.free_to_vector_jac(free_val[:ng])
         ig = eta[self._is]
         jl = np.concatenate([np.ones(G), ig])
         dl_free = dl * jl ** 2 + np.concatenate([np.zeros(G), g[self._is] * ig])
-        cross = (Jg.T @ Hgl) * jl[None, :]
+        # the coupled rows have element-wise packing maps (identity / exp): their rows of J are diagonal
+        jrow = self._global_jac_diag(free_val[:ng])[xrows]
+        cross = (jrow[:, None] * Hx) * jl[None, :]
         gi, li = np.arange(ng), np.arange(ng, D)
         H = get_sparse_sub_hessian(Hgg_free, gi, D)
-        H = H + get_sparse_sub_matrix(cross, gi, li, D, D) + get_sparse_sub_matrix(cross.T, li, gi, D, D)
+        H = H + get_sparse_sub_matrix(cross, xrows, li, D, D) + get_sparse_sub_matrix(cross.T, li, xrows, D, D)
         return (H + sp_sparse.diags(np.concatenate([np.zeros(ng), dl_free]), format='csr')).tocsr()
+
+    def _global_jac_diag(self, free_g):
+        """Diagonal of d eta_g / d free_g from the device packing Jacobian of the global block."""
+        return np.diag(self._gctx.free_to_vector_jac(free_g)).copy()
 
     # ---- arrow structure: Schur complement onto the global block, free coordinates --------------------
     def global_hessian(self, free_val):
@@ -298,7 +308,7 @@ class LMMObjective(object):
         matrix whose inverse is the linear-response covariance block of the global parameters."""
         free_val = _hip.as_f64(free_val).ravel()
         eta = self.ctx.constrain(free_val)
-        g, Hgg, Hgl, dl = self._arrow(eta, kron_block=False)
+        g, Hgg, (rows, Hx), dl = self._arrow(eta, kron_block=False)
         Gc, P = self._kron_factors
         ng, G = self.n_global, self.G
         # packing of the global block through a layout that covers only the global parameters
@@ -328,10 +338,9 @@ class LMMObjective(object):
         dl_free = dl * jl ** 2 + np.concatenate([np.zeros(G), g[self._is] * ig])
         # only the mean of q(beta) and the five scalar parameters couple to the group effects; their packing
         # maps are element-wise (identity / exp), so the free cross block is a row scaling of those rows
-        rows = np.flatnonzero(np.any(Hgl != 0.0, axis=1))
         assert not np.any((rows >= self._ls.start) & (rows < self._ls.stop))
-        jrow = np.diag(gc.free_to_vector_jac(free_val[:ng]))[rows]      # those rows of J are diagonal
-        cross = (jrow[:, None] * Hgl[rows]) * jl[None, :]
+        jrow = self._global_jac_diag(free_val[:ng])[rows]               # those rows of J are diagonal
+        cross = (jrow[:, None] * Hx) * jl[None, :]
         HS = Hgg_free
         HS[np.ix_(rows, rows)] -= (cross / dl_free[None, :]) @ cross.T
         return HS

@@ -61,7 +61,9 @@ def test_arrow_hessian_matches_ad(p, G, N):
     np.testing.assert_allclose(g, g_ad, rtol=0, atol=1e-10 * np.max(np.abs(g_ad)))
     np.testing.assert_allclose(H, H_ad, rtol=0, atol=1e-10 * np.max(np.abs(H_ad)))
     # Schur complement algebra in vector coordinates: inverse of H restricted to the global block
-    _, Hgg, Hgl, dl = f._arrow(eta)
+    _, Hgg, (xrows, Hx), dl = f._arrow(eta)          # cross block row-sparse: p + 5 coupled rows
     ng = f.n_global
-    schur = Hgg - (Hgl / dl[None, :]) @ Hgl.T
+    assert xrows.size == p + 5 and Hx.shape == (p + 5, 2 * G)
+    schur = Hgg.copy()
+    schur[np.ix_(xrows, xrows)] -= (Hx / dl[None, :]) @ Hx.T
     np.testing.assert_allclose(np.linalg.inv(schur), np.linalg.inv(H_ad)[:ng, :ng], rtol=1e-8, atol=1e-10)
