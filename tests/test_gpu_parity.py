@@ -350,6 +350,63 @@ def test_full_size_properties_headline_shape(vb):
     assert torch.equal(G, G.T) and torch.linalg.eigvalsh(G).min().item() > -1e-9 * G.abs().max().item()
 
 
+def test_more_than_2_31_matrix_elements(vb):
+    """Maximum sizes: N x D = 2.2e6 x 1024 = 2.25e9 doubles (18 GB) -- element offsets no longer fit in
+    32 bits.  Size-independent checks: additivity over a row split (each half indexes below 2^31), the last
+    rows of the per-observation gradient against torch, H v == HVP, and the blocked CG against a dense solve."""
+    import torch
+    N, P = 2_200_000, 1024
+    assert N * P > 2 ** 31
+    dev = torch.device('cuda', 0)
+    g = torch.Generator(device=dev); g.manual_seed(77)
+    X = torch.randn((N, P), dtype=torch.float64, device=dev, generator=g) / P ** 0.5
+    beta = torch.randn((P,), dtype=torch.float64, device=dev, generator=g)
+    yv = (torch.sigmoid(X @ beta) > torch.rand((N,), dtype=torch.float64, device=dev, generator=g)).double()
+    w = torch.rand((N,), dtype=torch.float64, device=dev, generator=g) + 0.5
+    theta = 0.3 * torch.randn((P,), dtype=torch.float64, device=dev, generator=g)
+    blocks = [dict(kind=0, free_size=P, vec_size=P, dim0=P, dim1=0, lb=-np.inf, ub=np.inf)]
+
+    def make(r0, r1, prior):
+        ctx = vb.DeviceContext(blocks, loss='logistic', n_obs=r1 - r0, n_cols=P, quad_kind=vb._hip.QUAD_DIAG)
+        ctx.set_data_dev(0, X[r0:r1].data_ptr(), r1 - r0, P)
+        ctx.set_data_dev(1, yv[r0:r1].data_ptr(), r1 - r0, 1)
+        ctx.set_weights_dev(w[r0:r1].data_ptr(), r1 - r0)
+        ctx.set_data(vb._hip.SLOT_QUAD_A, np.full(P, prior))
+        return ctx
+
+    def hessian(ctx):
+        H = torch.empty((P, P), dtype=torch.float64, device=dev)
+        ctx.hessian_dev(theta.data_ptr(), H.data_ptr(), P); ctx.sync()
+        return H
+
+    n1 = 1_100_003
+    full, top, bottom = make(0, N, 1.0), make(0, n1, 1.0), make(n1, N, 0.0)
+    H = hessian(full)
+    Hsum = hessian(top) + hessian(bottom)
+    scale = H.abs().max().item()
+    assert torch.equal(H, H.T)
+    assert (H - Hsum).abs().max().item() < 1e-12 * scale
+    th = theta.cpu().numpy()
+    v_full, v_parts = full.value(th), top.value(th) + bottom.value(th)
+    assert abs(v_full - v_parts) < 1e-12 * abs(v_full)
+    g_full, g_parts = full.grad(th), top.grad(th) + bottom.grad(th)
+    assert rel_err(g_full, g_parts) < 1e-12
+    # rows at the far end of the matrix (element offsets above 2^31)
+    z = X[N - 7:] @ theta
+    l1 = torch.sigmoid(z) - yv[N - 7:]                     # d2 f / d theta d w_n carries no weight
+    assert rel_err(full.obs_grad(th, N - 7, N), (l1[:, None] * X[N - 7:]).cpu().numpy()) < 1e-12
+    # Hessian-vector products, one vector and a block of them through CG
+    vv = torch.randn((P,), dtype=torch.float64, device=dev, generator=g)
+    out = torch.empty_like(vv)
+    full.hvp_dev(theta.data_ptr(), vv.data_ptr(), out.data_ptr()); full.sync()
+    assert (out - H @ vv).abs().max().item() < 1e-11 * (H @ vv).abs().max().item()
+    B = torch.randn((3, P), dtype=torch.float64, device=dev, generator=g)
+    Xs, info, iters = full.cg_solve_multi(th, B.cpu().numpy(), tol=1e-10)
+    assert np.all(info == 0)
+    want = torch.linalg.solve(H, B.T).T.cpu().numpy()
+    assert rel_err(Xs, want) < 1e-8
+
+
 @pytest.mark.parametrize('N,P', [(1, 1), (3, 2), (15, 7), (16, 16), (17, 33), (100, 64), (129, 65), (1000, 127), (700, 129)])
 def test_edge_shapes(vb, N, P):
     """Ragged sizes around every internal granule: 16-row stages, 32/64-column narrow kernels, the
