@@ -93,24 +93,36 @@ void hvp_multi_kernel(const double* __restrict__ X, int Preal, i64 N, const doub
         d4 tp = (d4){0.0, 0.0, 0.0, 0.0};
         const double* arow = Xs + (l15 & 7) * STRIDE + pc0 + 8 * l4;
         // (MFMA rows 8..15 are padding: lanes with l15 >= 8 re-read rows 0..7, which only feeds the unused half of T)
+        // fragments of block b + 1 are read while the 8 MFMAs of block b run (explicit register double buffer;
+        // left to itself hipcc issues one 16-byte read, waits for it, and feeds two MFMAs: half the MFMA rate)
+        d2 fr[2][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fr[0][i] = *reinterpret_cast<const d2*>(arow + 2 * i);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const d2 v0 = *reinterpret_cast<const d2*>(arow + 32 * b);
-            const d2 v1 = *reinterpret_cast<const d2*>(arow + 32 * b + 2);
-            const d2 v2 = *reinterpret_cast<const d2*>(arow + 32 * b + 4);
-            const d2 v3 = *reinterpret_cast<const d2*>(arow + 32 * b + 6);
-            const double af[8] = {v0[0], v0[1], v1[0], v1[1], v2[0], v2[1], v3[0], v3[1]};
+            const int cur = b & 1;
+            if (b + 1 < NB) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fr[cur ^ 1][i] = *reinterpret_cast<const d2*>(arow + 32 * (b + 1) + 2 * i);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < 8; ++t)
-                tp = __builtin_amdgcn_mfma_f64_16x16x4f64(af[t], uf[b][t], tp, 0, 0, 0);
+                tp = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[cur][t >> 1][t & 1], uf[b][t], tp, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         // ---- the four partial tiles meet in LDS; every wave leaves with the full T, scaled by c ----------
         Tpart[(wave * 2 + 0) * 64 + lane] = tp[0];             // rows l4       (register 0)
         Tpart[(wave * 2 + 1) * 64 + lane] = tp[1];             // rows l4 + 4   (register 1)
-        __syncthreads();
-        double t0 = 0.0, t1 = 0.0;
+        // LDS traffic only: a __syncthreads() here makes hipcc drain vmcnt(0) as well, i.e. wait for the NEXT
+        // chunk's LDS-DMA in the middle of this one -- the prefetch would overlap step A and nothing else
+        __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        double pa[4], pb[4];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) { t0 += Tpart[(w * 2 + 0) * 64 + lane]; t1 += Tpart[(w * 2 + 1) * 64 + lane]; }
+        for (int w = 0; w < 4; ++w) { pa[w] = Tpart[(w * 2 + 0) * 64 + lane]; pb[w] = Tpart[(w * 2 + 1) * 64 + lane]; }
+        __builtin_amdgcn_sched_barrier(0);                    // all eight reads in flight before the first add
+        double t0 = ((pa[0] + pa[1]) + pa[2]) + pa[3], t1 = ((pb[0] + pb[1]) + pb[2]) + pb[3];
         t0 *= c0; t1 *= c1;
         if (TONLY) {
             if (wave == 0 && l15 < Q) {
@@ -126,14 +138,22 @@ void hvp_multi_kernel(const double* __restrict__ X, int Preal, i64 N, const doub
         // one 16-byte read feeds two tiles: tile m takes the columns pc0 + 32 (m >> 1) + 2 i + (m & 1)
         const double* brow0 = Xs + l4 * STRIDE + pc0 + 2 * l15;
         const double* brow1 = brow0 + 4 * STRIDE;
+        d2 xr[2][2];
+        xr[0][0] = *reinterpret_cast<const d2*>(brow0);
+        xr[0][1] = *reinterpret_cast<const d2*>(brow1);
 #pragma unroll
         for (int h = 0; h < NT / 2; ++h) {
-            const d2 x0 = *reinterpret_cast<const d2*>(brow0 + 32 * h);
-            const d2 x1 = *reinterpret_cast<const d2*>(brow1 + 32 * h);
-            acc[2 * h]     = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[0], t0, acc[2 * h], 0, 0, 0);
-            acc[2 * h + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[1], t0, acc[2 * h + 1], 0, 0, 0);
-            acc[2 * h]     = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[0], t1, acc[2 * h], 0, 0, 0);
-            acc[2 * h + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[1], t1, acc[2 * h + 1], 0, 0, 0);
+            const int cur = h & 1;
+            if (h + 1 < NT / 2) {
+                xr[cur ^ 1][0] = *reinterpret_cast<const d2*>(brow0 + 32 * (h + 1));
+                xr[cur ^ 1][1] = *reinterpret_cast<const d2*>(brow1 + 32 * (h + 1));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[2 * h]     = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[cur][0][0], t0, acc[2 * h], 0, 0, 0);
+            acc[2 * h + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[cur][0][1], t0, acc[2 * h + 1], 0, 0, 0);
+            acc[2 * h]     = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[cur][1][0], t1, acc[2 * h], 0, 0, 0);
+            acc[2 * h + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[cur][1][1], t1, acc[2 * h + 1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         buf ^= 1;
     }
