@@ -90,27 +90,41 @@ void hvp_multi_kernel(const double* __restrict__ X, int Preal, i64 N, const doub
         const double* Xs = lds + buf * (HM_ROWS * STRIDE);
 
         // ---- step A: partial T over this wave's columns ------------------------------------------------
-        d4 tp = (d4){0.0, 0.0, 0.0, 0.0};
-        const double* arow = Xs + (l15 & 7) * STRIDE + pc0 + 8 * l4;
-        // (MFMA rows 8..15 are padding: lanes with l15 >= 8 re-read rows 0..7, which only feeds the unused half of T)
-        // fragments of block b + 1 are read while the 8 MFMAs of block b run (explicit register double buffer;
-        // left to itself hipcc issues one 16-byte read, waits for it, and feeds two MFMAs: half the MFMA rate)
-        d2 fr[2][4];
+        // v_mfma_f64_4x4x4_4b: four independent 4 x 4 x 4 blocks per instruction, A lane = i + 4 blk + 16 k,
+        // B lane = j + 4 blk + 16 k, D lane = j + 4 blk + 16 i (tools/mfma_f64_4x4_probe.hip).  Block blk takes the
+        // vectors q = 4 blk + j, all four blocks the same four observations: one instruction per row group of four,
+        // two per k-step -- a 16 x 16 x 4 tile would spend half of its rows on padding (8-row chunks).
+        // The result lands as T[row = 4 rg + l4][q = l15], the layout step B wants.
+        const double* arow = Xs + (lane & 3) * STRIDE + pc0 + 8 * l4;
+        double tpa[2] = {0.0, 0.0}, tpb[2] = {0.0, 0.0};       // [row group]; even / odd k-steps on separate chains
+        // fragments of block b + 1 are read while the 16 MFMAs of block b run (explicit register double buffer)
+        d2 fr[2][8];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fr[0][i] = *reinterpret_cast<const d2*>(arow + 2 * i);
+        for (int i = 0; i < 4; ++i) {
+            fr[0][i] = *reinterpret_cast<const d2*>(arow + 2 * i);
+            fr[0][4 + i] = *reinterpret_cast<const d2*>(arow + 4 * STRIDE + 2 * i);
+        }
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const int cur = b & 1;
             if (b + 1 < NB) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) fr[cur ^ 1][i] = *reinterpret_cast<const d2*>(arow + 32 * (b + 1) + 2 * i);
+                for (int i = 0; i < 4; ++i) {
+                    fr[cur ^ 1][i] = *reinterpret_cast<const d2*>(arow + 32 * (b + 1) + 2 * i);
+                    fr[cur ^ 1][4 + i] = *reinterpret_cast<const d2*>(arow + 4 * STRIDE + 32 * (b + 1) + 2 * i);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int t = 0; t < 8; ++t)
-                tp = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[cur][t >> 1][t & 1], uf[b][t], tp, 0, 0, 0);
+            for (int t = 0; t < 8; t += 2) {
+                tpa[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(fr[cur][t >> 1][0], uf[b][t], tpa[0], 0, 0, 0);
+                tpa[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(fr[cur][4 + (t >> 1)][0], uf[b][t], tpa[1], 0, 0, 0);
+                tpb[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(fr[cur][t >> 1][1], uf[b][t + 1], tpb[0], 0, 0, 0);
+                tpb[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(fr[cur][4 + (t >> 1)][1], uf[b][t + 1], tpb[1], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
+        const double tp[2] = {tpa[0] + tpb[0], tpa[1] + tpb[1]};
         // ---- the four partial tiles meet in LDS; every wave leaves with the full T, scaled by c ----------
         Tpart[(wave * 2 + 0) * 64 + lane] = tp[0];             // rows l4       (register 0)
         Tpart[(wave * 2 + 1) * 64 + lane] = tp[1];             // rows l4 + 4   (register 1)

