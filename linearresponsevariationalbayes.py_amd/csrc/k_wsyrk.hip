@@ -22,6 +22,7 @@
 // With S_ij = sum_n c_n X_ni X_nj the contraction index k is the observation, so both
 // operands are read from the staged rows with the SAME (row = k, col = i or j) pattern.
 #include "lrvb_internal.h"
+#include <type_traits>
 #include <math.h>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -641,6 +642,15 @@ void atb_glds_kernel(const double* __restrict__ A, i64 lda, int PA, const double
 
     const int l15 = lane & 15, l4 = lane >> 4;
     const int wr = wave >> 1, wc = wave & 1;
+    // 16-column MFMA tiles of this wave's 64 x 64 block that hold at least one real column (wave-uniform)
+    int mt_a = (PA - bi * WS_TILE - wr * 64 + 15) / 16; mt_a = mt_a < 0 ? 0 : (mt_a > 4 ? 4 : mt_a);
+    int mt_b = (PB - bj * WS_TILE - wc * 64 + 15) / 16; mt_b = mt_b < 0 ? 0 : (mt_b > 4 ? 4 : mt_b);
+    mt_a = __builtin_amdgcn_readfirstlane(mt_a); mt_b = __builtin_amdgcn_readfirstlane(mt_b);
+    const bool full = (mt_a == 4) && (mt_b == 4);
+    // the chunk loop exists twice: interior workgroups run the unguarded copy (guards inside one loop made hipcc
+    // spill the accumulators)
+    auto run = [&](auto edge_tag) {
+    constexpr bool EDGE = decltype(edge_tag)::value;
     int buf = 0;
     for (int ch = 0; ch < nch; ++ch) {
         if (ch + 1 < nch) issue_stage(ch + 1, buf ^ 1);
@@ -666,17 +676,30 @@ void atb_glds_kernel(const double* __restrict__ A, i64 lda, int PA, const double
             __builtin_amdgcn_sched_barrier(0);
             if (kk + 1 < WS_KC / 4) read_frags(kk + 1, set ^ 1);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!EDGE) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+                for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int n = 0; n < 4; ++n)
-                    acc[m * 4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[m], bf[set][n], acc[m * 4 + n], 0, 0, 0);
+                    for (int n = 0; n < 4; ++n)
+                        acc[m * 4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[m], bf[set][n], acc[m * 4 + n], 0, 0, 0);
+            } else {
+                // ragged edge of the operand widths (e.g. 528 = 4 x 128 + 16 columns): MFMA tiles that lie wholly past
+                // the last column are skipped (wave-uniform), so an edge workgroup costs its loads and little else
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        if (m < mt_a && n < mt_b)
+                            acc[m * 4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[m], bf[set][n], acc[m * 4 + n], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): LDS-DMA of the stage has landed
         __syncthreads();
         buf ^= 1;
     }
+    };
+    if (full) run(std::false_type{}); else run(std::true_type{});
     double* out = partial + ((i64)split * T + t) * (i64)(WS_TILE * WS_TILE);
 #pragma unroll
     for (int m = 0; m < 4; ++m)
