@@ -280,11 +280,25 @@ def main():
             out['cpu_baseline'] = cpu_baseline(xs, ys, N_total, D, n_pos, args.loss, lik_info, prior_info,
                                                theta.cpu().numpy())
             # parity of the timed result on the sample's leading block (cheap sanity, not the test suite)
-    if rank == 0:
-        print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
+    return out if rank == 0 else None
+
+
+def run_with_clean_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries underneath write there too (RCCL prints a five-line
+    version banner to stdout when the first communicator comes up, on every rank), so file descriptor 1 points at
+    stderr while the bench runs and is restored only for the result line."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    out = main()
+    sys.stdout.flush()
+    if out is not None:                      # rank 0; the other ranks keep writing to stderr until they exit
+        os.dup2(saved, 1)
+        os.close(saved)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':
-    main()
+    run_with_clean_stdout()

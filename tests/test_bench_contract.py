@@ -38,3 +38,30 @@ def test_cpu_baseline_leg_on_a_small_sample():
     assert out['value'] > 0 and out['strong_numpy_value'] > 0 and 'rows' in out['sample']
     # the port really is the D-pass structure: it cannot beat the closed form on the same sample
     assert out['value'] <= out['strong_numpy_value'] * 1.5
+
+
+def test_stdout_carries_only_the_result_line(monkeypatch, capfd):
+    """Libraries underneath the bench (RCCL's version banner) write to file descriptor 1; the wrapper must
+    send all of that to stderr and put exactly the JSON line on stdout."""
+    import json
+    bench = _bench()
+
+    def noisy_main():
+        os.write(1, b'banner from a native library\n')           # what librccl does at communicator start-up
+        return {'metric': 'm', 'value': 1.0}
+
+    monkeypatch.setattr(bench, 'main', noisy_main)
+    bench.run_with_clean_stdout()
+    out, err = capfd.readouterr()
+    assert out.count('\n') == 1 and json.loads(out) == {'metric': 'm', 'value': 1.0}
+    assert 'banner from a native library' in err
+    # ranks other than 0 return nothing and print nothing
+    monkeypatch.setattr(bench, 'main', lambda: None)
+    saved = os.dup(1)
+    try:
+        bench.run_with_clean_stdout()
+        out, _ = capfd.readouterr()
+        assert out == ''
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
