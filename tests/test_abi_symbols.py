@@ -37,3 +37,20 @@ def test_library_reports_version_and_fails_loudly_without_gpu():
         par = lrvb_amd.VectorParam('x', 2)
         with pytest.raises(RuntimeError):
             lrvb_amd.QuadraticObjective(par, A=np.ones(2))       # no silent CPU fallback
+
+
+def test_missing_library_is_an_error_not_a_fallback(monkeypatch, tmp_path):
+    """Without the built HIP library every device object refuses to construct: there is no CPU route."""
+    import numpy as np
+    import pytest
+    import lrvb_amd
+    monkeypatch.setattr(lrvb_amd._hip, '_lib', None)
+    monkeypatch.setattr(lrvb_amd._hip, 'LIB_PATH', str(tmp_path / 'liblrvb_hip.so'))
+    par = lrvb_amd.VectorParam('x', 2)
+    with pytest.raises(OSError, match='no CPU fallback'):
+        lrvb_amd.QuadraticObjective(par, A=np.ones(2))
+    with pytest.raises(OSError, match='no CPU fallback'):
+        lrvb_amd.DeviceContext([dict(kind=0, free_size=2, vec_size=2, dim0=2, dim1=0, lb=-np.inf, ub=np.inf)], quad_kind=1)
+    # host-only pieces (packing, exponential families) do not need it
+    par.set_free(np.array([0.5, -0.5]))
+    assert np.allclose(par.get(), [0.5, -0.5])
