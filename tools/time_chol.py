@@ -19,3 +19,9 @@ for rep in range(3):
     print('D=%d chol_factor %.3f ms, lrvb_cov(Q=D) %.3f ms' % (D, (t1 - t0) * 1e3, (t2 - t1) * 1e3), flush=True)
 ref = M @ torch.linalg.solve(H, M.T)
 print('cov rel err vs torch: %.2e' % ((cov - ref).abs().max() / ref.abs().max()).item())
+# the vendor route for comparison (torch.linalg on ROCm dispatches to rocSOLVER / MAGMA)
+for rep in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    Lt = torch.linalg.cholesky(H); torch.cuda.synchronize(); t1 = time.perf_counter()
+    Yt = torch.cholesky_solve(M.T.contiguous(), Lt); torch.cuda.synchronize(); t2 = time.perf_counter()
+print('torch.linalg.cholesky %.3f ms, torch.cholesky_solve(Q=D) %.3f ms' % ((t1 - t0) * 1e3, (t2 - t1) * 1e3))
