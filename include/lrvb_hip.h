@@ -320,6 +320,27 @@ int lrvb_hvp_dev    (lrvb_ctx* ctx, const double* free_dev, const double* v_dev,
 int lrvb_gram_dev   (lrvb_ctx* ctx, const double* free_dev, double* GtG_dev, int64_t ld);
 
 /* ---- profiling (bench.py's roofline.achieved) ------------------------------------------ */
+/* Trust-region Newton-CG minimisation of the objective in free coordinates, entirely on the device: the
+ * optimiser `minimize_objective_trust_ncg` (LRVB/OptimizationUtils.py:44-75) hands to
+ * scipy.optimize.minimize(method='trust-ncg') with fun_free / fun_free_grad / fun_free_hvp -- or, with a
+ * preconditioner, the `_cond` family (LRVB/SparseObjectives.py:202-240: f(A y), A^T g, A^T H A v).  Same
+ * algorithm and constants (Steihaug-Toint CG subproblem; eta, radius rules), so the iterates agree with the
+ * scipy route to rounding, but no host callback per Hessian-vector product and ONE curvature pass per point.
+ * y0, y_out: iterate in the optimiser's coordinates (x = A y; A = `precond`, D x D row-major, nullable = identity);
+ * x_out (nullable): the minimiser in free coordinates.  maxiter <= 0 -> 200 D (scipy's default).
+ * status: 0 = ||gradient|| < gtol, 1 = maxiter reached, 2 = the quadratic model predicted no decrease.       */
+typedef struct lrvb_opt_result {
+    double  fun;             /* objective at the returned point                      */
+    double  jac_mag;         /* 2-norm of the (preconditioned) gradient there        */
+    double  trust_radius;    /* final radius                                         */
+    int32_t status, nit;     /* see above; outer iterations                          */
+    int32_t nfev, njev, nhev;/* value / gradient / Hessian-vector evaluations        */
+} lrvb_opt_result;
+int lrvb_minimize_trust_ncg(lrvb_ctx* ctx, const double* y0, int64_t D, const double* precond,
+                            double gtol, int64_t maxiter, double initial_trust_radius,
+                            double max_trust_radius, double eta,
+                            double* y_out, double* x_out, lrvb_opt_result* res);
+
 typedef struct lrvb_prof {
     double  wsyrk_ms;       /* HIP-event time of the weighted-SYRK kernel, summed           */
     int64_t wsyrk_calls;

@@ -84,6 +84,8 @@ _SIGNATURES = {
     'lrvb_weighted_gram': [_VP, _VP, c_i64],
     'lrvb_obs_quadform': [_VP, _VP, _VP, c_i64, c_i64, c_i64, _VP],
     'lrvb_mixture_rows': [_VP, ctypes.c_int32, _VP, _VP, _VP, _VP, _VP, _VP],
+    'lrvb_minimize_trust_ncg': [_VP, _VP, ctypes.c_int64, _VP, ctypes.c_double, ctypes.c_int64, ctypes.c_double,
+                                ctypes.c_double, ctypes.c_double, _VP, _VP, _VP],
     'lrvb_mixture_schur': [_VP, ctypes.c_int32, ctypes.c_int32, _VP, _VP, _VP, _VP, _VP, _VP],
     'lrvb_set_groups': [_VP, _VP, c_i64, c_i64],
     'lrvb_group_sums': [_VP, _VP],
@@ -111,6 +113,13 @@ _SIGNATURES = {
     'lrvb_profile_reset': [_VP],
     'lrvb_set_tuning': [_VP, ctypes.c_int, ctypes.c_int],
 }
+
+class OptResult(ctypes.Structure):
+    """lrvb_opt_result of include/lrvb_hip.h."""
+    _fields_ = [('fun', ctypes.c_double), ('jac_mag', ctypes.c_double), ('trust_radius', ctypes.c_double),
+                ('status', ctypes.c_int32), ('nit', ctypes.c_int32),
+                ('nfev', ctypes.c_int32), ('njev', ctypes.c_int32), ('nhev', ctypes.c_int32)]
+
 
 _lib = None
 

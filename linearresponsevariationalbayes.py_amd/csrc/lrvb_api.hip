@@ -170,7 +170,7 @@ extern "C" int lrvb_ctx_destroy(lrvb_ctx* c) {
     DevBuf* all[] = { &c->X, &c->y, &c->w, &c->quadA, &c->quadM, &c->quadB, &c->theta, &c->eta, &c->j1, &c->j2,
                       &c->vtmp, &c->vtmp2, &c->vtmp3, &c->g_eta, &c->g_free, &c->lp, &c->cw, &c->zbuf,
                       &c->part_vec, &c->part_val, &c->stats, &c->tile_part, &c->Heta, &c->Hfree, &c->Jdense,
-                      &c->Tdense, &c->work1, &c->chol, &c->cholW, &c->cgH, &c->groups, &c->mx_theta, &c->mx_lam, &c->mx_A, &c->mx_U, &c->mx_g, &c->mx_Xk, &c->mx_R, &c->cgT, &c->ones, &c->cgm[0], &c->cgm[1], &c->cgm[2], &c->cgm[3], &c->cgm[4], &c->cgm[5], &c->cgm[6], &c->cgm[7], &c->cgm[8], &c->rhs, &c->cgx, &c->cgr, &c->cgp, &c->cgq, &c->cgz, &c->scal };
+                      &c->Tdense, &c->work1, &c->chol, &c->cholW, &c->cgH, &c->groups, &c->mx_theta, &c->mx_lam, &c->mx_A, &c->mx_U, &c->mx_g, &c->mx_Xk, &c->mx_R, &c->cgT, &c->ones, &c->cgm[0], &c->cgm[1], &c->cgm[2], &c->cgm[3], &c->cgm[4], &c->cgm[5], &c->cgm[6], &c->cgm[7], &c->cgm[8], &c->rhs, &c->cgx, &c->cgr, &c->cgp, &c->cgq, &c->cgz, &c->scal, &c->opt };
     for (DevBuf* b : all) buf_free(*b);
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
     for (int k = 0; k < 3; ++k) for (hipEvent_t e : c->ev_pool[k]) (void)hipEventDestroy(e);
@@ -1481,6 +1481,179 @@ extern "C" int lrvb_cg_solve(lrvb_ctx* c, const double* free_in, const double* b
     LRVB_TRY(d2h(c, x_out, c->cgx.p, (size_t)D));
     if (info_out) *info_out = info;
     if (iters_out) *iters_out = it;
+    return LRVB_OK;
+}
+
+// ---- trust-region Newton-CG on the device -------------------------------------------------------------
+// The optimiser the reference runs through scipy (`minimize_objective_trust_ncg`, LRVB/OptimizationUtils.py:44-75:
+// scipy.optimize.minimize(method='trust-ncg') on fun_free / fun_free_grad / fun_free_hvp, or their `_cond`
+// versions, LRVB/SparseObjectives.py:202-240) as one library call: the outer trust-region iteration and the
+// Steihaug-Toint conjugate-gradient subproblem (Steihaug 1983; Nocedal & Wright, Algorithm 7.2, with the radius
+// update of their Algorithm 4.1 as scipy parametrises it: eta = 0.15, shrink by 1/4 below rho = 1/4, double on
+// the boundary above rho = 3/4) run here, every vector stays on the device, and the per-observation curvature is
+// computed ONCE per accepted point -- the callback route pays a gradient pass inside every Hessian-vector call.
+// Optional dense preconditioner A (D x D row-major): the iterate is y, x = A y, gradient A^T g, products A^T H A v.
+namespace {
+struct TrustNcg {
+    lrvb_ctx* c; i64 D; const double* A;       // A on the device or nullptr
+    double *y, *x, *g, *gc, *p, *z, *r, *d, *Bd, *t1, *t2, *yp;
+    int nfev = 0, njev = 0, nhev = 0;
+
+    int eval_point(const double* yv, double* f, double* gmag) {
+        if (A) LRVB_TRY(launch_gemv(c, false, D, D, 1.0, A, D, yv, 0.0, x));
+        else HIP_TRY(hipMemcpyAsync(x, yv, (size_t)D * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        LRVB_TRY(set_point(c, x, true));
+        LRVB_TRY(eval_grad_eta(c, c->stats.p, true));
+        LRVB_TRY(grad_to_free(c, x, g));
+        LRVB_TRY(prepare_general_hvp(c, x));
+        if (A) LRVB_TRY(launch_gemv(c, true, D, D, 1.0, A, D, g, 0.0, gc));
+        LRVB_TRY(launch_dot(c, gc, gc, D, c->scal.p));
+        double h[1];
+        LRVB_TRY(d2h(c, f, c->stats.p, 1));
+        LRVB_TRY(d2h(c, h, c->scal.p, 1));
+        *gmag = sqrt(h[0]);
+        ++nfev; ++njev;
+        return LRVB_OK;
+    }
+    int hessp(const double* v, double* out) {          // at the point of the last eval_point
+        ++nhev;
+        if (!A) return hvp_apply(c, x, true, v, out);
+        LRVB_TRY(launch_gemv(c, false, D, D, 1.0, A, D, v, 0.0, t1));
+        LRVB_TRY(hvp_apply(c, x, true, t1, t2));
+        return launch_gemv(c, true, D, D, 1.0, A, D, t2, 0.0, out);
+    }
+    int dots(int n, const double* const* a, const double* const* b, double* host) {
+        for (int k = 0; k < n; ++k) LRVB_TRY(launch_dot(c, a[k], b[k], D, c->scal.p + k));
+        return d2h(c, host, c->scal.p, (size_t)n);
+    }
+    // model value m(q) = f + gc.q + 1/2 q.Bq  (one Hessian-vector product)
+    int model(const double* q, double f, double* out) {
+        LRVB_TRY(hessp(q, Bd));
+        const double* a[2] = { gc, q }; const double* b[2] = { q, Bd };
+        double h[2];
+        LRVB_TRY(dots(2, a, b, h));
+        *out = f + h[0] + 0.5 * h[1];
+        return LRVB_OK;
+    }
+};
+// roots ta <= tb of ||z + t d|| = R from zz = z.z, zd = z.d, dd = d.d (cancellation-free form)
+static void boundary_roots(double zz, double zd, double dd, double R, double* ta, double* tb) {
+    const double a = dd, b = 2.0 * zd, cc = zz - R * R;
+    const double sq = sqrt(b * b - 4.0 * a * cc);
+    const double aux = b + copysign(sq, b);
+    double r1 = -aux / (2.0 * a), r2 = -2.0 * cc / aux;
+    if (r1 > r2) { const double t = r1; r1 = r2; r2 = t; }
+    *ta = r1; *tb = r2;
+}
+}  // namespace
+
+extern "C" int lrvb_minimize_trust_ncg(lrvb_ctx* c, const double* y0, int64_t D, const double* precond,
+                                       double gtol, int64_t maxiter, double initial_trust_radius,
+                                       double max_trust_radius, double eta,
+                                       double* y_out, double* x_out, lrvb_opt_result* res) {
+    LRVB_TRY(ctx_bind(c));
+    if (!y0 || !y_out || !res) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    LRVB_TRY(check_len(D, c->D, "free vector"));
+    LRVB_TRY(data_ready(c));
+    if (!(initial_trust_radius > 0.0) || !(max_trust_radius > 0.0) || initial_trust_radius >= max_trust_radius)
+        LRVB_FAIL(LRVB_ERR_INVALID, "need 0 < initial_trust_radius < max_trust_radius");
+    if (!(eta >= 0.0 && eta < 0.25)) LRVB_FAIL(LRVB_ERR_INVALID, "eta must lie in [0, 0.25)");
+    if (maxiter <= 0) maxiter = 200 * D;
+    const size_t nA = precond ? (size_t)D * (size_t)D : 0;
+    LRVB_TRY(buf_reserve(c, c->opt, 12 * (size_t)D + nA));
+    TrustNcg o;
+    o.c = c; o.D = D;
+    double* base = c->opt.p;
+    o.y = base; o.x = base + D; o.g = base + 2 * D; o.p = base + 4 * D; o.z = base + 5 * D; o.r = base + 6 * D;
+    o.d = base + 7 * D; o.Bd = base + 8 * D; o.t1 = base + 9 * D; o.t2 = base + 10 * D; o.yp = base + 11 * D;
+    o.A = precond ? base + 12 * D : nullptr;
+    o.gc = precond ? base + 3 * D : o.g;
+    if (precond) LRVB_TRY(h2d(c, base + 12 * D, precond, nA));
+    LRVB_TRY(h2d(c, o.y, y0, (size_t)D));
+
+    double f = 0.0, gmag = 0.0, radius = initial_trust_radius;
+    LRVB_TRY(o.eval_point(o.y, &f, &gmag));
+    int status = 0; i64 k = 0;
+    while (gmag >= gtol) {
+        // ---- Steihaug-Toint CG for the step p inside the ball of the current radius ---------------------------
+        bool hits_boundary = false;
+        const double tol_cg = fmin(0.5, sqrt(gmag)) * gmag;
+        HIP_TRY(hipMemsetAsync(o.z, 0, (size_t)D * sizeof(double), c->stream));
+        if (gmag < tol_cg) {
+            HIP_TRY(hipMemsetAsync(o.p, 0, (size_t)D * sizeof(double), c->stream));
+        } else {
+            LRVB_TRY(launch_axpby(c, D, 1.0, o.gc, 0.0, o.r));            // r = gradient
+            LRVB_TRY(launch_axpby(c, D, -1.0, o.gc, 0.0, o.d));           // d = -r
+            double rr = gmag * gmag, zz = 0.0;
+            for (;;) {
+                LRVB_TRY(o.hessp(o.d, o.Bd));
+                const double* a3[3] = { o.d, o.z, o.d }; const double* b3[3] = { o.Bd, o.d, o.d };
+                double h[3];
+                LRVB_TRY(o.dots(3, a3, b3, h));
+                const double dBd = h[0], zd = h[1], dd = h[2];
+                if (dBd <= 0.0) {
+                    // negative curvature: the better of the two boundary points along d
+                    double ta, tb, ma, mb;
+                    boundary_roots(zz, zd, dd, radius, &ta, &tb);
+                    LRVB_TRY(launch_axpby(c, D, 1.0, o.z, 0.0, o.p)); LRVB_TRY(launch_axpby(c, D, ta, o.d, 1.0, o.p));
+                    LRVB_TRY(launch_axpby(c, D, 1.0, o.z, 0.0, o.yp)); LRVB_TRY(launch_axpby(c, D, tb, o.d, 1.0, o.yp));
+                    LRVB_TRY(o.model(o.p, f, &ma));
+                    LRVB_TRY(o.model(o.yp, f, &mb));
+                    if (!(ma < mb)) LRVB_TRY(launch_axpby(c, D, 1.0, o.yp, 0.0, o.p));
+                    hits_boundary = true;
+                    break;
+                }
+                const double alpha = rr / dBd;
+                const double zz_next = zz + 2.0 * alpha * zd + alpha * alpha * dd;
+                if (sqrt(zz_next) >= radius) {
+                    double ta, tb;
+                    boundary_roots(zz, zd, dd, radius, &ta, &tb);
+                    LRVB_TRY(launch_axpby(c, D, 1.0, o.z, 0.0, o.p)); LRVB_TRY(launch_axpby(c, D, tb, o.d, 1.0, o.p));
+                    hits_boundary = true;
+                    break;
+                }
+                LRVB_TRY(launch_axpby(c, D, alpha, o.d, 1.0, o.z));       // z += alpha d
+                LRVB_TRY(launch_axpby(c, D, alpha, o.Bd, 1.0, o.r));      // r += alpha B d
+                const double* a1[2] = { o.r, o.z }; const double* b1[2] = { o.r, o.z };
+                double h2[2];
+                LRVB_TRY(o.dots(2, a1, b1, h2));
+                const double rr_next = h2[0];
+                zz = h2[1];
+                if (sqrt(rr_next) < tol_cg) { LRVB_TRY(launch_axpby(c, D, 1.0, o.z, 0.0, o.p)); break; }
+                LRVB_TRY(launch_axpby(c, D, -1.0, o.r, rr_next / rr, o.d));   // d = -r + beta d
+                rr = rr_next;
+            }
+        }
+        // ---- ratio of actual to predicted reduction, radius update, acceptance -------------------------------
+        double predicted_value;
+        LRVB_TRY(o.model(o.p, f, &predicted_value));
+        LRVB_TRY(launch_axpby(c, D, 1.0, o.y, 0.0, o.yp));
+        LRVB_TRY(launch_axpby(c, D, 1.0, o.p, 1.0, o.yp));
+        double f_new, gmag_new;
+        LRVB_TRY(o.eval_point(o.yp, &f_new, &gmag_new));
+        const double actual = f - f_new, predicted = f - predicted_value;
+        if (!(predicted > 0.0)) {
+            status = 2;                                  // the quadratic model does not decrease: stop where we are
+            LRVB_TRY(o.eval_point(o.y, &f, &gmag));
+            break;
+        }
+        const double rho = actual / predicted;
+        if (rho < 0.25) radius *= 0.25;
+        else if (rho > 0.75 && hits_boundary) radius = fmin(2.0 * radius, max_trust_radius);
+        if (rho > eta) {
+            LRVB_TRY(launch_axpby(c, D, 1.0, o.yp, 0.0, o.y));
+            f = f_new; gmag = gmag_new;
+        } else {
+            LRVB_TRY(o.eval_point(o.y, &f, &gmag));       // rejected: restore the point state (rare)
+        }
+        ++k;
+        if (gmag < gtol) { status = 0; break; }
+        if (k >= maxiter) { status = 1; break; }
+    }
+    LRVB_TRY(d2h(c, y_out, o.y, (size_t)D));
+    if (x_out) LRVB_TRY(d2h(c, x_out, o.x, (size_t)D));
+    res->fun = f; res->jac_mag = gmag; res->trust_radius = radius;
+    res->status = status; res->nit = (int32_t)k; res->nfev = o.nfev; res->njev = o.njev; res->nhev = o.nhev;
     return LRVB_OK;
 }
 

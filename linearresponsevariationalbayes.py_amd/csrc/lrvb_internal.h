@@ -67,6 +67,7 @@ struct lrvb_ctx {
     bool hvec_open = false;        // between lrvb_hvec_begin and lrvb_hvec_finish
     i64 chol_n = 0;
     DevBuf rhs, cgx, cgr, cgp, cgq, cgz, scal;
+    DevBuf opt;                    // trust-region Newton-CG: 12 D-vectors (+ the D x D preconditioner)
     DevBuf cgm[9];                 // blocked CG: B, X, R, P, Q, Z (Q x D), U, W (Q x V), R^T (P x Q)
     DevBuf cgT;                    // N x Q products X U^T of the blocked HVP
     DevBuf ones; i64 ones_n = 0;   // [1 x n | 0 x 64] contraction weights of the plain TN GEMM

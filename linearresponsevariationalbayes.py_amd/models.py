@@ -347,6 +347,25 @@ class DeviceContext(object):
                                            ctypes.byref(info), ctypes.byref(iters)))
         return x, info.value, iters.value
 
+    def minimize_trust_ncg(self, y0, precond=None, gtol=1e-6, maxiter=0, initial_trust_radius=1.0,
+                           max_trust_radius=1000.0, eta=0.15):
+        """Trust-region Newton-CG on the device (lrvb_minimize_trust_ncg).  The iterate y lives in the
+        optimiser's coordinates, x = precond @ y (precond None = identity).  Returns (y, x, info dict)."""
+        y0 = _hip.as_f64(y0).ravel()
+        if y0.size != self.D:
+            raise ValueError('Wrong size for the starting point.  Expected {}, got {}'.format(self.D, y0.size))
+        A = None if precond is None else _hip.as_f64(precond)
+        if A is not None and A.shape != (self.D, self.D):
+            raise ValueError('preconditioner must be {0} x {0}'.format(self.D))
+        y, x = np.empty(self.D), np.empty(self.D)
+        res = _hip.OptResult()
+        _hip.check(self._lib.lrvb_minimize_trust_ncg(self._h, _hip.ptr(y0), y0.size, _hip.ptr(A), float(gtol), int(maxiter),
+                                                     float(initial_trust_radius), float(max_trust_radius), float(eta),
+                                                     _hip.ptr(y), _hip.ptr(x), ctypes.byref(res)))
+        info = dict(fun=res.fun, jac_mag=res.jac_mag, trust_radius=res.trust_radius, status=res.status, nit=res.nit,
+                    nfev=res.nfev, njev=res.njev, nhev=res.nhev)
+        return y, x, info
+
     def cg_solve_multi(self, free, B, X0=None, Minv=None, tol=1e-8, maxiter=0):
         """Rows of B are right-hand sides; returns (X (Q x D), info (Q,), iterations (Q,))."""
         f, B = _hip.as_f64(free).ravel(), _hip.as_f64(B)

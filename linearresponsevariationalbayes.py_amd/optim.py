@@ -57,8 +57,48 @@ def _minimize(objective, init_x, precondition, method, options, with_hessp, prin
     return back(res.x), res
 
 
+_TRUST_NCG_MESSAGES = ('Optimization terminated successfully.',
+                       'Maximum number of iterations has been exceeded.',
+                       'A bad approximation caused failure to predict improvement.')
+
+
+def _trust_ncg_on_device(objective, init_x, precondition, maxiter, gtol, disp):
+    """The same optimiser as one library call (lrvb_minimize_trust_ncg): outer trust-region loop and Steihaug CG on
+    the device, one curvature pass per accepted point.  Needs a device functor without extra arguments."""
+    fun = objective.fun
+    ctx = getattr(fun, 'ctx', None)
+    if ctx is None or not hasattr(ctx, 'minimize_trust_ncg') or not hasattr(fun, '_push_state'):
+        raise NotImplementedError('on_device=True needs an objective built on a device functor (DeviceObjective, '
+                                  'GLMObjective, QuadraticObjective); this one is evaluated through host callbacks')
+    A = None
+    start = np.asarray(init_x, dtype=np.float64)
+    if precondition:
+        assert objective.preconditioner is not None
+        A = np.asarray(objective.preconditioner, dtype=np.float64)
+        start = np.linalg.solve(A, start)
+    fun._push_state()                                        # weights / data the functor keeps on the host side
+    y, x, info = ctx.minimize_trust_ncg(start, precond=A, gtol=gtol, maxiter=maxiter)
+    objective.par.set_free(x)                                # side effect of every evaluation: par sits at the last point
+    res = scipy.optimize.OptimizeResult(
+        x=y, fun=info['fun'], status=info['status'], success=info['status'] == 0,
+        message=_TRUST_NCG_MESSAGES[info['status']], nit=info['nit'], nfev=info['nfev'], njev=info['njev'],
+        nhev=info['nhev'], jac_mag=info['jac_mag'], trust_radius=info['trust_radius'])
+    if disp:
+        print('{}\n         Current function value: {:f}\n         Iterations: {:d}\n         Function evaluations: {:d}'
+              '\n         Gradient evaluations: {:d}\n         Hessian evaluations: {:d}'.format(
+                  res.message, res.fun, res.nit, res.nfev, res.njev, res.nhev))
+    return x, res
+
+
 def minimize_objective_trust_ncg(objective, init_x, precondition, maxiter=50, gtol=1e-6, disp=True,
-                                 print_every=None, init_logger=True):
+                                 print_every=None, init_logger=True, on_device=False):
+    """on_device=False: scipy drives, every callback is a device evaluation (the reference's structure).
+    on_device=True: the whole optimisation is one call into the HIP library."""
+    if on_device:
+        if init_logger:
+            objective.logger.initialize()
+        objective.preconditioning = precondition
+        return _trust_ncg_on_device(objective, init_x, precondition, maxiter, gtol, disp)
     return _minimize(objective, init_x, precondition, 'trust-ncg', {'maxiter': maxiter, 'gtol': gtol, 'disp': disp},
                      True, print_every, init_logger)
 

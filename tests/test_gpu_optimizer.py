@@ -1,0 +1,139 @@
+"""the optimiser loop on the device.  `minimize_objective_trust_ncg(...,
+on_device=True)` must walk the same iterates as the reference's route -- scipy's trust-ncg driving
+fun_free / fun_free_grad / fun_free_hvp (LRVB/OptimizationUtils.py:44-75; with a preconditioner the `_cond`
+family, LRVB/SparseObjectives.py:202-240) -- and end at a point where the ORACLE's gradient vanishes.
+The reference's own check of this wrapper (LRVB/test_objectives.py:400-445) is the same: both routes reach the
+known optimum of a quadratic model."""
+import numpy as np
+import pytest
+import scipy.optimize
+
+from oracle import models as om
+from helpers import make_par, glm_data, rel_err, LOSS_NAME
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def vb():
+    import lrvb_amd
+    assert lrvb_amd._hip.device_count() >= 1
+    return lrvb_amd
+
+
+def build(vb, loss, N, spec, seed, prior=0.7, lik_info=1.0):
+    rng = np.random.default_rng(seed)
+    par, lay = make_par(vb, spec)
+    P = lay.V
+    x, y, w = glm_data(rng, N, P, loss)
+    fun = vb.DeviceObjective(par, x=x, y=y, loss=LOSS_NAME[loss], lik_info=lik_info, quad_A=np.full(P, prior), weights=w)
+    model = om.DeclaredModel(lay, loss=loss, x=x, y=y, w=w, lik_info=lik_info, quad_A=np.full(P, prior))
+    return vb.Objective(par, fun), model, rng
+
+
+@pytest.mark.parametrize('loss,N,spec', [
+    (om.GAUSSIAN, 400, [('box', 'b', 12, -np.inf, np.inf)]),
+    (om.LOGISTIC, 900, [('box', 'u', 20, -np.inf, np.inf), ('box', 'pos', 12, 0.0, np.inf)]),
+    (om.POISSON, 700, [('box', 'lo', 9, -1.0, np.inf), ('box', 'both', 7, -2.0, 3.0)]),
+])
+def test_device_trust_ncg_walks_the_scipy_iterates(vb, loss, N, spec):
+    obj, model, rng = build(vb, loss, N, spec, seed=N)
+    D = model.layout.D
+    x0 = rng.normal(size=D) * 0.3
+    x_host, res_host = vb.OptimizationUtils.minimize_objective_trust_ncg(obj, x0, False, maxiter=200, gtol=1e-6, disp=False)
+    x_dev, res_dev = vb.OptimizationUtils.minimize_objective_trust_ncg(obj, x0, False, maxiter=200, gtol=1e-6, disp=False,
+                                                                       on_device=True)
+    assert res_host.success and res_dev.success and res_dev.status == 0
+    assert res_dev.nit == res_host.nit                       # same algorithm, same constants: same path
+    assert rel_err(x_dev, x_host) < 1e-8
+    assert abs(res_dev.fun - res_host.fun) <= 1e-11 * max(1.0, abs(res_host.fun))
+    # the oracle agrees that this is a stationary point, and a minimum
+    g = model.grad(x_dev)
+    assert np.linalg.norm(g) < 1e-6                         # gtol, judged by the oracle's gradient
+    assert np.min(np.linalg.eigvalsh(model.hessian(x_dev))) > 0
+    # side effect of the reference's wrappers: the parameter object sits at the optimum afterwards
+    assert rel_err(obj.par.get_free(), x_dev) < 1e-14
+    # the callback route pays a gradient pass inside every HVP; the device loop one pass per point
+    assert res_dev.nhev >= res_dev.nit and res_dev.nfev <= 2 * res_dev.nit + 2
+
+
+def test_every_truncated_run_matches(vb):
+    """Stopping after k outer iterations gives the same point on both routes for every k (status 1 = maxiter)."""
+    obj, model, rng = build(vb, om.LOGISTIC, 600, [('box', 'a', 10, -np.inf, np.inf), ('box', 'b', 6, 0.5, np.inf)], seed=5)
+    x0 = rng.normal(size=model.layout.D) * 0.5
+    for k in (1, 2, 3, 5):
+        xh, rh = vb.OptimizationUtils.minimize_objective_trust_ncg(obj, x0, False, maxiter=k, gtol=1e-12, disp=False)
+        xd, rd = vb.OptimizationUtils.minimize_objective_trust_ncg(obj, x0, False, maxiter=k, gtol=1e-12, disp=False,
+                                                                   on_device=True)
+        assert rd.nit == rh.nit == k and rd.status == rh.status == 1 and not rd.success
+        assert rel_err(xd, xh) < 1e-10
+        assert abs(rd.fun - model.value(xd)) <= 1e-12 * max(1.0, abs(rd.fun))
+
+
+def test_preconditioned_route(vb):
+    """`_cond` family: y = A^-1 x, f(A y), A^T g, A^T H A v with A = H^-1/2 from set_objective_preconditioner."""
+    obj, model, rng = build(vb, om.POISSON, 800, [('box', 'a', 14, -np.inf, np.inf), ('box', 'b', 10, 0.0, np.inf)], seed=8)
+    D = model.layout.D
+    x0 = rng.normal(size=D) * 0.2
+    vb.OptimizationUtils.set_objective_preconditioner(obj, free_par=x0, ev_min=1e-3)
+    xh, rh = vb.OptimizationUtils.minimize_objective_trust_ncg(obj, x0, True, maxiter=100, gtol=1e-6, disp=False)
+    xd, rd = vb.OptimizationUtils.minimize_objective_trust_ncg(obj, x0, True, maxiter=100, gtol=1e-6, disp=False,
+                                                               on_device=True)
+    assert rh.success and rd.success and rd.nit == rh.nit
+    assert rel_err(xd, xh) < 1e-8
+    assert rel_err(obj.preconditioner @ rd.x, xd) < 1e-13            # result.x is in the optimiser's coordinates
+    assert np.linalg.norm(obj.preconditioner.T @ model.grad(xd)) < 1e-6      # gtol applies to the preconditioned gradient
+    # Newton from the preconditioned start converges in fewer outer iterations than the plain route
+    _, plain = vb.OptimizationUtils.minimize_objective_trust_ncg(obj, x0, False, maxiter=100, gtol=1e-6, disp=False,
+                                                                 on_device=True)
+    assert rd.nit <= plain.nit
+    with pytest.raises(AssertionError):                             # `_cond` without a preconditioner: the reference asserts
+        obj.preconditioner = None
+        vb.OptimizationUtils.minimize_objective_trust_ncg(obj, x0, True, disp=False, on_device=True)
+
+
+def test_general_layout_and_quadratic_model(vb):
+    """PSD and simplex blocks (dense packing Jacobian, third-order term) and the reference's own test model:
+    a quadratic with known optimum (LRVB/test_objectives.py:400-445)."""
+    rng = np.random.default_rng(21)
+    spec = [('box', 'pre', 2, -np.inf, np.inf), ('box', 'beta', 6, -1.0, np.inf), ('psd', 'm', 3, 0.2), ('simplex', 's', 2, 3)]
+    par, lay = make_par(vb, spec)
+    N, P = 500, 6
+    x, y, w = glm_data(rng, N, P, om.LOGISTIC)
+    A = rng.normal(size=(lay.V, lay.V)); A = A @ A.T / lay.V + 3.0 * np.eye(lay.V)
+    fun = vb.DeviceObjective(par, x=x, y=y, loss='logistic', glm_param='beta', quad_A=A, weights=w)
+    obj = vb.Objective(par, fun)
+    x0 = rng.normal(size=lay.D) * 0.05
+    xh, rh = vb.OptimizationUtils.minimize_objective_trust_ncg(obj, x0, False, maxiter=300, gtol=1e-8, disp=False)
+    xd, rd = vb.OptimizationUtils.minimize_objective_trust_ncg(obj, x0, False, maxiter=300, gtol=1e-8, disp=False, on_device=True)
+    assert rd.status == rh.status and rd.nit == rh.nit
+    assert rel_err(xd, xh) < 1e-7
+    # quadratic model: f(x) = 1/2 (x - t)^T Q (x - t), optimum t, reached exactly
+    D = 9
+    Q = rng.normal(size=(D, D)); Q = Q @ Q.T + np.eye(D)
+    t = rng.normal(size=D)
+    qpar = vb.VectorParam('x', D)
+    qfun = vb.QuadraticObjective(qpar, A=Q, b=-Q @ t)
+    qobj = vb.Objective(qpar, qfun)
+    xq, rq = vb.OptimizationUtils.minimize_objective_trust_ncg(qobj, np.zeros(D), False, gtol=1e-8, disp=False, on_device=True)
+    assert rq.success and rel_err(xq, t) < 1e-7
+
+
+def test_refusals(vb):
+    par = vb.VectorParam('x', 3)
+    host_obj = vb.Objective(par, lambda: float(np.sum(par.get() ** 2)))          # opaque closure: host callbacks only
+    with pytest.raises(NotImplementedError):
+        vb.OptimizationUtils.minimize_objective_trust_ncg(host_obj, np.ones(3), False, disp=False, on_device=True)
+    obj, model, rng = build(vb, om.GAUSSIAN, 50, [('box', 'b', 4, -np.inf, np.inf)], seed=2)
+    ctx = obj.fun.ctx
+    with pytest.raises(ValueError):
+        ctx.minimize_trust_ncg(np.zeros(5))
+    with pytest.raises(ValueError):
+        ctx.minimize_trust_ncg(np.zeros(4), precond=np.eye(3))
+    with pytest.raises(ValueError):
+        ctx.minimize_trust_ncg(np.zeros(4), initial_trust_radius=0.0)
+    with pytest.raises(ValueError):
+        ctx.minimize_trust_ncg(np.zeros(4), eta=0.3)
+    # a start that already satisfies gtol returns at once
+    y, x, info = ctx.minimize_trust_ncg(np.zeros(4), gtol=1e30)
+    assert info['nit'] == 0 and info['status'] == 0 and np.array_equal(x, np.zeros(4))

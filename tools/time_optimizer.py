@@ -1,0 +1,30 @@
+"""Trust-region Newton-CG at the headline shape (N = 1e6, D = 1024, logistic): scipy driving device callbacks
+(the reference's structure, LRVB/OptimizationUtils.py:44-75) against the same optimiser as one library call."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch, scipy.optimize
+import lrvb_amd as vb
+N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1000000
+P = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+dev = torch.device('cuda:0')
+g = torch.Generator(device=dev); g.manual_seed(3)
+X = torch.randn((N, P), dtype=torch.float64, device=dev, generator=g) / P ** 0.5
+beta = torch.randn((P,), dtype=torch.float64, device=dev, generator=g)
+y = (torch.sigmoid(X @ beta) > torch.rand((N,), dtype=torch.float64, device=dev, generator=g)).double()
+w = torch.ones((N,), dtype=torch.float64, device=dev)
+blocks = [dict(kind=0, free_size=P - P // 4, vec_size=P - P // 4, dim0=P - P // 4, dim1=0, lb=-np.inf, ub=np.inf),
+          dict(kind=0, free_size=P // 4, vec_size=P // 4, dim0=P // 4, dim1=0, lb=0.0, ub=np.inf)]
+ctx = vb.DeviceContext(blocks, loss='logistic', n_obs=N, n_cols=P, quad_kind=1)
+ctx.set_data_dev(0, X.data_ptr(), N, P); ctx.set_data_dev(1, y.data_ptr(), N, 1); ctx.set_weights_dev(w.data_ptr(), N)
+ctx.set_data(2, np.ones(P))
+x0 = np.zeros(P)
+for rep in range(2):
+    t0 = time.perf_counter()
+    res = scipy.optimize.minimize(ctx.value, x0, jac=ctx.grad, hessp=ctx.hvp, method='trust-ncg',
+                                  options=dict(gtol=1e-4, maxiter=100))
+    t1 = time.perf_counter()
+    yd, xd, info = ctx.minimize_trust_ncg(x0, gtol=1e-4, maxiter=100)
+    t2 = time.perf_counter()
+print('scipy + device callbacks: %.1f ms, nit %d, nfev %d, njev %d, nhev %d, f = %.6f' % ((t1 - t0) * 1e3, res.nit, res.nfev, res.njev, res.nhev, res.fun))
+print('device loop:              %.1f ms, nit %d, nfev %d, njev %d, nhev %d, f = %.6f' % ((t2 - t1) * 1e3, info['nit'], info['nfev'], info['njev'], info['nhev'], info['fun']))
+print('max |x_dev - x_scipy| = %.2e' % np.max(np.abs(xd - res.x)))
