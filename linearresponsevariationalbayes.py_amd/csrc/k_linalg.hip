@@ -336,6 +336,60 @@ int launch_dot(lrvb_ctx* c, const double* a, const double* b, i64 n, double* out
     return LRVB_OK;
 }
 
+// three dot products in one launch (one workgroup, fixed reduction tree: deterministic): out[k] = a_k . b_k
+__global__ __launch_bounds__(1024)
+void dot3_kernel(const double* __restrict__ a0, const double* __restrict__ b0, const double* __restrict__ a1,
+                 const double* __restrict__ b1, const double* __restrict__ a2, const double* __restrict__ b2,
+                 i64 n, double* __restrict__ out)
+{
+    __shared__ double sh[3][1024];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (i64 i = threadIdx.x; i < n; i += 1024) { s0 += a0[i] * b0[i]; s1 += a1[i] * b1[i]; s2 += a2[i] * b2[i]; }
+    sh[0][threadIdx.x] = s0; sh[1][threadIdx.x] = s1; sh[2][threadIdx.x] = s2;
+    __syncthreads();
+    for (int off = 512; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + off];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + off];
+            sh[2][threadIdx.x] += sh[2][threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) out[threadIdx.x] = sh[threadIdx.x][0];
+}
+int launch_dot3(lrvb_ctx* c, const double* a0, const double* b0, const double* a1, const double* b1,
+                const double* a2, const double* b2, i64 n, double* out3_dev) {
+    hipLaunchKernelGGL(dot3_kernel, dim3(1), dim3(1024), 0, c->stream, a0, b0, a1, b1, a2, b2, n, out3_dev);
+    HIP_TRY(hipGetLastError());
+    return LRVB_OK;
+}
+
+// conjugate-gradient update in one launch: z += alpha d, r += alpha q, out = [r . r, z . z] of the updated vectors
+__global__ __launch_bounds__(1024)
+void cg_update_kernel(i64 n, double alpha, const double* __restrict__ d, const double* __restrict__ q,
+                      double* __restrict__ z, double* __restrict__ r, double* __restrict__ out)
+{
+    __shared__ double sh[2][1024];
+    double s0 = 0.0, s1 = 0.0;
+    for (i64 i = threadIdx.x; i < n; i += 1024) {
+        const double zi = z[i] + alpha * d[i], ri = r[i] + alpha * q[i];
+        z[i] = zi; r[i] = ri;
+        s0 += ri * ri; s1 += zi * zi;
+    }
+    sh[0][threadIdx.x] = s0; sh[1][threadIdx.x] = s1;
+    __syncthreads();
+    for (int off = 512; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) { sh[0][threadIdx.x] += sh[0][threadIdx.x + off]; sh[1][threadIdx.x] += sh[1][threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x < 2) out[threadIdx.x] = sh[threadIdx.x][0];
+}
+int launch_cg_update(lrvb_ctx* c, i64 n, double alpha, const double* d, const double* q, double* z, double* r, double* out2_dev) {
+    hipLaunchKernelGGL(cg_update_kernel, dim3(1), dim3(1024), 0, c->stream, n, alpha, d, q, z, r, out2_dev);
+    HIP_TRY(hipGetLastError());
+    return LRVB_OK;
+}
+
 __global__ void axpby_kernel(i64 n, double alpha, const double* __restrict__ x, double beta, double* __restrict__ y)
 {
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;

@@ -54,6 +54,7 @@ void buf_free(DevBuf& b) {
 
 static int ctx_bind(lrvb_ctx* c) {
     if (!c) LRVB_FAIL(LRVB_ERR_INVALID, "null context");
+    c->hvp_pt_valid = false;
     HIP_TRY(hipSetDevice(c->device));
     return LRVB_OK;
 }
@@ -276,6 +277,7 @@ extern "C" int lrvb_set_weights_dev(lrvb_ctx* c, const double* w_dev, int64_t n)
 }
 
 extern "C" int lrvb_set_quad_scale(lrvb_ctx* c, double scale) {
+    if (c) c->hvp_pt_valid = false;
     if (!c) LRVB_FAIL(LRVB_ERR_INVALID, "null context");
     c->quad_scale = scale;
     return LRVB_OK;
@@ -284,6 +286,7 @@ extern "C" int lrvb_set_quad_scale(lrvb_ctx* c, double scale) {
 extern "C" int lrvb_set_tuning(lrvb_ctx* c, int n_splits, int reserved) {
     if (!c) LRVB_FAIL(LRVB_ERR_INVALID, "null context");
     if (n_splits < 0 || n_splits > 1024) LRVB_FAIL(LRVB_ERR_INVALID, "n_splits out of range");
+    c->hvp_pt_valid = false;
     c->n_splits_user = n_splits;
     c->force_generic_wsyrk = (reserved & 1) != 0;
     c->force_dense_rows = (reserved & 2) ? 1 : 0;
@@ -556,16 +559,27 @@ extern "C" int lrvb_hvp_dev(lrvb_ctx* c, const double* free_dev, const double* v
     return hvp_dev_impl(c, free_dev, true, v_dev, out_dev);
 }
 static int hvp_host(lrvb_ctx* c, const double* point, const double* v, i64 n_in, bool is_free, double* out) {
+    // same point as the previous call, nothing else in between: its eta / J / g_eta / curvature are still in place
+    const bool reuse = c && point && c->hvp_pt_valid && c->hvp_pt_free == is_free && (i64)c->hvp_pt.size() == n_in &&
+                       memcmp(c->hvp_pt.data(), point, (size_t)n_in * sizeof(double)) == 0;
     LRVB_TRY(ctx_bind(c));
     if (!point || !v || !out) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
     const i64 n = is_free ? c->D : c->V;
     LRVB_TRY(check_len(n_in, n, is_free ? "free vector" : "vector"));
     LRVB_TRY(buf_reserve(c, c->cgp, (size_t)n));
     LRVB_TRY(buf_reserve(c, c->cgq, (size_t)n));
-    LRVB_TRY(h2d(c, c->theta.p, point, (size_t)n));
     LRVB_TRY(h2d(c, c->cgp.p, v, (size_t)n));
-    LRVB_TRY(hvp_dev_impl(c, c->theta.p, is_free, c->cgp.p, c->cgq.p));
-    return d2h(c, out, c->cgq.p, (size_t)n);
+    if (reuse) {
+        LRVB_TRY(hvp_apply(c, c->theta.p, is_free, c->cgp.p, c->cgq.p));
+    } else {
+        LRVB_TRY(h2d(c, c->theta.p, point, (size_t)n));
+        LRVB_TRY(hvp_dev_impl(c, c->theta.p, is_free, c->cgp.p, c->cgq.p));
+    }
+    LRVB_TRY(d2h(c, out, c->cgq.p, (size_t)n));
+    c->hvp_pt.assign(point, point + n);
+    c->hvp_pt_free = is_free;
+    c->hvp_pt_valid = true;
+    return LRVB_OK;
 }
 extern "C" int lrvb_hvp(lrvb_ctx* c, const double* free_in, const double* v, int64_t D, double* out) {
     return hvp_host(c, free_in, v, D, true, out);
@@ -1587,9 +1601,9 @@ extern "C" int lrvb_minimize_trust_ncg(lrvb_ctx* c, const double* y0, int64_t D,
             double rr = gmag * gmag, zz = 0.0;
             for (;;) {
                 LRVB_TRY(o.hessp(o.d, o.Bd));
-                const double* a3[3] = { o.d, o.z, o.d }; const double* b3[3] = { o.Bd, o.d, o.d };
                 double h[3];
-                LRVB_TRY(o.dots(3, a3, b3, h));
+                LRVB_TRY(launch_dot3(c, o.d, o.Bd, o.z, o.d, o.d, o.d, D, c->scal.p));
+                LRVB_TRY(d2h(c, h, c->scal.p, 3));
                 const double dBd = h[0], zd = h[1], dd = h[2];
                 if (dBd <= 0.0) {
                     // negative curvature: the better of the two boundary points along d
@@ -1612,11 +1626,9 @@ extern "C" int lrvb_minimize_trust_ncg(lrvb_ctx* c, const double* y0, int64_t D,
                     hits_boundary = true;
                     break;
                 }
-                LRVB_TRY(launch_axpby(c, D, alpha, o.d, 1.0, o.z));       // z += alpha d
-                LRVB_TRY(launch_axpby(c, D, alpha, o.Bd, 1.0, o.r));      // r += alpha B d
-                const double* a1[2] = { o.r, o.z }; const double* b1[2] = { o.r, o.z };
-                double h2[2];
-                LRVB_TRY(o.dots(2, a1, b1, h2));
+                double h2[2];                                              // z += alpha d, r += alpha B d, [r.r, z.z]
+                LRVB_TRY(launch_cg_update(c, D, alpha, o.d, o.Bd, o.z, o.r, c->scal.p));
+                LRVB_TRY(d2h(c, h2, c->scal.p, 2));
                 const double rr_next = h2[0];
                 zz = h2[1];
                 if (sqrt(rr_next) < tol_cg) { LRVB_TRY(launch_axpby(c, D, 1.0, o.z, 0.0, o.p)); break; }

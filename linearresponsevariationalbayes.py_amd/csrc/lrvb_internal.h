@@ -67,6 +67,10 @@ struct lrvb_ctx {
     bool hvec_open = false;        // between lrvb_hvec_begin and lrvb_hvec_finish
     i64 chol_n = 0;
     DevBuf rhs, cgx, cgr, cgp, cgq, cgz, scal;
+    // host-callback optimisers call lrvb_hvp many times at ONE point: the point state (eta, J, g_eta, curvature)
+    // of the last lrvb_hvp / lrvb_hvp_vec call is reused when the next call names the same point and no other
+    // entry point ran in between (every entry point clears the flag in ctx_bind)
+    std::vector<double> hvp_pt; bool hvp_pt_valid = false; bool hvp_pt_free = false;
     DevBuf opt;                    // trust-region Newton-CG: 12 D-vectors (+ the D x D preconditioner)
     DevBuf cgm[9];                 // blocked CG: B, X, R, P, Q, Z (Q x D), U, W (Q x V), R^T (P x Q)
     DevBuf cgT;                    // N x Q products X U^T of the blocked HVP
@@ -139,6 +143,9 @@ int launch_potrs_lower(lrvb_ctx* c, const double* L, i64 n, i64 ldl, double* B, 
 int launch_trsm_lower_forward(lrvb_ctx* c, const double* L, i64 n, i64 ldl, double* B, i64 nrhs, i64 ldb);
 int launch_dot(lrvb_ctx* c, const double* a, const double* b, i64 n, double* out_dev);
 int launch_axpby(lrvb_ctx* c, i64 n, double alpha, const double* x, double beta, double* y);
+int launch_dot3(lrvb_ctx* c, const double* a0, const double* b0, const double* a1, const double* b1,
+                const double* a2, const double* b2, i64 n, double* out3_dev);
+int launch_cg_update(lrvb_ctx* c, i64 n, double alpha, const double* d, const double* q, double* z, double* r, double* out2_dev);
 int launch_gemv(lrvb_ctx* c, bool trans, i64 M, i64 Nn, double alpha, const double* A, i64 lda,
                 const double* x, double beta, double* y);
 

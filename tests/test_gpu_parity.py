@@ -350,6 +350,47 @@ def test_full_size_properties_headline_shape(vb):
     assert torch.equal(G, G.T) and torch.linalg.eigvalsh(G).min().item() > -1e-9 * G.abs().max().item()
 
 
+def test_repeated_hvp_at_one_point(vb):
+    """Host-callback optimisers (scipy's cg / trust-ncg, as the reference uses them) call fun_free_hvp many times at
+    one point; the library keeps that point's state between consecutive calls.  Every way of changing the
+    objective or the point in between must be seen."""
+    rng = np.random.default_rng(77)
+    spec = [('box', 'u', 9, -np.inf, np.inf), ('box', 'pos', 7, 0.0, np.inf)]
+    par, lay = make_par(vb, spec)
+    N, P = 333, 16
+    x, y, w = glm_data(rng, N, P, om.POISSON)
+    fun = vb.DeviceObjective(par, x=x, y=y, loss='poisson', quad_A=np.full(P, 0.6), weights=w)
+    model = om.DeclaredModel(lay, loss=om.POISSON, x=x, y=y, w=w, quad_A=np.full(P, 0.6))
+    obj = vb.Objective(par, fun)
+    th1, th2 = rng.normal(size=P) * 0.2, rng.normal(size=P) * 0.2
+    vs = rng.normal(size=(4, P))
+    H1, H2 = model.hessian(th1), model.hessian(th2)
+    for v in vs:                                                  # first call prepares, the others reuse
+        assert rel_err(obj.fun_free_hvp(th1, v), H1 @ v) < TOL
+    assert rel_err(obj.fun_free_hvp(th2, vs[0]), H2 @ vs[0]) < TOL         # another point
+    assert rel_err(obj.fun_free_hvp(th1, vs[1]), H1 @ vs[1]) < TOL         # and back
+    # other entry points in between (they overwrite the per-observation scratch) invalidate the state
+    obj.fun_free_hvp(th1, vs[0]); fun.gram(th2); obj.fun_free_grad(th2)
+    assert rel_err(obj.fun_free_hvp(th1, vs[2]), H1 @ vs[2]) < TOL
+    # new weights at the same point
+    obj.fun_free_hvp(th1, vs[0])
+    w2 = w * rng.uniform(0.5, 1.5, N)
+    fun.weights_par.set_vector(w2); model.w = w2
+    assert rel_err(obj.fun_free_hvp(th1, vs[3]), model.hessian(th1) @ vs[3]) < TOL
+    # vector coordinates keep their own state; switching coordinate systems at numerically equal input is seen
+    eta = lay.constrain(th1)
+    Hv = model.hessian_vec(eta)
+    assert rel_err(obj.fun_vector_hvp(eta, vs[0]), Hv @ vs[0]) < TOL
+    assert rel_err(obj.fun_vector_hvp(eta, vs[1]), Hv @ vs[1]) < TOL
+    assert rel_err(obj.fun_free_hvp(eta, vs[1]), model.hessian(eta) @ vs[1]) < TOL
+    # scipy's cg over a LinearOperator of fun_free_hvp at a fixed point (LRVB/ConjugateGradient.py:63-85)
+    import scipy.sparse.linalg as sla
+    op = sla.LinearOperator((P, P), matvec=lambda v: obj.fun_free_hvp(th1, v))
+    b = rng.normal(size=P)
+    sol, info = sla.cg(op, b, rtol=1e-10, atol=0.0)
+    assert info == 0 and rel_err(sol, np.linalg.solve(model.hessian(th1), b)) < 1e-8
+
+
 def test_more_than_2_31_matrix_elements(vb):
     """Maximum sizes: N x D = 2.2e6 x 1024 = 2.25e9 doubles (18 GB) -- element offsets no longer fit in
     32 bits.  Size-independent checks: additivity over a row split (each half indexes below 2^31), the last
