@@ -164,7 +164,11 @@ int lrvb_grad   (lrvb_ctx* ctx, const double* free_in, int64_t D, double* value_
 /* Objective.fun_free_hessian (LRVB/SparseObjectives.py:156-158, autograd.hessian at :103).
  * H_out is D x D with leading dimension ld (>= D).  Both triangles are written.            */
 int lrvb_hessian(lrvb_ctx* ctx, const double* free_in, int64_t D, double* H_out, int64_t ld);
-/* Objective.fun_free_hvp (LRVB/SparseObjectives.py:183-187): out = H(theta) v               */
+/* Objective.fun_free_hvp (LRVB/SparseObjectives.py:183-187): out = H(theta) v.  Host-callback optimisers
+ * (scipy's cg and trust-ncg, as the reference drives them) call this many times at one point: the point state
+ * (eta, packing Jacobian, per-observation curvature) of the last lrvb_hvp / lrvb_hvp_vec call is kept and reused
+ * when the next call names the same point and no other entry point of this context ran in between.  Data
+ * installed zero-copy with lrvb_set_data_dev must be installed again after its contents change.               */
 int lrvb_hvp    (lrvb_ctx* ctx, const double* free_in, const double* v, int64_t D, double* out);
 
 /* ---- objective in vector coordinates: Objective.fun_vector* (:127-129, 164-174, 189-193) */
