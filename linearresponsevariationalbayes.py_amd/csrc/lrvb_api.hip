@@ -512,20 +512,38 @@ extern "C" int lrvb_hessian_vec(lrvb_ctx* c, const double* vec_in, int64_t V, do
 }
 
 // ---- value / gradient ------------------------------------------------------------------
+// Is (point, is_free) the point whose state the last value / gradient / HVP call left in place?  Must be asked
+// BEFORE ctx_bind, which clears the flag for every entry point.
+static bool same_point(const lrvb_ctx* c, const double* point, i64 n_in, bool is_free) {
+    return c && point && c->hvp_pt_valid && c->hvp_pt_free == is_free && (i64)c->hvp_pt.size() == n_in &&
+           memcmp(c->hvp_pt.data(), point, (size_t)n_in * sizeof(double)) == 0;
+}
+static void remember_point(lrvb_ctx* c, const double* point, i64 n, bool is_free, bool prepared) {
+    c->hvp_pt.assign(point, point + n);
+    c->hvp_pt_free = is_free;
+    c->hvp_pt_prepared = prepared;
+    c->hvp_pt_valid = true;
+}
+
 static int grad_host(lrvb_ctx* c, const double* point, i64 n_in, bool is_free, double* value_out, double* g_out) {
+    const bool reuse = same_point(c, point, n_in, is_free);          // fun(x) then jac(x), as scipy calls them
+    const bool prepared = reuse && c->hvp_pt_prepared;
     LRVB_TRY(ctx_bind(c));
     if (!point) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
     const i64 n = is_free ? c->D : c->V;
     LRVB_TRY(check_len(n_in, n, is_free ? "free vector" : "vector"));
     LRVB_TRY(data_ready(c));
-    LRVB_TRY(h2d(c, c->theta.p, point, (size_t)n));
-    LRVB_TRY(set_point(c, c->theta.p, is_free));
-    LRVB_TRY(eval_grad_eta(c, c->stats.p, true));
+    if (!reuse) {
+        LRVB_TRY(h2d(c, c->theta.p, point, (size_t)n));
+        LRVB_TRY(set_point(c, c->theta.p, is_free));
+        LRVB_TRY(eval_grad_eta(c, c->stats.p, true));
+    }
     if (g_out) {
         if (is_free) { LRVB_TRY(grad_to_free(c, c->theta.p, c->g_free.p)); LRVB_TRY(d2h(c, g_out, c->g_free.p, (size_t)n)); }
         else LRVB_TRY(d2h(c, g_out, c->g_eta.p, (size_t)n));
     }
     if (value_out) LRVB_TRY(d2h(c, value_out, c->stats.p, 1));
+    remember_point(c, point, n, is_free, prepared);       // (grad_to_free rebuilds the same dense Jacobian)
     return LRVB_OK;
 }
 extern "C" int lrvb_value(lrvb_ctx* c, const double* free_in, int64_t D, double* out) {
@@ -560,25 +578,25 @@ extern "C" int lrvb_hvp_dev(lrvb_ctx* c, const double* free_dev, const double* v
 }
 static int hvp_host(lrvb_ctx* c, const double* point, const double* v, i64 n_in, bool is_free, double* out) {
     // same point as the previous call, nothing else in between: its eta / J / g_eta / curvature are still in place
-    const bool reuse = c && point && c->hvp_pt_valid && c->hvp_pt_free == is_free && (i64)c->hvp_pt.size() == n_in &&
-                       memcmp(c->hvp_pt.data(), point, (size_t)n_in * sizeof(double)) == 0;
+    const bool reuse = same_point(c, point, n_in, is_free);
+    const bool prepared = reuse && c->hvp_pt_prepared;
     LRVB_TRY(ctx_bind(c));
     if (!point || !v || !out) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
     const i64 n = is_free ? c->D : c->V;
     LRVB_TRY(check_len(n_in, n, is_free ? "free vector" : "vector"));
+    LRVB_TRY(data_ready(c));
     LRVB_TRY(buf_reserve(c, c->cgp, (size_t)n));
     LRVB_TRY(buf_reserve(c, c->cgq, (size_t)n));
     LRVB_TRY(h2d(c, c->cgp.p, v, (size_t)n));
-    if (reuse) {
-        LRVB_TRY(hvp_apply(c, c->theta.p, is_free, c->cgp.p, c->cgq.p));
-    } else {
+    if (!reuse) {
         LRVB_TRY(h2d(c, c->theta.p, point, (size_t)n));
-        LRVB_TRY(hvp_dev_impl(c, c->theta.p, is_free, c->cgp.p, c->cgq.p));
+        LRVB_TRY(set_point(c, c->theta.p, is_free));
+        LRVB_TRY(eval_grad_eta(c, c->stats.p, true));
     }
+    if (!prepared && is_free) LRVB_TRY(prepare_general_hvp(c, c->theta.p));
+    LRVB_TRY(hvp_apply(c, c->theta.p, is_free, c->cgp.p, c->cgq.p));
     LRVB_TRY(d2h(c, out, c->cgq.p, (size_t)n));
-    c->hvp_pt.assign(point, point + n);
-    c->hvp_pt_free = is_free;
-    c->hvp_pt_valid = true;
+    remember_point(c, point, n, is_free, true);
     return LRVB_OK;
 }
 extern "C" int lrvb_hvp(lrvb_ctx* c, const double* free_in, const double* v, int64_t D, double* out) {

@@ -372,6 +372,14 @@ def test_repeated_hvp_at_one_point(vb):
     # other entry points in between (they overwrite the per-observation scratch) invalidate the state
     obj.fun_free_hvp(th1, vs[0]); fun.gram(th2); obj.fun_free_grad(th2)
     assert rel_err(obj.fun_free_hvp(th1, vs[2]), H1 @ vs[2]) < TOL
+    # value, gradient and products at one point share one state, in every order (scipy: fun(x), jac(x), hessp(x, .))
+    assert abs(obj.fun_free(th2) - model.value(th2)) <= 1e-12 * abs(model.value(th2))
+    assert rel_err(obj.fun_free_grad(th2), model.grad(th2)) < TOL
+    assert rel_err(obj.fun_free_hvp(th2, vs[3]), H2 @ vs[3]) < TOL
+    assert rel_err(obj.fun_free_grad(th2), model.grad(th2)) < TOL
+    assert abs(obj.fun_free(th2) - model.value(th2)) <= 1e-12 * abs(model.value(th2))
+    assert rel_err(obj.fun_free_grad(th1), model.grad(th1)) < TOL
+    assert rel_err(obj.fun_free_hvp(th1, vs[0]), H1 @ vs[0]) < TOL
     # new weights at the same point
     obj.fun_free_hvp(th1, vs[0])
     w2 = w * rng.uniform(0.5, 1.5, N)
