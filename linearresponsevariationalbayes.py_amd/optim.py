@@ -70,6 +70,8 @@ def _trust_ncg_on_device(objective, init_x, precondition, maxiter, gtol, disp):
     if ctx is None or not hasattr(ctx, 'minimize_trust_ncg') or not hasattr(fun, '_push_state'):
         raise NotImplementedError('on_device=True needs an objective built on a device functor (DeviceObjective, '
                                   'GLMObjective, QuadraticObjective); this one is evaluated through host callbacks')
+    if getattr(fun, 'scale_fun', None) is not None:
+        raise NotImplementedError('on_device=True takes no extra objective arguments (this functor declares scale_fun)')
     A = None
     start = np.asarray(init_x, dtype=np.float64)
     if precondition:
