@@ -71,6 +71,54 @@ class ShardedHessian(object):
         return self.engine.finish(theta, stats)
 
 
+class ShardedObjective(object):
+    """Value, gradient, Hessian-vector products, CG solves and trust-ncg fits of an objective whose observations
+    are sharded over the ranks of a process group ("one D-vector all-reduce per CG
+    iteration when the HVP is data-sharded").
+
+    Every rank holds a context over ITS rows.  The N-independent quadratic term is scaled by 1 / world_size on
+    every rank (`set_quad_scale`), which makes the global objective the plain sum of the local ones -- and with it
+    the value, the gradient and every Hessian-vector product, packing terms included, because all of them are linear
+    in the objective.  One sum all-reduce of the local result is then the global result, identical on every rank,
+    so host-side iterations (scipy's cg / trust-ncg, as the reference drives them) stay in lockstep without any
+    further coordination.  Consecutive products at one point reuse the rank's point state (one pass over the local
+    rows each).  `ctx` needs value / grad / hvp / set_quad_scale and D (DeviceContext has them)."""
+
+    def __init__(self, ctx, torch_device=None, group=None):
+        import torch.distributed as dist
+        self.ctx = ctx
+        self.device = torch_device
+        self.group = group
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        ctx.set_quad_scale(1.0 / self.world)
+
+    def _sum(self, arr):
+        return allreduce_stats(np.atleast_1d(np.asarray(arr, dtype=np.float64)), self.device, self.group)
+
+    def value(self, theta):
+        return float(self._sum(self.ctx.value(theta))[0])
+
+    def grad(self, theta):
+        return self._sum(self.ctx.grad(theta))
+
+    def hvp(self, theta, v):
+        return self._sum(self.ctx.hvp(theta, v))
+
+    def cg_solve(self, theta, b, x0=None, tol=1e-8, maxiter=None, M=None):
+        """H(theta)^-1 b by scipy's cg over the sharded product (LRVB/ConjugateGradient.py:63-85): returns (x, info)."""
+        import scipy.sparse.linalg as sla
+        theta = np.asarray(theta, dtype=np.float64)
+        D = theta.size
+        op = sla.LinearOperator((D, D), matvec=lambda v: self.hvp(theta, np.asarray(v, dtype=np.float64).ravel()))
+        return sla.cg(op, np.asarray(b, dtype=np.float64), x0=x0, rtol=tol, atol=0.0, maxiter=maxiter, M=M)
+
+    def minimize_trust_ncg(self, x0, gtol=1e-6, maxiter=50, disp=False):
+        """The fit of `minimize_objective_trust_ncg` (LRVB/OptimizationUtils.py:44-75) over sharded observations."""
+        import scipy.optimize
+        return scipy.optimize.minimize(self.value, np.asarray(x0, dtype=np.float64), jac=self.grad, hessp=self.hvp,
+                                       method='trust-ncg', options={'maxiter': maxiter, 'gtol': gtol, 'disp': disp})
+
+
 def allreduce_stats(flat, torch_device=None, group=None):
     """Sum a flat float64 statistics vector over all ranks (sufficient statistics of the
     quadratic-in-data and hierarchical objectives: `LMMObjective.local_stats()`), returning a numpy

@@ -229,3 +229,79 @@ def test_two_rank_quadratic_data_statistics_allreduce(tmp_path):
     out_path = str(tmp_path / 'err.npy')
     mp.spawn(_mvn_worker, args=(2, _free_port(), out_path), nprocs=2, join=True)
     assert np.all(np.load(out_path) < 1e-12)
+
+
+class OracleShardCtx(object):
+    """The slice of DeviceContext that ShardedObjective uses, with the oracle's arithmetic (no GPU in this suite)."""
+
+    def __init__(self, model):
+        self.model = model
+        self.D = model.layout.D
+
+    def set_quad_scale(self, s):
+        self.model.quad_scale = s
+
+    def value(self, x):
+        return self.model.value(x)
+
+    def grad(self, x):
+        return self.model.grad(x)
+
+    def hvp(self, x, v):
+        return self.model.hvp(x, v)
+
+
+def _objective_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from lrvb_amd.distributed import ShardedObjective, shard_rows
+    N, theta, model = _make_problem()
+    r0, r1 = shard_rows(N, rank, world)
+    obj = ShardedObjective(OracleShardCtx(model(slice(r0, r1))))
+    rng = np.random.default_rng(5)                    # same stream on every rank
+    v, b = rng.normal(size=theta.size), rng.normal(size=theta.size)
+    val, g, hv = obj.value(theta), obj.grad(theta), obj.hvp(theta, v)
+    sol, info = obj.cg_solve(theta, b, tol=1e-10)
+    fit = obj.minimize_trust_ncg(theta, gtol=1e-7, maxiter=100)
+    flat = np.concatenate([[val], g, hv, sol, [float(info)], fit.x, [float(fit.nit), float(fit.status)]])
+    t = torch.from_numpy(flat.copy())
+    gathered = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(gathered, t)
+    if rank == 0:
+        assert all(torch.equal(gathered[0], x) for x in gathered)       # bitwise the same on every rank
+        np.save(out_path, flat)
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_value_gradient_hvp_cg_and_fit(tmp_path):
+    """the HVP / CG path over sharded observations, one D-vector all-reduce per product."""
+    import scipy.optimize
+    world = 2
+    port = _free_port()
+    out_path = str(tmp_path / 'obj.npy')
+    mp.spawn(_objective_worker, args=(world, port, out_path), nprocs=world, join=True)
+    flat = np.load(out_path)
+    N, theta, model = _make_problem()
+    full = model(slice(0, N))
+    D = theta.size
+    rng = np.random.default_rng(5)
+    v, b = rng.normal(size=D), rng.normal(size=D)
+    o = 0
+    assert abs(flat[o] - full.value(theta)) < 1e-12 * abs(full.value(theta)); o += 1
+    np.testing.assert_allclose(flat[o:o + D], full.grad(theta), rtol=1e-11, atol=1e-12); o += D
+    H = full.hessian(theta)
+    np.testing.assert_allclose(flat[o:o + D], H @ v, rtol=1e-11, atol=1e-12); o += D
+    np.testing.assert_allclose(flat[o:o + D], np.linalg.solve(H, b), rtol=1e-7, atol=1e-9); o += D
+    assert flat[o] == 0.0; o += 1
+    fit = scipy.optimize.minimize(full.value, theta, jac=full.grad, hessp=lambda x, p: full.hvp(x, p), method='trust-ncg',
+                                  options={'maxiter': 100, 'gtol': 1e-7})
+    # the lower-bounded coordinates are nearly flat in free coordinates (exp map), so two runs that both meet gtol may
+    # sit 1e-4 apart there; the objective value and the stationarity are the sharp statements
+    x_sharded = flat[o:o + D]; o += D
+    np.testing.assert_allclose(x_sharded, fit.x, rtol=0, atol=1e-3)
+    assert abs(full.value(x_sharded) - fit.fun) < 1e-10 * abs(fit.fun)
+    assert abs(flat[o] - fit.nit) <= 1 and flat[o + 1] == fit.status == 0
+    assert np.linalg.norm(full.grad(x_sharded)) < 1e-6

@@ -137,3 +137,52 @@ def test_refusals(vb):
     # a start that already satisfies gtol returns at once
     y, x, info = ctx.minimize_trust_ncg(np.zeros(4), gtol=1e30)
     assert info['nit'] == 0 and info['status'] == 0 and np.array_equal(x, np.zeros(4))
+
+
+def test_sharded_objective_on_the_device(vb):
+    """SURVEY section 8(e), HVP / CG path: with the quadratic term scaled by 1 / world on every shard, value, gradient
+    and Hessian-vector products of the shards ADD UP to the full objective's -- on the real device contexts (two
+    shards in one process here; the collective itself is covered by the 2-rank gloo test) -- and ShardedObjective over a
+    one-rank group reproduces the unsharded answers."""
+    import torch.distributed as dist
+    from lrvb_amd.distributed import ShardedObjective, shard_rows
+    rng = np.random.default_rng(12)
+    spec = [('box', 'u', 20, -np.inf, np.inf), ('box', 'pos', 12, 0.0, np.inf)]
+    N, P = 1501, 32
+    x, y, w = glm_data(rng, N, P, om.LOGISTIC)
+    par, lay = make_par(vb, spec)
+    model = om.DeclaredModel(lay, loss=om.LOGISTIC, x=x, y=y, w=w, quad_A=np.full(P, 0.9))
+    theta, v = rng.normal(size=P) * 0.2, rng.normal(size=P)
+    parts = []
+    for r in range(2):
+        r0, r1 = shard_rows(N, r, 2)
+        p_r, _ = make_par(vb, spec)
+        f_r = vb.DeviceObjective(p_r, x=x[r0:r1], y=y[r0:r1], loss='logistic', quad_A=np.full(P, 0.9), weights=w[r0:r1])
+        f_r._push_state()
+        f_r.ctx.set_quad_scale(0.5)
+        parts.append(f_r.ctx)
+    assert abs(sum(c.value(theta) for c in parts) - model.value(theta)) < 1e-12 * abs(model.value(theta))
+    assert rel_err(sum(c.grad(theta) for c in parts), model.grad(theta)) < 1e-12
+    assert rel_err(sum(c.hvp(theta, v) for c in parts), model.hessian(theta) @ v) < 1e-12
+    # one-rank process group: the class end to end on a device context
+    started = False
+    if not dist.is_initialized():
+        import os, socket
+        s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+        os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+        dist.init_process_group('gloo', rank=0, world_size=1)
+        started = True
+    try:
+        fun = vb.DeviceObjective(par, x=x, y=y, loss='logistic', quad_A=np.full(P, 0.9), weights=w)
+        fun._push_state()
+        so = ShardedObjective(fun.ctx)
+        assert so.world == 1
+        assert rel_err(so.hvp(theta, v), model.hessian(theta) @ v) < 1e-12
+        b = rng.normal(size=P)
+        sol, info = so.cg_solve(theta, b, tol=1e-10)
+        assert info == 0 and rel_err(sol, np.linalg.solve(model.hessian(theta), b)) < 1e-8
+        fit = so.minimize_trust_ncg(theta, gtol=1e-7, maxiter=100)
+        assert fit.status == 0 and np.linalg.norm(model.grad(fit.x)) < 1e-6
+    finally:
+        if started:
+            dist.destroy_process_group()
