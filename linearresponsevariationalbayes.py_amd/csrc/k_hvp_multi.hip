@@ -28,17 +28,21 @@ constexpr int HM_ROWS = 8;               // observations per chunk
 
 // TONLY = true stops after step A and writes the scaled rows of T instead (out[n][q] = c_n (X U)[n][q]):
 // the streamed weight-sensitivity product of lrvb_obs_influence.
-template <int NB, bool TONLY>            // NB = P / 128: column blocks of 32 per wave = NB
-__global__ __launch_bounds__(256, 1)
+// NW waves per workgroup (4, or 8 = two per SIMD where the column count allows it: while one wave sits in a barrier or
+// waits for LDS the other keeps the MFMA pipe busy).
+template <int NB, bool TONLY, int NW>    // NB = P / 128
+__global__ __launch_bounds__(64 * NW, 1)
 void hvp_multi_kernel(const double* __restrict__ X, int Preal, i64 N, const double* __restrict__ cw,
                       const double* __restrict__ U, i64 ldu, int Q, double* __restrict__ Rpart,
                       double* __restrict__ Tout, i64 ldt)
 {
     constexpr int P = NB * 128;           // columns rounded up to whole 128-column DMA instructions (Preal is even)
-    constexpr int PW = P / 4;             // columns per wave
+    constexpr int PW = P / NW;            // columns per wave (a multiple of 32)
+    constexpr int NBW = PW / 32;          // 32-column blocks per wave
+    constexpr int RPW = HM_ROWS / NW;     // rows of a chunk staged by one wave (2 or 1)
     constexpr int STRIDE = P + 2;         // doubles; (STRIDE / 2) odd -> rows land on distinct 16-byte bank groups
     constexpr int NT = PW / 16;           // 16-column tiles of R per wave
-    extern __shared__ double lds[];       // [2][HM_ROWS][STRIDE] chunk buffers | [4][2][64] partial T tiles
+    extern __shared__ double lds[];       // [2][HM_ROWS][STRIDE] chunk buffers | [NW][2][64] partial T tiles
     double* Tpart = lds + 2 * HM_ROWS * STRIDE;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -47,9 +51,9 @@ void hvp_multi_kernel(const double* __restrict__ X, int Preal, i64 N, const doub
     const int pc0 = wave * PW;
 
     // this wave's slice of U as MFMA B operands: block b (32 columns), sub-step t: k = pc0 + 32 b + 8 l4 + t, q = l15
-    double uf[NB][8];
+    double uf[NBW][8];
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
+    for (int b = 0; b < NBW; ++b)
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const int k = pc0 + 32 * b + 8 * l4 + t;
@@ -62,11 +66,11 @@ void hvp_multi_kernel(const double* __restrict__ X, int Preal, i64 N, const doub
 
     const i64 nchunks = (N + HM_ROWS - 1) / HM_ROWS;
     auto issue = [&](i64 ch, int buf) {
-        // wave w stages rows {2 w, 2 w + 1} of the chunk: P / 128 instructions of 1 KiB per row
+        // wave w stages RPW rows of the chunk: P / 128 instructions of 1 KiB per row
         double* base = lds + buf * (HM_ROWS * STRIDE);
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int row = 2 * wave + rr;
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int row = RPW * wave + rr;
             i64 n = ch * HM_ROWS + row; if (n > N - 1) n = N - 1;       // rows past N carry weight zero
             const double* rowp = X + n * (i64)Preal;
 #pragma unroll
@@ -105,9 +109,9 @@ void hvp_multi_kernel(const double* __restrict__ X, int Preal, i64 N, const doub
             fr[0][4 + i] = *reinterpret_cast<const d2*>(arow + 4 * STRIDE + 2 * i);
         }
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
+        for (int b = 0; b < NBW; ++b) {
             const int cur = b & 1;
-            if (b + 1 < NB) {
+            if (b + 1 < NBW) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     fr[cur ^ 1][i] = *reinterpret_cast<const d2*>(arow + 32 * (b + 1) + 2 * i);
@@ -132,11 +136,13 @@ void hvp_multi_kernel(const double* __restrict__ X, int Preal, i64 N, const doub
         // chunk's LDS-DMA in the middle of this one -- the prefetch would overlap step A and nothing else
         __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
-        double pa[4], pb[4];
+        double pa[NW], pb[NW];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) { pa[w] = Tpart[(w * 2 + 0) * 64 + lane]; pb[w] = Tpart[(w * 2 + 1) * 64 + lane]; }
-        __builtin_amdgcn_sched_barrier(0);                    // all eight reads in flight before the first add
-        double t0 = ((pa[0] + pa[1]) + pa[2]) + pa[3], t1 = ((pb[0] + pb[1]) + pb[2]) + pb[3];
+        for (int w = 0; w < NW; ++w) { pa[w] = Tpart[(w * 2 + 0) * 64 + lane]; pb[w] = Tpart[(w * 2 + 1) * 64 + lane]; }
+        __builtin_amdgcn_sched_barrier(0);                    // all reads in flight before the first add
+        double t0 = pa[0], t1 = pb[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) { t0 += pa[w]; t1 += pb[w]; }
         t0 *= c0; t1 *= c1;
         if (TONLY) {
             if (wave == 0 && l15 < Q) {
@@ -211,16 +217,21 @@ int launch_hvp_multi(lrvb_ctx* c, i64 Q, const double* U_dev, i64 ldu, double* O
     int grid = 256;                                           // one workgroup per CU (64+ KiB of LDS each)
     if (grid > nchunks) grid = (int)nchunks;
     LRVB_TRY(buf_reserve(c, c->part_vec, (size_t)grid * (size_t)P * 16));
-    const size_t lds_bytes = (size_t)(2 * HM_ROWS * (P + 2) + 4 * 2 * 64) * sizeof(double);
     const double* Uoff = U_dev + c->glm_off;
-#define HM_LAUNCH(NB) do { \
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&hvp_multi_kernel<NB, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
-        hipLaunchKernelGGL((hvp_multi_kernel<NB, false>), dim3((unsigned)grid), dim3(256), lds_bytes, c->stream, \
+    const bool eight = ((P / 128) % 2 == 0) && !c->hm_four_waves;      // two waves per SIMD where the columns split evenly
+    const size_t lds_bytes = (size_t)(2 * HM_ROWS * (P + 2) + (eight ? 8 : 4) * 2 * 64) * sizeof(double);
+#define HM_LAUNCH_W(NB, NW) do { \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&hvp_multi_kernel<NB, false, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+        hipLaunchKernelGGL((hvp_multi_kernel<NB, false, NW>), dim3((unsigned)grid), dim3(64 * NW), lds_bytes, c->stream, \
                            c->X.p, Preal, c->N, c->cw.p, Uoff, ldu, (int)Q, c->part_vec.p, (double*)nullptr, (i64)0); } while (0)
+#define HM_LAUNCH(NB) HM_LAUNCH_W(NB, 4)
+#define HM_LAUNCH_E(NB) do { if (eight) HM_LAUNCH_W(NB, 8); else HM_LAUNCH_W(NB, 4); } while (0)
     switch (P / 128) {
-    case 1: HM_LAUNCH(1); break; case 2: HM_LAUNCH(2); break; case 3: HM_LAUNCH(3); break; case 4: HM_LAUNCH(4); break;
-    case 5: HM_LAUNCH(5); break; case 6: HM_LAUNCH(6); break; case 7: HM_LAUNCH(7); break; default: HM_LAUNCH(8); break;
+    case 1: HM_LAUNCH(1); break; case 2: HM_LAUNCH_E(2); break; case 3: HM_LAUNCH(3); break; case 4: HM_LAUNCH_E(4); break;
+    case 5: HM_LAUNCH(5); break; case 6: HM_LAUNCH_E(6); break; case 7: HM_LAUNCH(7); break; default: HM_LAUNCH_E(8); break;
     }
+#undef HM_LAUNCH_E
+#undef HM_LAUNCH_W
 #undef HM_LAUNCH
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(hvp_multi_reduce_kernel, dim3((unsigned)((Preal * 16 + 255) / 256)), dim3(256), 0, c->stream,
@@ -242,15 +253,20 @@ int launch_rows_times_matrix(lrvb_ctx* c, i64 n0, i64 n1, i64 Q, const double* Z
     const i64 nchunks = (rows + HM_ROWS - 1) / HM_ROWS;
     int grid = 256;
     if (grid > nchunks) grid = (int)nchunks;
-    const size_t lds_bytes = (size_t)(2 * HM_ROWS * (P + 2) + 4 * 2 * 64) * sizeof(double);
-#define HM_LAUNCH_T(NB) do { \
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&hvp_multi_kernel<NB, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
-        hipLaunchKernelGGL((hvp_multi_kernel<NB, true>), dim3((unsigned)grid), dim3(256), lds_bytes, c->stream, \
+    const bool eight = ((P / 128) % 2 == 0) && !c->hm_four_waves;
+    const size_t lds_bytes = (size_t)(2 * HM_ROWS * (P + 2) + (eight ? 8 : 4) * 2 * 64) * sizeof(double);
+#define HM_LAUNCH_TW(NB, NW) do { \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&hvp_multi_kernel<NB, true, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+        hipLaunchKernelGGL((hvp_multi_kernel<NB, true, NW>), dim3((unsigned)grid), dim3(64 * NW), lds_bytes, c->stream, \
                            c->X.p + n0 * (i64)Preal, Preal, rows, rowscale_dev + n0, Zt_dev, ldz, (int)Q, (double*)nullptr, Tout_dev, ldt); } while (0)
+#define HM_LAUNCH_T(NB) HM_LAUNCH_TW(NB, 4)
+#define HM_LAUNCH_TE(NB) do { if (eight) HM_LAUNCH_TW(NB, 8); else HM_LAUNCH_TW(NB, 4); } while (0)
     switch (P / 128) {
-    case 1: HM_LAUNCH_T(1); break; case 2: HM_LAUNCH_T(2); break; case 3: HM_LAUNCH_T(3); break; case 4: HM_LAUNCH_T(4); break;
-    case 5: HM_LAUNCH_T(5); break; case 6: HM_LAUNCH_T(6); break; case 7: HM_LAUNCH_T(7); break; default: HM_LAUNCH_T(8); break;
+    case 1: HM_LAUNCH_T(1); break; case 2: HM_LAUNCH_TE(2); break; case 3: HM_LAUNCH_T(3); break; case 4: HM_LAUNCH_TE(4); break;
+    case 5: HM_LAUNCH_T(5); break; case 6: HM_LAUNCH_TE(6); break; case 7: HM_LAUNCH_T(7); break; default: HM_LAUNCH_TE(8); break;
     }
+#undef HM_LAUNCH_TE
+#undef HM_LAUNCH_TW
 #undef HM_LAUNCH_T
     HIP_TRY(hipGetLastError());
     return LRVB_OK;

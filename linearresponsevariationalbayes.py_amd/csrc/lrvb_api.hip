@@ -290,6 +290,7 @@ extern "C" int lrvb_set_tuning(lrvb_ctx* c, int n_splits, int reserved) {
     c->n_splits_user = n_splits;
     c->force_generic_wsyrk = (reserved & 1) != 0;
     c->force_dense_rows = (reserved & 2) ? 1 : 0;
+    c->hm_four_waves = (reserved & 4) != 0;
     c->dbg_bits = (reserved >> 8) & 7;
     c->stagger_shift = ((reserved >> 16) & 0xff) - 1;
     return LRVB_OK;

@@ -83,6 +83,7 @@ struct lrvb_ctx {
     int  dbg_bits = 0;                  // timing-lab variants of the weighted-SYRK kernel (wrong results)
     bool force_generic_wsyrk = false;   // tuning/testing: use the register-staged kernel
     int  mx_res_K = 0, mx_res_q = 0;    // shape of the expanded mixture operand R resident in mx_A (0 = none)
+    bool hm_four_waves = false;         // tuning/testing: fused multi-vector pass with four waves per workgroup
     int  force_dense_rows = 0;          // tuning/testing: mixture rows always take the dense factorisation
     int pass_grid = 0;
 
