@@ -361,7 +361,8 @@ int lrvb_profile_get   (lrvb_ctx* ctx, lrvb_prof* out);
 int lrvb_profile_reset (lrvb_ctx* ctx);
 /* Tuning knobs: number of row splits of the weighted-SYRK grid (0 = automatic); `reserved` bit 0 =
  * always use the register-staged SYRK kernel, bit 1 = mixture rows always take the dense per-row
- * factorisation (both exist so that tests can compare the two code paths).                  */
+ * factorisation, bit 2 = the fused multi-vector pass (blocked CG, streamed influence) with four
+ * waves per workgroup instead of eight (all exist so that tests can compare the code paths).  */
 int lrvb_set_tuning(lrvb_ctx* ctx, int n_splits, int reserved);
 
 #ifdef __cplusplus

@@ -77,6 +77,29 @@ def test_fused_pass_equals_two_gemm_route(vb):
     assert rel_err(X1, X2) < 1e-7
 
 
+def test_four_and_eight_wave_forms_agree(vb):
+    """The fused multi-vector pass runs with eight waves per workgroup when the 128-column blocks split evenly over
+    them (P = 256, 512, 768, 1024 after padding) and with four otherwise; tuning bit 2 forces four."""
+    rng = np.random.default_rng(19)
+    for P in (250, 512, 640, 1000):                     # padded to 256 (eight), 512 (eight), 640 (four), 1024 (eight)
+        N, Q = 1207, 9
+        par, lay = make_par(vb, [('box', 'a', P, -np.inf, np.inf)])
+        x, y, w = glm_data(rng, N, P, om.LOGISTIC)
+        fun = vb.DeviceObjective(par, x=x, y=y, loss='logistic', quad_A=np.full(P, 2.0), weights=w)
+        model = om.DeclaredModel(lay, loss=om.LOGISTIC, x=x, y=y, w=w, quad_A=np.full(P, 2.0))
+        theta = rng.normal(size=P) * 0.05
+        fun._push_state()
+        B = rng.normal(size=(Q, P))
+        X8, info8, _ = fun.ctx.cg_solve_multi(theta, B, tol=1e-11)
+        fun.ctx.set_tuning(0, 4)
+        X4, info4, _ = fun.ctx.cg_solve_multi(theta, B, tol=1e-11)
+        fun.ctx.set_tuning(0, 0)
+        assert np.all(info8 == 0) and np.all(info4 == 0)
+        want = np.linalg.solve(model.hessian(theta), B.T).T
+        assert rel_err(X8, want) < 1e-8 and rel_err(X4, want) < 1e-8
+        assert rel_err(X8, X4) < 1e-9
+
+
 def test_general_layout(vb):
     rng = np.random.default_rng(7)
     spec = [('box', 'pre', 2, -np.inf, np.inf), ('box', 'beta', 6, -1.0, np.inf), ('psd', 'm', 3, 0.2), ('simplex', 's', 2, 3)]
