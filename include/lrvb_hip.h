@@ -324,6 +324,16 @@ int lrvb_hvp_dev    (lrvb_ctx* ctx, const double* free_dev, const double* v_dev,
 int lrvb_gram_dev   (lrvb_ctx* ctx, const double* free_dev, double* GtG_dev, int64_t ld);
 
 /* ---- profiling (bench.py's roofline.achieved) ------------------------------------------ */
+/* D^j g [u_1 .. u_j]: the j-th directional derivative of the vector-coordinate gradient g = d f / d eta along the
+ * rows of U (j x V, row-major; j = `order` in 0..6, j = 0 returns g itself).  The reference's higher-order
+ * sensitivity (`ParametricSensitivityTaylorExpansion`, LRVB/ModelSensitivity.py:382-515) builds this from j nested
+ * autograd JVPs of the gradient closure (`append_jvp`, :38-62; `generate_two_term_derivative_array`, :221-234).
+ * w_override (N, nullable): evaluate with these observation weights instead of the context's -- the derivative
+ * of g along a direction in WEIGHT space, since the objective is linear in the weights; include_quad = 0
+ * drops the N-independent quadratic term (it does not depend on the weights).  All host pointers.          */
+int lrvb_dk_grad_vec(lrvb_ctx* ctx, const double* vec_in, int64_t V, int32_t order, const double* U,
+                     const double* w_override, int32_t include_quad, double* out);
+
 /* Trust-region Newton-CG minimisation of the objective in free coordinates, entirely on the device: the
  * optimiser `minimize_objective_trust_ncg` (LRVB/OptimizationUtils.py:44-75) hands to
  * scipy.optimize.minimize(method='trust-ncg') with fun_free / fun_free_grad / fun_free_hvp -- or, with a

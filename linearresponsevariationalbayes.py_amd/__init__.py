@@ -23,6 +23,7 @@ from .families import (UVNParam, UVNParamVector, UVNParamArray, UVNMomentParamAr
 from .objectives import (Objective, TwoParameterObjective, ParameterConverter, ParametricSensitivity,
                          LinearConverter, ElementwiseConverter, Logger, Timer)
 from .sensitivity import ParametricSensitivityLinearApproximation
+from .taylor import ParametricSensitivityTaylorExpansion
 from .cg import ConjugateGradientSolver
 from .models import (DeviceContext, DeviceObjective, GLMObjective, QuadraticObjective, LinearMoments)
 from .quadform import (QuadraticDataObjective, NormalRegressionObjective, MVNRegressionObjective,

@@ -84,6 +84,7 @@ _SIGNATURES = {
     'lrvb_weighted_gram': [_VP, _VP, c_i64],
     'lrvb_obs_quadform': [_VP, _VP, _VP, c_i64, c_i64, c_i64, _VP],
     'lrvb_mixture_rows': [_VP, ctypes.c_int32, _VP, _VP, _VP, _VP, _VP, _VP],
+    'lrvb_dk_grad_vec': [_VP, _VP, ctypes.c_int64, ctypes.c_int32, _VP, _VP, ctypes.c_int32, _VP],
     'lrvb_minimize_trust_ncg': [_VP, _VP, ctypes.c_int64, _VP, ctypes.c_double, ctypes.c_int64, ctypes.c_double,
                                 ctypes.c_double, ctypes.c_double, _VP, _VP, _VP],
     'lrvb_mixture_schur': [_VP, ctypes.c_int32, ctypes.c_int32, _VP, _VP, _VP, _VP, _VP, _VP],

@@ -171,7 +171,7 @@ extern "C" int lrvb_ctx_destroy(lrvb_ctx* c) {
     DevBuf* all[] = { &c->X, &c->y, &c->w, &c->quadA, &c->quadM, &c->quadB, &c->theta, &c->eta, &c->j1, &c->j2,
                       &c->vtmp, &c->vtmp2, &c->vtmp3, &c->g_eta, &c->g_free, &c->lp, &c->cw, &c->zbuf,
                       &c->part_vec, &c->part_val, &c->stats, &c->tile_part, &c->Heta, &c->Hfree, &c->Jdense,
-                      &c->Tdense, &c->work1, &c->chol, &c->cholW, &c->cgH, &c->groups, &c->mx_theta, &c->mx_lam, &c->mx_A, &c->mx_U, &c->mx_g, &c->mx_Xk, &c->mx_R, &c->cgT, &c->ones, &c->cgm[0], &c->cgm[1], &c->cgm[2], &c->cgm[3], &c->cgm[4], &c->cgm[5], &c->cgm[6], &c->cgm[7], &c->cgm[8], &c->rhs, &c->cgx, &c->cgr, &c->cgp, &c->cgq, &c->cgz, &c->scal, &c->opt };
+                      &c->Tdense, &c->work1, &c->chol, &c->cholW, &c->cgH, &c->groups, &c->mx_theta, &c->mx_lam, &c->mx_A, &c->mx_U, &c->mx_g, &c->mx_Xk, &c->mx_R, &c->cgT, &c->ones, &c->cgm[0], &c->cgm[1], &c->cgm[2], &c->cgm[3], &c->cgm[4], &c->cgm[5], &c->cgm[6], &c->cgm[7], &c->cgm[8], &c->rhs, &c->cgx, &c->cgr, &c->cgp, &c->cgq, &c->cgz, &c->scal, &c->opt, &c->dkw };
     for (DevBuf* b : all) buf_free(*b);
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
     for (int k = 0; k < 3; ++k) for (hipEvent_t e : c->ev_pool[k]) (void)hipEventDestroy(e);
@@ -385,6 +385,18 @@ static int heta_apply(lrvb_ctx* c, const double* u_vec, double* out_vec) {
         LRVB_TRY(launch_scatter_glm(c, nullptr, out_vec));
     }
     return launch_quad_hvp(c, u_vec, out_vec);
+}
+
+// the same pass with whatever per-observation coefficient sits in c->cw, quadratic term optional
+static int heta_apply_coef(lrvb_ctx* c, const double* u_vec, double* out_vec, bool with_quad) {
+    if (c->loss != LRVB_LOSS_NONE) {
+        LRVB_TRY(buf_reserve(c, c->vtmp3, (size_t)(c->V > c->P ? c->V : c->P)));
+        LRVB_TRY(launch_glm_pass(c, PASS_HVP_C, nullptr, u_vec + c->glm_off, c->vtmp3.p, nullptr, false));
+        LRVB_TRY(launch_scatter_glm(c, c->vtmp3.p, out_vec));
+    } else {
+        LRVB_TRY(launch_scatter_glm(c, nullptr, out_vec));
+    }
+    return with_quad ? launch_quad_hvp(c, u_vec, out_vec) : LRVB_OK;
 }
 
 // full HVP at the current point.  Requires set_point + eval_grad_eta done (g_eta, cw valid).
@@ -1515,6 +1527,92 @@ extern "C" int lrvb_cg_solve(lrvb_ctx* c, const double* free_in, const double* b
     if (info_out) *info_out = info;
     if (iters_out) *iters_out = it;
     return LRVB_OK;
+}
+
+// ---- higher-order directional derivatives of the gradient (vector coordinates) -------------------------
+// D^j g_eta [u_1 .. u_j] for the declared objective: the building block of the reference's higher-order
+// sensitivity (`ParametricSensitivityTaylorExpansion`, LRVB/ModelSensitivity.py:382-515, which obtains the
+// same quantity from j nested autograd JVPs of the gradient closure, :38-62, 221-234).  In vector coordinates
+// the linear predictor is linear in eta, so the mixed derivative has the closed form
+//   X^T ( w o loss^(j+1)(z) o (X u_2) o ... o (X u_j) o (X u_1) )   [+ s A u_1 when j = 1],
+// i.e. the cached-curvature Hessian-vector pass with a different per-observation coefficient: one skinny
+// product for z and the X u_k, one elementwise kernel, one fused pass.  j = 0 is the gradient itself.
+__device__ __forceinline__ double loss_derivative(int loss, double lik, int m, double y, double z) {
+    if (loss == LRVB_LOSS_GAUSSIAN) return m == 1 ? lik * (z - y) : (m == 2 ? lik : 0.0);
+    if (loss == LRVB_LOSS_POISSON) { const double e = exp(z); return m == 1 ? e - y : e; }
+    // logistic: loss' = sigma - y, loss^(m) = sigma^(m-1), polynomials in s = sigma(z) from
+    // P_1 = s - s^2, P_(k+1) = P_k' (s - s^2)
+    const double s = 1.0 / (1.0 + exp(-z));
+    switch (m) {
+    case 1: return s - y;
+    case 2: return s * (1.0 - s);
+    case 3: return s * (1.0 + s * (-3.0 + s * 2.0));
+    case 4: return s * (1.0 + s * (-7.0 + s * (12.0 - s * 6.0)));
+    case 5: return s * (1.0 + s * (-15.0 + s * (50.0 + s * (-60.0 + s * 24.0))));
+    case 6: return s * (1.0 + s * (-31.0 + s * (180.0 + s * (-390.0 + s * (360.0 - s * 120.0)))));
+    case 7: return s * (1.0 + s * (-63.0 + s * (602.0 + s * (-2100.0 + s * (3360.0 + s * (-2520.0 + s * 720.0))))));
+    default: return 0.0;
+    }
+}
+__global__ void dk_coef_kernel(i64 n, int loss, double lik, int m, const double* __restrict__ w, const double* __restrict__ y,
+                               const double* __restrict__ T, int Q, double* __restrict__ coef) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double p = w[i] * loss_derivative(loss, lik, m, y[i], T[i * Q]);
+    for (int k = 1; k < Q; ++k) p *= T[i * Q + k];
+    coef[i] = p;
+}
+
+extern "C" int lrvb_dk_grad_vec(lrvb_ctx* c, const double* vec_in, int64_t V, int32_t order, const double* U,
+                                const double* w_override, int32_t include_quad, double* out) {
+    LRVB_TRY(ctx_bind(c));
+    if (!vec_in || !out || (order > 0 && !U)) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    if (order < 0 || order > 6) LRVB_FAIL(LRVB_ERR_INVALID, "order must lie in 0..6");
+    LRVB_TRY(check_len(V, c->V, "vector"));
+    LRVB_TRY(data_ready(c));
+    const i64 N = c->N, P = c->P;
+    const bool glm = c->loss != LRVB_LOSS_NONE;
+    LRVB_TRY(h2d(c, c->theta.p, vec_in, (size_t)V));
+    LRVB_TRY(set_point(c, c->theta.p, false));
+    // weights of this evaluation: the context's, or the caller's direction in weight space
+    const double* wsrc = c->w.p;
+    if (w_override && glm) {
+        LRVB_TRY(reserve_obs_vec(c, c->dkw));
+        LRVB_TRY(h2d(c, c->dkw.p, w_override, (size_t)N));
+        wsrc = c->dkw.p;
+    }
+    LRVB_TRY(buf_reserve(c, c->rhs, (size_t)V));
+    if (order == 0) {
+        double* saved = c->w.p;                                   // the gradient pass reads c->w
+        c->w.p = const_cast<double*>(wsrc);
+        const int st = eval_grad_eta(c, c->stats.p, include_quad != 0);
+        c->w.p = saved;
+        LRVB_TRY(st);
+        return d2h(c, out, c->g_eta.p, (size_t)V);
+    }
+    const i64 Q = order;                                          // columns: z, X u_2, ..., X u_order
+    LRVB_TRY(buf_reserve(c, c->cgT, (size_t)(order * V)));
+    LRVB_TRY(h2d(c, c->cgT.p, U, (size_t)(order * V)));
+    if (glm) {
+        // Zt (Q x P): eta's and u_2 .. u_order's GLM slices
+        LRVB_TRY(buf_reserve(c, c->vtmp3, (size_t)(Q * P > V ? Q * P : V)));
+        HIP_TRY(hipMemcpyAsync(c->vtmp3.p, c->eta.p + c->glm_off, (size_t)P * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        for (i64 k = 1; k < Q; ++k)
+            HIP_TRY(hipMemcpyAsync(c->vtmp3.p + k * P, c->cgT.p + k * V + c->glm_off, (size_t)P * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        LRVB_TRY(buf_reserve(c, c->work1, (size_t)(N * Q)));
+        if (hvp_multi_supported(c, Q) && !c->force_generic_wsyrk) {
+            LRVB_TRY(reserve_obs_vec(c, c->zbuf));
+            EW(fill_kernel, N, 1.0, c->zbuf.p);
+            LRVB_TRY(launch_rows_times_matrix(c, 0, N, Q, c->vtmp3.p, P, c->zbuf.p, c->work1.p, Q));
+        } else {
+            LRVB_TRY(launch_gemm(c, false, true, N, Q, P, 1.0, c->X.p, P, c->vtmp3.p, P, 0.0, c->work1.p, Q));
+        }
+        LRVB_TRY(reserve_obs_vec(c, c->cw));
+        EW(dk_coef_kernel, N, (int)c->loss, c->lik_info, (int)order + 1, wsrc, (const double*)c->y.p, (const double*)c->work1.p, (int)Q, c->cw.p);
+    }
+    // out = X^T (coef o (X u_1)), scattered into the vector layout; the quadratic term only has a second derivative
+    LRVB_TRY(heta_apply_coef(c, c->cgT.p, c->rhs.p, order == 1 && include_quad != 0));
+    return d2h(c, out, c->rhs.p, (size_t)V);
 }
 
 // ---- trust-region Newton-CG on the device -------------------------------------------------------------

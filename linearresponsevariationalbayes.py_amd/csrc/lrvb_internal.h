@@ -72,6 +72,7 @@ struct lrvb_ctx {
     // entry point ran in between (every entry point clears the flag in ctx_bind)
     std::vector<double> hvp_pt; bool hvp_pt_valid = false; bool hvp_pt_free = false;
     bool hvp_pt_prepared = false;   // the dense packing Jacobian / third-order matrix of general layouts are built too
+    DevBuf dkw;                    // lrvb_dk_grad_vec: the caller's weight direction (N)
     DevBuf opt;                    // trust-region Newton-CG: 12 D-vectors (+ the D x D preconditioner)
     DevBuf cgm[9];                 // blocked CG: B, X, R, P, Q, Z (Q x D), U, W (Q x V), R^T (P x Q)
     DevBuf cgT;                    // N x Q products X U^T of the blocked HVP

@@ -347,6 +347,25 @@ class DeviceContext(object):
                                            ctypes.byref(info), ctypes.byref(iters)))
         return x, info.value, iters.value
 
+    def dk_grad_vec(self, eta, U=None, w_override=None, include_quad=True):
+        """D^j g [u_1 .. u_j] in vector coordinates (lrvb_dk_grad_vec): rows of U are the directions, U None or empty
+        gives the gradient itself; w_override evaluates with other observation weights (a direction in weight space)."""
+        eta = _hip.as_f64(eta).ravel()
+        if eta.size != self.V:
+            raise ValueError('Wrong size for the vector.  Expected {}, got {}'.format(self.V, eta.size))
+        order = 0
+        if U is not None:
+            U = _hip.as_f64(U).reshape(-1, self.V) if np.size(U) else None
+            order = 0 if U is None else U.shape[0]
+        if w_override is not None:
+            w_override = _hip.as_f64(w_override).ravel()
+            if w_override.size != self.n_obs:
+                raise ValueError('expected {} weights'.format(self.n_obs))
+        out = np.empty(self.V)
+        _hip.check(self._lib.lrvb_dk_grad_vec(self._h, _hip.ptr(eta), eta.size, int(order), _hip.ptr(U), _hip.ptr(w_override),
+                                              1 if include_quad else 0, _hip.ptr(out)))
+        return out
+
     def minimize_trust_ncg(self, y0, precond=None, gtol=1e-6, maxiter=0, initial_trust_radius=1.0,
                            max_trust_radius=1000.0, eta=0.15):
         """Trust-region Newton-CG on the device (lrvb_minimize_trust_ncg).  The iterate y lives in the

@@ -138,3 +138,8 @@ class ParametricSensitivityLinearApproximation(object):
         """LRVB covariance M H^-1 M^T of moments with Jacobian M (Example.ipynb:398-415), reusing
         the resident factor."""
         return self.hess0_chol.lrvb_cov(np.asarray(moment_jac, dtype=np.float64))
+
+
+# the k-th order class and its term algebra live in taylor.py; the reference keeps them in this module
+from .taylor import (ParametricSensitivityTaylorExpansion, DerivativeTerm, get_taylor_base_terms,   # noqa: E402,F401
+                     consolidate_terms, differentiate_terms)

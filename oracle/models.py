@@ -41,6 +41,32 @@ def loss_terms(loss, y, z, lik_info=1.0):
     raise ValueError('unknown loss')
 
 
+def sigmoid_derivative_polys(max_order):
+    """sigma^(m)(z) as a polynomial in s = sigma(z), ascending coefficients, m = 1..max_order:
+    P_1 = s - s^2 and, by the chain rule, P_(m+1) = P_m'(s) (s - s^2)."""
+    from numpy.polynomial import polynomial as Pl
+    polys = [None, np.array([0.0, 1.0, -1.0])]
+    for m in range(1, max_order):
+        polys.append(Pl.polymul(Pl.polyder(polys[m]), np.array([0.0, 1.0, -1.0])))
+    return polys
+
+
+def loss_derivative(loss, m, y, z, lik_info=1.0):
+    """d^m loss / d z^m elementwise, m >= 1 (what m nested JVPs of the loss along z give)."""
+    from numpy.polynomial import polynomial as Pl
+    if m <= 2:
+        return loss_terms(loss, y, z, lik_info)[m]
+    if loss == GAUSSIAN:
+        return np.zeros_like(z)
+    if loss == POISSON:
+        return np.exp(z)
+    if loss == LOGISTIC:                       # loss' = sigma - y  ->  loss^(m) = sigma^(m-1)
+        ez = np.exp(-np.abs(z))
+        sig = np.where(z >= 0, 1.0 / (1.0 + ez), ez / (1.0 + ez))
+        return Pl.polyval(sig, sigmoid_derivative_polys(m - 1)[m - 1])
+    raise ValueError('unknown loss')
+
+
 class DeclaredModel(object):
     def __init__(self, layout, loss=0, x=None, y=None, w=None, glm_off=0, lik_info=1.0,
                  quad_A=None, quad_m=None, quad_b=None, quad_scale=1.0):
@@ -123,6 +149,29 @@ class DeclaredModel(object):
             out[self.glm_off:self.glm_off + self.P] += self.x.T @ (self.w * l2 * t)
         if self.quad_A is not None:
             out += self.quad_scale * self._A_apply(u)
+        return out
+
+    def dk_grad_vec(self, eta, U=None, w_override=None, include_quad=True):
+        """D^j g [u_1 .. u_j] of the vector-coordinate gradient g = grad_vec along the rows of U (j x V); j = 0 is g.
+        The reference gets this from j nested autograd JVPs of the gradient closure (LRVB/ModelSensitivity.py:38-62,
+        221-234); here the closed form: X^T (w o loss^(j+1)(z) o prod_k (X u_k)), plus s A u_1 when j = 1."""
+        eta = np.asarray(eta, dtype=np.float64)
+        U = np.zeros((0, self.layout.V)) if U is None else np.asarray(U, dtype=np.float64).reshape(-1, self.layout.V)
+        j = U.shape[0]
+        w = self.w if w_override is None else np.asarray(w_override, dtype=np.float64)
+        out = np.zeros(self.layout.V)
+        s = slice(self.glm_off, self.glm_off + self.P)
+        if self.loss:
+            z = self.x @ self._beta(eta)
+            coef = w * loss_derivative(self.loss, j + 1, self.y, z, self.lik_info)
+            for k in range(j):
+                coef = coef * (self.x @ U[k, s])
+            out[s] += self.x.T @ coef
+        if include_quad and self.quad_A is not None:
+            if j == 0:
+                out += self.quad_scale * (self._A_apply(eta - self.quad_m) + self.quad_b)
+            elif j == 1:
+                out += self.quad_scale * self._A_apply(U[0])
         return out
 
     # ---- free coordinates ---------------------------------------------------------------
