@@ -214,13 +214,21 @@ class ParametricSensitivityTaylorExpansion(object):
 
     def _h(self, dirs_eta, eps_dir):
         """D_eta^r h [dirs] in vector coordinates, h = g_eta (eps_dir None) or d g_eta / d eps [eps_dir]."""
-        self.objective_functor._push_state()
         r = len(dirs_eta)
+        # the derivative is symmetric in its directions and the same leaves recur across subsets and partitions:
+        # memoised per evaluation (the key is the multiset of direction vectors)
+        key = (eps_dir is None, tuple(sorted(np.ascontiguousarray(u).tobytes() for u in dirs_eta)))
+        memo = self._cache.setdefault('h', {})
+        if key in memo:
+            return memo[key]
+        self.objective_functor._push_state()
         U = np.array(dirs_eta) if r else None
         if eps_dir is None:
-            return self.ctx.dk_grad_vec(self._eta0(), U, None, True)
+            memo[key] = self.ctx.dk_grad_vec(self._eta0(), U, None, True)
+            return memo[key]
         if self.hyper_kind == 'weights':
-            return self.ctx.dk_grad_vec(self._eta0(), U, eps_dir, False)
+            memo[key] = self.ctx.dk_grad_vec(self._eta0(), U, eps_dir, False)
+            return memo[key]
         # tilt: the objective holds eps^T eta, so d g_eta / d eps [d eps] = d eps, constant in eta
         if r > 0:
             return np.zeros(self.input_val0.size if not self.input_is_free else self._eta0().size)
@@ -276,6 +284,7 @@ class ParametricSensitivityTaylorExpansion(object):
         dhyper = np.asarray(dhyper, dtype=np.float64).ravel()
         if dhyper.size != self.hyper_val0.size:
             raise ValueError('dhyper is the wrong size')
+        self._cache['h'] = {}                                    # leaves are memoised per direction dhyper
         derivs = []
         for j in range(1, k + 1):
             rhs = np.zeros(self.input_val0.size)
