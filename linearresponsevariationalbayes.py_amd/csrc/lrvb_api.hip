@@ -1615,6 +1615,20 @@ extern "C" int lrvb_dk_grad_vec(lrvb_ctx* c, const double* vec_in, int64_t V, in
     return d2h(c, out, c->rhs.p, (size_t)V);
 }
 
+// ---- timing lab for the next round's SYRK tile shape (not part of the boundary: no header entry) ---------------
+extern "C" int lrvb_lab_syrk(lrvb_ctx* c, int variant, int n_splits, int reps, double* ms_out) {
+    LRVB_TRY(ctx_bind(c));
+    if (!ms_out || reps < 1) LRVB_FAIL(LRVB_ERR_INVALID, "bad argument");
+    LRVB_TRY(data_ready(c));
+    LRVB_TRY(reserve_obs_vec(c, c->zbuf));
+    EW(fill_kernel, c->N, 1.0, c->zbuf.p);
+    LRVB_TRY(buf_reserve(c, c->work1, (size_t)n_splits * 16 * 512));
+    float ms = 0.f;
+    LRVB_TRY(launch_wsyrk_lab(c, variant, n_splits, reps, c->zbuf.p, c->work1.p, &ms));
+    *ms_out = ms;
+    return LRVB_OK;
+}
+
 // ---- trust-region Newton-CG on the device -------------------------------------------------------------
 // The optimiser the reference runs through scipy (`minimize_objective_trust_ncg`, LRVB/OptimizationUtils.py:44-75:
 // scipy.optimize.minimize(method='trust-ncg') on fun_free / fun_free_grad / fun_free_hvp, or their `_cond`

@@ -123,6 +123,7 @@ int launch_obs_grad(lrvb_ctx* c, i64 n0, i64 n1, double* G_dev, int mode, const 
 
 // k_wsyrk.hip
 int  wsyrk_num_tiles(i64 P);
+int  launch_wsyrk_lab(lrvb_ctx* c, int variant, int n_splits, int reps, const double* cpad, double* sink, float* ms_out);   // timing lab
 int  wsyrk_auto_splits(const lrvb_ctx* c);
 int  launch_wsyrk(lrvb_ctx* c, const double* cvec_dev, double* tiles_out_dev /* T*128*128 */);
 int  launch_gram_small_on(lrvb_ctx* c, const double* Z, i64 N, i64 P, const double* cvec_dev, double* tiles_out_dev);
