@@ -24,9 +24,11 @@ def vb():
     return lrvb_amd
 
 
-@pytest.mark.parametrize('loss,N,P', [(om.GAUSSIAN, 211, 6), (om.LOGISTIC, 300, 7), (om.POISSON, 257, 8), (om.LOGISTIC, 1000, 130)])
+@pytest.mark.parametrize('loss,N,P', [(om.GAUSSIAN, 211, 6), (om.LOGISTIC, 300, 7), (om.POISSON, 257, 8), (om.LOGISTIC, 1000, 130),
+                                      (om.POISSON, 300, 1030), (om.LOGISTIC, 5, 2)])
 def test_directional_derivatives_of_the_gradient(vb, loss, N, P):
-    """Odd P takes the generic product for z and X u_k, even P the fused multi-vector pass."""
+    """Odd P takes the generic product for z and X u_k, even P the fused multi-vector pass; P = 1030 the wide-design
+    passes; N = 5 a single partial chunk."""
     rng = np.random.default_rng(N + P)
     spec = [('box', 'pre', 2, -np.inf, np.inf), ('box', 'beta', P, -np.inf, np.inf), ('box', 'post', 1, -np.inf, np.inf)]
     par, lay = make_par(vb, spec)
