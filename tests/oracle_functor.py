@@ -30,6 +30,9 @@ class OracleCtx(object):
     def lrvb_cov(self, M):
         return np.asarray(M) @ scipy.linalg.cho_solve(self._chol, np.asarray(M).T)
 
+    def dk_grad_vec(self, eta, U=None, w_override=None, include_quad=True):
+        return self.f.model.dk_grad_vec(eta, U, w_override, include_quad)
+
     def cg_solve(self, free, b, x0=None, Minv=None, tol=1e-8, maxiter=0):
         self.f._sync()
         x, info, iters = osv.cg_solve(lambda v: self.f.model.hvp(free, v), b, x0=x0, tol=tol,
@@ -79,6 +82,13 @@ class OracleFunctor(object):
     def hvp(self, x, v, is_free, *argv, **argk):
         self._sync(argv, argk)
         return self.model.hvp(x, v) if is_free else self.model.hvp_vec(x, v)
+
+    def hyper_kind(self, hyper_par):
+        if hyper_par is self.weights_par:
+            return 'weights'
+        if hyper_par is self.tilt_par:
+            return 'tilt'
+        raise NotImplementedError('unknown hyper-parameter')
 
     def cross_hessian(self, hyper_par, val1, val1_is_free, *argv, **argk):
         self._sync(argv, argk)

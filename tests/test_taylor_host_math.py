@@ -91,3 +91,88 @@ def test_oracle_directional_derivatives_against_nested_jvps(loss):
         if loss == om.POISSON:
             want = np.exp(z) - (y[:7] if m == 1 else 0.0)
             np.testing.assert_allclose(om.loss_derivative(loss, m, y[:7], z), want, rtol=1e-14)
+
+
+# ---- the class itself on the CPU: oracle arithmetic behind the device-functor protocol (tests/oracle_functor.py) ----
+def _oracle_setup(loss, spec_blocks, N, seed):
+    from oracle_functor import OracleFunctor
+    rng = np.random.default_rng(seed)
+    par = vb.ModelParamsDict('p')
+    blocks = []
+    for name, n, lb, ub in spec_blocks:
+        par.push_param(vb.VectorParam(name, n, lb=lb, ub=ub))
+        blocks.append(opk.box_block(n, lb=lb, ub=ub))
+    lay = opk.Layout(blocks)
+    P = lay.V
+    x, y, w = glm_data(rng, N, P, loss)
+    model = om.DeclaredModel(lay, loss=loss, x=x, y=y, w=w.copy(), quad_A=np.full(P, 0.8), quad_b=np.zeros(P))
+    wpar = vb.VectorParam('weights', N, val=w.copy())
+    tpar = vb.VectorParam('tilt', P, val=np.zeros(P))
+    fun = OracleFunctor(par, model, weights_par=wpar, tilt_par=tpar)
+    return rng, par, lay, model, fun, w
+
+
+@pytest.mark.parametrize('loss', [om.LOGISTIC, om.POISSON])
+def test_taylor_class_against_refits(loss):
+    """d^k phi_hat / d w^k along dw, k = 1..3, against 8th-order central differences of the refitted optimum."""
+    spec = [('u', 2, -np.inf, np.inf), ('lo', 2, -1.0, np.inf), ('hi', 1, -np.inf, 2.0), ('both', 2, -2.0, 3.0)]
+    rng, par, lay, model, fun, w0 = _oracle_setup(loss, spec, 120, seed=10 + loss)
+
+    def optimum(w, start):
+        model.w = w
+        phi = start.copy()
+        for _ in range(60):
+            step = np.linalg.solve(model.hessian(phi), model.grad(phi))
+            phi = phi - step
+            if np.max(np.abs(step)) < 1e-14:
+                break
+        model.w = w0
+        return phi
+
+    phi0 = optimum(w0, np.zeros(lay.D))
+    assert np.linalg.norm(model.grad(phi0)) < 1e-10
+    tay = vb.ParametricSensitivityTaylorExpansion(fun, par, fun.weights_par, phi0, w0, 3)
+    dw = rng.normal(size=w0.size) * 0.5
+    h = 2e-2
+    path = {m: optimum(w0 + m * h * dw, phi0) for m in range(-4, 5)}
+    # central differences of 8th / 8th / 6th order for the first three derivatives
+    d1 = (672 * (path[1] - path[-1]) - 168 * (path[2] - path[-2]) + 32 * (path[3] - path[-3]) - 3 * (path[4] - path[-4])) / (840 * h)
+    d2 = (-14350 * path[0] + 8064 * (path[1] + path[-1]) - 1008 * (path[2] + path[-2]) + 128 * (path[3] + path[-3])
+          - 9 * (path[4] + path[-4])) / (5040 * h * h)
+    d3 = (-488 * (path[1] - path[-1]) + 338 * (path[2] - path[-2]) - 72 * (path[3] - path[-3]) + 7 * (path[4] - path[-4])) / (240 * h ** 3)
+    for k, want, tol in ((1, d1, 1e-8), (2, d2, 1e-6), (3, d3, 1e-4)):
+        got = tay.evaluate_dkinput_dhyperk(dw, k)
+        assert np.max(np.abs(got - want)) < tol * max(1.0, np.max(np.abs(want))), (k, got, want)
+    # the series at a finite step beats the linear approximation by orders of magnitude
+    t = 0.1
+    truth = optimum(w0 + t * dw, phi0)
+    e1 = np.max(np.abs(tay.evaluate_taylor_series(t * dw, max_order=1) - truth))
+    e3 = np.max(np.abs(tay.evaluate_taylor_series(t * dw, max_order=3) - truth))
+    assert e3 < 1e-2 * e1
+    np.testing.assert_allclose(par.get_free(), phi0, rtol=1e-12, atol=1e-14)    # base values restored (free -> vector -> free)
+
+
+def test_taylor_class_tilt_and_vector_coordinates():
+    spec = [('a', 3, -10.0, np.inf)]
+    rng, par, lay, model, fun, w0 = _oracle_setup(om.GAUSSIAN, spec, 40, seed=3)
+    H = model.hessian_vec(np.zeros(3))                                   # Gaussian loss: constant in eta
+    lam0 = rng.normal(size=3)
+    fun.tilt_par.set_vector(lam0)
+    model.quad_b = lam0.copy()
+    eta0 = -np.linalg.solve(H, model.grad_vec(np.zeros(3)))               # quadratic objective: one Newton step from 0
+    par.set_vector(eta0)
+    phi0 = par.get_free()
+    d = rng.normal(size=3)
+    b = -np.linalg.solve(H, d)                                            # eta_hat is linear in the tilt
+    tay = vb.ParametricSensitivityTaylorExpansion(fun, par, fun.tilt_par, phi0, lam0, 4)
+    ratio = b / (eta0 + 10.0)
+    for k in range(1, 5):
+        want = (-1.0) ** (k - 1) * math.factorial(k - 1) * ratio ** k
+        np.testing.assert_allclose(tay.evaluate_dkinput_dhyperk(d, k), want, rtol=1e-8, atol=1e-12)
+    tv = vb.ParametricSensitivityTaylorExpansion(fun, par, fun.tilt_par, eta0, lam0, 3, input_is_free=False)
+    np.testing.assert_allclose(tv.evaluate_dkinput_dhyperk(d, 1), b, rtol=1e-10)
+    assert np.max(np.abs(tv.evaluate_dkinput_dhyperk(d, 2))) < 1e-10
+    with pytest.raises(ValueError):
+        tay.evaluate_dkinput_dhyperk(d, 5)
+    with pytest.raises(ValueError):
+        tay.evaluate_taylor_series(d[:2])
