@@ -121,9 +121,12 @@ def test_taylor_class_against_refits(loss):
     def optimum(w, start):
         model.w = w
         phi = start.copy()
-        for _ in range(60):
+        for _ in range(200):                                   # Newton with step halving on the value
             step = np.linalg.solve(model.hessian(phi), model.grad(phi))
-            phi = phi - step
+            t, f0 = 1.0, model.value(phi)
+            while not model.value(phi - t * step) <= f0 and t > 1e-8:
+                t *= 0.5
+            phi = phi - t * step
             if np.max(np.abs(step)) < 1e-14:
                 break
         model.w = w0
