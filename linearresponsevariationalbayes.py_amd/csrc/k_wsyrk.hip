@@ -1144,8 +1144,9 @@ void wsyrk_lab_kernel(const double* __restrict__ X, i64 ldx, i64 N, const double
 // times `reps` launches of the lab kernel over the rectangle rows [512, 1024) x columns [0, 512) of S (P >= 1024)
 int launch_wsyrk_lab(lrvb_ctx* c, int variant, int n_splits, int reps, const double* cpad, double* sink, float* ms_out)
 {
-    if (c->P < 1024 || (variant != 2 && variant != 4) || n_splits % 8 != 0 || n_splits <= 0)
-        LRVB_FAIL(LRVB_ERR_INVALID, "lab: need n_cols >= 1024, variant 2 or 4, n_splits a multiple of 8");
+    if (c->P < 1024 || c->P % 2 != 0 || (((uintptr_t)c->X.p) & 15) != 0 || (variant != 2 && variant != 4) ||
+        n_splits % 8 != 0 || n_splits <= 0 || n_splits > 1024)
+        LRVB_FAIL(LRVB_ERR_INVALID, "lab: need even n_cols >= 1024, 16-byte aligned rows, variant 2 or 4, n_splits a multiple of 8");
     const int ntr = 512 / (64 * variant), ntc = 4;
     const i64 rows_per_split = ((c->N + n_splits - 1) / n_splits + WS_KC - 1) / WS_KC * WS_KC;
     const unsigned grid = (unsigned)(n_splits * ntr * ntc);
