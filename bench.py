@@ -237,6 +237,13 @@ def main():
                      if prof['pass_ms'] > 0 else None},
     }
 
+    # the same data for every world size (chunks are seeded by their global index), so the built matrix must not depend on
+    # it: a fingerprint of H that can be compared across the N = 1, 2, 4, 8 lines (agreement to ~1e-12 relative)
+    torch.cuda.synchronize()
+    out['config']['hessian_fingerprint'] = {'trace': float(torch.trace(Hout).item()),
+                                           'sum_abs_64x64': float(Hout[:64, :64].abs().sum().item()),
+                                           'last_row_sum': float(Hout[D - 1].sum().item())}
+
     if world == 1:
         # LRVB-covariance solve time: cho_factor(H) + M H^-1 M^T with Q = D moments (worst case)
         M = torch.eye(D, dtype=torch.float64, device=dev)
