@@ -29,7 +29,7 @@ PEAK_FP64_MFMA_TFLOPS = 78.6     # MI355X fp64 matrix peak (vendor figure; see D
 PEAK_HBM_GBS = 8000.0
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
@@ -38,60 +38,180 @@ def parse():
     ap.add_argument('--n-free', type=int, default=1024)
     ap.add_argument('--loss', default='gaussian', choices=['gaussian', 'logistic', 'poisson'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample-rows', type=int, default=16384)
+    ap.add_argument('--cpu-budget-s', type=float, default=30.0,
+                    help='rough bound on the CPU work of the cpu_baseline leg (seconds)')
     ap.add_argument('--n-splits', type=int, default=0)
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(x_sample, y_sample, n_total, D, n_pos, loss, lik_info, prior_info, theta):
-    """Reference-faithful port: what autograd.hessian executes (LRVB/SparseObjectives.py:103) --
-    one gradient + D Hessian-vector products, each a full pass over the observations -- timed on a
-    row sample with numpy (BLAS threads = all host cores) and extrapolated linearly in N.  The
-    strong numpy path (one dsyrk-like X^T diag(c) X) is timed beside it."""
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_command(n_ranks, argv, port):
+    """The child command that runs this script on n_ranks ranks of ONE node, one rank per GPU (the form the driver
+    itself uses for N > 1): torchrun with a loopback rendezvous."""
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node={}'.format(int(n_ranks)),
+            '--master-addr', '127.0.0.1', '--master-port', str(int(port)), os.path.abspath(__file__)] + list(argv)
+
+
+def needs_launch(args, environ):
+    """`python bench.py --gpus N` with N > 1 and no rank environment: this process is not a rank, it starts them."""
+    return args.gpus > 1 and 'RANK' not in environ and 'WORLD_SIZE' not in environ
+
+
+def launch_ranks(args, argv):
+    """Start the N ranks as a fresh child process tree and relay rank 0's JSON line.  This parent has not touched
+    the GPU (no torch import, no HIP call) and never execs: it waits for the child and exits with its code."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = launch_command(args.gpus, argv, _free_port())
+    print('bench: starting {} ranks: {}'.format(args.gpus, ' '.join(cmd)), file=sys.stderr, flush=True)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    lines = [ln for ln in proc.stdout.decode('utf-8', 'replace').splitlines() if ln.startswith('{')]
+    if proc.returncode != 0 or not lines:
+        print('bench: the {}-rank run failed (exit code {}, {} result lines)'.format(args.gpus, proc.returncode, len(lines)),
+              file=sys.stderr, flush=True)
+        return proc.returncode or 1
+    print(lines[-1], flush=True)
+    return 0
+
+
+def _blas_threads_scan(np, candidates):
+    """Pick the BLAS thread count that runs a 2048^3 dgemm fastest on this host (the box may expose more logical CPUs
+    than its share of the machine).  Returns (threads, {threads: GFLOP/s})."""
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:
+        return None, {}
+    a = np.ones((2048, 2048)) * 0.5
+    rates = {}
+    for t in candidates:
+        with threadpool_limits(limits=t):
+            a @ a
+            t0 = time.perf_counter()
+            a @ a
+            rates[t] = 2.0 * 2048 ** 3 / (time.perf_counter() - t0) / 1e9
+    return max(rates, key=rates.get), rates
+
+
+def cpu_baseline(fetch_rows, n_total, D, n_pos, loss, lik_info, prior_info, theta, budget_s=30.0):
+    """The two CPU baselines of SURVEY.md section 8(d), timed on this host with numpy / BLAS.
+
+    fetch_rows(a, b) -> (x[a:b], y[a:b]) host arrays of the bench's own synthetic rows.
+
+    1. `strong_numpy`: the closed-form build the oracle's `hessian` makes -- curvature pass, X^T diag(c) X through BLAS,
+       packing assembly -- MEASURED over all n_total rows in 65,536-row chunks (only the compute of each chunk is
+       timed, not fetching it), the N-independent assembly timed once and added.  Its GFLOP/s is printed so the
+       figure can be sanity-checked.
+    2. `port` (the `value`): the cost structure of `autograd.hessian` (LRVB/SparseObjectives.py:103) -- one gradient,
+       then D Hessian-vector products against the standard basis, each a pass over the observations
+       (`DeclaredModel.hessian_by_hvps`).  Timed at TWO sample sizes; the per-column time is fitted as a + b N, only
+       b N is scaled to n_total, and the N-independent part is added unscaled.  Raw timings are in the record."""
     import numpy as np
     from oracle import packing as opk, models as om
     try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get('num_threads', 1) for p in threadpool_info()] + [1])
-    except Exception:
-        threads = os.cpu_count() or 1
-    loss_id = {'gaussian': om.GAUSSIAN, 'logistic': om.LOGISTIC, 'poisson': om.POISSON}[loss]
-    layout = opk.Layout([opk.box_block(D - n_pos), opk.box_block(n_pos, lb=0.0)])
-    model = om.DeclaredModel(layout, loss=loss_id, x=x_sample, y=y_sample, lik_info=lik_info,
-                             quad_A=np.full(D, prior_info))
-    ns = x_sample.shape[0]
-    # time a prefix of the D columns if the full sweep would exceed ~25 s
-    t0 = time.time()
-    model.hessian_by_hvps(theta, n_columns=16)
-    per_col = (time.time() - t0) / 16
-    ncol = int(min(D, max(16, 25.0 / max(per_col, 1e-9))))
-    t0 = time.time()
-    model.grad(theta)
-    model.hessian_by_hvps(theta, n_columns=ncol)
-    t_sample = time.time() - t0
-    t_full = t_sample * (D / ncol) * (n_total / ns)
-    # strong path on the same sample
-    t0 = time.time()
-    model.hessian(theta)
-    t_strong = (time.time() - t0) * (n_total / ns)
-    try:
         affinity = len(os.sched_getaffinity(0))
     except Exception:
-        affinity = None
+        affinity = os.cpu_count() or 1
+    cands = sorted({t for t in (8, 16, 32, 64, 128) if t <= affinity} | {min(affinity, 256)})
+    threads, scan = _blas_threads_scan(np, cands)
+    try:
+        from threadpoolctl import threadpool_limits, threadpool_info
+        limiter = threadpool_limits(limits=threads) if threads else None
+        blas = sorted({(p_.get('internal_api'), p_.get('version')) for p_ in threadpool_info()
+                       if p_.get('user_api') == 'blas'})
+    except Exception:
+        limiter, blas = None, []
+    if threads is None:
+        threads = affinity
+    loss_id = {'gaussian': om.GAUSSIAN, 'logistic': om.LOGISTIC, 'poisson': om.POISSON}[loss]
+    layout = opk.Layout([opk.box_block(D - n_pos), opk.box_block(n_pos, lb=0.0)])
+    n_total = int(n_total)
+    raw = {}
+
+    # ---- strong path, full N, chunked ------------------------------------------------------------------
+    chunk = 65536
+    eta = layout.constrain(theta)
+    S = np.zeros((D, D)); g = np.zeros(D)
+    t_compute = 0.0
+    rows_done = 0
+    budget_strong = 0.45 * budget_s
+    for a in range(0, n_total, chunk):
+        b = min(a + chunk, n_total)
+        xc, yc = fetch_rows(a, b)
+        t0 = time.perf_counter()
+        z = xc @ eta
+        _, l1, l2 = om.loss_terms(loss_id, yc, z, lik_info)
+        g += xc.T @ l1
+        S += xc.T @ (l2[:, None] * xc)
+        t_compute += time.perf_counter() - t0
+        rows_done = b
+        if t_compute > budget_strong:                 # slow host: stop and say so (scaled by rows only)
+            break
+    model0 = om.DeclaredModel(layout, loss=0, quad_A=np.full(D, prior_info))
+    t0 = time.perf_counter()
+    gq = g + model0.grad_vec(eta)
+    opk.convert_vector_to_free_hessian(layout, theta, gq, S + model0.hessian_vec(eta))
+    t_assembly = time.perf_counter() - t0
+    t_strong = t_compute * (n_total / rows_done) + t_assembly
+    raw['strong'] = {'rows_timed': rows_done, 'compute_s': t_compute, 'assembly_s': t_assembly,
+                     'gflops': 2.0 * rows_done * D * (D + 1) / max(t_compute, 1e-12) / 1e9}
+
+    # ---- port path at two sample sizes -----------------------------------------------------------------
+    n_small, n_large = min(10000, n_total), min(100000, n_total)
+    per_col = {}
+    t_grad = {}
+    budget_port = 0.5 * budget_s
+    for ns, share in ((n_small, 0.25), (n_large, 0.75)):
+        xs, ys = fetch_rows(0, ns)
+        model = om.DeclaredModel(layout, loss=loss_id, x=xs, y=ys, lik_info=lik_info, quad_A=np.full(D, prior_info))
+        t0 = time.perf_counter()
+        model.hessian_by_hvps(theta, n_columns=2)
+        est = (time.perf_counter() - t0) / 2
+        ncol = int(min(D, max(4, share * budget_port / max(est, 1e-9))))
+        t0 = time.perf_counter()
+        model.grad(theta)
+        t_grad[ns] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        model.hessian_by_hvps(theta, n_columns=ncol)
+        dt = time.perf_counter() - t0
+        per_col[ns] = dt / ncol
+        raw['port_n{}'.format(ns)] = {'rows': ns, 'columns_timed': ncol, 'seconds': dt, 'gradient_s': t_grad[ns]}
+        if n_small == n_large:
+            break
+    if n_large > n_small:
+        slope = max((per_col[n_large] - per_col[n_small]) / (n_large - n_small), 0.0)
+        fixed = max(per_col[n_small] - slope * n_small, 0.0)
+        g_slope = max((t_grad[n_large] - t_grad[n_small]) / (n_large - n_small), 0.0)
+    else:
+        slope, fixed, g_slope = per_col[n_small] / n_small, 0.0, t_grad[n_small] / n_small
+    t_port = D * (fixed + slope * n_total) + g_slope * n_total
+    raw['port_fit'] = {'per_column_fixed_s': fixed, 'per_column_per_row_s': slope}
+    if limiter is not None:
+        limiter.restore_original_limits()
     return {
-        'value': 1.0 / t_full, 'unit': 'hessian_builds/s', 'cores': int(threads), 'kind': 'port',
-        'cpu_affinity': affinity,
-        'sample': '{} of {} rows x {} of {} HVP columns, numpy oracle (gradient + D Hessian-vector '
-                  'products = the passes autograd.hessian makes), extrapolated linearly in rows and '
-                  'columns'.format(ns, int(n_total), ncol, D),
-        'seconds_on_sample': t_sample,
+        'value': 1.0 / t_port, 'unit': 'hessian_builds/s', 'cores': int(threads), 'kind': 'port',
+        'cpu_affinity': affinity, 'blas': ['{} {}'.format(*b_) for b_ in blas], 'blas_thread_scan_gflops': scan,
+        'sample': 'numpy oracle, gradient + D Hessian-vector products (the passes autograd.hessian makes): {} and {} of '
+                  '{} rows, a prefix of the {} columns each; per-column time fitted as a + b N, only b N scaled to full '
+                  'N'.format(n_small, n_large, n_total, D),
+        'seconds_per_build': t_port,
         'strong_numpy_value': 1.0 / t_strong,
-        'strong_numpy_note': 'closed-form X^T diag(c) X through BLAS on the same row sample, extrapolated in rows',
+        'strong_numpy_seconds_per_build': t_strong,
+        'strong_numpy_note': 'closed-form X^T diag(c) X through BLAS, measured over {} of {} rows in 65,536-row chunks '
+                             '(compute only), N-independent assembly added once'.format(rows_done, n_total),
+        'raw_timings': raw,
     }
 
 
-def main():
-    args = parse()
+def main(args):
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -101,25 +221,36 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        raise SystemExit('bench: --gpus {} but WORLD_SIZE is {} (start the ranks with `python bench.py --gpus N` or '
+                         'with torchrun --nproc-per-node N bench.py --gpus N)'.format(args.gpus, world))
     # LRVB_BENCH_FORCE_SHARDED=1 runs the multi-GPU code path (process group, stats all-reduce,
     # finish) even with one rank -- used to rehearse the N > 1 path on a one-GPU box
     force_sharded = os.environ.get('LRVB_BENCH_FORCE_SHARDED', '0') == '1'
     use_dist = world > 1 or force_sharded
+    # LRVB_BENCH_REHEARSE_ONE_GPU=1: every rank uses GPU 0 and the exchange goes over gloo -- a correctness
+    # rehearsal of the multi-rank path on a one-GPU box (RCCL refuses two ranks on one device); the numbers it
+    # prints are not a measurement
+    rehearse = os.environ.get('LRVB_BENCH_REHEARSE_ONE_GPU', '0') == '1'
+    backend = None
+    if rehearse:
+        local_rank = 0
+    n_dev = torch.cuda.device_count()
+    if local_rank >= n_dev:
+        raise SystemExit('bench: rank {} needs GPU {} but this node shows {} GPU(s); a one-GPU box can only REHEARSE '
+                         'the multi-rank path (LRVB_BENCH_REHEARSE_ONE_GPU=1: all ranks on GPU 0, gloo exchange)'
+                         .format(rank, local_rank, n_dev))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29531')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        # LRVB_BENCH_REHEARSE_ONE_GPU=1: every rank uses GPU 0 and the exchange goes over gloo -- a
-        # correctness rehearsal of the multi-rank path on a one-GPU box (RCCL refuses two ranks on one
-        # device); the numbers it prints are not a measurement
-        rehearse = os.environ.get('LRVB_BENCH_REHEARSE_ONE_GPU', '0') == '1'
-        dist.init_process_group('gloo' if rehearse else 'nccl', rank=rank, world_size=world)
-        if rehearse:
-            local_rank = 0
-    if args.gpus != world and rank == 0:
-        print('warning: --gpus {} but WORLD_SIZE {}'.format(args.gpus, world), file=sys.stderr)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+        backend = 'gloo' if rehearse else 'nccl'
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
 
     N_total, D = int(args.n_obs), int(args.n_free)
     n_pos = D // 4                       # box constraint (lb = 0) on the last quarter
@@ -202,7 +333,10 @@ def main():
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if use_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if backend == 'gloo':
+            th = t.cpu(); dist.all_reduce(th, op=dist.ReduceOp.MAX); t = th
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
     value = args.steps / elapsed
@@ -211,15 +345,21 @@ def main():
     ws_ms = prof['wsyrk_ms'] / max(prof['wsyrk_calls'], 1)
     ws_flops = float(n_local) * D * (D + 1)
     achieved = ws_flops / (ws_ms * 1e-3) / 1e12 if ws_ms > 0 else 0.0
-    traffic = None
+    # HBM traffic of that kernel comes from a separate rocprofv3 --pmc run (counters cannot be read inside a timed
+    # run): the committed summary names the commit and kernel it was measured on, and is quoted only for the exact
+    # shape it was measured at
+    traffic, traffic_src = None, None
     tfile = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-    if os.path.exists(tfile) and world == 1 and N_total == 1000000 and D == 1024:
+    if os.path.exists(tfile) and world == 1 and N_total == 1000000 and D == 1024 and not args.n_splits:
         try:
-            traffic = json.load(open(tfile)).get('wsyrk_hbm_bytes_per_launch')
+            rec = json.load(open(tfile))
+            traffic = rec.get('wsyrk_hbm_bytes_per_launch')
+            traffic_src = {k: rec.get(k) for k in ('measured_at_commit', 'kernel', 'source', 'method') if k in rec}
         except Exception:
             traffic = None
+    pass_ms = prof['pass_ms'] / max(prof['pass_calls'], 1)
     out = {
-        'metric': 'ELBO-Hessian builds/sec, N=1e6 obs x D=1024 free params',
+        'metric': 'ELBO-Hessian builds/sec, N={:g} obs x D={} free params'.format(float(N_total), D),
         'value': value, 'unit': 'hessian_builds/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
         'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
@@ -227,14 +367,15 @@ def main():
                                'parameters (last {} box-constrained lb=0), Gaussian prior; one step = one dense '
                                'Hessian build'.format(args.loss, N_total, D, n_pos),
                    'n_obs_total': N_total, 'n_obs_per_gpu': n_local, 'n_free': D,
+                   'ranks_seen': dist.get_world_size() if use_dist else 1,
+                   'backend': backend if use_dist else 'none (single process)',
                    'parallelism': 'observation shards x{} + 1 sum all-reduce per build'.format(world)},
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP64_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': achieved / PEAK_FP64_MFMA_TFLOPS, 'traffic': traffic,
-                     'kernel': 'wsyrk_glds_kernel (v_mfma_f64_16x16x4_f64)', 'kernel_ms': ws_ms,
+                     'frac': achieved / PEAK_FP64_MFMA_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_src,
+                     'kernel': 'weighted SYRK (v_mfma_f64_16x16x4_f64)', 'kernel_ms': ws_ms,
                      'flops_per_launch': ws_flops,
-                     'pass_kernel_ms': prof['pass_ms'] / max(prof['pass_calls'], 1),
-                     'pass_kernel_GBs': (8.0 * n_local * (D + 3)) / (prof['pass_ms'] / max(prof['pass_calls'], 1) * 1e-3) / 1e9
-                     if prof['pass_ms'] > 0 else None},
+                     'pass_kernel_ms': pass_ms,
+                     'pass_kernel_GBs': (8.0 * n_local * (D + 3)) / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else None},
     }
 
     # the same data for every world size (chunks are seeded by their global index), so the built matrix must not depend on
@@ -281,25 +422,23 @@ def main():
         out['lrvb_solve_ms']['cg_iterations'] = [int(i) if f == 0 else -1 for i, f in zip(its, infos)]
         out['lrvb_solve_ms']['cg_iterations_one_by_one'] = iters
         if not args.no_cpu_baseline and rank == 0:
-            ns = min(args.cpu_sample_rows, n_local)
-            xs = X[:ns].cpu().numpy()
-            ys = y[:ns].cpu().numpy()
-            out['cpu_baseline'] = cpu_baseline(xs, ys, N_total, D, n_pos, args.loss, lik_info, prior_info,
-                                               theta.cpu().numpy())
-            # parity of the timed result on the sample's leading block (cheap sanity, not the test suite)
+            def fetch_rows(a, b):
+                return X[a:b].cpu().numpy(), y[a:b].cpu().numpy()
+            out['cpu_baseline'] = cpu_baseline(fetch_rows, N_total, D, n_pos, args.loss, lik_info, prior_info,
+                                               theta.cpu().numpy(), budget_s=args.cpu_budget_s)
     if use_dist:
         dist.destroy_process_group()
     return out if rank == 0 else None
 
 
-def run_with_clean_stdout():
+def run_with_clean_stdout(args=None):
     """The contract is ONE JSON line on stdout.  Libraries underneath write there too (RCCL prints a five-line
     version banner to stdout when the first communicator comes up, on every rank), so file descriptor 1 points at
     stderr while the bench runs and is restored only for the result line."""
     sys.stdout.flush()
     saved = os.dup(1)
     os.dup2(2, 1)
-    out = main()
+    out = main(args) if args is not None else main()
     sys.stdout.flush()
     if out is not None:                      # rank 0; the other ranks keep writing to stderr until they exit
         os.dup2(saved, 1)
@@ -308,4 +447,7 @@ def run_with_clean_stdout():
 
 
 if __name__ == '__main__':
-    run_with_clean_stdout()
+    _args = parse()
+    if needs_launch(_args, os.environ):
+        sys.exit(launch_ranks(_args, sys.argv[1:]))
+    run_with_clean_stdout(_args)

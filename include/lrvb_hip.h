@@ -320,6 +320,22 @@ int lrvb_hessian_finish_dev (lrvb_ctx* ctx, const double* free_dev, const double
                              double* H_dev, int64_t ld);
 /* Single-GPU convenience = partial + finish with everything resident.                      */
 int lrvb_hessian_dev(lrvb_ctx* ctx, const double* free_dev, double* H_dev, int64_t ld);
+
+/* Sum-over-ranks hook.  With a hook installed, every sum over observations that the declared-objective entry
+ * points form -- [value | gradient] of lrvb_value / lrvb_grad (and their _vec forms), the product of lrvb_hvp /
+ * lrvb_hvp_dev, the block products of lrvb_cg_solve_multi, the statistics buffer inside lrvb_hessian /
+ * lrvb_hessian_dev, the tiles of lrvb_gram, every product inside lrvb_cg_solve, lrvb_minimize_trust_ncg and
+ * lrvb_dk_grad_vec -- is handed to `fn(user, buf_dev, n, hip_stream)` BEFORE the N-independent terms (quadratic
+ * term, packing second-order terms) are added.  `fn` must replace buf_dev[0 .. n) by its sum over all ranks, ordered
+ * after the work already queued on `hip_stream` (the context's stream) and before whatever is queued on it next
+ * -- e.g. an RCCL all-reduce launched on that stream -- and return 0.  Every rank then holds the global value,
+ * gradient, product, Hessian and iterates, bit-identical, so the device CG / trust-region loops stay in lockstep
+ * with one D-vector all-reduce per product; no counterpart in the reference, which is
+ * single-process.  lrvb_hessian_partial_dev, the per-observation row outputs (lrvb_obs_*) and the raw statistics
+ * calls (lrvb_weighted_gram, lrvb_group_sums, lrvb_mixture_rows, lrvb_quadform_gram) stay rank-local by contract.
+ * fn == NULL removes the hook.                                                                                */
+typedef int (*lrvb_reduce_fn)(void* user, double* buf_dev, int64_t n, void* hip_stream);
+int lrvb_set_reduce_hook(lrvb_ctx* ctx, lrvb_reduce_fn fn, void* user);
 int lrvb_hvp_dev    (lrvb_ctx* ctx, const double* free_dev, const double* v_dev, double* out_dev);
 int lrvb_gram_dev   (lrvb_ctx* ctx, const double* free_dev, double* GtG_dev, int64_t ld);
 

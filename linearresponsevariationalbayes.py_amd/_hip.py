@@ -113,7 +113,11 @@ _SIGNATURES = {
     'lrvb_profile_get': [_VP, ctypes.POINTER(Prof)],
     'lrvb_profile_reset': [_VP],
     'lrvb_set_tuning': [_VP, ctypes.c_int, ctypes.c_int],
+    'lrvb_set_reduce_hook': [_VP, _VP, _VP],
 }
+
+# lrvb_reduce_fn of include/lrvb_hip.h: int fn(void* user, double* buf_dev, int64_t n, void* hip_stream)
+REDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
 
 class OptResult(ctypes.Structure):
     """lrvb_opt_result of include/lrvb_hip.h."""

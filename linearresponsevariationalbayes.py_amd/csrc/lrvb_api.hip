@@ -349,10 +349,27 @@ static int set_point(lrvb_ctx* c, const double* point_dev, bool is_free) {
     return LRVB_OK;
 }
 
+// Sum of a device buffer of observation sums over the ranks of the job (no-op in a single process).
+static int obs_reduce(lrvb_ctx* c, double* buf_dev, i64 n) {
+    if (!c->reduce_fn || n <= 0) return LRVB_OK;
+    const int st = c->reduce_fn(c->reduce_user, buf_dev, (int64_t)n, (void*)c->stream);
+    if (st != 0) LRVB_FAIL(LRVB_ERR_STATE, "the reduce hook failed with status %d", st);
+    return LRVB_OK;
+}
+extern "C" int lrvb_set_reduce_hook(lrvb_ctx* c, lrvb_reduce_fn fn, void* user) {
+    if (!c) LRVB_FAIL(LRVB_ERR_INVALID, "null context");
+    c->hvp_pt_valid = false;
+    c->reduce_fn = fn; c->reduce_user = fn ? user : nullptr;
+    return LRVB_OK;
+}
+
 // value and d f / d eta at the current eta; per-observation lp, cw stored.  stats: [value | g_glm].
-static int eval_grad_eta(lrvb_ctx* c, double* stats_dev, bool include_quad) {
+// reduce: hand [value | g_glm] to the sum-over-ranks hook (callers that reduce a larger buffer themselves, or that
+// only want the per-observation l', pass false).
+static int eval_grad_eta(lrvb_ctx* c, double* stats_dev, bool include_quad, bool reduce = true) {
     if (c->loss != LRVB_LOSS_NONE) {
         LRVB_TRY(launch_glm_pass(c, PASS_GRAD, c->eta.p + c->glm_off, nullptr, stats_dev + 1, stats_dev, true));
+        if (reduce) LRVB_TRY(obs_reduce(c, stats_dev, 1 + c->P));
         LRVB_TRY(launch_scatter_glm(c, stats_dev + 1, c->g_eta.p));
     } else {
         HIP_TRY(hipMemsetAsync(stats_dev, 0, sizeof(double), c->stream));
@@ -379,6 +396,7 @@ static int heta_apply(lrvb_ctx* c, const double* u_vec, double* out_vec) {
     if (c->loss != LRVB_LOSS_NONE) {
         LRVB_TRY(buf_reserve(c, c->vtmp3, (size_t)(c->V > c->P ? c->V : c->P)));
         LRVB_TRY(launch_glm_pass(c, PASS_HVP_C, nullptr, u_vec + c->glm_off, c->vtmp3.p, nullptr, false));
+        LRVB_TRY(obs_reduce(c, c->vtmp3.p, c->P));
         // vtmp3 holds the P-vector; scatter into out_vec
         LRVB_TRY(launch_scatter_glm(c, c->vtmp3.p, out_vec));
     } else {
@@ -392,6 +410,7 @@ static int heta_apply_coef(lrvb_ctx* c, const double* u_vec, double* out_vec, bo
     if (c->loss != LRVB_LOSS_NONE) {
         LRVB_TRY(buf_reserve(c, c->vtmp3, (size_t)(c->V > c->P ? c->V : c->P)));
         LRVB_TRY(launch_glm_pass(c, PASS_HVP_C, nullptr, u_vec + c->glm_off, c->vtmp3.p, nullptr, false));
+        LRVB_TRY(obs_reduce(c, c->vtmp3.p, c->P));
         LRVB_TRY(launch_scatter_glm(c, c->vtmp3.p, out_vec));
     } else {
         LRVB_TRY(launch_scatter_glm(c, nullptr, out_vec));
@@ -435,7 +454,7 @@ extern "C" int lrvb_stats_size(lrvb_ctx* c, int64_t* n) {
 static int hessian_partial(lrvb_ctx* c, const double* point_dev, bool is_free, double* stats_dev) {
     LRVB_TRY(data_ready(c));
     LRVB_TRY(set_point(c, point_dev, is_free));
-    LRVB_TRY(eval_grad_eta(c, stats_dev, false));
+    LRVB_TRY(eval_grad_eta(c, stats_dev, false, false));
     if (c->loss != LRVB_LOSS_NONE)
         LRVB_TRY(launch_wsyrk(c, c->cw.p, stats_dev + 1 + c->P));
     return LRVB_OK;
@@ -478,6 +497,14 @@ static int hessian_finish(lrvb_ctx* c, const double* point_dev, bool is_free, co
     return LRVB_OK;
 }
 
+// the whole statistics buffer [value | g_glm | tiles] of a build in ONE reduction
+static int stats_reduce(lrvb_ctx* c) {
+    if (!c->reduce_fn || c->loss == LRVB_LOSS_NONE) return LRVB_OK;
+    int64_t n = 0;
+    LRVB_TRY(lrvb_stats_size(c, &n));
+    return obs_reduce(c, c->stats.p, n);
+}
+
 extern "C" int lrvb_hessian_partial_dev(lrvb_ctx* c, const double* free_dev, double* stats_dev) {
     LRVB_TRY(ctx_bind(c));
     if (!free_dev || !stats_dev) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
@@ -493,6 +520,7 @@ extern "C" int lrvb_hessian_dev(lrvb_ctx* c, const double* free_dev, double* H_d
     if (!free_dev || !H_dev) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
     if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_BUILD));
     LRVB_TRY(hessian_partial(c, free_dev, true, c->stats.p));
+    LRVB_TRY(stats_reduce(c));
     LRVB_TRY(hessian_finish(c, free_dev, true, c->stats.p, H_dev, ld));
     if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_BUILD));
     return LRVB_OK;
@@ -512,6 +540,7 @@ static int hessian_host(lrvb_ctx* c, const double* point, i64 n_in, bool is_free
     LRVB_TRY(h2d(c, c->theta.p, point, (size_t)n));           // theta buffer doubles as the vector-mode input
     LRVB_TRY(buf_reserve(c, c->Hfree, (size_t)n * (size_t)n));
     LRVB_TRY(hessian_partial(c, c->theta.p, is_free, c->stats.p));
+    LRVB_TRY(stats_reduce(c));
     LRVB_TRY(hessian_finish(c, c->theta.p, is_free, c->stats.p, c->Hfree.p, n));
     HIP_TRY(hipMemcpy2DAsync(H_out, (size_t)ld * 8, c->Hfree.p, (size_t)n * 8, (size_t)n * 8, (size_t)n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -786,7 +815,7 @@ static int obs_grad_impl(lrvb_ctx* c, const double* point, i64 n_in, bool is_fre
     LRVB_TRY(data_ready(c));
     LRVB_TRY(h2d(c, c->theta.p, point, (size_t)width));
     LRVB_TRY(set_point(c, c->theta.p, is_free));
-    LRVB_TRY(eval_grad_eta(c, c->stats.p, false));
+    LRVB_TRY(eval_grad_eta(c, c->stats.p, false, false));        // per-observation l' only: rank-local
     const bool diag_path = !is_free || c->all_box;
     if (!is_free) EW(fill_kernel, c->V, 1.0, c->vtmp.p);
     if (is_free && !c->all_box) LRVB_TRY(ensure_dense_J(c, c->theta.p));
@@ -842,11 +871,12 @@ static int gram_dev_impl(lrvb_ctx* c, const double* free_dev, double* G_dev, i64
     if (ld < c->D) LRVB_FAIL(LRVB_ERR_SIZE, "leading dimension too small");
     LRVB_TRY(data_ready(c));
     LRVB_TRY(set_point(c, free_dev, true));
-    LRVB_TRY(eval_grad_eta(c, c->stats.p, false));
+    LRVB_TRY(eval_grad_eta(c, c->stats.p, false, false));
     LRVB_TRY(reserve_obs_vec(c, c->zbuf));
     EW(square_kernel, c->N, c->lp.p, c->zbuf.p);
     double* tiles = c->stats.p + 1 + c->P;
     LRVB_TRY(launch_wsyrk(c, c->zbuf.p, tiles));
+    LRVB_TRY(obs_reduce(c, tiles, (i64)wsyrk_num_tiles(c->P) * WS_TILE * WS_TILE));
     const int saved_quad = c->quad_kind;
     c->quad_kind = LRVB_QUAD_NONE;               // G^T G has no quadratic-term contribution
     int st;
@@ -1406,7 +1436,7 @@ static int obs_influence_impl(lrvb_ctx* c, const double* point, i64 n_in, bool i
     LRVB_TRY(data_ready(c));
     LRVB_TRY(h2d(c, c->theta.p, point, (size_t)width));
     LRVB_TRY(set_point(c, c->theta.p, is_free));
-    LRVB_TRY(eval_grad_eta(c, c->stats.p, false));                 // leaves l'_n in c->lp
+    LRVB_TRY(eval_grad_eta(c, c->stats.p, false, false));          // leaves l'_n in c->lp (rank-local rows)
     // W = H^-1 M^T
     LRVB_TRY(buf_reserve(c, c->work1, (size_t)Q * (size_t)width));
     LRVB_TRY(h2d(c, c->work1.p, M, (size_t)Q * (size_t)width));
@@ -1863,6 +1893,7 @@ static int heta_apply_multi(lrvb_ctx* c, i64 Q, const double* U /* Q x V */, dou
             }
         }
     }
+    if (c->loss != LRVB_LOSS_NONE) LRVB_TRY(obs_reduce(c, Out, Q * V));
     if (c->quad_kind == LRVB_QUAD_DIAG) {
         EW(diag_mul_add_rows_kernel, Q * V, V, c->quad_scale, c->quadA.p, U, Out);
     } else if (c->quad_kind == LRVB_QUAD_DENSE) {

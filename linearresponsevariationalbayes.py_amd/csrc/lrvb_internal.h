@@ -48,6 +48,9 @@ struct lrvb_ctx {
     int quad_kind = LRVB_QUAD_NONE;
     double quad_scale = 1.0;
 
+    // sum-over-ranks hook (lrvb_set_reduce_hook): null = single process
+    lrvb_reduce_fn reduce_fn = nullptr; void* reduce_user = nullptr;
+
     // resident data
     DevBuf X, y, w, quadA, quadM, quadB;
     bool have_X = false, have_y = false;

@@ -71,18 +71,46 @@ class ShardedHessian(object):
         return self.engine.finish(theta, stats)
 
 
+class _DevicePointer(object):
+    """A raw device address as a `__cuda_array_interface__` object, so that torch can wrap library-owned memory."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {'shape': (int(n),), 'typestr': '<f8', 'data': (int(ptr), False), 'version': 2}
+
+
+def torch_reduce_hook(torch_device, group=None):
+    """The callable for `DeviceContext.set_reduce_hook`: one `torch.distributed` sum all-reduce (RCCL over xGMI with
+    the `nccl` backend) of the library's own device buffer, in place -- no host hop.  The context must run on
+    torch's current stream (`ctx.set_stream(torch.cuda.current_stream().cuda_stream)`) so that the collective is
+    ordered between the kernels that produce and consume the buffer.  (With the `gloo` backend -- one-GPU rehearsals
+    of the multi-rank path -- torch stages the same device tensor through the host itself.)"""
+    import torch
+    import torch.distributed as dist
+    views = {}
+
+    def hook(ptr, n, stream):
+        t = views.get((ptr, n))
+        if t is None:
+            t = views[(ptr, n)] = torch.as_tensor(_DevicePointer(ptr, n), device=torch_device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return hook
+
+
 class ShardedObjective(object):
     """Value, gradient, Hessian-vector products, CG solves and trust-ncg fits of an objective whose observations
     are sharded over the ranks of a process group ("one D-vector all-reduce per CG
-    iteration when the HVP is data-sharded").
+    iteration when the HVP is data-sharded").  Every rank holds a context over ITS rows; every method returns the
+    GLOBAL quantity, bit-identical on every rank, so host-side iterations (scipy's cg / trust-ncg, as the reference
+    drives them) stay in lockstep without further coordination.
 
-    Every rank holds a context over ITS rows.  The N-independent quadratic term is scaled by 1 / world_size on
-    every rank (`set_quad_scale`), which makes the global objective the plain sum of the local ones -- and with it
-    the value, the gradient and every Hessian-vector product, packing terms included, because all of them are linear
-    in the objective.  One sum all-reduce of the local result is then the global result, identical on every rank,
-    so host-side iterations (scipy's cg / trust-ncg, as the reference drives them) stay in lockstep without any
-    further coordination.  Consecutive products at one point reuse the rank's point state (one pass over the local
-    rows each).  `ctx` needs value / grad / hvp / set_quad_scale and D (DeviceContext has them)."""
+    * `DeviceContext` on a GPU (`torch_device` given): the library's sum-over-ranks hook is installed
+      (`lrvb_set_reduce_hook`).  Each sum over observations is all-reduced ON THE DEVICE, in the library's own buffer,
+      before the N-independent terms are added; nothing about the context is rescaled, so the same context goes on to
+      build the sharded Hessian (`ShardedHessian`, or `ctx.hessian` directly) correctly, and the device-side loops
+      (`cg_solve`, `cg_solve_multi`, `minimize_trust_ncg(on_device=True)`) run sharded with no host hop per product.
+    * any other object with `value / grad / hvp / set_quad_scale` (the CPU stand-ins of the gloo tests): the
+      N-independent quadratic term is scaled by 1 / world_size AROUND each call and restored afterwards, which makes the
+      global objective the plain sum of the local ones; the local result is summed with one all-reduce."""
 
     def __init__(self, ctx, torch_device=None, group=None):
         import torch.distributed as dist
@@ -90,30 +118,62 @@ class ShardedObjective(object):
         self.device = torch_device
         self.group = group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-        ctx.set_quad_scale(1.0 / self.world)
+        self.on_device = torch_device is not None and hasattr(ctx, 'set_reduce_hook')
+        if self.on_device:
+            import torch
+            ctx.set_stream(torch.cuda.current_stream(torch_device).cuda_stream)
+            if self.world > 1 or (dist.is_available() and dist.is_initialized()):
+                ctx.set_reduce_hook(torch_reduce_hook(torch_device, group))
 
-    def _sum(self, arr):
-        return allreduce_stats(np.atleast_1d(np.asarray(arr, dtype=np.float64)), self.device, self.group)
+    def close(self):
+        """Remove the hook (the context is a plain single-process context again)."""
+        if self.on_device:
+            self.ctx.set_reduce_hook(None)
+
+    def _summed(self, call, *args):
+        if self.on_device:
+            return np.atleast_1d(np.asarray(call(*args), dtype=np.float64))        # reduced inside the library
+        base = float(getattr(self.ctx, 'quad_scale', 1.0))
+        self.ctx.set_quad_scale(base / self.world)
+        try:
+            local = np.atleast_1d(np.asarray(call(*args), dtype=np.float64))
+        finally:
+            self.ctx.set_quad_scale(base)
+        return allreduce_stats(local, self.device, self.group)
 
     def value(self, theta):
-        return float(self._sum(self.ctx.value(theta))[0])
+        return float(self._summed(self.ctx.value, theta)[0])
 
     def grad(self, theta):
-        return self._sum(self.ctx.grad(theta))
+        return self._summed(self.ctx.grad, theta)
 
     def hvp(self, theta, v):
-        return self._sum(self.ctx.hvp(theta, v))
+        return self._summed(self.ctx.hvp, theta, v)
 
     def cg_solve(self, theta, b, x0=None, tol=1e-8, maxiter=None, M=None):
-        """H(theta)^-1 b by scipy's cg over the sharded product (LRVB/ConjugateGradient.py:63-85): returns (x, info)."""
-        import scipy.sparse.linalg as sla
+        """H(theta)^-1 b (LRVB/ConjugateGradient.py:63-85): returns (x, info).  On the device the whole loop runs in
+        the library (`lrvb_cg_solve`), one in-place D-vector all-reduce per iteration; otherwise scipy's cg drives
+        the sharded product."""
         theta = np.asarray(theta, dtype=np.float64)
+        if self.on_device:
+            x, info, _ = self.ctx.cg_solve(theta, np.asarray(b, dtype=np.float64), x0=x0, Minv=M, tol=tol,
+                                           maxiter=maxiter or 0)
+            return x, info
+        import scipy.sparse.linalg as sla
         D = theta.size
         op = sla.LinearOperator((D, D), matvec=lambda v: self.hvp(theta, np.asarray(v, dtype=np.float64).ravel()))
         return sla.cg(op, np.asarray(b, dtype=np.float64), x0=x0, rtol=tol, atol=0.0, maxiter=maxiter, M=M)
 
-    def minimize_trust_ncg(self, x0, gtol=1e-6, maxiter=50, disp=False):
-        """The fit of `minimize_objective_trust_ncg` (LRVB/OptimizationUtils.py:44-75) over sharded observations."""
+    def minimize_trust_ncg(self, x0, gtol=1e-6, maxiter=50, disp=False, on_device=False):
+        """The fit of `minimize_objective_trust_ncg` (LRVB/OptimizationUtils.py:44-75) over sharded observations;
+        `on_device=True` runs the optimiser loop in the library (`lrvb_minimize_trust_ncg`) on every rank."""
+        if on_device:
+            if not self.on_device:
+                raise ValueError('on_device needs a DeviceContext on a GPU')
+            import scipy.optimize
+            _, x, info = self.ctx.minimize_trust_ncg(np.asarray(x0, dtype=np.float64), gtol=gtol, maxiter=maxiter)
+            return scipy.optimize.OptimizeResult(x=x, fun=info['fun'], status=info['status'], success=info['status'] == 0,
+                                                 nit=info['nit'], nfev=info['nfev'], njev=info['njev'], nhev=info['nhev'])
         import scipy.optimize
         return scipy.optimize.minimize(self.value, np.asarray(x0, dtype=np.float64), jac=self.grad, hessp=self.hvp,
                                        method='trust-ncg', options={'maxiter': maxiter, 'gtol': gtol, 'disp': disp})

@@ -53,9 +53,10 @@ class DeviceContext(object):
         desc.quad_kind = int(quad_kind)
         self._h = ctypes.c_void_p()
         self.chol_token = 0            # bumped by every factorisation: lets holders of a factor notice a replacement
-        _hip.check(self._lib.lrvb_ctx_create(ctypes.byref(self._h), int(device), ctypes.byref(desc)))
+        self._check(self._lib.lrvb_ctx_create(ctypes.byref(self._h), int(device), ctypes.byref(desc)))
         self.n_obs, self.n_cols = int(n_obs), int(n_cols)
         self.device = int(device)
+        self.quad_scale = 1.0
 
     def close(self):
         if getattr(self, '_h', None) is not None and self._h.value:
@@ -72,46 +73,76 @@ class DeviceContext(object):
     def set_data(self, slot, arr):
         a = _hip.as_f64(arr)
         rows, cols = (a.shape[0], a.shape[1]) if a.ndim == 2 else (a.size, 1)
-        _hip.check(self._lib.lrvb_set_data(self._h, slot, _hip.ptr(a), rows, cols))
+        self._check(self._lib.lrvb_set_data(self._h, slot, _hip.ptr(a), rows, cols))
 
     def set_data_dev(self, slot, dev_ptr, rows, cols):
-        _hip.check(self._lib.lrvb_set_data_dev(self._h, slot, ctypes.c_void_p(dev_ptr), rows, cols))
+        self._check(self._lib.lrvb_set_data_dev(self._h, slot, ctypes.c_void_p(dev_ptr), rows, cols))
 
     def set_weights(self, w):
         a = _hip.as_f64(w).ravel()
-        _hip.check(self._lib.lrvb_set_weights(self._h, _hip.ptr(a), a.size))
+        self._check(self._lib.lrvb_set_weights(self._h, _hip.ptr(a), a.size))
 
     def set_weights_dev(self, dev_ptr, n):
-        _hip.check(self._lib.lrvb_set_weights_dev(self._h, ctypes.c_void_p(dev_ptr), n))
+        self._check(self._lib.lrvb_set_weights_dev(self._h, ctypes.c_void_p(dev_ptr), n))
 
     def set_quad_scale(self, s):
-        _hip.check(self._lib.lrvb_set_quad_scale(self._h, float(s)))
+        self._check(self._lib.lrvb_set_quad_scale(self._h, float(s)))
+        self.quad_scale = float(s)
+
+    def set_reduce_hook(self, fn):
+        """Install the sum-over-ranks hook of include/lrvb_hip.h (`lrvb_set_reduce_hook`): `fn(dev_ptr, n, hip_stream)`
+        must replace the n doubles at device address dev_ptr by their sum over all ranks, in stream order on
+        hip_stream (the context's stream).  None removes it.  An exception raised by `fn` fails the library call
+        that triggered it and is re-raised from there."""
+        self._hook_error = None
+        if fn is None:
+            self._hook_cb = None
+            self._check(self._lib.lrvb_set_reduce_hook(self._h, None, None))
+            return
+
+        def trampoline(_user, buf, n, stream):
+            try:
+                fn(int(buf or 0), int(n), int(stream or 0))
+                return 0
+            except BaseException as e:            # never let an exception cross the C frame
+                self._hook_error = e
+                return -1
+        self._hook_cb = _hip.REDUCE_FN(trampoline)      # keep the callback object alive as long as it is installed
+        self._check(self._lib.lrvb_set_reduce_hook(self._h, ctypes.cast(self._hook_cb, ctypes.c_void_p), None))
+
+    def _check(self, status):
+        """_hip.check, re-raising an exception that the reduce hook raised inside the call."""
+        err = getattr(self, '_hook_error', None)
+        if err is not None:
+            self._hook_error = None
+            raise err
+        _hip.check(status)
 
     def set_tuning(self, n_splits=0, flags=0):
-        _hip.check(self._lib.lrvb_set_tuning(self._h, int(n_splits), int(flags)))
+        self._check(self._lib.lrvb_set_tuning(self._h, int(n_splits), int(flags)))
 
     def sync(self):
-        _hip.check(self._lib.lrvb_ctx_sync(self._h))
+        self._check(self._lib.lrvb_ctx_sync(self._h))
 
     def set_stream(self, hip_stream_handle):
         """Run on a caller-owned HIP stream (an integer handle such as
         torch.cuda.current_stream().cuda_stream); None restores a private stream."""
         if hip_stream_handle is None:
-            _hip.check(self._lib.lrvb_ctx_set_stream(self._h, None, 0))
+            self._check(self._lib.lrvb_ctx_set_stream(self._h, None, 0))
         else:       # 0 is a valid handle: the legacy default stream
-            _hip.check(self._lib.lrvb_ctx_set_stream(self._h, ctypes.c_void_p(int(hip_stream_handle)), 1))
+            self._check(self._lib.lrvb_ctx_set_stream(self._h, ctypes.c_void_p(int(hip_stream_handle)), 1))
 
     # -- packing ------------------------------------------------------------------------
     def constrain(self, free):
         f = _hip.as_f64(free).ravel()
         out = np.empty(self.V)
-        _hip.check(self._lib.lrvb_constrain(self._h, _hip.ptr(f), f.size, _hip.ptr(out), out.size))
+        self._check(self._lib.lrvb_constrain(self._h, _hip.ptr(f), f.size, _hip.ptr(out), out.size))
         return out
 
     def unconstrain(self, vec):
         v = _hip.as_f64(vec).ravel()
         out = np.empty(self.D)
-        _hip.check(self._lib.lrvb_unconstrain(self._h, _hip.ptr(v), v.size, _hip.ptr(out), out.size))
+        self._check(self._lib.lrvb_unconstrain(self._h, _hip.ptr(v), v.size, _hip.ptr(out), out.size))
         return out
 
     def free_to_vector_jac(self, free):
@@ -119,7 +150,7 @@ class DeviceContext(object):
         if f.size != self.D:
             raise ValueError('Wrong size for free vector.  Expected {}, got {}'.format(self.D, f.size))
         out = np.empty((self.V, self.D))
-        _hip.check(self._lib.lrvb_free_to_vector_jac(self._h, _hip.ptr(f), f.size, _hip.ptr(out)))
+        self._check(self._lib.lrvb_free_to_vector_jac(self._h, _hip.ptr(f), f.size, _hip.ptr(out)))
         return out
 
     def free_hessian_from_vector(self, free, g_vec, H_vec):
@@ -127,7 +158,7 @@ class DeviceContext(object):
         if f.size != self.D or g.size != self.V or H.shape != (self.V, self.V):
             raise ValueError('Wrong sizes for free_hessian_from_vector')
         out = np.empty((self.D, self.D))
-        _hip.check(self._lib.lrvb_free_hessian_from_vector(self._h, _hip.ptr(f), _hip.ptr(g), _hip.ptr(H), _hip.ptr(out)))
+        self._check(self._lib.lrvb_free_hessian_from_vector(self._h, _hip.ptr(f), _hip.ptr(g), _hip.ptr(H), _hip.ptr(out)))
         return out
 
     # -- objective ----------------------------------------------------------------------
@@ -138,14 +169,14 @@ class DeviceContext(object):
         x = _hip.as_f64(x).ravel()
         out = np.empty(1)
         fn = self._lib.lrvb_value if is_free else self._lib.lrvb_value_vec
-        _hip.check(fn(self._h, _hip.ptr(x), x.size, _hip.ptr(out)))
+        self._check(fn(self._h, _hip.ptr(x), x.size, _hip.ptr(out)))
         return float(out[0])
 
     def grad(self, x, is_free=True):
         x = _hip.as_f64(x).ravel()
         g = np.empty(self._n(is_free))
         fn = self._lib.lrvb_grad if is_free else self._lib.lrvb_grad_vec
-        _hip.check(fn(self._h, _hip.ptr(x), x.size, None, _hip.ptr(g)))
+        self._check(fn(self._h, _hip.ptr(x), x.size, None, _hip.ptr(g)))
         return g
 
     def hessian(self, x, is_free=True):
@@ -153,7 +184,7 @@ class DeviceContext(object):
         n = self._n(is_free)
         H = np.empty((n, n))
         fn = self._lib.lrvb_hessian if is_free else self._lib.lrvb_hessian_vec
-        _hip.check(fn(self._h, _hip.ptr(x), x.size, _hip.ptr(H), n))
+        self._check(fn(self._h, _hip.ptr(x), x.size, _hip.ptr(H), n))
         return H
 
     def hvp(self, x, v, is_free=True):
@@ -162,7 +193,7 @@ class DeviceContext(object):
             raise ValueError('Wrong size for the vector of a Hessian-vector product')
         out = np.empty(self._n(is_free))
         fn = self._lib.lrvb_hvp if is_free else self._lib.lrvb_hvp_vec
-        _hip.check(fn(self._h, _hip.ptr(x), _hip.ptr(v), x.size, _hip.ptr(out)))
+        self._check(fn(self._h, _hip.ptr(x), _hip.ptr(v), x.size, _hip.ptr(out)))
         return out
 
     def obs_grad(self, x, n0=0, n1=None, is_free=True):
@@ -170,7 +201,7 @@ class DeviceContext(object):
         n1 = self.n_obs if n1 is None else n1
         G = np.empty((max(n1 - n0, 0), self._n(is_free)))
         fn = self._lib.lrvb_obs_grad if is_free else self._lib.lrvb_obs_grad_vec
-        _hip.check(fn(self._h, _hip.ptr(x), x.size, n0, n1, _hip.ptr(G)))
+        self._check(fn(self._h, _hip.ptr(x), x.size, n0, n1, _hip.ptr(G)))
         return G
 
     def obs_influence(self, x, moment_jac, n0=0, n1=None, is_free=True):
@@ -182,23 +213,23 @@ class DeviceContext(object):
         n1 = self.n_obs if n1 is None else n1
         out = np.empty((max(n1 - n0, 0), M.shape[0]))
         fn = self._lib.lrvb_obs_influence if is_free else self._lib.lrvb_obs_influence_vec
-        _hip.check(fn(self._h, _hip.ptr(x), x.size, _hip.ptr(M), M.shape[0], n0, n1, _hip.ptr(out)))
+        self._check(fn(self._h, _hip.ptr(x), x.size, _hip.ptr(M), M.shape[0], n0, n1, _hip.ptr(out)))
         return out
 
     # -- vector-coordinate Hessian assembled on the device from small host blocks ---------------------
     def hvec_begin(self):
-        _hip.check(self._lib.lrvb_hvec_begin(self._h))
+        self._check(self._lib.lrvb_hvec_begin(self._h))
 
     def hvec_add_block(self, block, row_off, col_off, mirror=False):
         B = _hip.as_f64(block)
         B = B.reshape(B.shape[0], -1) if B.ndim > 1 else B.reshape(-1, 1)
-        _hip.check(self._lib.lrvb_hvec_add_block(self._h, _hip.ptr(B), B.shape[0], B.shape[1], int(row_off), int(col_off), int(bool(mirror))))
+        self._check(self._lib.lrvb_hvec_add_block(self._h, _hip.ptr(B), B.shape[0], B.shape[1], int(row_off), int(col_off), int(bool(mirror))))
 
     def hvec_add_symkron(self, A, B, coef, row_off, col_off, mirror=False):
         A, B = _hip.as_f64(A), _hip.as_f64(B)
         if A.ndim != 2 or A.shape[0] != A.shape[1] or A.shape != B.shape:
             raise ValueError('expected two square matrices of the same order')
-        _hip.check(self._lib.lrvb_hvec_add_symkron(self._h, _hip.ptr(A), _hip.ptr(B), A.shape[0], float(coef),
+        self._check(self._lib.lrvb_hvec_add_symkron(self._h, _hip.ptr(A), _hip.ptr(B), A.shape[0], float(coef),
                                                    int(row_off), int(col_off), int(bool(mirror))))
 
     def hvec_finish(self, x, g_vec, is_free=True, want_host=True):
@@ -206,7 +237,7 @@ class DeviceContext(object):
         g = _hip.as_f64(g_vec).ravel()
         n = self._n(is_free)
         out = np.empty((n, n)) if want_host else None
-        _hip.check(self._lib.lrvb_hvec_finish(self._h, _hip.ptr(x), x.size, int(bool(is_free)), _hip.ptr(g), _hip.ptr(out)))
+        self._check(self._lib.lrvb_hvec_finish(self._h, _hip.ptr(x), x.size, int(bool(is_free)), _hip.ptr(g), _hip.ptr(out)))
         if is_free:
             self.chol_token += 0          # (the resident free Hessian is what chol_factor_last factors)
         return out
@@ -214,19 +245,19 @@ class DeviceContext(object):
     def cross_hessian_tilt(self, free):
         f = _hip.as_f64(free).ravel()
         C = np.empty((self.D, self.V))
-        _hip.check(self._lib.lrvb_cross_hessian_tilt(self._h, _hip.ptr(f), f.size, _hip.ptr(C)))
+        self._check(self._lib.lrvb_cross_hessian_tilt(self._h, _hip.ptr(f), f.size, _hip.ptr(C)))
         return C
 
     def gram(self, free):
         f = _hip.as_f64(free).ravel()
         G = np.empty((self.D, self.D))
-        _hip.check(self._lib.lrvb_gram(self._h, _hip.ptr(f), f.size, _hip.ptr(G), self.D))
+        self._check(self._lib.lrvb_gram(self._h, _hip.ptr(f), f.size, _hip.ptr(G), self.D))
         return G
 
     # -- objectives quadratic in the data -------------------------------------------------
     def weighted_gram(self):
         S = np.empty((self.n_cols, self.n_cols))
-        _hip.check(self._lib.lrvb_weighted_gram(self._h, _hip.ptr(S), self.n_cols))
+        self._check(self._lib.lrvb_weighted_gram(self._h, _hip.ptr(S), self.n_cols))
         return S
 
     def obs_quadform(self, M, c=None, n0=0, n1=None):
@@ -237,7 +268,7 @@ class DeviceContext(object):
         c = None if c is None else _hip.as_f64(c).ravel()
         n1 = self.n_obs if n1 is None else n1
         out = np.empty((max(n1 - n0, 0), K))
-        _hip.check(self._lib.lrvb_obs_quadform(self._h, _hip.ptr(M), _hip.ptr(c), K, n0, n1, _hip.ptr(out)))
+        self._check(self._lib.lrvb_obs_quadform(self._h, _hip.ptr(M), _hip.ptr(c), K, n0, n1, _hip.ptr(out)))
         return out
 
     def mixture_rows(self, K, theta_z, lam, want_grad=True, want_schur=True):
@@ -249,7 +280,7 @@ class DeviceContext(object):
         gfree = np.empty((self.n_obs, K - 1)) if want_grad else None
         S64 = np.empty((64, 64))
         R = np.empty(((V + 1) ** 2, K * K)) if want_schur else None
-        _hip.check(self._lib.lrvb_mixture_rows(self._h, int(K), _hip.ptr(tz), _hip.ptr(lam), _hip.ptr(val2),
+        self._check(self._lib.lrvb_mixture_rows(self._h, int(K), _hip.ptr(tz), _hip.ptr(lam), _hip.ptr(val2),
                                                _hip.ptr(gfree), _hip.ptr(S64), _hip.ptr(R)))
         return val2, gfree, S64, R
 
@@ -270,18 +301,18 @@ class DeviceContext(object):
             if v is not None and v.size != n:
                 raise ValueError('expected vectors of length {}'.format(n))
         out = np.empty((n, n))
-        _hip.check(self._lib.lrvb_mixture_schur(self._h, int(K), int(q), _hip.ptr(R), _hip.ptr(jlam), _hip.ptr(hgg),
+        self._check(self._lib.lrvb_mixture_schur(self._h, int(K), int(q), _hip.ptr(R), _hip.ptr(jlam), _hip.ptr(hgg),
                                                 _hip.ptr(scale), _hip.ptr(diag_add), _hip.ptr(out)))
         return out
 
     def set_groups(self, gid, n_groups):
         g = np.ascontiguousarray(gid, dtype=np.int32).ravel()
-        _hip.check(self._lib.lrvb_set_groups(self._h, g.ctypes.data_as(ctypes.c_void_p), g.size, int(n_groups)))
+        self._check(self._lib.lrvb_set_groups(self._h, g.ctypes.data_as(ctypes.c_void_p), g.size, int(n_groups)))
         self.n_groups = int(n_groups)
 
     def group_sums(self):
         out = np.empty((self.n_groups, self.n_cols + 1))
-        _hip.check(self._lib.lrvb_group_sums(self._h, _hip.ptr(out)))
+        self._check(self._lib.lrvb_group_sums(self._h, _hip.ptr(out)))
         return out
 
     def quadform_gram(self, M, c, free):
@@ -289,7 +320,7 @@ class DeviceContext(object):
         if M.shape != (self.V, self.n_cols, self.n_cols) or c.size != self.V:
             raise ValueError('expected M of shape ({0}, {1}, {1}) and c of length {0}'.format(self.V, self.n_cols))
         out = np.empty((self.D, self.D))
-        _hip.check(self._lib.lrvb_quadform_gram(self._h, _hip.ptr(M), _hip.ptr(c), self.V, _hip.ptr(f),
+        self._check(self._lib.lrvb_quadform_gram(self._h, _hip.ptr(M), _hip.ptr(c), self.V, _hip.ptr(f),
                                                 _hip.ptr(out), self.D))
         return out
 
@@ -302,7 +333,7 @@ class DeviceContext(object):
         x = np.empty(D)
         info = ctypes.c_int(0)
         iters = ctypes.c_int64(0)
-        _hip.check(self._lib.lrvb_cg_solve_matrix(self._h, _hip.ptr(H), _hip.ptr(b), _hip.ptr(x0), _hip.ptr(Minv),
+        self._check(self._lib.lrvb_cg_solve_matrix(self._h, _hip.ptr(H), _hip.ptr(b), _hip.ptr(x0), _hip.ptr(Minv),
                                                   float(tol), int(maxiter), D, _hip.ptr(x),
                                                   ctypes.byref(info), ctypes.byref(iters)))
         return x, info.value, iters.value
@@ -312,25 +343,25 @@ class DeviceContext(object):
         H = _hip.as_f64(H)
         if H.ndim != 2 or H.shape[0] != H.shape[1]:
             raise ValueError('expected a square matrix')
-        _hip.check(self._lib.lrvb_chol_factor(self._h, _hip.ptr(H), H.shape[0]))
+        self._check(self._lib.lrvb_chol_factor(self._h, _hip.ptr(H), H.shape[0]))
         self.chol_token += 1
 
     def chol_factor_last(self):
-        _hip.check(self._lib.lrvb_chol_factor_last(self._h))
+        self._check(self._lib.lrvb_chol_factor_last(self._h))
         self.chol_token += 1
 
     def chol_solve(self, B):
         B = _hip.as_f64(B)
         B2 = B.reshape(B.shape[0], -1)
         X = np.empty_like(B2)
-        _hip.check(self._lib.lrvb_chol_solve(self._h, _hip.ptr(B2), B2.shape[0], B2.shape[1], _hip.ptr(X)))
+        self._check(self._lib.lrvb_chol_solve(self._h, _hip.ptr(B2), B2.shape[0], B2.shape[1], _hip.ptr(X)))
         return X.reshape(B.shape)
 
     def lrvb_cov(self, M):
         M = _hip.as_f64(M)
         Q, D = M.shape
         out = np.empty((Q, Q))
-        _hip.check(self._lib.lrvb_lrvb_cov(self._h, _hip.ptr(M), Q, D, _hip.ptr(out)))
+        self._check(self._lib.lrvb_lrvb_cov(self._h, _hip.ptr(M), Q, D, _hip.ptr(out)))
         return out
 
     def cg_solve(self, free, b, x0=None, Minv=None, tol=1e-8, maxiter=0):
@@ -342,7 +373,7 @@ class DeviceContext(object):
         x = np.empty(self.D)
         info = ctypes.c_int(0)
         iters = ctypes.c_int64(0)
-        _hip.check(self._lib.lrvb_cg_solve(self._h, _hip.ptr(f), _hip.ptr(b), _hip.ptr(x0), _hip.ptr(Minv),
+        self._check(self._lib.lrvb_cg_solve(self._h, _hip.ptr(f), _hip.ptr(b), _hip.ptr(x0), _hip.ptr(Minv),
                                            float(tol), int(maxiter), f.size, _hip.ptr(x),
                                            ctypes.byref(info), ctypes.byref(iters)))
         return x, info.value, iters.value
@@ -362,7 +393,7 @@ class DeviceContext(object):
             if w_override.size != self.n_obs:
                 raise ValueError('expected {} weights'.format(self.n_obs))
         out = np.empty(self.V)
-        _hip.check(self._lib.lrvb_dk_grad_vec(self._h, _hip.ptr(eta), eta.size, int(order), _hip.ptr(U), _hip.ptr(w_override),
+        self._check(self._lib.lrvb_dk_grad_vec(self._h, _hip.ptr(eta), eta.size, int(order), _hip.ptr(U), _hip.ptr(w_override),
                                               1 if include_quad else 0, _hip.ptr(out)))
         return out
 
@@ -378,7 +409,7 @@ class DeviceContext(object):
             raise ValueError('preconditioner must be {0} x {0}'.format(self.D))
         y, x = np.empty(self.D), np.empty(self.D)
         res = _hip.OptResult()
-        _hip.check(self._lib.lrvb_minimize_trust_ncg(self._h, _hip.ptr(y0), y0.size, _hip.ptr(A), float(gtol), int(maxiter),
+        self._check(self._lib.lrvb_minimize_trust_ncg(self._h, _hip.ptr(y0), y0.size, _hip.ptr(A), float(gtol), int(maxiter),
                                                      float(initial_trust_radius), float(max_trust_radius), float(eta),
                                                      _hip.ptr(y), _hip.ptr(x), ctypes.byref(res)))
         info = dict(fun=res.fun, jac_mag=res.jac_mag, trust_radius=res.trust_radius, status=res.status, nit=res.nit,
@@ -396,7 +427,7 @@ class DeviceContext(object):
         X = np.empty((Q, self.D))
         info = np.zeros(Q, dtype=np.int32)
         iters = np.zeros(Q, dtype=np.int64)
-        _hip.check(self._lib.lrvb_cg_solve_multi(self._h, _hip.ptr(f), _hip.ptr(B), _hip.ptr(X0), _hip.ptr(Minv),
+        self._check(self._lib.lrvb_cg_solve_multi(self._h, _hip.ptr(f), _hip.ptr(B), _hip.ptr(X0), _hip.ptr(Minv),
                                                  float(tol), int(maxiter), f.size, Q, _hip.ptr(X),
                                                  info.ctypes.data_as(ctypes.c_void_p), iters.ctypes.data_as(ctypes.c_void_p)))
         return X, info, iters
@@ -404,45 +435,45 @@ class DeviceContext(object):
     # -- device-resident / multi-GPU -------------------------------------------------------
     def stats_size(self):
         n = ctypes.c_int64(0)
-        _hip.check(self._lib.lrvb_stats_size(self._h, ctypes.byref(n)))
+        self._check(self._lib.lrvb_stats_size(self._h, ctypes.byref(n)))
         return n.value
 
     def hessian_partial_dev(self, free_ptr, stats_ptr):
-        _hip.check(self._lib.lrvb_hessian_partial_dev(self._h, ctypes.c_void_p(free_ptr), ctypes.c_void_p(stats_ptr)))
+        self._check(self._lib.lrvb_hessian_partial_dev(self._h, ctypes.c_void_p(free_ptr), ctypes.c_void_p(stats_ptr)))
 
     def hessian_finish_dev(self, free_ptr, stats_ptr, H_ptr, ld):
-        _hip.check(self._lib.lrvb_hessian_finish_dev(self._h, ctypes.c_void_p(free_ptr), ctypes.c_void_p(stats_ptr),
+        self._check(self._lib.lrvb_hessian_finish_dev(self._h, ctypes.c_void_p(free_ptr), ctypes.c_void_p(stats_ptr),
                                                      ctypes.c_void_p(H_ptr), ld))
 
     def hessian_dev(self, free_ptr, H_ptr, ld):
-        _hip.check(self._lib.lrvb_hessian_dev(self._h, ctypes.c_void_p(free_ptr), ctypes.c_void_p(H_ptr), ld))
+        self._check(self._lib.lrvb_hessian_dev(self._h, ctypes.c_void_p(free_ptr), ctypes.c_void_p(H_ptr), ld))
 
     def hvp_dev(self, free_ptr, v_ptr, out_ptr):
-        _hip.check(self._lib.lrvb_hvp_dev(self._h, ctypes.c_void_p(free_ptr), ctypes.c_void_p(v_ptr), ctypes.c_void_p(out_ptr)))
+        self._check(self._lib.lrvb_hvp_dev(self._h, ctypes.c_void_p(free_ptr), ctypes.c_void_p(v_ptr), ctypes.c_void_p(out_ptr)))
 
     def gram_dev(self, free_ptr, G_ptr, ld):
-        _hip.check(self._lib.lrvb_gram_dev(self._h, ctypes.c_void_p(free_ptr), ctypes.c_void_p(G_ptr), ld))
+        self._check(self._lib.lrvb_gram_dev(self._h, ctypes.c_void_p(free_ptr), ctypes.c_void_p(G_ptr), ld))
 
     def chol_factor_dev(self, H_ptr, D, ld):
         self.chol_token += 1
-        _hip.check(self._lib.lrvb_chol_factor_dev(self._h, ctypes.c_void_p(H_ptr), D, ld))
+        self._check(self._lib.lrvb_chol_factor_dev(self._h, ctypes.c_void_p(H_ptr), D, ld))
 
     def chol_solve_dev(self, B_ptr, D, nrhs):
-        _hip.check(self._lib.lrvb_chol_solve_dev(self._h, ctypes.c_void_p(B_ptr), D, nrhs))
+        self._check(self._lib.lrvb_chol_solve_dev(self._h, ctypes.c_void_p(B_ptr), D, nrhs))
 
     def lrvb_cov_dev(self, M_ptr, Q, D, cov_ptr):
-        _hip.check(self._lib.lrvb_lrvb_cov_dev(self._h, ctypes.c_void_p(M_ptr), Q, D, ctypes.c_void_p(cov_ptr)))
+        self._check(self._lib.lrvb_lrvb_cov_dev(self._h, ctypes.c_void_p(M_ptr), Q, D, ctypes.c_void_p(cov_ptr)))
 
     # -- profiling ---------------------------------------------------------------------------
     def profile_enable(self, on=True):
-        _hip.check(self._lib.lrvb_profile_enable(self._h, 1 if on else 0))
+        self._check(self._lib.lrvb_profile_enable(self._h, 1 if on else 0))
 
     def profile_reset(self):
-        _hip.check(self._lib.lrvb_profile_reset(self._h))
+        self._check(self._lib.lrvb_profile_reset(self._h))
 
     def profile_get(self):
         p = _hip.Prof()
-        _hip.check(self._lib.lrvb_profile_get(self._h, ctypes.byref(p)))
+        self._check(self._lib.lrvb_profile_get(self._h, ctypes.byref(p)))
         return {name: getattr(p, name) for name, _ in _hip.Prof._fields_}
 
 

@@ -29,15 +29,63 @@ def test_argument_contract(monkeypatch):
 def test_cpu_baseline_leg_on_a_small_sample():
     bench = _bench()
     rng = np.random.default_rng(0)
-    ns, D, n_pos = 256, 32, 8
-    x = rng.normal(size=(ns, D)) / np.sqrt(D)
-    y = rng.normal(size=ns)
-    out = bench.cpu_baseline(x, y, n_total=4096, D=D, n_pos=n_pos, loss='gaussian', lik_info=2.0, prior_info=1.0,
-                             theta=rng.normal(size=D) * 0.05)
+    N, D, n_pos = 30000, 32, 8
+    x = rng.normal(size=(N, D)) / np.sqrt(D)
+    y = rng.normal(size=N)
+    out = bench.cpu_baseline(lambda a, b: (x[a:b], y[a:b]), n_total=N, D=D, n_pos=n_pos, loss='gaussian', lik_info=2.0,
+                             prior_info=1.0, theta=rng.normal(size=D) * 0.05, budget_s=2.0)
     assert out['kind'] == 'port' and out['unit'] == 'hessian_builds/s' and out['cores'] >= 1
     assert out['value'] > 0 and out['strong_numpy_value'] > 0 and 'rows' in out['sample']
-    # the port really is the D-pass structure: it cannot beat the closed form on the same sample
+    raw = out['raw_timings']
+    # the strong path is a measurement over ALL rows, not an extrapolation; the port path is timed at two sizes
+    assert raw['strong']['rows_timed'] == N and raw['strong']['gflops'] > 0
+    assert raw['port_n10000']['rows'] == 10000 and raw['port_n30000']['rows'] == 30000
+    assert raw['port_fit']['per_column_per_row_s'] >= 0 and raw['port_fit']['per_column_fixed_s'] >= 0
+    # the port really is the D-pass structure: it cannot beat the closed form
     assert out['value'] <= out['strong_numpy_value'] * 1.5
+
+
+def test_gpus_flag_starts_the_ranks_itself(monkeypatch):
+    """`python bench.py --gpus N` (no rank environment) must start N ranks as a child torchrun; inside a rank
+    (RANK / WORLD_SIZE set, as torchrun and the driver's own launcher set them) it must not."""
+    bench = _bench()
+    a = bench.parse(['--gpus', '8', '--steps', '5', '--warmup', '2'])
+    assert bench.needs_launch(a, {}) and not bench.needs_launch(a, {'RANK': '3', 'WORLD_SIZE': '8'})
+    assert not bench.needs_launch(bench.parse([]), {})
+    cmd = bench.launch_command(8, ['--gpus', '8', '--steps', '5', '--warmup', '2'], 29555)
+    assert cmd[0] == sys.executable and cmd[1:3] == ['-m', 'torch.distributed.run']
+    assert '--nproc-per-node=8' in cmd and '--nnodes=1' in cmd
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[cmd.index('--master-port') + 1] == '29555'
+    i = cmd.index(os.path.join(ROOT, 'bench.py'))
+    assert cmd[i + 1:] == ['--gpus', '8', '--steps', '5', '--warmup', '2']
+
+
+def test_launcher_relays_one_line_and_the_exit_code(monkeypatch, capfd):
+    """The parent relays exactly rank 0's JSON line and fails loudly when the ranks fail."""
+    import subprocess
+    bench = _bench()
+    a = bench.parse(['--gpus', '2'])
+
+    class Done(object):
+        def __init__(self, rc, out):
+            self.returncode, self.stdout = rc, out
+    monkeypatch.setattr(subprocess, 'run', lambda cmd, **kw: Done(0, b'banner\n{"metric": "m", "n_gpus": 2}\n'))
+    assert bench.launch_ranks(a, ['--gpus', '2']) == 0
+    out, _ = capfd.readouterr()
+    assert out == '{"metric": "m", "n_gpus": 2}\n'
+    monkeypatch.setattr(subprocess, 'run', lambda cmd, **kw: Done(1, b''))
+    assert bench.launch_ranks(a, ['--gpus', '2']) != 0
+    out, err = capfd.readouterr()
+    assert out == '' and 'failed' in err
+
+
+def test_a_rank_count_mismatch_is_an_error(monkeypatch):
+    """--gpus N inside a world of another size is refused (it used to print a warning and measure one GPU)."""
+    import pytest
+    bench = _bench()
+    monkeypatch.setenv('WORLD_SIZE', '2'); monkeypatch.setenv('RANK', '0')
+    with pytest.raises(SystemExit):
+        bench.main(bench.parse(['--gpus', '4']))
 
 
 def test_stdout_carries_only_the_result_line(monkeypatch, capfd):

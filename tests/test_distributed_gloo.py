@@ -238,6 +238,10 @@ class OracleShardCtx(object):
         self.model = model
         self.D = model.layout.D
 
+    @property
+    def quad_scale(self):
+        return self.model.quad_scale
+
     def set_quad_scale(self, s):
         self.model.quad_scale = s
 
@@ -257,16 +261,21 @@ def _objective_worker(rank, world, port, out_path):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    from lrvb_amd.distributed import ShardedObjective, shard_rows
+    from lrvb_amd.distributed import ShardedObjective, ShardedHessian, shard_rows
     N, theta, model = _make_problem()
     r0, r1 = shard_rows(N, rank, world)
-    obj = ShardedObjective(OracleShardCtx(model(slice(r0, r1))))
+    local = model(slice(r0, r1))
+    obj = ShardedObjective(OracleShardCtx(local))
     rng = np.random.default_rng(5)                    # same stream on every rank
     v, b = rng.normal(size=theta.size), rng.normal(size=theta.size)
     val, g, hv = obj.value(theta), obj.grad(theta), obj.hvp(theta, v)
     sol, info = obj.cg_solve(theta, b, tol=1e-10)
     fit = obj.minimize_trust_ncg(theta, gtol=1e-7, maxiter=100)
-    flat = np.concatenate([[val], g, hv, sol, [float(info)], fit.x, [float(fit.nit), float(fit.status)]])
+    # fit first, THEN the sharded Hessian build on the same shard object: the objective calls must leave nothing
+    # rescaled behind (the N-independent term enters the finished Hessian once, at full weight)
+    assert local.quad_scale == 1.0
+    H = ShardedHessian(OracleEngine(local)).build(torch.from_numpy(theta)).numpy()
+    flat = np.concatenate([[val], g, hv, sol, [float(info)], fit.x, [float(fit.nit), float(fit.status)], H.ravel()])
     t = torch.from_numpy(flat.copy())
     gathered = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(gathered, t)
@@ -305,3 +314,6 @@ def test_two_rank_sharded_value_gradient_hvp_cg_and_fit(tmp_path):
     assert abs(full.value(x_sharded) - fit.fun) < 1e-10 * abs(fit.fun)
     assert abs(flat[o] - fit.nit) <= 1 and flat[o + 1] == fit.status == 0
     assert np.linalg.norm(full.grad(x_sharded)) < 1e-6
+    o += 2
+    H_sharded = flat[o:o + D * D].reshape(D, D)
+    assert np.max(np.abs(H_sharded - H)) < 1e-11 * np.max(np.abs(H))
