@@ -142,15 +142,19 @@ def cpu_baseline(fetch_rows, n_total, D, n_pos, loss, lik_info, prior_info, thet
     S = np.zeros((D, D)); g = np.zeros(D)
     t_compute = 0.0
     rows_done = 0
+    scaled = None
     budget_strong = 0.45 * budget_s
     for a in range(0, n_total, chunk):
         b = min(a + chunk, n_total)
         xc, yc = fetch_rows(a, b)
+        if scaled is None or scaled.shape != xc.shape:
+            scaled = np.empty_like(xc)
         t0 = time.perf_counter()
         z = xc @ eta
         _, l1, l2 = om.loss_terms(loss_id, yc, z, lik_info)
         g += xc.T @ l1
-        S += xc.T @ (l2[:, None] * xc)
+        np.multiply(xc, l2[:, None], out=scaled)
+        S += xc.T @ scaled
         t_compute += time.perf_counter() - t0
         rows_done = b
         if t_compute > budget_strong:                 # slow host: stop and say so (scaled by rows only)

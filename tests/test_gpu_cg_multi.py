@@ -111,8 +111,7 @@ def test_general_layout(vb):
     model = om.DeclaredModel(lay, loss=om.LOGISTIC, x=x, y=y, w=w, glm_off=2, quad_A=A)
     theta = rng.normal(size=lay.D) * 0.05
     H = model.hessian(theta)
-    if np.min(np.linalg.eigvalsh(H)) <= 0:
-        pytest.skip('Hessian not positive definite at this point')
+    assert np.min(np.linalg.eigvalsh(H)) > 0            # dense prior precision >= 3 I dominates at this seeded point
     fun._push_state()
     B = rng.normal(size=(Q, lay.D))
     X, info, iters = fun.ctx.cg_solve_multi(theta, B)

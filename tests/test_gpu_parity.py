@@ -501,10 +501,12 @@ def test_wide_designs(vb, loss, N, P):
     eta = lay.constrain(theta)
     assert rel_err(obj.fun_vector_hvp(eta, v), model.hessian_vec(eta) @ v) < TOL
     assert rel_err(fun.ctx.obs_grad(theta, 0, min(N, 50)), model.obs_grad(theta, 0, min(N, 50))) < TOL
-    if np.min(np.linalg.eigvalsh(Hw)) > 0:
-        B = rng.normal(size=(3, P))
-        X, info, _ = fun.ctx.cg_solve_multi(theta, B)
-        assert np.all(info == 0) and rel_err(X, np.linalg.solve(Hw, B.T).T) < 1e-6
+    # convex losses, non-negative weights, a positive prior precision and (at this theta) positive packing
+    # second-order terms: the Hessian is positive definite, which the CG route needs
+    assert np.min(np.linalg.eigvalsh(Hw)) > 0
+    B = rng.normal(size=(3, P))
+    X, info, _ = fun.ctx.cg_solve_multi(theta, B)
+    assert np.all(info == 0) and rel_err(X, np.linalg.solve(Hw, B.T).T) < 1e-6
 
 
 def test_nan_and_overflow_inputs_do_not_fault(vb):

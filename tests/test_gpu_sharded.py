@@ -123,7 +123,10 @@ def test_two_ranks_on_one_gpu_every_sharded_route(tmp_path):
     x_host = flat[o:o + P]; o += P
     nit_host = flat[o]; o += 1
     assert status_dev == 0 and np.linalg.norm(full.grad(x_dev)) < 1e-6 and np.linalg.norm(full.grad(x_host)) < 1e-6
-    assert nit_dev == nit_host and np.max(np.abs(x_dev - x_host)) < 1e-8 * max(1.0, np.max(np.abs(x_host)))
+    # same iterates on both routes; compared in constrained coordinates (a lower-bounded coefficient near its bound
+    # is flat in its free coordinate: exp(-20))
+    lay = _layout(P)
+    assert nit_dev == nit_host and np.max(np.abs(lay.constrain(x_dev) - lay.constrain(x_host))) < 1e-8
     for name in ('hook', 'sharded'):
         Hs = flat[o:o + P * P].reshape(P, P); o += P * P
         assert np.max(np.abs(Hs - H)) < 1e-11 * np.max(np.abs(H)), name

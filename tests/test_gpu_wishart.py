@@ -21,6 +21,28 @@ def vb():
     return lrvb_amd
 
 
+def cavi_optimum(y, w, mu0, lam0, nu0, w0, sweeps=200):
+    """The minimiser of the -ELBO in vector coordinates, from the stationarity conditions of the model's closed form
+    (standard conjugate updates): nu = sum w + nu0, then iterate V^-1 = W0 + sum w (y-m)(y-m)^T + (sum w) Lambda_mu^-1,
+    Lambda_mu = (sum w) nu V + Lambda0, m = Lambda_mu^-1 (nu V sum w y + Lambda0 mu0).  At (and near) it the Hessian
+    is positive definite, which the CG checks need -- chosen by construction instead of testing a random point."""
+    d = y.shape[1]
+    W = float(np.sum(w)); sy = y.T @ w; Syy = y.T @ (w[:, None] * y)
+    nu = W + nu0
+    m = sy / W; P = np.eye(d) / W
+    for _ in range(sweeps):
+        A = Syy - np.outer(sy, m) - np.outer(m, sy) + W * np.outer(m, m)
+        v = np.linalg.inv(A + w0 + W * P)
+        C = W * nu * v + lam0
+        P = np.linalg.inv(C)
+        m_new = P @ (nu * v @ sy + lam0 @ mu0)
+        done = np.max(np.abs(m_new - m)) < 1e-14
+        m = m_new
+        if done:
+            break
+    return np.concatenate([m, C[np.tril_indices(d)], [nu], v[np.tril_indices(d)]])
+
+
 def _build(vb, rng, N, d):
     a = rng.normal(size=(d, d)); cov = a @ a.T / d + np.eye(d)
     y = rng.multivariate_normal(rng.normal(size=d), cov, size=N)
@@ -54,13 +76,19 @@ def test_small_all_derivatives(vb, d, N):
     assert rel_err(two.fun_hessian_free1_vector2(theta, w), cross) < 1e-9
     # Gram matrix of the per-observation gradients: Kronecker-row kernel vs G^T G of the AD cross Hessian
     assert rel_err(fun.gram(theta), cross @ cross.T) < 1e-9
-    # conjugate gradients through the reference's solver class, on the device-resident dense Hessian
-    Hs = 0.5 * (H_ad + H_ad.T) + 10.0 * np.abs(H_ad).max() * np.eye(D) * 0     # SPD at this point? use H^T H shift if not
-    if np.min(np.linalg.eigvalsh(Hs)) > 0:
-        solver = vb.ConjugateGradientSolver(objective.fun_free_hvp, theta)
-        b = rng.normal(size=D)
-        x, info = solver.get_hinv_vec(b)
-        assert info == 0 and np.max(np.abs(x - np.linalg.solve(H_ad, b))) < 1e-6 * np.max(np.abs(np.linalg.solve(H_ad, b)))
+    # conjugate gradients through the reference's solver class, at a point where the Hessian is positive definite by
+    # construction: next to the optimum (slightly off it, so that the packing second-order terms are not zero)
+    mu0 = np.zeros(d); lam0 = 0.5 * np.eye(d); nu0 = d + 2.0; w0 = np.eye(d)
+    theta_opt = lay.unconstrain(cavi_optimum(y, w, mu0, lam0, nu0, w0))
+    assert np.linalg.norm(objective.fun_free_grad(theta_opt)) < 1e-6 * max(1.0, abs(objective.fun_free(theta_opt)))
+    theta_cg = theta_opt + 1e-3 * rng.normal(size=D)
+    H_cg = torch.func.hessian(ft)(torch.tensor(theta_cg), tw).numpy()
+    assert np.min(np.linalg.eigvalsh(0.5 * (H_cg + H_cg.T))) > 0
+    solver = vb.ConjugateGradientSolver(objective.fun_free_hvp, theta_cg)
+    b = rng.normal(size=D)
+    x, info = solver.get_hinv_vec(b)
+    want = np.linalg.solve(H_cg, b)
+    assert info == 0 and np.max(np.abs(x - want)) < 1e-6 * np.max(np.abs(want))
 
 
 def test_config5_d63(vb):
@@ -83,23 +111,36 @@ def test_config5_d63(vb):
         hv_ad = torch.func.jvp(lambda th: grad_fn(th, w1), (tt,), (torch.tensor(v),))[1].numpy()
         assert rel_err(H @ v, hv_ad) < 1e-8
     assert rel_err(objective.fun_free_grad(theta), grad_fn(tt, w1).numpy()) < 1e-9
-    # G^T G: numpy evaluation of the same per-observation gradients
-    eta = lay.constrain(theta)
-    M, c = fun._obs_terms(eta)
-    z = np.hstack([y, np.ones((N, 1))])
-    zz = (z[:, :, None] * z[:, None, :]).reshape(N, -1)
-    G = 0.5 * zz @ M.reshape(M.shape[0], -1).T + c[None, :]
-    J = lay.jac(theta)
-    want = J.T @ (G.T @ G) @ J
+    # G^T G.  Row n of G is d/dtheta of observation n's own term, so (i) on a row subsample the AD cross Hessian
+    # d2 f / d theta d w^T (forward mode over the weights of an objective built on those rows) gives G itself, and
+    # (ii) the Gram matrix is additive over any split of the rows -- which carries (i) to all N rows.
+    ns = 48
+    par_s = vb.ModelParamsDict('params')
+    par_s.push_param(vb.MVNParam('mu', dim=d)); par_s.push_param(vb.WishartParam('lambda', size=d))
+    mu0 = np.zeros(d); lam0 = 0.5 * np.eye(d); nu0 = d + 2.0; w0 = np.eye(d)
+    fun_s = vb.WishartMVNObjective(par_s, y[:ns], prior_mean=mu0, prior_info=lam0, prior_df=nu0, prior_inv_scale=w0)
+    ft_s = tr.wishart_mvn_objective(y[:ns], d, mu0, lam0, nu0, w0, layout=lay)
+    cross = torch.func.jacfwd(torch.func.grad(ft_s, argnums=0), argnums=1)(tt, torch.ones(ns, dtype=torch.float64)).numpy()
+    assert cross.shape == (D, ns)
+    assert rel_err(fun_s.gram(theta), cross @ cross.T) < 1e-9
     got = fun.gram(theta)
-    assert rel_err(got, want) < 1e-9
     assert np.allclose(got, got.T, rtol=0, atol=1e-10 * np.abs(got).max())
-    # LRVB solve by conjugate gradients (tol 1e-8) at D = 4096, against the device Cholesky
-    lam_min = np.min(np.linalg.eigvalsh(0.5 * (H + H.T)))
-    if lam_min > 0:
-        b = rng.normal(size=D)
-        x, info, iters = fun.cg_solve(theta, b, tol=1e-10, maxiter=20000)
-        fun.ctx.chol_factor(H)
-        xc = fun.ctx.chol_solve(b)
-        assert info == 0
-        assert np.max(np.abs(x - xc)) < 1e-6 * np.max(np.abs(xc))
+    parts = []
+    for rows in (slice(0, ns), slice(ns, 1500), slice(1500, N)):
+        par_r = vb.ModelParamsDict('params')
+        par_r.push_param(vb.MVNParam('mu', dim=d)); par_r.push_param(vb.WishartParam('lambda', size=d))
+        parts.append(vb.WishartMVNObjective(par_r, y[rows], prior_mean=mu0, prior_info=lam0, prior_df=nu0,
+                                            prior_inv_scale=w0).gram(theta))
+    assert rel_err(parts[0], cross @ cross.T) < 1e-9
+    assert rel_err(got, parts[0] + parts[1] + parts[2]) < 1e-11
+    # LRVB solve by conjugate gradients (tol 1e-10) at D = 4096 against the device Cholesky, next to the optimum,
+    # where the Hessian is positive definite
+    theta_cg = lay.unconstrain(cavi_optimum(y, np.ones(N), mu0, lam0, nu0, w0)) + 1e-4 * rng.normal(size=D)
+    H_cg = objective.fun_free_hessian(theta_cg)
+    assert np.min(np.linalg.eigvalsh(0.5 * (H_cg + H_cg.T))) > 0
+    b = rng.normal(size=D)
+    x, info, iters = fun.cg_solve(theta_cg, b, tol=1e-10, maxiter=20000)
+    fun.ctx.chol_factor(H_cg)
+    xc = fun.ctx.chol_solve(b)
+    assert info == 0
+    assert np.max(np.abs(x - xc)) < 1e-6 * np.max(np.abs(xc))

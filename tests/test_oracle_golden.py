@@ -49,3 +49,14 @@ def test_cg_matches_reference_solver():
     for m, rhs in zip(G['cg_masks'], G['cg_vecs']):
         want = np.zeros(len(m)); want[m] = G['cg_x'][m]
         assert np.array_equal(rhs, want)
+
+
+def test_optimiser_wrappers_match_reference_runs():
+    """The package's OptimizationUtils (host logic) on the oracle-backed functor against what the reference's own
+    functions returned for the same model; the device functor takes the same route in tests/test_gpu_reference_golden.py."""
+    import lrvb_amd as vb
+    from golden_problems import optimiser_problem, check_optimiser_wrappers
+    from oracle_functor import OracleFunctor
+    par, lay, model, arr = optimiser_problem(vb)
+    objective = vb.Objective(par, OracleFunctor(par, model))
+    check_optimiser_wrappers(vb, objective, lay, on_device_too=False)
