@@ -32,6 +32,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: exactly the functions declared below are exported. */
+#pragma GCC visibility push(default)
+
 
 #define LRVB_ABI_VERSION 1
 
@@ -388,8 +391,11 @@ int lrvb_profile_reset (lrvb_ctx* ctx);
 /* Tuning knobs: number of row splits of the weighted-SYRK grid (0 = automatic); `reserved` bit 0 =
  * always use the register-staged SYRK kernel, bit 1 = mixture rows always take the dense per-row
  * factorisation, bit 2 = the fused multi-vector pass (blocked CG, streamed influence) with four
- * waves per workgroup instead of eight (all exist so that tests can compare the code paths).  */
+ * waves per workgroup instead of eight.  Every setting computes the same results by another code path
+ * (they exist so that tests can compare the paths); any other bit of `reserved` is LRVB_ERR_INVALID.  */
 int lrvb_set_tuning(lrvb_ctx* ctx, int n_splits, int reserved);
+
+#pragma GCC visibility pop
 
 #ifdef __cplusplus
 }

@@ -9,7 +9,7 @@ SRCS="lrvb_api.hip k_wsyrk.hip k_glm.hip k_pack.hip k_linalg.hip k_finish.hip k_
       k_mixture_inst0.hip k_mixture_inst1.hip k_mixture_inst2.hip k_mixture_inst3.hip"
 OBJDIR=.obj
 mkdir -p "$OBJDIR"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable ${LRVB_HIPCC_EXTRA:-}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -fvisibility-inlines-hidden -Wall -Wno-unused-function -Wno-unused-variable ${LRVB_HIPCC_EXTRA:-}"
 pids=()
 for f in $SRCS; do
     extra=""
@@ -24,4 +24,4 @@ for p in "${pids[@]}"; do wait "$p" || fail=1; done
 [ "$fail" -eq 0 ] || { echo "compilation failed" >&2; exit 1; }
 OBJS=""
 for f in $SRCS; do OBJS="$OBJS $OBJDIR/${f%.hip}.o"; done
-exec hipcc --offload-arch=gfx950 -fPIC -shared $OBJS -o "$OUT"
+exec hipcc --offload-arch=gfx950 -fPIC -shared -fvisibility=hidden -Wl,--exclude-libs,ALL -Wl,--version-script=exports.map $OBJS -o "$OUT"

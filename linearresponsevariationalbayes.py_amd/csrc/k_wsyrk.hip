@@ -209,11 +209,10 @@ constexpr int WS_BUF = 2 * WS_PANEL + 32;                // A panel, B panel, 32
 #define WS_GLDS4(gp, lp) __builtin_amdgcn_global_load_lds( \
     (const __attribute__((address_space(1))) void*)(gp), (__attribute__((address_space(3))) void*)(lp), 4, 0, 0)
 
-template <int DBG>     // timing-lab bits (0 in production): 1 = no global loads, 2 = no barrier, 4 = no LDS reads
 __global__ __launch_bounds__(WS_THREADS, 2)
 void wsyrk_glds_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
                        const double* __restrict__ cpad, int n_splits, int nb, i64 rows_per_split,
-                       double* __restrict__ partial, int stagger_shift)
+                       double* __restrict__ partial)
 {
     __shared__ double lds[2 * WS_BUF];
 
@@ -263,7 +262,6 @@ void wsyrk_glds_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
     int cb = bj * WS_TILE + 2 * lane; if (cb > P - 2) cb = P - 2;
 
     auto issue_stage = [&](int ch, int buf) {
-        if (DBG & 1) return;
         double* base = lds + buf * WS_BUF;
         const i64 n0 = r0 + (i64)ch * WS_KC;
 #pragma unroll
@@ -279,7 +277,6 @@ void wsyrk_glds_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
     };
 
     if (nch > 0) issue_stage(0, 0);
-    if (stagger_shift >= 0 && (((blockIdx.x >> 3) >> stagger_shift) & 1)) __builtin_amdgcn_s_sleep(77);
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): LDS-DMA of the stage has landed
     __syncthreads();
 
@@ -297,12 +294,6 @@ void wsyrk_glds_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
             double af[2][4], bf[2][4], cv[2];
             auto read_frags = [&](int kk, int set) {
                 const int krow = kk * 4 + l4;
-                if (DBG & 4) {
-                    cv[set] = 1.0 + krow;
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) { af[set][m] = 0.5 + m + lane; bf[set][m] = 0.25 + m - lane; }
-                    return;
-                }
                 cv[set] = Cs[krow];
                 // 16-byte fragment reads: MFMA tile m takes the columns 32 (m >> 1) + 2 i + (m & 1) of the
                 // wave's 64 (i = lane & 15), so one ds_read_b128 feeds two tiles; the store below undoes it
@@ -336,7 +327,7 @@ void wsyrk_glds_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (!(DBG & 2)) { __builtin_amdgcn_s_waitcnt(0x0F70); __syncthreads(); }      // explicit vmcnt(0): the DMA of the next stage must have landed in every wave
+            __builtin_amdgcn_s_waitcnt(0x0F70); __syncthreads();      // explicit vmcnt(0): the DMA of the next stage must have landed in every wave
             buf ^= 1;
         }
         double* out = partial + ((i64)split * T + t) * (i64)(WS_TILE * WS_TILE);
@@ -357,12 +348,6 @@ void wsyrk_glds_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
             double a0[2], a1[2], bf[2][8], cv[2];
             auto read_frags = [&](int kk, int set) {
                 const int krow = kk * 4 + l4;
-                if (DBG & 4) {
-                    cv[set] = 1.0 + krow; a0[set] = 0.5 + lane; a1[set] = 0.75 - lane;
-#pragma unroll
-                    for (int n = 0; n < 8; ++n) bf[set][n] = 0.25 + n - lane;
-                    return;
-                }
                 const double* rowp = As + krow * WS_LDS_STRIDE + l15;
                 cv[set] = Cs[krow];
                 a0[set] = rowp[rb0 * 16];
@@ -386,7 +371,7 @@ void wsyrk_glds_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
                     if (n <= rb1) acc[4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(s1, bf[set][n], acc[4 + n], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (!(DBG & 2)) { __builtin_amdgcn_s_waitcnt(0x0F70); __syncthreads(); }
+            __builtin_amdgcn_s_waitcnt(0x0F70); __syncthreads();
             buf ^= 1;
         }
         // lower-triangle blocks get the sums, the rest of the two block rows is zeroed (never read,
@@ -997,14 +982,8 @@ int launch_wsyrk(lrvb_ctx* c, const double* cvec_dev, double* tiles_out_dev) {
     const int grid = S * T;
     if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
     if (vec_ok && c->P >= 2 && !c->force_generic_wsyrk)     // cvec_dev carries >= 32 zeros past N (reserve_obs_vec)
-        switch (c->dbg_bits) {
-#define WS_LAUNCH(D) hipLaunchKernelGGL(wsyrk_glds_kernel<D>, dim3(grid), dim3(WS_THREADS), 0, c->stream, \
-                           c->X.p, ldx, c->N, (int)c->P, cvec_dev, S, (int)((c->P + WS_TILE - 1) / WS_TILE), rps, c->tile_part.p, c->stagger_shift)
-        case 1: WS_LAUNCH(1); break; case 2: WS_LAUNCH(2); break; case 3: WS_LAUNCH(3); break;
-        case 4: WS_LAUNCH(4); break; case 5: WS_LAUNCH(5); break; case 7: WS_LAUNCH(7); break;
-        default: WS_LAUNCH(0); break;
-#undef WS_LAUNCH
-        }
+        hipLaunchKernelGGL(wsyrk_glds_kernel, dim3(grid), dim3(WS_THREADS), 0, c->stream,
+                           c->X.p, ldx, c->N, (int)c->P, cvec_dev, S, (int)((c->P + WS_TILE - 1) / WS_TILE), rps, c->tile_part.p);
     else if (vec_ok)
         hipLaunchKernelGGL(wsyrk_kernel<true>, dim3(grid), dim3(WS_THREADS), 0, c->stream,
                            c->X.p, ldx, c->N, (int)c->P, cvec_dev, S, T, rps, c->tile_part.p);
@@ -1048,125 +1027,5 @@ int launch_tiles_to_dense(lrvb_ctx* c, const double* tiles_dev, i64 P, double* d
     hipLaunchKernelGGL(tiles_to_dense_kernel, grid, dim3(256), 0, c->stream,
                        tiles_dev, P, dense_dev, ld, row_off, col_off, accumulate ? 1 : 0);
     HIP_TRY(hipGetLastError());
-    return LRVB_OK;
-}
-
-// ---- TIMING LAB (not a product path; results are discarded) ----------------------------------------------
-// One question for the next round: does a 256 x 128 workgroup tile (eight waves, one workgroup per CU, 6 LDS-DMA
-// instructions per wave and stage instead of 8) beat the 128 x 128 tile (four waves, two workgroups per CU) on
-// full off-diagonal rectangles?  Same code for both, NWR = wave rows (2 or 4); the sums go to a sink.
-template <int NWR>
-__global__ __launch_bounds__(128 * NWR, NWR == 2 ? 2 : 1)
-void wsyrk_lab_kernel(const double* __restrict__ X, i64 ldx, i64 N, const double* __restrict__ cpad, i64 rows_per_split,
-                      int row0, int col0, int ntr, int ntc, double* __restrict__ sink)
-{
-    constexpr int TA = 64 * NWR, SA = TA + 16, SB = WS_TILE + 16;
-    constexpr int PANEL_A = WS_KC * SA, PANEL_B = WS_KC * SB, BUF = PANEL_A + PANEL_B + 32, NW = 2 * NWR;
-    extern __shared__ double lds[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
-    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3, T = ntr * ntc;
-    const int split = (q / T) * 8 + xcd, t = q % T, bi = t / ntc, bj = t % ntc;
-    i64 r0 = (i64)split * rows_per_split, r1 = r0 + rows_per_split;
-    if (r1 > N) r1 = N;
-    if (r0 > N) r0 = N;
-    const int nch = (int)((r1 - r0 + WS_KC - 1) / WS_KC);
-    const int ca = row0 + bi * TA + 2 * lane, cb = col0 + bj * WS_TILE + 2 * lane;
-    d4 acc[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
-    auto issue_stage = [&](int ch, int buf) {
-        double* base = lds + buf * BUF;
-        const i64 n0 = r0 + (i64)ch * WS_KC;
-#pragma unroll
-        for (int i = 0; i < WS_KC / NW; ++i) {
-            const int row = wave + NW * i;
-            i64 n = n0 + row; if (n > N - 1) n = N - 1;
-            const double* rowp = X + n * ldx;
-#pragma unroll
-            for (int h = 0; h < TA / 128; ++h) WS_GLDS16(rowp + ca + 128 * h, base + row * SA + 128 * h);
-            WS_GLDS16(rowp + cb, base + PANEL_A + row * SB);
-        }
-        if (wave == 0) WS_GLDS4(reinterpret_cast<const float*>(cpad + n0) + lane, base + PANEL_A + PANEL_B);
-    };
-    if (nch > 0) issue_stage(0, 0);
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
-    const int l15 = lane & 15, l4 = lane >> 4;
-    int buf = 0;
-    for (int ch = 0; ch < nch; ++ch) {
-        if (ch + 1 < nch) issue_stage(ch + 1, buf ^ 1);
-        const double* As = lds + buf * BUF;
-        const double* Bs = As + PANEL_A;
-        const double* Cs = Bs + PANEL_B;
-        double af[2][4], bf[2][4], cv[2];
-        auto read_frags = [&](int kk, int set) {
-            const int krow = kk * 4 + l4;
-            cv[set] = Cs[krow];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const d2 va = *reinterpret_cast<const d2*>(As + krow * SA + wr * 64 + h * 32 + 2 * l15);
-                const d2 vb = *reinterpret_cast<const d2*>(Bs + krow * SB + wc * 64 + h * 32 + 2 * l15);
-                af[set][2 * h] = va[0]; af[set][2 * h + 1] = va[1];
-                bf[set][2 * h] = vb[0]; bf[set][2 * h + 1] = vb[1];
-            }
-        };
-        read_frags(0, 0);
-#pragma unroll
-        for (int kk = 0; kk < WS_KC / 4; ++kk) {
-            const int set = kk & 1;
-            double as[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) as[m] = af[set][m] * cv[set];
-            __builtin_amdgcn_sched_barrier(0);
-            if (kk + 1 < WS_KC / 4) read_frags(kk + 1, set ^ 1);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int n = 0; n < 4; ++n)
-                    acc[m * 4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[m], bf[set][n], acc[m * 4 + n], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        __syncthreads();
-        buf ^= 1;
-    }
-    double sum = 0.0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) sum += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
-    sink[(i64)blockIdx.x * blockDim.x + tid] = sum;
-}
-
-// times `reps` launches of the lab kernel over the rectangle rows [512, 1024) x columns [0, 512) of S (P >= 1024)
-int launch_wsyrk_lab(lrvb_ctx* c, int variant, int n_splits, int reps, const double* cpad, double* sink, float* ms_out)
-{
-    if (c->P < 1024 || c->P % 2 != 0 || (((uintptr_t)c->X.p) & 15) != 0 || (variant != 2 && variant != 4) ||
-        n_splits % 8 != 0 || n_splits <= 0 || n_splits > 1024)
-        LRVB_FAIL(LRVB_ERR_INVALID, "lab: need even n_cols >= 1024, 16-byte aligned rows, variant 2 or 4, n_splits a multiple of 8");
-    const int ntr = 512 / (64 * variant), ntc = 4;
-    const i64 rows_per_split = ((c->N + n_splits - 1) / n_splits + WS_KC - 1) / WS_KC * WS_KC;
-    const unsigned grid = (unsigned)(n_splits * ntr * ntc);
-    const size_t lds = (size_t)2 * (WS_KC * (64 * variant + 16) + WS_KC * (WS_TILE + 16) + 32) * sizeof(double);
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-    if (variant == 2) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&wsyrk_lab_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    else              HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&wsyrk_lab_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    for (int r = 0; r <= reps; ++r) {
-        if (r == 1) HIP_TRY(hipEventRecord(e0, c->stream));          // launch 0 is the warm-up
-        if (variant == 2)
-            hipLaunchKernelGGL(wsyrk_lab_kernel<2>, dim3(grid), dim3(256), lds, c->stream, c->X.p, c->P, c->N, cpad, rows_per_split, 512, 0, ntr, ntc, sink);
-        else
-            hipLaunchKernelGGL(wsyrk_lab_kernel<4>, dim3(grid), dim3(512), lds, c->stream, c->X.p, c->P, c->N, cpad, rows_per_split, 512, 0, ntr, ntc, sink);
-        HIP_TRY(hipGetLastError());
-    }
-    HIP_TRY(hipEventRecord(e1, c->stream));
-    HIP_TRY(hipEventSynchronize(e1));
-    HIP_TRY(hipEventElapsedTime(ms_out, e0, e1));
-    *ms_out /= (float)reps;
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return LRVB_OK;
 }

@@ -286,13 +286,12 @@ extern "C" int lrvb_set_quad_scale(lrvb_ctx* c, double scale) {
 extern "C" int lrvb_set_tuning(lrvb_ctx* c, int n_splits, int reserved) {
     if (!c) LRVB_FAIL(LRVB_ERR_INVALID, "null context");
     if (n_splits < 0 || n_splits > 1024) LRVB_FAIL(LRVB_ERR_INVALID, "n_splits out of range");
+    if (reserved & ~7) LRVB_FAIL(LRVB_ERR_INVALID, "reserved = %d: only bits 0-2 are defined (include/lrvb_hip.h)", reserved);
     c->hvp_pt_valid = false;
     c->n_splits_user = n_splits;
     c->force_generic_wsyrk = (reserved & 1) != 0;
     c->force_dense_rows = (reserved & 2) ? 1 : 0;
     c->hm_four_waves = (reserved & 4) != 0;
-    c->dbg_bits = (reserved >> 8) & 7;
-    c->stagger_shift = ((reserved >> 16) & 0xff) - 1;
     return LRVB_OK;
 }
 
@@ -1643,20 +1642,6 @@ extern "C" int lrvb_dk_grad_vec(lrvb_ctx* c, const double* vec_in, int64_t V, in
     // out = X^T (coef o (X u_1)), scattered into the vector layout; the quadratic term only has a second derivative
     LRVB_TRY(heta_apply_coef(c, c->cgT.p, c->rhs.p, order == 1 && include_quad != 0));
     return d2h(c, out, c->rhs.p, (size_t)V);
-}
-
-// ---- timing lab for the next round's SYRK tile shape (not part of the boundary: no header entry) ---------------
-extern "C" int lrvb_lab_syrk(lrvb_ctx* c, int variant, int n_splits, int reps, double* ms_out) {
-    LRVB_TRY(ctx_bind(c));
-    if (!ms_out || reps < 1) LRVB_FAIL(LRVB_ERR_INVALID, "bad argument");
-    LRVB_TRY(data_ready(c));
-    LRVB_TRY(reserve_obs_vec(c, c->zbuf));
-    EW(fill_kernel, c->N, 1.0, c->zbuf.p);
-    LRVB_TRY(buf_reserve(c, c->work1, (size_t)n_splits * 16 * 512));
-    float ms = 0.f;
-    LRVB_TRY(launch_wsyrk_lab(c, variant, n_splits, reps, c->zbuf.p, c->work1.p, &ms));
-    *ms_out = ms;
-    return LRVB_OK;
 }
 
 // ---- trust-region Newton-CG on the device -------------------------------------------------------------

@@ -83,8 +83,6 @@ struct lrvb_ctx {
     double* host_pinned = nullptr; size_t host_pinned_n = 0;
 
     int n_splits_user = 0;
-    int  stagger_shift = -1;            // timing lab: delay blocks whose queue position has this bit set
-    int  dbg_bits = 0;                  // timing-lab variants of the weighted-SYRK kernel (wrong results)
     bool force_generic_wsyrk = false;   // tuning/testing: use the register-staged kernel
     int  mx_res_K = 0, mx_res_q = 0;    // shape of the expanded mixture operand R resident in mx_A (0 = none)
     bool hm_four_waves = false;         // tuning/testing: fused multi-vector pass with four waves per workgroup
@@ -126,7 +124,6 @@ int launch_obs_grad(lrvb_ctx* c, i64 n0, i64 n1, double* G_dev, int mode, const 
 
 // k_wsyrk.hip
 int  wsyrk_num_tiles(i64 P);
-int  launch_wsyrk_lab(lrvb_ctx* c, int variant, int n_splits, int reps, const double* cpad, double* sink, float* ms_out);   // timing lab
 int  wsyrk_auto_splits(const lrvb_ctx* c);
 int  launch_wsyrk(lrvb_ctx* c, const double* cvec_dev, double* tiles_out_dev /* T*128*128 */);
 int  launch_gram_small_on(lrvb_ctx* c, const double* Z, i64 N, i64 P, const double* cvec_dev, double* tiles_out_dev);

@@ -27,6 +27,16 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert set(declared) == bound, (set(declared) ^ bound)
 
 
+def test_nothing_but_the_header_is_exported():
+    """`nm -D`: the dynamic symbol table of the library defines exactly the header's functions -- no kernel stubs, no
+    C++ helpers, no undeclared entry points (timing-lab code is not part of the product)."""
+    import subprocess
+    import lrvb_amd
+    out = subprocess.run(['nm', '-D', '--defined-only', lrvb_amd._hip.LIB_PATH], capture_output=True, text=True, check=True)
+    exported = sorted({ln.split()[-1].split('@')[0] for ln in out.stdout.splitlines() if ln.strip()})
+    assert exported == _declared(), set(exported) ^ set(_declared())
+
+
 def test_library_reports_version_and_fails_loudly_without_gpu():
     import lrvb_amd
     lib = lrvb_amd._hip.load()

@@ -345,6 +345,11 @@ def test_full_size_properties_headline_shape(vb):
     Hg = build(w1)
     ctx.set_tuning(0, 0)
     assert (Hg - H1).abs().max().item() < 1e-12 * scale
+    # only the three documented bits exist; anything else is refused and changes nothing
+    for bad in (8, 1 << 8, 7 << 8, 1 << 16, -1):
+        with pytest.raises(ValueError):
+            ctx.set_tuning(0, bad)
+    assert torch.equal(build(w1), H1)
     G = torch.empty((P, P), dtype=torch.float64, device=dev)
     ctx.gram_dev(theta.data_ptr(), G.data_ptr(), P); ctx.sync()
     assert torch.equal(G, G.T) and torch.linalg.eigvalsh(G).min().item() > -1e-9 * G.abs().max().item()
