@@ -208,6 +208,12 @@ constexpr int WS_BUF = 2 * WS_PANEL + 32;                // A panel, B panel, 32
     (const __attribute__((address_space(1))) void*)(gp), (__attribute__((address_space(3))) void*)(lp), 16, 0, 0)
 #define WS_GLDS4(gp, lp) __builtin_amdgcn_global_load_lds( \
     (const __attribute__((address_space(1))) void*)(gp), (__attribute__((address_space(3))) void*)(lp), 4, 0, 0)
+// scalar-base form: global address = sbase (SGPR pair, wave-uniform) + voff (32-bit per-lane byte offset); the LDS
+// destination base travels in M0 (the hardware adds lane * size)
+#define WS_GLDS16_S(sbase, voff, ldsaddr) asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" \
+    :: "v"(voff), "s"(sbase), "s"(ldsaddr) : "memory")
+#define WS_GLDS4_S(sbase, voff, ldsaddr) asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dword %0, %1" \
+    :: "v"(voff), "s"(sbase), "s"(ldsaddr) : "memory")
 
 __global__ __launch_bounds__(WS_THREADS, 2)
 void wsyrk_glds_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
@@ -261,19 +267,45 @@ void wsyrk_glds_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
     int ca = bi * WS_TILE + 2 * lane; if (ca > P - 2) ca = P - 2;
     int cb = bj * WS_TILE + 2 * lane; if (cb > P - 2) cb = P - 2;
 
-    auto issue_stage = [&](int ch, int buf) {
-        double* base = lds + buf * WS_BUF;
-        const i64 n0 = r0 + (i64)ch * WS_KC;
+    // LDS-DMA of one stage.  Every address is (wave-uniform 64-bit base in SGPRs) + (32-bit per-lane byte offset that
+    // never changes): the instruction takes both directly, so a stage costs NO vector-ALU work -- beside a stream of
+    // fp64 MFMAs every VALU instruction costs the SIMD ~8 cycles of matrix time (tools/mfma_vmem_probe.hip), and the
+    // 64-bit per-lane address arithmetic of the pointer form was 13 of them per stage.
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) double*)lds;
+    unsigned voffA[4], voffB[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = wave + 4 * i;
-            i64 n = n0 + row; if (n > N - 1) n = N - 1;
-            const double* rowp = X + n * ldx;
-            WS_GLDS16(rowp + ca, base + row * WS_LDS_STRIDE);
-            if (!diag) WS_GLDS16(rowp + cb, base + WS_PANEL + row * WS_LDS_STRIDE);
+    for (int i = 0; i < 4; ++i) {
+        voffA[i] = (unsigned)(((i64)(wave + 4 * i) * ldx + ca) * 8);
+        voffB[i] = (unsigned)(((i64)(wave + 4 * i) * ldx + cb) * 8);
+    }
+    const unsigned voffC = (unsigned)lane * 4u;
+    i64 full = (N - r0) / WS_KC;                                  // stages of this split with all 16 rows inside X
+    const int nch_full = (int)(full < nch ? full : nch);
+
+    auto issue_stage = [&](int ch, int buf) {
+        const unsigned base = lds0 + (unsigned)(buf * WS_BUF) * 8u;
+        const i64 n0 = r0 + (i64)ch * WS_KC;
+        if (ch < nch_full) {                                     // wave-uniform: all 16 rows exist
+            const char* sb = reinterpret_cast<const char*>(X) + n0 * ldx * 8;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned la = base + (unsigned)((wave + 4 * i) * WS_LDS_STRIDE) * 8u;
+                WS_GLDS16_S(sb, voffA[i], la);
+                if (!diag) WS_GLDS16_S(sb, voffB[i], la + (unsigned)WS_PANEL * 8u);
+            }
+        } else {                                                 // last rows of the matrix: clamp to a readable row
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wave + 4 * i;
+                i64 n = n0 + row; if (n > N - 1) n = N - 1;
+                const char* sb = reinterpret_cast<const char*>(X) + (n - row) * ldx * 8;
+                const unsigned la = base + (unsigned)(row * WS_LDS_STRIDE) * 8u;
+                WS_GLDS16_S(sb, voffA[i], la);
+                if (!diag) WS_GLDS16_S(sb, voffB[i], la + (unsigned)WS_PANEL * 8u);
+            }
         }
         if (wave == 0)       // 64 dwords = c[n0 .. n0+31]; reads past N hit the zero padding
-            WS_GLDS4(reinterpret_cast<const float*>(cpad + n0) + lane, base + 2 * WS_PANEL);
+            WS_GLDS4_S(reinterpret_cast<const char*>(cpad + n0), voffC, base + (unsigned)(2 * WS_PANEL) * 8u);
     };
 
     if (nch > 0) issue_stage(0, 0);

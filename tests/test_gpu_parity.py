@@ -506,12 +506,17 @@ def test_wide_designs(vb, loss, N, P):
     eta = lay.constrain(theta)
     assert rel_err(obj.fun_vector_hvp(eta, v), model.hessian_vec(eta) @ v) < TOL
     assert rel_err(fun.ctx.obs_grad(theta, 0, min(N, 50)), model.obs_grad(theta, 0, min(N, 50))) < TOL
-    # convex losses, non-negative weights, a positive prior precision and (at this theta) positive packing
-    # second-order terms: the Hessian is positive definite, which the CG route needs
-    assert np.min(np.linalg.eigvalsh(Hw)) > 0
+    # CG needs a positive definite Hessian: the same wide design with every coefficient unconstrained, where
+    # H = X^T diag(w loss'') X + prior precision is positive definite by construction at any point
+    par_u, lay_u = make_par(vb, [('box', 'u', P, -np.inf, np.inf)])
+    fun_u = vb.DeviceObjective(par_u, x=x, y=y, loss=LOSS_NAME[loss], lik_info=1.3, quad_A=np.full(P, 0.7), weights=w)
+    model_u = om.DeclaredModel(lay_u, loss=loss, x=x, y=y, w=w, lik_info=1.3, quad_A=np.full(P, 0.7))
+    fun_u._push_state()
+    H_u = model_u.hessian(theta)
+    assert np.min(np.linalg.eigvalsh(H_u)) > 0
     B = rng.normal(size=(3, P))
-    X, info, _ = fun.ctx.cg_solve_multi(theta, B)
-    assert np.all(info == 0) and rel_err(X, np.linalg.solve(Hw, B.T).T) < 1e-6
+    X, info, _ = fun_u.ctx.cg_solve_multi(theta, B)
+    assert np.all(info == 0) and rel_err(X, np.linalg.solve(H_u, B.T).T) < 1e-6
 
 
 def test_nan_and_overflow_inputs_do_not_fault(vb):
