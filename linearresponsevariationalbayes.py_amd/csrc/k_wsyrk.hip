@@ -315,25 +315,26 @@ void wsyrk_glds_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
     const int l15 = lane & 15, l4 = lane >> 4;
     int buf = 0;
     if (!diag) {
-        const int wr = wave >> 1, wc = wave & 1;
-        for (int ch = 0; ch < nch; ++ch) {
-            if (ch + 1 < nch) issue_stage(ch + 1, buf ^ 1);
-            const double* As = lds + buf * WS_BUF;
-            const double* Bs = As + WS_PANEL;
-            const double* Cs = As + 2 * WS_PANEL;
-            // fragments of k-step kk+1 are read while the 16 MFMAs of k-step kk run (explicit
-            // register double buffer; sched_barrier keeps hipcc from sinking the reads to their use)
-            double af[2][4], bf[2][4], cv[2];
+        // Wave w owns rows [32 w, 32 w + 32) of the tile and all 128 columns: 2 A fragments x 8 B fragments = 16 MFMAs
+        // per k-step, and only TWO c_n multiplies (the scaling sits on the A side).  With 16-byte LDS reads MFMA tile
+        // (m, n = 2 h + p) holds rows {32 w + 2 i + m}, columns {32 h + 2 j + p}; the store below undoes it.
+        // Every LDS address of the loop is a loop-invariant register + an immediate: the stage loop is unrolled over
+        // the two buffers so that no address is recomputed (each VALU instruction costs ~8 cycles of matrix time).
+        const double* a_base = lds + l4 * WS_LDS_STRIDE + 32 * wave + 2 * l15;
+        const double* b_base = lds + WS_PANEL + l4 * WS_LDS_STRIDE + 2 * l15;
+        const double* c_base = lds + 2 * WS_PANEL + l4;
+        auto stage = [&](auto buf_tag) {
+            constexpr int BUF = decltype(buf_tag)::value;
+            double af[2][2], bf[2][8], cv[2];
             auto read_frags = [&](int kk, int set) {
-                const int krow = kk * 4 + l4;
-                cv[set] = Cs[krow];
-                // 16-byte fragment reads: MFMA tile m takes the columns 32 (m >> 1) + 2 i + (m & 1) of the
-                // wave's 64 (i = lane & 15), so one ds_read_b128 feeds two tiles; the store below undoes it
+                constexpr int dummy = 0; (void)dummy;
+                const int o = BUF * WS_BUF + kk * 4 * WS_LDS_STRIDE;
+                cv[set] = c_base[BUF * WS_BUF + kk * 4];
+                const d2 va = *reinterpret_cast<const d2*>(a_base + o);
+                af[set][0] = va[0]; af[set][1] = va[1];
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const d2 va = *reinterpret_cast<const d2*>(As + krow * WS_LDS_STRIDE + wr * 64 + h * 32 + 2 * l15);
-                    const d2 vb = *reinterpret_cast<const d2*>(Bs + krow * WS_LDS_STRIDE + wc * 64 + h * 32 + 2 * l15);
-                    af[set][2 * h] = va[0]; af[set][2 * h + 1] = va[1];
+                for (int h = 0; h < 4; ++h) {
+                    const d2 vb = *reinterpret_cast<const d2*>(b_base + o + 32 * h);
                     bf[set][2 * h] = vb[0]; bf[set][2 * h + 1] = vb[1];
                 }
             };
@@ -341,36 +342,39 @@ void wsyrk_glds_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
 #pragma unroll
             for (int kk = 0; kk < WS_KC / 4; ++kk) {
                 const int set = kk & 1;
-                // order: (wait for set kk, all that is outstanding) -> scale -> issue reads of set
-                // kk+1 -> 16 MFMAs.  The only lgkmcnt wait of the k-step then sits a full MFMA
-                // block after the reads it covers.
-                double as[4];
-#pragma unroll
-                for (int m = 0; m < 4; ++m) as[m] = af[set][m] * cv[set];
+                // order: (wait for set kk) -> scale -> issue reads of set kk+1 -> 16 MFMAs: the only lgkmcnt wait of
+                // the k-step sits a full MFMA block after the reads it covers
+                const double as0 = af[set][0] * cv[set], as1 = af[set][1] * cv[set];
                 __builtin_amdgcn_sched_barrier(0);
                 if (kk + 1 < WS_KC / 4) read_frags(kk + 1, set ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int n = 0; n < 4; ++n)
-                        acc[m * 4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[m], bf[set][n], acc[m * 4 + n], 0, 0, 0);
+                for (int n = 0; n < 8; ++n) {
+                    acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(as0, bf[set][n], acc[n], 0, 0, 0);
+                    acc[8 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(as1, bf[set][n], acc[8 + n], 0, 0, 0);
+                }
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_s_waitcnt(0x0F70); __syncthreads();      // explicit vmcnt(0): the DMA of the next stage must have landed in every wave
-            buf ^= 1;
+        };
+        for (int ch = 0; ch < nch; ch += 2) {
+            if (ch + 1 < nch) issue_stage(ch + 1, 1);
+            stage(std::integral_constant<int, 0>{});
+            if (ch + 1 < nch) {
+                if (ch + 2 < nch) issue_stage(ch + 2, 0);
+                stage(std::integral_constant<int, 1>{});
+            }
         }
         double* out = partial + ((i64)split * T + t) * (i64)(WS_TILE * WS_TILE);
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int n = 0; n < 4; ++n)
+            for (int n = 0; n < 8; ++n)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    out[(wr * 64 + 32 * (m >> 1) + 2 * (l4 + 4 * r) + (m & 1)) * WS_TILE
-                        + wc * 64 + 32 * (n >> 1) + 2 * l15 + (n & 1)] = acc[m * 4 + n][r];
+                    out[(32 * wave + 2 * (l4 + 4 * r) + m) * WS_TILE + 32 * (n >> 1) + 2 * l15 + (n & 1)] = acc[m * 8 + n][r];
     } else {
         const int rb0 = wave, rb1 = 7 - wave;        // this wave's two 16-row blocks
         for (int ch = 0; ch < nch; ++ch) {
