@@ -313,7 +313,6 @@ void wsyrk_glds_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
     __syncthreads();
 
     const int l15 = lane & 15, l4 = lane >> 4;
-    int buf = 0;
     if (!diag) {
         // Wave w owns rows [32 w, 32 w + 32) of the tile and all 128 columns: 2 A fragments x 8 B fragments = 16 MFMAs
         // per k-step, and only TWO c_n multiplies (the scaling sits on the A side).  With 16-byte LDS reads MFMA tile
@@ -377,15 +376,14 @@ void wsyrk_glds_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
                     out[(32 * wave + 2 * (l4 + 4 * r) + m) * WS_TILE + 32 * (n >> 1) + 2 * l15 + (n & 1)] = acc[m * 8 + n][r];
     } else {
         const int rb0 = wave, rb1 = 7 - wave;        // this wave's two 16-row blocks
-        for (int ch = 0; ch < nch; ++ch) {
-            if (ch + 1 < nch) issue_stage(ch + 1, buf ^ 1);
-            const double* As = lds + buf * WS_BUF;
-            const double* Cs = As + 2 * WS_PANEL;
+        const double* row_base = lds + l4 * WS_LDS_STRIDE + l15;       // loop-invariant LDS addresses, as above
+        const double* c_base = lds + 2 * WS_PANEL + l4;
+        auto stage = [&](auto buf_tag) {
+            constexpr int BUF = decltype(buf_tag)::value;
             double a0[2], a1[2], bf[2][8], cv[2];
             auto read_frags = [&](int kk, int set) {
-                const int krow = kk * 4 + l4;
-                const double* rowp = As + krow * WS_LDS_STRIDE + l15;
-                cv[set] = Cs[krow];
+                const double* rowp = row_base + BUF * WS_BUF + kk * 4 * WS_LDS_STRIDE;
+                cv[set] = c_base[BUF * WS_BUF + kk * 4];
                 a0[set] = rowp[rb0 * 16];
                 a1[set] = rowp[rb1 * 16];
 #pragma unroll
@@ -408,7 +406,14 @@ void wsyrk_glds_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
                 __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_s_waitcnt(0x0F70); __syncthreads();
-            buf ^= 1;
+        };
+        for (int ch = 0; ch < nch; ch += 2) {
+            if (ch + 1 < nch) issue_stage(ch + 1, 1);
+            stage(std::integral_constant<int, 0>{});
+            if (ch + 1 < nch) {
+                if (ch + 2 < nch) issue_stage(ch + 2, 0);
+                stage(std::integral_constant<int, 1>{});
+            }
         }
         // lower-triangle blocks get the sums, the rest of the two block rows is zeroed (never read,
         // but kept finite for the split reduction / all-reduce)
