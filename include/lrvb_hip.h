@@ -202,6 +202,11 @@ int lrvb_hvec_finish(lrvb_ctx* ctx, const double* point, int64_t n_in, int is_fr
  * of the D x N cross Hessian w.r.t. the observation weights (Example.ipynb:425-441).        */
 int lrvb_obs_grad(lrvb_ctx* ctx, const double* free_in, int64_t D, int64_t n0, int64_t n1,
                   double* G_out);
+/* l(y_n, z_n) for rows n0..n1: the gradient of the objective with respect to the observation weights,
+ * TwoParameterObjective.fun_grad2 (LRVB/SparseObjectives.py:381-387) with par2 = the weights in vector
+ * coordinates; `point` is the free vector (is_free != 0) or the vector-coordinate point.             */
+int lrvb_obs_loss(lrvb_ctx* ctx, const double* point, int64_t n_in, int is_free, int64_t n0, int64_t n1,
+                  double* out);
 /* Same in vector coordinates ((n1-n0) x V): TwoParameterObjective.fun_vector_hessian21
  * (LRVB/SparseObjectives.py:418-427) with par2 = the weights.                               */
 int lrvb_obs_grad_vec(lrvb_ctx* ctx, const double* vec_in, int64_t V, int64_t n0, int64_t n1,

@@ -73,6 +73,7 @@ _SIGNATURES = {
     'lrvb_hvp_vec': [_VP, _VP, _VP, c_i64, _VP],
     'lrvb_obs_grad': [_VP, _VP, c_i64, c_i64, c_i64, _VP],
     'lrvb_obs_grad_vec': [_VP, _VP, c_i64, c_i64, c_i64, _VP],
+    'lrvb_obs_loss': [_VP, _VP, c_i64, ctypes.c_int, c_i64, c_i64, _VP],
     'lrvb_hvec_begin': [_VP],
     'lrvb_hvec_add_block': [_VP, _VP, c_i64, c_i64, c_i64, c_i64, ctypes.c_int],
     'lrvb_hvec_add_symkron': [_VP, _VP, _VP, c_i64, ctypes.c_double, c_i64, c_i64, ctypes.c_int],

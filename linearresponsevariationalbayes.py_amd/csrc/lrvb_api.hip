@@ -1592,6 +1592,45 @@ __global__ void dk_coef_kernel(i64 n, int loss, double lik, int m, const double*
     coef[i] = p;
 }
 
+// ---- per-observation loss values: the gradient of the objective with respect to the weights -----------------
+__global__ void obs_loss_kernel(i64 n, int loss, double lik, const double* __restrict__ y, const double* __restrict__ z,
+                                double* __restrict__ out) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double zi = z[i], yi = y[i];
+    double v;
+    if (loss == LRVB_LOSS_GAUSSIAN) { const double d = zi - yi; v = 0.5 * lik * d * d; }
+    else if (loss == LRVB_LOSS_POISSON) v = exp(zi) - yi * zi;
+    else v = (zi > 0.0 ? zi + log1p(exp(-zi)) : log1p(exp(zi))) - yi * zi;       // log(1 + e^z) - y z, overflow-free
+    out[i] = v;
+}
+
+extern "C" int lrvb_obs_loss(lrvb_ctx* c, const double* point, int64_t n_in, int is_free, int64_t n0, int64_t n1, double* out) {
+    LRVB_TRY(ctx_bind(c));
+    if (!point || !out) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    const i64 width = is_free ? c->D : c->V;
+    LRVB_TRY(check_len(n_in, width, is_free ? "free vector" : "vector"));
+    if (c->loss == LRVB_LOSS_NONE || c->data_only) LRVB_FAIL(LRVB_ERR_STATE, "model has no declared data term");
+    if (n0 < 0 || n1 > c->N || n0 > n1) LRVB_FAIL(LRVB_ERR_INVALID, "row range [%lld, %lld) outside [0, %lld)", (long long)n0, (long long)n1, (long long)c->N);
+    LRVB_TRY(data_ready(c));
+    const i64 rows = n1 - n0, P = c->P;
+    if (rows == 0) return LRVB_OK;
+    LRVB_TRY(h2d(c, c->theta.p, point, (size_t)width));
+    LRVB_TRY(set_point(c, c->theta.p, is_free != 0));
+    // z = X[n0:n1] beta: the one-vector case of the skinny row product
+    LRVB_TRY(buf_reserve(c, c->work1, (size_t)rows * 2));
+    double* z = c->work1.p; double* lv = c->work1.p + rows;
+    if (hvp_multi_supported(c, 1) && !c->force_generic_wsyrk) {
+        LRVB_TRY(reserve_obs_vec(c, c->zbuf));
+        EW(fill_kernel, c->N, 1.0, c->zbuf.p);
+        LRVB_TRY(launch_rows_times_matrix(c, n0, n1, 1, c->eta.p + c->glm_off, P, c->zbuf.p, z, 1));
+    } else {
+        LRVB_TRY(launch_gemv(c, false, rows, P, 1.0, c->X.p + n0 * P, P, c->eta.p + c->glm_off, 0.0, z));
+    }
+    EW(obs_loss_kernel, rows, (int)c->loss, c->lik_info, (const double*)(c->y.p + n0), (const double*)z, lv);
+    return d2h(c, out, lv, (size_t)rows);
+}
+
 extern "C" int lrvb_dk_grad_vec(lrvb_ctx* c, const double* vec_in, int64_t V, int32_t order, const double* U,
                                 const double* w_override, int32_t include_quad, double* out) {
     LRVB_TRY(ctx_bind(c));

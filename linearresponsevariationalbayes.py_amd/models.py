@@ -204,6 +204,14 @@ class DeviceContext(object):
         self._check(fn(self._h, _hip.ptr(x), x.size, n0, n1, _hip.ptr(G)))
         return G
 
+    def obs_loss(self, x, n0=0, n1=None, is_free=True):
+        """l(y_n, z_n) for rows n0..n1 at the point x: d f / d w_n."""
+        x = _hip.as_f64(x).ravel()
+        n1 = self.n_obs if n1 is None else n1
+        out = np.empty(max(n1 - n0, 0))
+        self._check(self._lib.lrvb_obs_loss(self._h, _hip.ptr(x), x.size, 1 if is_free else 0, n0, n1, _hip.ptr(out)))
+        return out
+
     def obs_influence(self, x, moment_jac, n0=0, n1=None, is_free=True):
         """d moments / d weights for observations n0..n1 ((n1 - n0) x Q), from the resident factor."""
         x = _hip.as_f64(x).ravel()
@@ -609,6 +617,18 @@ class DeviceObjective(object):
             return self.ctx.cross_hessian_tilt(val1)
         s = self.scale_fun(*argv, **argk) if self.scale_fun is not None else 1.0
         return s * np.eye(self.ctx.V)
+
+    def hyper_grad(self, hyper_par, val1, val1_is_free, *argv, **argk):
+        """d f / d hyper with hyper in VECTOR coordinates (TwoParameterObjective.fun_grad2,
+        LRVB/SparseObjectives.py:381-387): the objective is linear in both declared hyper-parameters, so the gradient is
+        the per-observation loss l(y_n, z_n) for the weights (one skinny pass over X) and s * eta for the tilt."""
+        kind = self.hyper_kind(hyper_par)
+        self._push(argv, argk)
+        if kind == 'weights':
+            return self.ctx.obs_loss(val1, 0, self.n_obs, val1_is_free)
+        s = self.scale_fun(*argv, **argk) if self.scale_fun is not None else 1.0
+        eta = self.ctx.constrain(val1) if val1_is_free else np.asarray(val1, dtype=np.float64)
+        return s * eta
 
     def gram(self, free_val):
         self._push_state()

@@ -39,69 +39,82 @@ def _functor(fun):
 
 
 def safe_matmul(x, y):
-    """Dense or scipy-sparse product.  LRVB/SparseObjectives.py:21-25."""
-    if sparse.issparse(x) or sparse.issparse(y):
-        return x * y
-    return np.matmul(x, y)
+    """x y for any mix of dense arrays and scipy sparse matrices (the reference's helper of the same name,
+    LRVB/SparseObjectives.py:21-25)."""
+    sparse_operand = sparse.issparse(x) or sparse.issparse(y)
+    return x * y if sparse_operand else np.matmul(x, y)
 
 
 def compress(x):
-    if sparse.issparse(x):
-        return np.squeeze(np.asarray(x.todense()))
-    return np.squeeze(np.asarray(x))
+    """A dense, squeezed ndarray from a dense or sparse result (LRVB/SparseObjectives.py:27-31)."""
+    return np.squeeze(np.asarray(x.todense() if sparse.issparse(x) else x))
 
 
 class Timer(object):
-    """tic/toc dictionary of wall times.  LRVB/SparseObjectives.py:35-45."""
+    """Named wall-clock intervals: tic() starts the clock, toc(name) stores the time since in `time_dict[name]`
+    (and prints it unless verbose=False).  Same surface as the reference's utility (LRVB/SparseObjectives.py:35-45)."""
 
     def __init__(self):
         self.time_dict = {}
+        self.tic_time = None
 
     def tic(self):
-        self.tic_time = time.time()
+        self.tic_time = time.perf_counter()
 
     def toc(self, time_name, verbose=True):
-        self.time_dict[time_name] = time.time() - self.tic_time
+        if self.tic_time is None:
+            raise RuntimeError('toc() without a preceding tic()')
+        elapsed = time.perf_counter() - self.tic_time
+        self.time_dict[time_name] = elapsed
         if verbose:
-            print('{}: {} seconds'.format(time_name, self.time_dict[time_name]))
+            print('{}: {} seconds'.format(time_name, elapsed))
+        return elapsed
 
     def __str__(self):
         return str(self.time_dict)
 
 
 class Logger(object):
-    """Iteration log fed by fun_free(..., verbose=True).  LRVB/SparseObjectives.py:48-87."""
+    """Iteration log of an optimisation: `fun_free(..., verbose=True)` hands every evaluation to `log(value, x)`.
+    Attribute names are the reference's (LRVB/SparseObjectives.py:48-87: iter, x, value, last_x, last_value, x_array,
+    val_array, print_every, callback), because optimiser callbacks read them; the history lists are the state and the
+    `last_*` / current fields are views of their tails."""
 
     def __init__(self, print_every=1):
         self.print_every = print_every
-        self.initialize()
         self.print_x_diff = True
         self.callback = None
+        self.initialize()
 
     def initialize(self):
         self.iter = 0
-        self.last_x = None
-        self.x = None
-        self.value = None
-        self.last_value = None
         self.x_array = []
         self.val_array = []
+
+    def _tail(self, seq, back):
+        return seq[-back] if len(seq) >= back else None
+
+    x = property(lambda self: self._tail(self.x_array, 1))
+    value = property(lambda self: self._tail(self.val_array, 1))
+    # after log() returns, the reference's last_x / last_value equal the point just logged
+    last_x = property(lambda self: self._tail(self.x_array, 1))
+    last_value = property(lambda self: self._tail(self.val_array, 1))
+
+    @property
+    def x_diff(self):
+        """Largest coordinate change between the two most recent points (inf before there are two)."""
+        if len(self.x_array) < 2:
+            return float('inf')
+        return float(np.max(np.abs(np.asarray(self.x_array[-1]) - np.asarray(self.x_array[-2]))))
 
     def print_message(self):
         print('Iter ', self.iter, ' value: ', self.value)
 
     def log(self, value, x):
-        self.value = value
-        self.x = x
         self.x_array.append(x)
         self.val_array.append(value)
-        self.last_x = x
-        self.last_value = value
-        if self.iter % self.print_every == 0:
-            if self.callback is None:
-                self.print_message()
-            else:
-                self.callback(self)
+        if self.print_every and self.iter % self.print_every == 0:
+            (self.callback or type(self).print_message)(self)
         self.iter += 1
 
 
@@ -218,30 +231,31 @@ class ParameterConverter(object):
         self.par_out = par_out
         self.converter = converter
 
-    def converter_free_to_vec(self, free_par_in):
-        self.par_in.set_free(free_par_in)
+    def _convert(self, val_in, in_is_free, out_is_free):
+        set_par(self.par_in, val_in, in_is_free)
         self.converter()
-        return self.par_out.get_vector()
+        return self.par_out.get_free() if out_is_free else self.par_out.get_vector()
+
+    def converter_free_to_vec(self, free_par_in):
+        return self._convert(free_par_in, True, False)
 
     def converter_free_to_free(self, free_par_in):
-        self.par_in.set_free(free_par_in)
-        self.converter()
-        return self.par_out.get_free()
+        return self._convert(free_par_in, True, True)
 
     def converter_vec_to_vec(self, vec_par_in):
-        self.par_in.set_vector(vec_par_in)
-        self.converter()
-        return self.par_out.get_vector()
+        return self._convert(vec_par_in, False, False)
 
     def converter_vec_to_free(self, vec_par_in):
-        self.par_in.set_vector(vec_par_in)
-        self.converter()
-        return self.par_out.get_free()
+        return self._convert(vec_par_in, False, True)
 
     def _vec_jac(self, vec_in):
-        if not hasattr(self.converter, 'vec_jacobian'):
-            raise NotImplementedError(_NO_DERIV)
-        return np.asarray(self.converter.vec_jacobian(np.asarray(vec_in, dtype=np.float64)))
+        """d vec_out / d vec_in^T: the converter's own `vec_jacobian` if it declares one; otherwise -- an opaque
+        Python closure, which the reference hands to autograd -- Richardson-extrapolated central differences of the
+        closure itself (converters are small N-independent maps on the host; error ~1e-10 relative)."""
+        vec_in = np.asarray(vec_in, dtype=np.float64)
+        if hasattr(self.converter, 'vec_jacobian'):
+            return np.asarray(self.converter.vec_jacobian(vec_in))
+        return numeric_jacobian(self.converter_vec_to_vec, vec_in)
 
     def _out_free_from_vec(self):
         # d free_out / d vec_out = (d vec_out / d free_out)^-1 at the current par_out
@@ -306,6 +320,22 @@ class ElementwiseConverter(object):
         return np.diag(self.dg(vec_in))
 
 
+def numeric_jacobian(f, x, rel_step=1e-3):
+    """Jacobian of a smooth vector function by central differences with two Richardson extrapolations (steps h, h/2,
+    h/4: error O(h^6)); used for opaque host-side converters only."""
+    x = np.asarray(x, dtype=np.float64)
+    cols = []
+    for k in range(x.size):
+        h = rel_step * max(1.0, abs(x[k]))
+        d = []
+        for step in (h, h / 2, h / 4):
+            e = np.zeros_like(x); e[k] = step
+            d.append((np.asarray(f(x + e), dtype=np.float64) - np.asarray(f(x - e), dtype=np.float64)) / (2 * step))
+        r1 = [(4 * d[1] - d[0]) / 3, (4 * d[2] - d[1]) / 3]
+        cols.append((16 * r1[1] - r1[0]) / 15)
+    return np.stack(cols, axis=1)
+
+
 def set_par(par, val, is_free):
     if is_free:
         par.set_free(val)
@@ -358,8 +388,17 @@ class TwoParameterObjective(object):
         return g
 
     def fun_grad2(self, val1, val2, val1_is_free, val2_is_free, *argv, **argk):
-        raise NotImplementedError('the gradient with respect to a hyper-parameter alone is not on the '
-                                  'linear-response path; use the cross Hessians')
+        """d f / d par2 (LRVB/SparseObjectives.py:381-387): per-observation losses for the weights, s * eta for the
+        tilt, chained through par2's packing Jacobian when val2 is free."""
+        f = _functor(self.fun)
+        set_par(self.par2, val2, val2_is_free)
+        g = np.asarray(f.hyper_grad(self.par2, np.asarray(val1, dtype=np.float64), val1_is_free, *argv, **argk))
+        J2 = self._jac2(val2, val2_is_free)
+        if J2 is not None:
+            g = np.asarray(J2.T @ g).ravel()
+        set_par(self.par1, val1, val1_is_free)
+        set_par(self.par2, val2, val2_is_free)
+        return g
 
     def fun_free_hessian12(self, free_val1, free_val2, *argv, **argk):
         return self._cross12(free_val1, free_val2, True, True, *argv, **argk)
@@ -401,20 +440,20 @@ class ParametricSensitivity(object):
         self.set_optimal_input_par(optimal_input_par, objective_hessian)
 
     def set_optimal_input_par(self, optimal_input_par=None, objective_hessian=None):
+        """Base point of the approximation: Hessian (given or built on the device), output Jacobian, cross Hessian with
+        the hyper-parameter, one Cholesky solve -- the sequence of LRVB/SparseObjectives.py:524-552."""
         from .sensitivity import _factor_and_solve
-        self.optimal_input_par = self.input_par.get_free() if optimal_input_par is None else deepcopy(optimal_input_par)
-        if objective_hessian is None:
-            self.objective_hessian = self.objective.fun_free_hessian(self.optimal_input_par)
-        else:
-            self.objective_hessian = objective_hessian
-        self.dout_din = self.parameter_converter.free_to_vec_jacobian(self.optimal_input_par)
+        theta = self.input_par.get_free() if optimal_input_par is None else deepcopy(optimal_input_par)
+        self.optimal_input_par = theta
+        self.objective_hessian = (self.objective.fun_free_hessian(theta) if objective_hessian is None
+                                  else objective_hessian)
+        self.dout_din = self.parameter_converter.free_to_vec_jacobian(theta)
         self.optimal_hyper_par = self.hyper_par.get_vector()
-        self.hyper_par_cross_hessian = self.sensitivity_objective.fun_hessian_free1_vector2(
-            self.optimal_input_par, self.optimal_hyper_par)
         self.optimal_output_par = self.output_par.get_vector()
-        self.hessian_chol, solved = _factor_and_solve(self.objective_fun, self.objective_hessian,
-                                                     self.hyper_par_cross_hessian)
-        self.hyper_par_sensitivity = -1 * solved
+        cross = self.sensitivity_objective.fun_hessian_free1_vector2(theta, self.optimal_hyper_par)
+        self.hyper_par_cross_hessian = cross
+        self.hessian_chol, h_inv_cross = _factor_and_solve(self.objective_fun, self.objective_hessian, cross)
+        self.hyper_par_sensitivity = -h_inv_cross
 
     def get_dinput_dhyper(self):
         return self.hyper_par_sensitivity
@@ -422,15 +461,17 @@ class ParametricSensitivity(object):
     def get_doutput_dhyper(self):
         return self.dout_din @ self.hyper_par_sensitivity
 
+    def _input_shift(self, new_hyper_par):
+        return self.hyper_par_sensitivity @ (np.asarray(new_hyper_par) - self.optimal_hyper_par)
+
     def predict_input_par_from_hyperparameters(self, new_hyper_par):
-        return self.optimal_input_par + self.hyper_par_sensitivity @ (new_hyper_par - self.optimal_hyper_par)
+        return self.optimal_input_par + self._input_shift(new_hyper_par)
 
     def predict_output_par_from_hyperparameters(self, new_hyper_par, linear):
+        """linear=True: first-order in the output too; False: the converter applied to the predicted input."""
         if linear:
-            return self.optimal_output_par + \
-                self.dout_din @ self.hyper_par_sensitivity @ (new_hyper_par - self.optimal_hyper_par)
-        return self.parameter_converter.converter_free_to_vec(
-            self.predict_input_par_from_hyperparameters(new_hyper_par))
+            return self.optimal_output_par + self.dout_din @ self._input_shift(new_hyper_par)
+        return self.parameter_converter.converter_free_to_vec(self.predict_input_par_from_hyperparameters(new_hyper_par))
 
 
 # ---- index / sparse helpers (LRVB/SparseObjectives.py:581-657) --------------------------------

@@ -90,6 +90,17 @@ class OracleFunctor(object):
             return 'tilt'
         raise NotImplementedError('unknown hyper-parameter')
 
+    def hyper_grad(self, hyper_par, val1, val1_is_free, *argv, **argk):
+        self._sync(argv, argk)
+        m = self.model
+        eta = m.layout.constrain(val1) if val1_is_free else np.asarray(val1, dtype=np.float64)
+        if hyper_par is self.weights_par:
+            z = m.x @ eta[m.glm_off:m.glm_off + m.P]
+            return om.loss_terms(m.loss, m.y, z, m.lik_info)[0]
+        if hyper_par is self.tilt_par:
+            return m.quad_scale * eta
+        raise NotImplementedError('unknown hyper-parameter')
+
     def cross_hessian(self, hyper_par, val1, val1_is_free, *argv, **argk):
         self._sync(argv, argk)
         if hyper_par is self.weights_par:

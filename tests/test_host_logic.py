@@ -185,6 +185,66 @@ def test_two_parameter_objective_and_converter():
     np.testing.assert_allclose(px.get_free(), f_in)              # inputs restored (:280-292)
 
 
+def test_fun_grad2_and_opaque_converters():
+    """TwoParameterObjective.fun_grad2 (LRVB/SparseObjectives.py:381-387) for both declared hyper-parameters, in vector
+    and free coordinates of the hyper-parameter; ParameterConverter with an opaque closure (no declared Jacobian): the
+    numeric route agrees with the declared one."""
+    rng = np.random.default_rng(8)
+    N, P = 40, 5
+    lay = opk.Layout([opk.box_block(3), opk.box_block(2, lb=0.0)])
+    par = vb.ModelParamsDict('p'); par.push_param(vb.VectorParam('a', 3)); par.push_param(vb.VectorParam('b', 2, lb=0.0))
+    x = rng.normal(size=(N, P)); y = rng.integers(0, 2, N).astype(float)
+    model = om.DeclaredModel(lay, loss=om.LOGISTIC, x=x, y=y, quad_A=np.full(P, 0.7))
+    wpar = vb.VectorParam('weights', N, lb=0.0, val=np.ones(N))
+    tpar = vb.VectorParam('tilt', P, val=np.zeros(P))
+    fun = OracleFunctor(par, model, weights_par=wpar, tilt_par=tpar)
+    theta = rng.normal(size=P) * 0.3
+    w = rng.uniform(0.5, 1.5, N)
+    eta = lay.constrain(theta)
+    losses = om.loss_terms(om.LOGISTIC, y, x @ eta, 1.0)[0]
+    two = vb.TwoParameterObjective(par, wpar, fun)
+    np.testing.assert_allclose(two.fun_grad2(theta, w, True, False), losses, atol=1e-13)
+    np.testing.assert_allclose(two.fun_grad2(eta, w, False, False), losses, atol=1e-13)
+    # free weights: w = exp(f), d f / d f_n = loss_n w_n; finite-difference check of the whole map
+    fw = np.log(w)
+    np.testing.assert_allclose(two.fun_grad2(theta, fw, True, True), losses * w, atol=1e-12)
+    h = 1e-6
+    e0 = np.zeros(N); e0[3] = h
+    fd = (two.fun_free(theta, fw + e0) - two.fun_free(theta, fw - e0)) / (2 * h)
+    assert abs(fd - (losses * w)[3]) < 1e-7
+    two_t = vb.TwoParameterObjective(par, tpar, fun)
+    b = rng.normal(size=P)
+    np.testing.assert_allclose(two_t.fun_grad2(theta, b, True, False), eta, atol=1e-13)
+    np.testing.assert_allclose(tpar.get_vector(), b)                 # left at the evaluation point
+    # opaque converter: y = x^2 + 1.5 as a closure only
+    px = vb.VectorParam('x', 3, lb=0.0); py = vb.VectorParam('y', 3, lb=1.0)
+    px.set_free(rng.normal(size=3) * 0.3)
+    declared = vb.ParameterConverter(px, py, vb.ElementwiseConverter(px, py, lambda v: v ** 2 + 1.5, lambda v: 2 * v))
+    opaque = vb.ParameterConverter(px, py, lambda: py.set_vector(px.get_vector() ** 2 + 1.5))
+    f_in, xv = px.get_free(), px.get_vector()
+    for name, arg in (('vec_to_vec_jacobian', xv), ('free_to_vec_jacobian', f_in), ('free_to_free_jacobian', f_in),
+                      ('vec_to_free_jacobian', xv)):
+        np.testing.assert_allclose(getattr(opaque, name)(arg), getattr(declared, name)(arg), rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(px.get_free(), f_in)
+
+
+def test_logger_and_timer_surface():
+    """The utility classes keep the attribute surface optimiser callbacks read (LRVB/SparseObjectives.py:35-87)."""
+    log = vb.SparseObjectives.Logger(print_every=2)
+    seen = []
+    log.callback = lambda lg: seen.append((lg.iter, lg.value))
+    assert log.x is None and log.last_x is None and log.iter == 0 and log.x_diff == float('inf')
+    for k in range(5):
+        log.log(10.0 - k, np.array([k, 2.0 * k]))
+    assert log.iter == 5 and log.val_array == [10.0, 9.0, 8.0, 7.0, 6.0] and len(log.x_array) == 5
+    assert seen == [(0, 10.0), (2, 8.0), (4, 6.0)] and log.last_value == 6.0 and log.x_diff == 2.0
+    log.initialize()
+    assert log.iter == 0 and log.x_array == [] and log.value is None
+    t = vb.SparseObjectives.Timer()
+    t.tic(); dt = t.toc('step', verbose=False)
+    assert dt >= 0 and t.time_dict['step'] == dt and 'step' in str(t)
+
+
 def test_sensitivity_classes_quadratic_model():
     """LRVB/test_model_sensitivity.py:367-424 (linear approximation) and 427-525 (deprecated class)."""
     dim = 3
