@@ -22,7 +22,8 @@ from .families import (UVNParam, UVNParamVector, UVNParamArray, UVNMomentParamAr
                        MVNArray, GammaParam, WishartParam, DirichletParamArray)
 from .objectives import (Objective, TwoParameterObjective, ParameterConverter, ParametricSensitivity,
                          LinearConverter, ElementwiseConverter, Logger, Timer)
-from .sensitivity import ParametricSensitivityLinearApproximation
+from .sensitivity import (ParametricSensitivityLinearApproximation, HyperparameterSensitivityLinearApproximation,
+                          get_kl_hessian, get_lrvb_cov)
 from .taylor import ParametricSensitivityTaylorExpansion
 from .cg import ConjugateGradientSolver
 from .models import (DeviceContext, DeviceObjective, GLMObjective, QuadraticObjective, LinearMoments)

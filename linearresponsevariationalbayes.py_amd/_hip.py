@@ -130,20 +130,35 @@ class OptResult(ctypes.Structure):
 _lib = None
 
 
+def _map_shared_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64 (soname libamdhip64.so.7, next to its
+    own HSA runtime) and this library is linked against the same soname, which the dynamic linker resolves ONCE per
+    process: to whichever copy is mapped first.  If torch is already imported its copy is mapped and there is nothing to
+    do.  Otherwise the copy torch WOULD load is mapped here, by path, before liblrvb_hip.so -- so that a later
+    `import torch` finds its own runtime already in place instead of the system one (mixing torch's HSA runtime with
+    the system HIP runtime made torch report "No HIP GPUs are available").  torch itself is not imported; without an
+    installed torch the system ROCm copy is used.  LRVB_NO_TORCH_PRELOAD=1 skips this."""
+    import importlib.util
+    import sys
+    if os.environ.get('LRVB_NO_TORCH_PRELOAD', '0') == '1' or 'torch' in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    bundled = os.path.join(os.path.dirname(spec.origin), 'lib', 'libamdhip64.so')
+    if os.path.exists(bundled):
+        ctypes.CDLL(bundled, mode=ctypes.RTLD_GLOBAL)
+
+
 def load():
     """Loads the shared library (once).  Raises OSError if it has not been built."""
     global _lib
     if _lib is not None:
         return _lib
-    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.  If this library
-    # (linked against the system ROCm) initialises HIP first and torch is imported afterwards, the
-    # two copies can disagree ("No HIP GPUs are available" in torch).  Importing torch first makes
-    # the dynamic linker resolve libamdhip64.so.7 once for both.  LRVB_NO_TORCH_PRELOAD=1 skips it.
-    if os.environ.get('LRVB_NO_TORCH_PRELOAD', '0') != '1':
-        try:
-            import torch  # noqa: F401
-        except Exception:
-            pass
+    _map_shared_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise OSError(
             'liblrvb_hip.so not found at {}: build it with `python -c "import __graft_entry__ as g; '

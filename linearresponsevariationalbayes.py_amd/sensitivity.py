@@ -140,6 +140,28 @@ class ParametricSensitivityLinearApproximation(object):
         return self.hess0_chol.lrvb_cov(np.asarray(moment_jac, dtype=np.float64))
 
 
+# ---- the names BASELINE.json's north_star uses for the path (they belong to the author's later
+# code, not to this reference checkout; each is the reference object named beside it) ---------------------------------
+HyperparameterSensitivityLinearApproximation = ParametricSensitivityLinearApproximation   # LRVB/ModelSensitivity.py:555-612
+
+
+def get_kl_hessian(objective, free_val, *argv, **argk):
+    """Dense Hessian of the KL / -ELBO objective in free coordinates: `Objective.fun_free_hessian`
+    (LRVB/SparseObjectives.py:156-158) -- one device build."""
+    return objective.fun_free_hessian(free_val, *argv, **argk)
+
+
+def get_lrvb_cov(objective, free_val, moment_jac, kl_hessian=None):
+    """Linear-response covariance M H^-1 M^T of the moments with free-coordinate Jacobian M at the optimum `free_val`
+    (what Example.ipynb:398-415 computes inline with cho_factor / cho_solve): Hessian build (unless given), Cholesky
+    and the solve all on the device; the factor stays resident in the objective's context."""
+    hess = get_kl_hessian(objective, free_val) if kl_hessian is None else kl_hessian
+    ctx = getattr(objective.fun, 'ctx', None)
+    if ctx is None:
+        raise NotImplementedError('the objective functor exposes no device context for the solve')
+    return DeviceCholesky(ctx, hess).lrvb_cov(np.asarray(moment_jac, dtype=np.float64))
+
+
 # the k-th order class and its term algebra live in taylor.py; the reference keeps them in this module
 from .taylor import (ParametricSensitivityTaylorExpansion, DerivativeTerm, get_taylor_base_terms,   # noqa: E402,F401
                      consolidate_terms, differentiate_terms)

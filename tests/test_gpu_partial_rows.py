@@ -112,3 +112,55 @@ def test_deprecated_parametric_sensitivity_on_the_device(vb):
         warnings.simplefilter('ignore')
         ps2 = vb.ParametricSensitivity(fun, par, out_par, wpar, conv, optimal_input_par=theta0, objective_hessian=H)
     assert rel_err(ps2.get_dinput_dhyper(), S) < 1e-9
+
+
+def test_north_star_names(vb):
+    """BASELINE.json's names for the path resolve and run on the device: get_kl_hessian = Objective.fun_free_hessian,
+    get_lrvb_cov = M H^-1 M^T, HyperparameterSensitivityLinearApproximation = the linear-approximation class."""
+    rng = np.random.default_rng(5)
+    N, P = 600, 20
+    par, lay = make_par(vb, [('box', 'u', 12, -np.inf, np.inf), ('box', 'pos', 8, 0.0, np.inf)])
+    x, y, w = glm_data(rng, N, P, om.POISSON)
+    fun = vb.DeviceObjective(par, x=x, y=y, loss='poisson', quad_A=np.full(P, 1.1), weights=w)
+    model = om.DeclaredModel(lay, loss=om.POISSON, x=x, y=y, w=w, quad_A=np.full(P, 1.1))
+    objective = vb.Objective(par, fun)
+    theta = rng.normal(size=P) * 0.1
+    H = vb.get_kl_hessian(objective, theta)
+    assert rel_err(H, model.hessian(theta)) < 1e-11
+    M = rng.normal(size=(4, P))
+    want = M @ np.linalg.solve(model.hessian(theta), M.T)
+    assert rel_err(vb.get_lrvb_cov(objective, theta, M), want) < 1e-9
+    assert rel_err(vb.ModelSensitivity.get_lrvb_cov(objective, theta, M, kl_hessian=H), want) < 1e-9
+    assert vb.HyperparameterSensitivityLinearApproximation is vb.ParametricSensitivityLinearApproximation
+
+
+@pytest.mark.parametrize('order', ['library first', 'torch first'])
+def test_one_hip_runtime_whatever_the_import_order(order):
+    """The library maps the HIP runtime torch bundles (without importing torch), so both import orders end with ONE
+    libamdhip64 in the process, a working torch.cuda and a working library."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    first, second = ('import lrvb_amd as vb; vb._hip.load()', 'import torch') if order == 'library first' else \
+                    ('import torch', 'import lrvb_amd as vb; vb._hip.load()')
+    code = '''
+import sys
+sys.path.insert(0, {root!r})
+{first}
+assert ('torch' in sys.modules) == {torch_first}
+{second}
+import numpy as np, torch
+import lrvb_amd as vb
+assert torch.cuda.is_available() and vb._hip.device_count() >= 1
+par = vb.VectorParam('x', 3)
+H = vb.Objective(par, vb.QuadraticObjective(par, A=np.diag([1.0, 2.0, 3.0]))).fun_free_hessian(np.zeros(3))
+assert np.allclose(H, np.diag([1.0, 2.0, 3.0]))
+t = torch.ones(4, device='cuda') * 2
+assert float(t.sum()) == 8.0
+copies = sorted({{ln.split()[-1] for ln in open('/proc/self/maps') if 'libamdhip64' in ln}})
+assert len(copies) == 1, copies
+print('ok', copies[0])
+'''.format(root=root, first=first, second=second, torch_first=(order == 'torch first'))
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and 'ok' in out.stdout, out.stderr[-2000:]

@@ -228,6 +228,22 @@ def test_fun_grad2_and_opaque_converters():
     np.testing.assert_allclose(px.get_free(), f_in)
 
 
+def test_north_star_aliases_on_the_oracle_functor():
+    rng = np.random.default_rng(1)
+    P = 6
+    lay = opk.Layout([opk.box_block(P, lb=-3.0)])
+    par = vb.VectorParam('t', P, lb=-3.0)
+    a = rng.normal(size=(P, P)); A = a @ a.T + np.eye(P)
+    model = om.DeclaredModel(lay, quad_A=A, quad_b=rng.normal(size=P))
+    objective = vb.Objective(par, OracleFunctor(par, model))
+    theta = rng.normal(size=P) * 0.1
+    H = vb.get_kl_hessian(objective, theta)
+    np.testing.assert_allclose(H, model.hessian(theta), atol=1e-13)
+    M = rng.normal(size=(2, P))
+    np.testing.assert_allclose(vb.get_lrvb_cov(objective, theta, M), M @ np.linalg.solve(H, M.T), atol=1e-12)
+    assert vb.ModelSensitivity.HyperparameterSensitivityLinearApproximation is vb.ParametricSensitivityLinearApproximation
+
+
 def test_logger_and_timer_surface():
     """The utility classes keep the attribute surface optimiser callbacks read (LRVB/SparseObjectives.py:35-87)."""
     log = vb.SparseObjectives.Logger(print_every=2)
