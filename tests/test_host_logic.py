@@ -231,8 +231,8 @@ def test_fun_grad2_and_opaque_converters():
 def test_north_star_aliases_on_the_oracle_functor():
     rng = np.random.default_rng(1)
     P = 6
-    lay = opk.Layout([opk.box_block(P, lb=-3.0)])
-    par = vb.VectorParam('t', P, lb=-3.0)
+    lay = opk.Layout([opk.box_block(P)])
+    par = vb.VectorParam('t', P)
     a = rng.normal(size=(P, P)); A = a @ a.T + np.eye(P)
     model = om.DeclaredModel(lay, quad_A=A, quad_b=rng.normal(size=P))
     objective = vb.Objective(par, OracleFunctor(par, model))
