@@ -41,6 +41,9 @@ def parse(argv=None):
     ap.add_argument('--cpu-budget-s', type=float, default=30.0,
                     help='rough bound on the CPU work of the cpu_baseline leg (seconds)')
     ap.add_argument('--n-splits', type=int, default=0)
+    ap.add_argument('--config', default='h', choices=['h', 'c2', 'c3', 'c4', 'c5'],
+                    help='h = the headline metric (default, what the driver runs); c2..c5 = the other BASELINE.json '
+                         'configurations on one GPU, one line each with its own roofline')
     return ap.parse_args(argv)
 
 
@@ -215,8 +218,144 @@ def cpu_baseline(fetch_rows, n_total, D, n_pos, loss, lik_info, prior_info, thet
     }
 
 
+# ---- the other BASELINE.json configurations: one GPU, one line each -------------------------
+def _timed_steps(step, warmup, steps, ctx):
+    for _ in range(warmup):
+        step()
+    ctx.sync()
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    ctx.sync()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.profile_get()
+    ctx.profile_enable(False)
+    return elapsed, prof
+
+
+def run_config(args):
+    """Configurations 2-5: `value` = builds per second of the configuration's per-step product with the observations,
+    the weights and the evaluation point resident in HBM; `roofline` = the statistics kernel(s) of the step (HIP-event
+    time from the library's profile marks) against the algorithmic bytes / flops of SURVEY.md section 8(d)."""
+    import numpy as np
+    import lrvb_amd as vb
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    if int(os.environ.get('WORLD_SIZE', '1')) != 1 or args.gpus != 1:
+        raise SystemExit('bench: --config {} is a one-GPU line (the multi-GPU curve is the headline, --config h)'.format(args.config))
+    rng = np.random.default_rng(20240 + int(args.config[1]))
+    cfg = args.config
+    extra = {}
+    if cfg == 'c2':
+        N, k = 100_000, 21
+        x = rng.normal(size=(N, k)); y = x @ rng.normal(size=k) + rng.normal(size=N) / np.sqrt(2.0)
+        par = vb.ModelParamsDict('p'); par.push_param(vb.MVNParam('beta', dim=k)); par.push_param(vb.GammaParam('tau'))
+        fun = vb.MVNRegressionObjective(par, x, y, prior_mean=np.zeros(k), prior_info=np.eye(k), prior_shape=2.0, prior_rate=2.0,
+                                        weights=rng.uniform(0.5, 1.5, N))
+        obj = vb.Objective(par, fun)
+        theta = par.get_free()
+        D = theta.size
+
+        def step():
+            fun._S = None                                     # statistics recomputed from the resident rows and weights
+            fun._h_key = None
+            return obj.fun_free_hessian(theta)
+        metric = 'ELBO-Hessian builds/sec, MVNParam regression N=1e5 obs x D={} free params'.format(D)
+        workload = 'config 2: MVNParam regression (k=21 -> D={}), N=1e5; one step = weighted Gram of [x|y] on the GPU + closed-form assembly + device free-Hessian conversion'.format(D)
+        bound, alg, unit, peak = 'hbm', 8.0 * N * (k + 2), 'GB/s', PEAK_HBM_GBS
+        ctx = fun.ctx
+    elif cfg == 'c3':
+        from test_mixture_host_math import clustered_problem
+        N, V, K = int(args.n_obs) if args.n_obs != 1e6 else 1_000_000, 31, 32
+        x, w, fg, fz, lam = clustered_problem(N, V, K, seed=11)
+        theta = np.concatenate([fg, fz.ravel()])
+        par = vb.ModelParamsDict('params')
+        par.push_param(vb.DirichletParamArray('pi', shape=(K,)))
+        par.push_param(vb.DirichletParamArray('phi', shape=(V, K)))
+        par.push_param(vb.SimplexParam('z', shape=(N, K)))
+        fun = vb.MixtureObjective(par, x, pi_prior=1.2, phi_prior=0.9, weights=w)
+        fun.keep_logits_resident = True                       # the local part of the point (N x 31 logits) stays in HBM
+        D = fun.n_global
+
+        def step():
+            return fun.global_hessian(theta)
+        metric = 'Schur-complement ELBO-Hessian builds/sec, Dirichlet-multinomial mixture K=32, N={:g} obs x D={} global free params'.format(float(N), D)
+        workload = ('config 3: Dirichlet-multinomial mixture K=32, V=31, N={}; one step = per-row simplex blocks eliminated on the '
+                    'GPU (rows kernel + Kronecker GEMM + statistics) + device Schur assembly of the {} x {} global block').format(N, D, D)
+        bound, alg, unit, peak = 'hbm', 8.0 * N * (K - 1 + V) + 8.0 * D * D, 'GB/s', PEAK_HBM_GBS
+        ctx = fun.ctx
+        extra['repo_algorithm_flops'] = 2.0 * 528 * 528 * N
+    elif cfg == 'c4':
+        from test_lmm_host_math import make_par as lmm_par
+        N, p, G = 1_250_000, 43, 10_000
+        x = rng.normal(size=(N, p)); gid = rng.integers(0, G, size=N).astype(np.int32); gid[:G] = np.arange(G)
+        y = x @ rng.normal(size=p) + rng.normal(size=G)[gid] * 0.7 + rng.normal(size=N) * 0.5
+        par = lmm_par(p, G)
+        fun = vb.LMMObjective(par, x, y, gid, G, weights=rng.uniform(0.5, 1.5, N))
+        theta = par.get_free()
+        D = None
+
+        def step():
+            fun._stats_cache = None
+            fun.local_stats()
+            return fun.global_hessian(theta)
+        H0 = step()
+        D = H0.shape[0]
+        metric = 'arrow-Hessian Schur-complement builds/sec, hierarchical LMM G=1e4 groups, one GPU shard N=1.25e6 of 1e7 obs x D={} global free params'.format(D)
+        workload = ('config 4: hierarchical LMM p=43, G=1e4, ONE of the eight 1.25e6-row shards of the N=1e7 problem; one step = '
+                    'sufficient statistics of the shard on the GPU (Gram q=44 + per-group sums) + arrow-Hessian assembly and Schur complement')
+        bound, alg, unit, peak = 'hbm', float(N) * (8.0 * (p + 2) + 4.0), 'GB/s', PEAK_HBM_GBS
+        ctx = fun.ctx
+    else:
+        N, d = int(args.n_obs) if args.n_obs != 1e6 else 1_000_000, 63
+        yy = rng.normal(size=(N, d))
+        par = vb.ModelParamsDict('p'); par.push_param(vb.MVNParam('mu', dim=d)); par.push_param(vb.WishartParam('lambda', size=d))
+        fun = vb.WishartMVNObjective(par, yy)
+        par['lambda']['df'].set(d + 5.0)
+        theta = par.get_free()
+        D = theta.size
+
+        def step():
+            return fun.gram(theta)
+        metric = 'G^T G (per-observation ELBO-gradient Gram matrix) builds/sec, Wishart+MVN N={:g} obs x D={} free params'.format(float(N), D)
+        workload = ('config 5: Wishart + MVN full-covariance model d=63 -> D=4096, N={}; one step = G^T G with the Kronecker rows of G '
+                    'generated on chip (fp64-MFMA Kronecker SYRK + four 4096^3 TN products), result copied to the host').format(N)
+        bound, alg, unit, peak = 'mfma', float(N) * D * (D + 1), 'TFLOP/s', PEAK_FP64_MFMA_TFLOPS
+        ctx = fun.ctx
+    elapsed, prof = _timed_steps(step, args.warmup, args.steps, ctx)
+    kernel_ms = prof['wsyrk_ms'] / args.steps                 # all statistics-kernel launches of one step
+    scale = 1e9 if unit == 'GB/s' else 1e12
+    achieved = alg / (kernel_ms * 1e-3) / scale if kernel_ms > 0 else 0.0
+    out = {
+        'metric': metric, 'value': args.steps / elapsed, 'unit': 'builds/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+        'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': workload, 'n_obs_total': N, 'n_free': D, 'ranks_seen': 1, 'backend': 'none (single process)'},
+        'roofline': {'bound': bound, 'achieved': achieved, 'peak': peak, 'unit': unit, 'frac': achieved / peak, 'traffic': None,
+                     'kernel': 'statistics kernels of one step (library profile marks: {} launches per step)'.format(
+                         prof['wsyrk_calls'] // max(args.steps, 1)),
+                     'kernel_ms': kernel_ms, 'algorithmic_per_step': alg},
+    }
+    out['roofline'].update(extra)
+    if cfg == 'c5':
+        # the LRVB solve of the configuration: exact Hessian (sufficient statistics), Cholesky, CG on the resident matrix
+        obj = vb.Objective(par, fun)
+        t0 = time.perf_counter(); H = obj.fun_free_hessian(theta); t1 = time.perf_counter()
+        Hs = H + (0.1 - min(0.0, float(np.linalg.eigvalsh(H).min()))) * np.eye(D)      # not at an optimum: shifted for the timing
+        fun.ctx.chol_factor(Hs); t2 = time.perf_counter(); fun.ctx.chol_factor(Hs); t3 = time.perf_counter()
+        b = rng.normal(size=D)
+        fun.ctx.cg_solve_matrix(Hs, b, tol=1e-8); t4 = time.perf_counter()
+        _, info, iters = fun.ctx.cg_solve_matrix(None, b, tol=1e-8); t5 = time.perf_counter()
+        out['lrvb_solve_ms'] = {'exact_hessian_build': (t1 - t0) * 1e3, 'cho_factor_host_matrix_in': (t3 - t2) * 1e3,
+                                'cg_resident_matrix_tol1e-8': (t5 - t4) * 1e3, 'cg_iterations': int(iters), 'cg_info': int(info)}
+    return out
+
+
 def main(args):
     import numpy as np
+    if getattr(args, 'config', 'h') != 'h':
+        return run_config(args)
     import torch
     import torch.distributed as dist
     import lrvb_amd as vb

@@ -254,7 +254,8 @@ int lrvb_group_sums(lrvb_ctx* ctx, double* out);
  * the sufficient statistics S64 = [x~ | z]^T diag(w) [x~ | z] (64 x 64, x~ padded to 32, z to 32),
  * val2 = [-sum w z.s, sum w z log z] and the free local gradient (N x (K-1); may be NULL, as may
  * R_out).  s_n = x~_n Lam, Lam = [E log pi; E log phi] ((V+1) x K), x~_n = (1, x_n).
- * V + 1 <= 32, 2 <= K <= 32.                                                                     */
+ * V + 1 <= 32, 2 <= K <= 32.  theta_z == NULL evaluates at the simplex logits of the previous call, which
+ * stay resident in HBM (the local part of the evaluation point: N (K-1) doubles).                    */
 int lrvb_mixture_rows(lrvb_ctx* ctx, int32_t K, const double* theta_z, const double* Lam,
                       double* val2_out, double* gfree_out, double* S64_out, double* R_out);
 

@@ -1050,9 +1050,11 @@ extern "C" int lrvb_group_sums(lrvb_ctx* c, double* out) {
 extern "C" int lrvb_mixture_rows(lrvb_ctx* c, int32_t K, const double* theta_z, const double* Lam,
                                  double* val2_out, double* gfree_out, double* S64_out, double* R_out) {
     LRVB_TRY(ctx_bind(c));
-    if (!theta_z || !Lam || !val2_out || !S64_out) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    if (!Lam || !val2_out || !S64_out) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
     if (c->loss == LRVB_LOSS_NONE || !c->have_X) LRVB_FAIL(LRVB_ERR_STATE, "no data matrix: call lrvb_set_data(LRVB_SLOT_X) first");
     const i64 N = c->N;
+    if (!theta_z && c->mx_theta_n != N * (i64)(K - 1))
+        LRVB_FAIL(LRVB_ERR_STATE, "theta_z is NULL and no simplex logits of this shape are resident from an earlier call");
     const int V = (int)c->P;
     if (V + 1 > 32 || K > 32 || K < 2) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "mixture kernel supports V + 1 <= 32 and 2 <= K <= 32");
     const i64 KM = K - 1, KK = (i64)K * K, QQ = (i64)(V + 1) * (V + 1);
@@ -1066,7 +1068,7 @@ extern "C" int lrvb_mixture_rows(lrvb_ctx* c, int32_t K, const double* theta_z, 
     if (st == LRVB_OK) st = buf_reserve(c, Amat, (size_t)(N * lda));
     if (st == LRVB_OK) st = buf_reserve(c, U, (size_t)(N * 64));
     if (st == LRVB_OK) st = buf_reserve(c, gfr, (size_t)(N * KM));
-    if (st == LRVB_OK) st = h2d(c, thz.p, theta_z, (size_t)(N * KM));
+    if (st == LRVB_OK && theta_z) { c->mx_theta_n = 0; st = h2d(c, thz.p, theta_z, (size_t)(N * KM)); if (st == LRVB_OK) c->mx_theta_n = N * KM; }
     if (st == LRVB_OK) st = h2d(c, lam.p, Lam, (size_t)((V + 1) * K));
     int* bad = reinterpret_cast<int*>(c->scal.p + 8);
     if (st == LRVB_OK) st = launch_mixture_rows(c, K, thz.p, lam.p, Amat.p, lda, U.p, gfr.p, c->scal.p, bad);

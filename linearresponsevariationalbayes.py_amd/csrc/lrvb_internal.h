@@ -64,6 +64,7 @@ struct lrvb_ctx {
     DevBuf Heta, Hfree, Jdense, Tdense, work1;   // dense V x V / D x D scratch
     DevBuf groups; i64 n_groups = 0;   // [perm (N) | offsets (G+1)] as int64
     DevBuf mx_theta, mx_lam, mx_A, mx_U, mx_g, mx_Xk, mx_R;   // mixture rows pipeline (kept between calls)
+    i64 mx_theta_n = 0;            // simplex logits resident in mx_theta (entries; 0 = none)
     DevBuf cgH; i64 cgH_n = 0;     // dense matrix of lrvb_cg_solve_matrix
     DevBuf chol, cholW;            // D x D Cholesky factor (lower); inverses of its 64 x 64 diagonal blocks
     bool chol_valid = false;

@@ -89,6 +89,21 @@ class MixtureObjective(object):
         self.tilt_par = None
         self._w_cache = None
         self._external_stats = None
+        # Opt-in for repeated evaluations at ONE local point (benchmarks, several moment sets at an optimum): the
+        # N (K - 1) simplex logits are uploaded by the first call and reused from HBM afterwards.  The caller promises
+        # not to change them while this is set; `drop_resident_logits()` forces the next upload.
+        self.keep_logits_resident = False
+        self._fz_on_device = False
+
+    def drop_resident_logits(self):
+        self._fz_on_device = False
+
+    def _fz_arg(self, fz):
+        keep = getattr(self, 'keep_logits_resident', False)
+        if keep and getattr(self, '_fz_on_device', False):
+            return None
+        self._fz_on_device = bool(keep)
+        return fz
 
     def _push_state(self):
         w = np.asarray(self.weights_par.get_vector(), dtype=np.float64)
@@ -141,6 +156,7 @@ class MixtureObjective(object):
 
     def _rows(self, free_val, want_grad, want_schur):
         fg, fz = self._split(free_val)
+        fz = self._fz_arg(fz)
         eta_g = self._lb + np.exp(fg)                        # lower-bounded box blocks (Parameters.py:24-54)
         alpha, beta, lam = self._lam(eta_g)
         gz = None
@@ -166,7 +182,7 @@ class MixtureObjective(object):
         self._push_state()
         fg, fz = self._split(free_val)
         _, _, lam = self._lam(self._lb + np.exp(fg))
-        val2, _, S64, R = self.ctx.mixture_rows(self.K, fz, lam, want_grad=False, want_schur=True)
+        val2, _, S64, R = self.ctx.mixture_rows(self.K, self._fz_arg(fz), lam, want_grad=False, want_schur=True)
         return np.concatenate([val2, S64.ravel(), R.ravel()])
 
     def set_reduced_stats(self, flat):

@@ -280,9 +280,10 @@ class DeviceContext(object):
         return out
 
     def mixture_rows(self, K, theta_z, lam, want_grad=True, want_schur=True):
-        tz, lam = _hip.as_f64(theta_z).ravel(), _hip.as_f64(lam)
+        """theta_z None: the simplex logits of the previous call, still resident on the device."""
+        tz, lam = (None if theta_z is None else _hip.as_f64(theta_z).ravel()), _hip.as_f64(lam)
         V = self.n_cols
-        if tz.size != self.n_obs * (K - 1) or lam.shape != (V + 1, K):
+        if (tz is not None and tz.size != self.n_obs * (K - 1)) or lam.shape != (V + 1, K):
             raise ValueError('expected theta_z with {} entries and Lam of shape {}'.format(self.n_obs * (K - 1), (V + 1, K)))
         val2 = np.empty(2)
         gfree = np.empty((self.n_obs, K - 1)) if want_grad else None
