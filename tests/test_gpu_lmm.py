@@ -117,3 +117,40 @@ def test_config4_shard_scale_statistics(vb):
     assert rel_err(gs, ref.cpu().numpy()) < 1e-11
     S = ctx.weighted_gram()
     assert rel_err(S, ((Z.T * w) @ Z).cpu().numpy()) < 1e-11
+
+
+def test_config4_full_pipeline_at_shard_scale(vb):
+    """The whole config-4 pipeline at one GPU's shard size (N = 1.25e6, p = 43, G = 1e4; global D = 995, 2e4 local
+    parameters): fit, device statistics, arrow-Hessian Schur complement, device Cholesky, LRVB covariance.  No oracle
+    finishes at this size, so the assertions are the properties that hold at any size: the fit is stationary, the Schur
+    complement of the arrow Hessian at the optimum is symmetric positive definite, and cov @ H_S = I."""
+    import scipy.optimize
+    rng = np.random.default_rng(44)
+    N, p, G = 1_250_000, 43, 10_000
+    x = rng.normal(size=(N, p))
+    gid = rng.integers(0, G, size=N).astype(np.int32); gid[:G] = np.arange(G)
+    u = rng.normal(size=G) * 0.7 + 0.3
+    y = x @ rng.normal(size=p) + u[gid] + rng.normal(size=N) * 0.5
+    par = make_par(p, G)
+    fun = vb.LMMObjective(par, x, y, gid, G, beta_prior_mean=np.zeros(p), beta_prior_info=0.2 * np.eye(p), mu_prior_mean=0.1,
+                          mu_prior_info=0.3, tau_y_prior=(2.0, 1.0), tau_mu_prior=(1.5, 0.5))
+    objective = vb.Objective(par, fun)
+    theta0 = np.asarray(par.get_free(), dtype=np.float64)
+    assert theta0.size == 995 + 2 * G
+    fit = scipy.optimize.minimize(objective.fun_free, theta0, jac=objective.fun_free_grad, method='L-BFGS-B',
+                                  options={'maxiter': 3000, 'maxfun': 6000, 'gtol': 1e-6, 'ftol': 1e-15})
+    g = objective.fun_free_grad(fit.x)
+    assert np.max(np.abs(g)) < 1e-6 * max(1.0, abs(fit.fun)), (fit.message, np.max(np.abs(g)))
+    HS = fun.global_hessian(fit.x)
+    assert HS.shape == (995, 995)
+    assert np.max(np.abs(HS - HS.T)) < 1e-9 * np.max(np.abs(HS))
+    lam = np.linalg.eigvalsh(0.5 * (HS + HS.T))
+    assert lam[0] > 0, lam[:3]
+    fun.ctx.chol_factor(HS)
+    cov = fun.ctx.lrvb_cov(np.eye(995))
+    assert np.max(np.abs(cov @ HS - np.eye(995))) < 1e-7 * (lam[-1] / lam[0]) ** 0.5
+    # the statistics are additive over a split of the rows (what the 8-GPU all-reduce relies on)
+    half = N // 2
+    fa = vb.LMMObjective(make_par(p, G), x[:half], y[:half], gid[:half], G)
+    fb = vb.LMMObjective(make_par(p, G), x[half:], y[half:], gid[half:], G)
+    assert rel_err(fa.local_stats() + fb.local_stats(), fun.local_stats()) < 1e-12

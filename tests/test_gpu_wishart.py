@@ -144,3 +144,36 @@ def test_config5_d63(vb):
     xc = fun.ctx.chol_solve(b)
     assert info == 0
     assert np.max(np.abs(x - xc)) < 1e-6 * np.max(np.abs(xc))
+
+
+def test_config5_full_size_gram_properties(vb):
+    """G^T G at the full configuration (N = 1e6, d = 63, D = 4096: the Kronecker-row fp64-MFMA kernel on 1.7e13
+    flops).  No oracle finishes at this size; the size-independent properties do: the matrix is symmetric positive
+    semi-definite, additive over a split of the rows, and the first 48 rows' share -- a split part of its own --
+    equals the AD cross Hessian d2 f / d theta d w^T of those rows."""
+    d, N, ns = 63, 1_000_000, 48
+    rng = np.random.default_rng(20246)
+    a = rng.normal(size=(d, d)); cov = a @ a.T / d + np.eye(d)
+    y = rng.normal(size=(N, d)) @ np.linalg.cholesky(cov).T + rng.normal(size=d)
+    mu0 = np.zeros(d); lam0 = 0.5 * np.eye(d); nu0 = d + 2.0; w0 = np.eye(d)
+    lay = opk.Layout([opk.box_block(d), opk.psd_block(d), opk.box_block(1, lb=d - 1.0), opk.psd_block(d)])
+    eta0 = random_point(rng, d)
+    eta0[d + d * (d + 1) // 2] = d + 10.0
+    theta = lay.unconstrain(eta0)
+
+    def gram_of(rows):
+        par = vb.ModelParamsDict('params')
+        par.push_param(vb.MVNParam('mu', dim=d)); par.push_param(vb.WishartParam('lambda', size=d))
+        return vb.WishartMVNObjective(par, y[rows], prior_mean=mu0, prior_info=lam0, prior_df=nu0, prior_inv_scale=w0).gram(theta)
+
+    full = gram_of(slice(0, N))
+    scale = np.abs(full).max()
+    assert np.max(np.abs(full - full.T)) < 1e-10 * scale
+    parts = [gram_of(slice(0, ns)), gram_of(slice(ns, 400_000)), gram_of(slice(400_000, N))]
+    assert rel_err(parts[0] + parts[1] + parts[2], full) < 1e-11
+    ft_s = tr.wishart_mvn_objective(y[:ns], d, mu0, lam0, nu0, w0, layout=lay)
+    cross = torch.func.jacfwd(torch.func.grad(ft_s, argnums=0), argnums=1)(torch.tensor(theta),
+                                                                          torch.ones(ns, dtype=torch.float64)).numpy()
+    assert rel_err(parts[0], cross @ cross.T) < 1e-9
+    lam = np.linalg.eigvalsh(full)
+    assert lam[0] > -1e-9 * lam[-1]
