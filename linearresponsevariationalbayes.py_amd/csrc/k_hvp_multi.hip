@@ -24,6 +24,10 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define HM_GLDS16(gp, lp) __builtin_amdgcn_global_load_lds( \
     (const __attribute__((address_space(1))) void*)(gp), (__attribute__((address_space(3))) void*)(lp), 16, 0, 0)
 
+// scalar-base form: global address = sbase (SGPR pair) + voff (32-bit per-lane byte offset), LDS destination base in M0
+#define HM_GLDS16_S(sbase, voff, ldsaddr) asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" \
+    :: "v"(voff), "s"(sbase), "s"(ldsaddr) : "memory")
+
 constexpr int HM_ROWS = 8;               // observations per chunk
 
 // TONLY = true stops after step A and writes the scaled rows of T instead (out[n][q] = c_n (X U)[n][q]):
@@ -65,28 +69,42 @@ void hvp_multi_kernel(const double* __restrict__ X, int Preal, i64 N, const doub
     for (int m = 0; m < NT; ++m) acc[m] = (d4){0.0, 0.0, 0.0, 0.0};
 
     const i64 nchunks = (N + HM_ROWS - 1) / HM_ROWS;
+    // LDS-DMA addresses: wave-uniform row base in SGPRs + a per-lane byte offset that never changes, so staging a
+    // chunk issues no vector-ALU instruction (beside fp64 MFMAs every VALU instruction costs the SIMD ~8 cycles of
+    // matrix time: tools/mfma_vmem_probe.hip)
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) double*)lds;
+    unsigned voff[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        int col = 128 * j + 2 * lane; if (col > Preal - 2) col = Preal - 2;     // stay inside the row; the duplicates meet zeros of U
+        voff[j] = (unsigned)col * 8u;
+    }
     auto issue = [&](i64 ch, int buf) {
         // wave w stages RPW rows of the chunk: P / 128 instructions of 1 KiB per row
-        double* base = lds + buf * (HM_ROWS * STRIDE);
+        const unsigned base = lds0 + (unsigned)(buf * (HM_ROWS * STRIDE)) * 8u;
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {
             const int row = RPW * wave + rr;
-            i64 n = ch * HM_ROWS + row; if (n > N - 1) n = N - 1;       // rows past N carry weight zero
-            const double* rowp = X + n * (i64)Preal;
+            i64 n = ch * HM_ROWS + row; if (n > N - 1) n = N - 1;       // rows past N carry weight zero (wave-uniform clamp)
+            const char* rowp = reinterpret_cast<const char*>(X + n * (i64)Preal);
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                int col = 128 * j + 2 * lane; if (col > Preal - 2) col = Preal - 2;     // stay inside the row; the duplicates meet zeros of U
-                HM_GLDS16(rowp + col, base + row * STRIDE + 128 * j);
-            }
+            for (int j = 0; j < NB; ++j)
+                HM_GLDS16_S(rowp, voff[j], base + (unsigned)(row * STRIDE + 128 * j) * 8u);
         }
     };
 
+    const unsigned cvoff = (unsigned)l4 * 8u;
     i64 ch = blockIdx.x;
     int buf = 0;
     if (ch < nchunks) issue(ch, 0);
     for (; ch < nchunks; ch += gridDim.x) {
         // weights of this chunk's rows in the D-register layout of T: reg s <-> row l4 + 4 s
-        const double c0 = cw[ch * HM_ROWS + l4], c1 = cw[ch * HM_ROWS + 4 + l4];
+        double c0, c1;
+        {
+            const double* cb = cw + ch * HM_ROWS;              // wave-uniform
+            asm volatile("global_load_dwordx2 %0, %2, %3\n\tglobal_load_dwordx2 %1, %2, %3 offset:32"
+                         : "=&v"(c0), "=&v"(c1) : "v"(cvoff), "s"(cb) : "memory");
+        }
         __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): this wave's part of the stage has landed
         __syncthreads();                                      // ... and everybody's; the other buffer is free again
         const i64 nxt = ch + gridDim.x;
@@ -189,17 +207,29 @@ void hvp_multi_kernel(const double* __restrict__ X, int Preal, i64 N, const doub
         }
 }
 
-// Out[q][off + p] = sum over workgroups of Rpart[g][p][q], fixed order (deterministic)
-__global__ void hvp_multi_reduce_kernel(const double* __restrict__ Rpart, int G, int P, int Ppad, int Q, i64 ldo, i64 off,
-                                        double* __restrict__ Out)
+// Out[q][off + p] = sum over workgroups of Rpart[g][p][q], fixed order (deterministic): a block owns 32 consecutive
+// elements e = p * 16 + q; its 8 thread rows each sum every 8th partial (coalesced 256-byte reads), then the eight row
+// sums are added in a fixed order through LDS -- G = 256 partials of 128 KiB are read at streaming rate
+// (the one-thread-per-element form took 64 us per call, 4 % of a blocked-CG iteration)
+__global__ __launch_bounds__(256)
+void hvp_multi_reduce_kernel(const double* __restrict__ Rpart, int G, int P, int Ppad, int Q, i64 ldo, i64 off,
+                             double* __restrict__ Out)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;       // e = p * 16 + q
-    if (e >= P * 16) return;
-    const int p = e >> 4, q = e & 15;
-    if (q >= Q) return;
+    __shared__ double sh[8][32];
+    const int col = threadIdx.x & 31, row = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + col;                         // e = p * 16 + q
     double s = 0.0;
-    for (int g = 0; g < G; ++g) s += Rpart[(i64)g * Ppad * 16 + e];
-    Out[(i64)q * ldo + off + p] = s;
+    if (e < P * 16)
+        for (int g = row; g < G; g += 8) s += Rpart[(i64)g * Ppad * 16 + e];
+    sh[row][col] = s;
+    __syncthreads();
+    if (row == 0 && e < P * 16) {
+        double t = sh[0][col];
+#pragma unroll
+        for (int r = 1; r < 8; ++r) t += sh[r][col];
+        const int p = e >> 4, q = e & 15;
+        if (q < Q) Out[(i64)q * ldo + off + p] = t;
+    }
 }
 
 bool hvp_multi_supported(const lrvb_ctx* c, i64 Q) {
@@ -234,7 +264,7 @@ int launch_hvp_multi(lrvb_ctx* c, i64 Q, const double* U_dev, i64 ldu, double* O
 #undef HM_LAUNCH_W
 #undef HM_LAUNCH
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(hvp_multi_reduce_kernel, dim3((unsigned)((Preal * 16 + 255) / 256)), dim3(256), 0, c->stream,
+    hipLaunchKernelGGL(hvp_multi_reduce_kernel, dim3((unsigned)((Preal * 16 + 31) / 32)), dim3(256), 0, c->stream,
                        c->part_vec.p, grid, Preal, P, (int)Q, ldo, c->glm_off, Out_dev);
     HIP_TRY(hipGetLastError());
     return LRVB_OK;
