@@ -10,11 +10,21 @@ mixed directional derivatives have closed forms that run on the device:
 * in free coordinates with element-wise packing maps eta = c(phi) (the four box kinds of LRVB/Parameters.py:31-61)
   the gradient is G(phi) = c'(phi) o g_eta(c(phi)), and D^i G [v_1 .. v_i] follows from the product rule over subsets
   of the directions and Faa di Bruno's formula over set partitions, each leaf being one `lrvb_dk_grad_vec` call;
+* with PSD (log-Cholesky) or simplex (softmax) blocks the packing map is not element-wise.  The same two rules then
+  read, for G(phi) = J(phi)^T g_eta(c(phi)):
+      D^i G [v_1 .. v_i] = sum over subsets S of the directions  ( D^(|S|+1) c [v_S, .] )^T
+                           sum over set partitions pi of the rest  D^|pi| g_eta [ D^|B| c [v_B] : B in pi ]
+  (multivariate Faa di Bruno).  The leaves D^r g_eta [...] are still `lrvb_dk_grad_vec` calls on the device -- every
+  O(N) contraction -- while the derivatives of the small N-independent map c come from forward-mode AD of c on the
+  host (torch.func.jvp, the counterpart of the autograd JVPs the reference applies to the whole objective,
+  LRVB/ModelSensitivity.py:38-62), see `PackingJet`.
 * the objective is LINEAR in the two hyper-parameters the device path declares (observation weights, linear tilt),
   so derivatives of order >= 2 in eps vanish and the first one is g evaluated with the direction as weights / tilt.
 
-PSD and simplex blocks are not element-wise: with them the class raises NotImplementedError (use vector coordinates).
 The recursion for d^k eta_hat / d eps^k is the implicit-function theorem applied k times to g(eta_hat(eps), eps) = 0.
+`append_jvp` and `generate_two_term_derivative_array` (LRVB/ModelSensitivity.py:38-62, 221-234) are provided for
+closures written with torch operations (torch.func in place of autograd), and `DerivativeTerm` carries the optional
+evaluator lists of the reference class so that such closures can be expanded with the same term algebra.
 """
 import math
 from copy import deepcopy
@@ -31,13 +41,40 @@ class DerivativeTerm(object):
     """prefactor * D_eta^(sum m) D_eps^(eps_order) g [eta^(1) x m_1, eta^(2) x m_2, ..., d eps x eps_order] with
     eta_orders = [m_1, m_2, ...] (LRVB/ModelSensitivity.py:83-204)."""
 
-    def __init__(self, eps_order, eta_orders, prefactor):
+    def __init__(self, eps_order, eta_orders, prefactor, eval_eta_derivs=None, eval_g_derivs=None):
         self.eps_order = int(eps_order)
         self.eta_orders = [int(m) for m in eta_orders]
         self.prefactor = float(prefactor)
         self.order = self.eps_order + sum((i + 1) * m for i, m in enumerate(self.eta_orders))
         assert self.eps_order >= 0 and all(m >= 0 for m in self.eta_orders)
         assert len(self.eta_orders) == self.order
+        # optional evaluators, as in the reference class: eval_eta_derivs[i](eta0, eps0, deps) = d^(i+1) eta / d eps^(i+1)
+        # along deps; eval_g_derivs[i][j](eta0, eps0, v_1 .. v_i, w_1 .. w_j) = D_eta^i D_eps^j g [v.., w..]
+        self.eval_eta_derivs = eval_eta_derivs
+        self.eval_g_derivs = eval_g_derivs
+        if eval_g_derivs is not None:
+            assert len(eval_g_derivs) > sum(self.eta_orders) and len(eval_g_derivs[sum(self.eta_orders)]) > self.eps_order
+            self.eval_g_deriv = eval_g_derivs[sum(self.eta_orders)][self.eps_order]
+
+    def evaluate(self, eta0, eps0, deps):
+        """prefactor * D g [eta^(1) x m_1, ..., deps x eps_order] through the evaluator lists (LRVB/ModelSensitivity.py:139-153)."""
+        if self.eval_g_derivs is None or self.eval_eta_derivs is None:
+            raise ValueError('this term carries no evaluators (it was built for the device path)')
+        vec_args = []
+        for i, m in enumerate(self.eta_orders):
+            if m > 0:
+                vec = self.eval_eta_derivs[i](eta0, eps0, deps)
+                vec_args += [vec] * m
+        vec_args += [deps] * self.eps_order
+        return self.prefactor * self.eval_g_deriv(eta0, eps0, *vec_args)
+
+    def check_similarity(self, term):
+        return self.key() == term.key()
+
+    def combine_with(self, term):
+        assert self.check_similarity(term)
+        return DerivativeTerm(self.eps_order, self.eta_orders, self.prefactor + term.prefactor,
+                              self.eval_eta_derivs, self.eval_g_derivs)
 
     def __str__(self):
         return 'Order: {}\t{} * eta{} * eps[{}]'.format(self.order, self.prefactor, self.eta_orders, self.eps_order)
@@ -45,26 +82,72 @@ class DerivativeTerm(object):
     def key(self):
         return (self.eps_order, tuple(self.eta_orders))
 
-    def differentiate(self):
+    def differentiate(self, eval_next_eta_deriv=None):
         """The terms of d/dt of this one: through the explicit eps argument, through g's eta argument (a new factor
-        eta^(1)), and through each factor eta^(i) -> eta^(i+1) (m_i ways)."""
+        eta^(1)), and through each factor eta^(i) -> eta^(i+1) (m_i ways).  `eval_next_eta_deriv` extends the
+        evaluator list when the term carries one (the reference's signature)."""
+        etas = self.eval_eta_derivs
+        if etas is not None and eval_next_eta_deriv is not None:
+            etas = list(etas) + [eval_next_eta_deriv]
+        gd = self.eval_g_derivs
         grown = self.eta_orders + [0]
-        out = [DerivativeTerm(self.eps_order + 1, grown, self.prefactor)]
+        out = [DerivativeTerm(self.eps_order + 1, grown, self.prefactor, etas, gd)]
         first = list(grown)
         first[0] += 1
-        out.append(DerivativeTerm(self.eps_order, first, self.prefactor))
+        out.append(DerivativeTerm(self.eps_order, first, self.prefactor, etas, gd))
         for i, m in enumerate(self.eta_orders):
             if m > 0:
                 moved = list(grown)
                 moved[i] -= 1
                 moved[i + 1] += 1
-                out.append(DerivativeTerm(self.eps_order, moved, self.prefactor * m))
+                out.append(DerivativeTerm(self.eps_order, moved, self.prefactor * m, etas, gd))
         return out
 
 
-def get_taylor_base_terms():
+def get_taylor_base_terms(eval_g_derivs=None):
     """d/dt g = D_eps g [d eps] + D_eta g [eta^(1)]  (LRVB/ModelSensitivity.py:282-298)."""
-    return [DerivativeTerm(1, [0], 1.0), DerivativeTerm(0, [1], 1.0)]
+    etas = None if eval_g_derivs is None else []
+    return [DerivativeTerm(1, [0], 1.0, etas, eval_g_derivs), DerivativeTerm(0, [1], 1.0, etas, eval_g_derivs)]
+
+
+def append_jvp(fun, num_base_args=1, argnum=0):
+    """fun(x_1 .. x_B, v_1 .. v_r) -> fun_jvp(x_1 .. x_B, v_1 .. v_r, v) = d fun / d x_argnum [v] at the same base
+    point and earlier directions: the building block of nested Jacobian-vector products (LRVB/ModelSensitivity.py:38-62),
+    for closures written with torch operations (torch.func.jvp in place of autograd.make_jvp)."""
+    import torch
+    assert argnum < num_base_args
+
+    def fun_jvp(*argv):
+        base, vecs = list(argv[:num_base_args]), argv[num_base_args:]
+        earlier, new = vecs[:-1], vecs[-1]
+
+        def of_x(x):
+            args = base[:argnum] + [x] + base[argnum + 1:]
+            return fun(*args, *earlier)
+        return torch.func.jvp(of_x, (base[argnum],), (new,))[1]
+    return fun_jvp
+
+
+def generate_two_term_derivative_array(fun, order):
+    """eval_fun_derivs[i][j](x1, x2, v_1 .. v_i, w_1 .. w_j) = D_x1^i D_x2^j fun [v.., w..], i, j <= order
+    (LRVB/ModelSensitivity.py:221-234)."""
+    derivs = [[fun]]
+    for i in range(order):
+        if i > 0:
+            derivs.append([append_jvp(derivs[i - 1][0], num_base_args=2, argnum=0)])
+        for j in range(order):
+            derivs[i].append(_append_x2(derivs[i][j], i))
+    return derivs
+
+
+def _append_x2(f, n_x1_dirs):
+    """One more x2 direction, appended AFTER the existing x2 directions (argument order x1, x2, v.., w..)."""
+    import torch
+
+    def g(*argv):
+        x1, x2, rest = argv[0], argv[1], argv[2:-1]
+        return torch.func.jvp(lambda z: f(x1, z, *rest), (x2,), (argv[-1],))[1]
+    return g
 
 
 def consolidate_terms(terms):
@@ -72,17 +155,14 @@ def consolidate_terms(terms):
     merged = {}
     for t in terms:
         k = t.key()
-        if k in merged:
-            merged[k] = DerivativeTerm(t.eps_order, t.eta_orders, merged[k].prefactor + t.prefactor)
-        else:
-            merged[k] = t
+        merged[k] = merged[k].combine_with(t) if k in merged else t
     return list(merged.values())
 
 
-def differentiate_terms(terms):
+def differentiate_terms(terms, eval_next_eta_deriv=None):
     out = []
     for t in terms:
-        out += t.differentiate()
+        out += t.differentiate(eval_next_eta_deriv)
     return consolidate_terms(out)
 
 
@@ -148,6 +228,79 @@ def box_map_derivatives(free_val, blocks, max_order):
     return out
 
 
+class PackingJet(object):
+    """Directional derivatives of the packing map c: free -> vector at one point phi, for ANY layout (box, log-Cholesky
+    PSD, softmax simplex blocks; LRVB/Parameters.py:47-61, MatrixParameters.py:101-112, SimplexParams.py:11-18):
+
+        vec(dirs)  = D^m c [w_1 .. w_m]        (a V-vector; m = 0 is c(phi) itself)
+        mat(dirs)  = D^(m+1) c [w_1 .. w_m, .]  (V x D: one slot left open)
+
+    by nested forward-mode AD (torch.func.jvp / jacfwd) of a torch restatement of the map.  The map is small and
+    N-independent; this is the host-side counterpart of the autograd JVPs the reference nests (it differentiates
+    the whole objective that way, :38-62).  Results are memoised per set of directions."""
+
+    def __init__(self, free_val, blocks):
+        import torch
+        self._torch = torch
+        self._phi = torch.tensor(np.asarray(free_val, dtype=np.float64))
+        self._blocks = [dict(b) for b in blocks]
+        self._memo = {}
+
+    def _map(self, phi):
+        torch = self._torch
+        out, off = [], 0
+        for b in self._blocks:
+            n = int(b['free_size'])
+            f = phi[off:off + n]
+            off += n
+            if b['kind'] == _hip.BLOCK_BOX:
+                lb, ub = b['lb'], b['ub']
+                if lb == -np.inf and ub == np.inf:
+                    out.append(f)
+                elif ub == np.inf:
+                    out.append(torch.exp(f) + lb)
+                elif lb == -np.inf:
+                    out.append(ub - torch.exp(-f))
+                else:
+                    out.append((ub - lb) * torch.sigmoid(f) + lb)
+            elif b['kind'] == _hip.BLOCK_PSD:
+                k = int(b['dim0'])
+                r, c = np.tril_indices(k)                      # row-major lower triangle: index c + r (r + 1) / 2
+                L = torch.zeros((k, k), dtype=phi.dtype).index_put((torch.tensor(r), torch.tensor(c)), f)
+                d = torch.diagonal(L)
+                L = L - torch.diag(d) + torch.diag(torch.exp(d))
+                A = L @ L.T + float(b['lb']) * torch.eye(k, dtype=phi.dtype)
+                out.append(A[torch.tensor(r), torch.tensor(c)])
+            else:                                              # simplex rows: softmax([0, f])
+                rows, K = int(b['dim0']), int(b['dim1'])
+                z = torch.cat([torch.zeros((rows, 1), dtype=phi.dtype), f.reshape(rows, K - 1)], dim=1)
+                out.append(torch.softmax(z, dim=1).reshape(-1))
+        return torch.cat(out)
+
+    def _directional(self, dirs):
+        torch = self._torch
+        f = self._map
+        for w in dirs:
+            f = (lambda g, wt: (lambda p: torch.func.jvp(g, (p,), (wt,))[1]))(f, torch.tensor(np.asarray(w, dtype=np.float64)))
+        return f
+
+    @staticmethod
+    def _key(dirs):
+        return tuple(sorted(np.ascontiguousarray(w, dtype=np.float64).tobytes() for w in dirs))
+
+    def vec(self, dirs):
+        key = ('v', self._key(dirs))
+        if key not in self._memo:
+            self._memo[key] = self._directional(dirs)(self._phi).numpy()
+        return self._memo[key]
+
+    def mat(self, dirs):
+        key = ('m', self._key(dirs))
+        if key not in self._memo:
+            self._memo[key] = self._torch.func.jacfwd(self._directional(dirs))(self._phi).numpy()
+        return self._memo[key]
+
+
 class ParametricSensitivityTaylorExpansion(object):
     """Same constructor and methods as the reference class (LRVB/ModelSensitivity.py:382-515).  `objective_functor`
     must be a device functor and `hyper_par` its `weights_par` or `tilt_par`, in vector coordinates."""
@@ -200,6 +353,15 @@ class ParametricSensitivityTaylorExpansion(object):
         return self.ctx.chol_solve(np.asarray(rhs, dtype=np.float64).reshape(-1, 1)).ravel()
 
     # ---- mixed directional derivatives of the gradient at the base point ----------------------------------------
+    def _all_box(self):
+        return all(b['kind'] == _hip.BLOCK_BOX for b in self.input_par.layout_blocks())
+
+    def _jet(self):
+        jet = self._cache.get('jet')
+        if jet is None:
+            jet = self._cache['jet'] = PackingJet(self.input_val0, self.input_par.layout_blocks())
+        return jet
+
     def _box(self, max_order):
         if not self.input_is_free:
             return None
@@ -210,7 +372,9 @@ class ParametricSensitivityTaylorExpansion(object):
         return have
 
     def _eta0(self):
-        return self._box(1)[0] if self.input_is_free else self.input_val0
+        if not self.input_is_free:
+            return self.input_val0
+        return self._box(1)[0] if self._all_box() else self._jet().vec([])
 
     def _h(self, dirs_eta, eps_dir):
         """D_eta^r h [dirs] in vector coordinates, h = g_eta (eps_dir None) or d g_eta / d eps [eps_dir]."""
@@ -239,6 +403,8 @@ class ParametricSensitivityTaylorExpansion(object):
         i = len(dirs)
         if not self.input_is_free:
             return self._h(list(dirs), eps_dir)
+        if not self._all_box():
+            return self._dg_general(dirs, eps_dir)
         c = self._box(i + 1)
         idx = list(range(i))
         total = np.zeros(self.input_val0.size)
@@ -259,6 +425,23 @@ class ParametricSensitivityTaylorExpansion(object):
                     vecs.append(u)
                 inner += self._h(vecs, eps_dir)
             total += lead * inner
+        return total
+
+    def _dg_general(self, dirs, eps_dir):
+        """The same sum for a packing map that is not element-wise (PSD / simplex blocks): the leading factor is the
+        transposed open-slot derivative of the map, the inner directions its directional derivatives."""
+        jet = self._jet()
+        idx = list(range(len(dirs)))
+        total = np.zeros(self.input_val0.size)
+        for S, T in _subsets(idx):
+            lead = jet.mat([dirs[k] for k in S])                 # V x D
+            if not T:
+                total += lead.T @ self._h([], eps_dir)
+                continue
+            inner = np.zeros(lead.shape[0])
+            for part in _set_partitions(T):
+                inner += self._h([jet.vec([dirs[k] for k in block]) for block in part], eps_dir)
+            total += lead.T @ inner
         return total
 
     def _evaluate_term(self, term, eta_derivs, dhyper):

@@ -3,7 +3,7 @@
 # bench command; raw output under gpurun_out/, condensed summaries for profiles/.
 # usage: tools/collect_profiles.sh r01
 set -euo pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof_$TAG
