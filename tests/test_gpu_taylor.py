@@ -170,12 +170,61 @@ def test_weight_sensitivity_to_fourth_order(vb, loss):
     assert errs[-1] < 1e-3 * errs[0]
 
 
+def test_free_coordinates_with_psd_and_simplex_blocks(vb):
+    """Layouts that are not element-wise: the device supplies every O(N) leaf (lrvb_dk_grad_vec), the host the
+    derivatives of the packing map; d^k phi_hat / d w^k for k <= 3 satisfies the optimality condition along the Taylor
+    polynomial (exact nested AD), and the series beats the linear approximation against a refit."""
+    rng = np.random.default_rng(31)
+    spec = [('box', 'beta', 6, -1.0, np.inf), ('psd', 'm', 3, 0.2), ('simplex', 's', 2, 3)]
+    par, lay = make_par(vb, spec)
+    N, P = 800, 6
+    x, y, w0 = glm_data(rng, N, P, om.LOGISTIC)
+    a = rng.normal(size=(lay.V, lay.V)); A = a @ a.T / lay.V + 2.0 * np.eye(lay.V)
+    qm = lay.constrain(rng.normal(size=lay.D) * 0.3)
+    fun = vb.DeviceObjective(par, x=x, y=y, loss='logistic', glm_param='beta', quad_A=A, quad_m=qm, weights=w0)
+    model = om.DeclaredModel(lay, loss=om.LOGISTIC, x=x, y=y, w=w0.copy(), glm_off=0, quad_A=A, quad_m=qm)
+    fit = scipy.optimize.minimize(model.value, np.zeros(lay.D), jac=model.grad, hess=model.hessian, method='trust-exact',
+                                  options={'gtol': 1e-13})
+    phi0 = fit.x
+    for _ in range(3):
+        phi0 = phi0 - np.linalg.solve(model.hessian(phi0), model.grad(phi0))
+    assert np.linalg.norm(model.grad(phi0)) < 1e-10
+    K = 3
+    tay = vb.ParametricSensitivityTaylorExpansion(fun, par, fun.weights_par, phi0, w0, K)
+    dw = rng.normal(size=N) * 0.5
+    derivs = [tay.evaluate_dkinput_dhyperk(dw, k) for k in range(1, K + 1)]
+    assert rel_err(derivs[0], -np.linalg.solve(model.hessian(phi0), model.obs_grad(phi0).T @ dw)) < 1e-8
+    tx, ty, tA, tm = torch.tensor(x), torch.tensor(y), torch.tensor(A), torch.tensor(qm)
+    coefs = [torch.tensor(phi0)] + [torch.tensor(dk / math.factorial(k)) for k, dk in enumerate(derivs, start=1)]
+    tw0, tdw = torch.tensor(w0), torch.tensor(dw)
+
+    def f_free(phi, w):
+        eta = tr.constrain(phi, lay)
+        z = tx @ eta[:P]
+        d = eta - tm
+        return torch.sum(w * (torch.nn.functional.softplus(z) - ty * z)) + 0.5 * torch.dot(d, tA @ d)
+
+    def residual(t):
+        phi = sum(c * t ** k for k, c in enumerate(coefs))
+        return torch.func.grad(f_free)(phi, tw0 + t * tdw)
+
+    t0, one = torch.zeros((), dtype=torch.float64), torch.ones((), dtype=torch.float64)
+    scale = np.linalg.norm(model.hessian(phi0) @ derivs[0])
+    h = residual
+    assert torch.linalg.norm(h(t0)).item() < 1e-9 * scale
+    for k in range(1, K + 1):
+        h = (lambda g: (lambda t: torch.func.jvp(g, (t,), (one,))[1]))(h)
+        assert torch.linalg.norm(h(t0)).item() < 1e-7 * scale * math.factorial(k), k
+    t = 0.2
+    model.w = w0 + t * dw
+    refit = phi0.copy()
+    for _ in range(30):
+        refit = refit - np.linalg.solve(model.hessian(refit), model.grad(refit))
+    errs = [np.max(np.abs(tay.evaluate_taylor_series(t * dw, max_order=k) - refit)) for k in range(1, K + 1)]
+    assert errs[2] < errs[1] < errs[0] and errs[2] < 1e-2 * errs[0]
+
+
 def test_refusals(vb):
-    par, lay = make_par(vb, [('psd', 'm', 2, 0.0)])
-    fun = vb.QuadraticObjective(par, A=np.eye(lay.V))
-    with pytest.raises(NotImplementedError):                       # not an element-wise packing map
-        vb.ParametricSensitivityTaylorExpansion(fun, par, fun.tilt_par, np.zeros(lay.D), np.zeros(lay.V), 2) \
-            .evaluate_dkinput_dhyperk(np.ones(lay.V), 2)
     p2 = vb.VectorParam('x', 3)
     host = lambda: float(np.sum(p2.get() ** 2))
     with pytest.raises(NotImplementedError):

@@ -179,3 +179,131 @@ def test_taylor_class_tilt_and_vector_coordinates():
         tay.evaluate_dkinput_dhyperk(d, 5)
     with pytest.raises(ValueError):
         tay.evaluate_taylor_series(d[:2])
+
+
+# ---- layouts with PSD and simplex blocks: multivariate Faa di Bruno through the packing-map jets ------------------
+def _mixed_setup(seed):
+    """Logistic GLM whose coefficient slice is a box block, next to a log-Cholesky PSD block and a simplex block that
+    enter through a dense quadratic term (so every block's higher map derivatives carry weight)."""
+    from oracle_functor import OracleFunctor
+    from helpers import make_par
+    rng = np.random.default_rng(seed)
+    spec = [('box', 'beta', 4, -1.0, np.inf), ('psd', 'm', 3, 0.2), ('simplex', 's', 2, 3), ('box', 'u', 2, -np.inf, np.inf)]
+    par, lay = make_par(vb, spec)
+    N, P = 150, 4
+    x, y, w = glm_data(rng, N, P, om.LOGISTIC)
+    a = rng.normal(size=(lay.V, lay.V)); A = a @ a.T / lay.V + 2.0 * np.eye(lay.V)
+    model = om.DeclaredModel(lay, loss=om.LOGISTIC, x=x, y=y, w=w.copy(), glm_off=0, quad_A=A,
+                             quad_m=lay.constrain(rng.normal(size=lay.D) * 0.3), quad_b=np.zeros(lay.V))
+    wpar = vb.VectorParam('weights', N, val=w.copy())
+    tpar = vb.VectorParam('tilt', lay.V, val=np.zeros(lay.V))
+    return rng, par, lay, model, OracleFunctor(par, model, weights_par=wpar, tilt_par=tpar), w
+
+
+def _optimum(model, start):
+    import scipy.optimize
+    fit = scipy.optimize.minimize(model.value, start, jac=model.grad, hess=model.hessian, method='trust-exact', options={'gtol': 1e-13})
+    phi = fit.x
+    for _ in range(3):
+        phi = phi - np.linalg.solve(model.hessian(phi), model.grad(phi))
+    return phi
+
+
+def test_packing_jet_against_nested_ad():
+    import torch_ref as tr
+    rng, par, lay, model, fun, w0 = _mixed_setup(21)
+    from lrvb_amd.taylor import PackingJet
+    phi = rng.normal(size=lay.D) * 0.4
+    jet = PackingJet(phi, par.layout_blocks())
+    np.testing.assert_allclose(jet.vec([]), lay.constrain(phi), rtol=1e-14, atol=1e-15)
+    np.testing.assert_allclose(jet.mat([]), lay.jac(phi), rtol=1e-13, atol=1e-14)
+    dirs = [rng.normal(size=lay.D) for _ in range(3)]
+    f = lambda p: tr.constrain(p, lay)
+    for m in (1, 2, 3):
+        g = f
+        for w in dirs[:m]:
+            g = (lambda h, wt: (lambda p: torch.func.jvp(h, (p,), (wt,))[1]))(g, torch.tensor(w))
+        np.testing.assert_allclose(jet.vec(dirs[:m]), g(torch.tensor(phi)).numpy(), rtol=1e-12, atol=1e-13)
+    # the open slot closes onto the next directional derivative
+    np.testing.assert_allclose(jet.mat(dirs[:2]) @ dirs[2], jet.vec(dirs[:3]), rtol=1e-12, atol=1e-13)
+
+
+@pytest.mark.parametrize('hyper', ['weights', 'tilt'])
+def test_taylor_class_with_psd_and_simplex_blocks(hyper):
+    """d^k/dt^k of the optimality condition along the Taylor polynomial vanishes for k <= K (exact nested AD of an
+    independent torch restatement), in FREE coordinates of a layout that is not element-wise."""
+    import torch_ref as tr
+    rng, par, lay, model, fun, w0 = _mixed_setup(22)
+    phi0 = _optimum(model, np.zeros(lay.D))
+    assert np.linalg.norm(model.grad(phi0)) < 1e-10
+    K = 3
+    hyper_par = fun.weights_par if hyper == 'weights' else fun.tilt_par
+    hyper0 = w0 if hyper == 'weights' else np.zeros(lay.V)
+    tay = vb.ParametricSensitivityTaylorExpansion(fun, par, hyper_par, phi0, hyper0, K)
+    de = rng.normal(size=hyper0.size) * 0.5
+    derivs = [tay.evaluate_dkinput_dhyperk(de, k) for k in range(1, K + 1)]
+    # first order = the linear-response formula with the oracle's dense matrices
+    cross = model.obs_grad(phi0).T if hyper == 'weights' else model.cross_hessian_tilt(phi0)
+    np.testing.assert_allclose(derivs[0], -np.linalg.solve(model.hessian(phi0), cross @ de), rtol=1e-8, atol=1e-10)
+    f_vec = tr.make_objective(model)
+    tx, ty = torch.tensor(model.x), torch.tensor(model.y)
+    A, mq = torch.tensor(model.quad_A), torch.tensor(model.quad_m)
+    coefs = [torch.tensor(phi0)] + [torch.tensor(dk / math.factorial(k)) for k, dk in enumerate(derivs, start=1)]
+    tde, th0 = torch.tensor(de), torch.tensor(hyper0)
+
+    def f_free(phi, eps):
+        eta = tr.constrain(phi, lay)
+        z = tx @ eta[:model.P]
+        l = torch.nn.functional.softplus(z) - ty * z
+        d = eta - mq
+        wts = eps if hyper == 'weights' else torch.tensor(w0)
+        b = eps if hyper == 'tilt' else torch.zeros(lay.V, dtype=torch.float64)
+        return torch.sum(wts * l) + 0.5 * torch.dot(d, A @ d) + torch.dot(b, eta)
+
+    def residual(t):
+        phi = sum(c * t ** k for k, c in enumerate(coefs))
+        return torch.func.grad(f_free)(phi, th0 + t * tde)
+
+    t0, one = torch.zeros((), dtype=torch.float64), torch.ones((), dtype=torch.float64)
+    scale = np.linalg.norm(model.hessian(phi0) @ derivs[0])
+    h = residual
+    assert torch.linalg.norm(h(t0)).item() < 1e-9 * scale
+    for k in range(1, K + 1):
+        h = (lambda g: (lambda t: torch.func.jvp(g, (t,), (one,))[1]))(h)
+        assert torch.linalg.norm(h(t0)).item() < 1e-7 * scale * math.factorial(k), k
+    h = (lambda g: (lambda t: torch.func.jvp(g, (t,), (one,))[1]))(h)
+    assert torch.linalg.norm(h(t0)).item() > 1e-6 * scale          # one order further it does not vanish
+    np.testing.assert_allclose(par.get_free(), phi0, rtol=1e-10, atol=1e-12)
+
+
+def test_append_jvp_and_derivative_array_counterparts():
+    """LRVB/ModelSensitivity.py:38-62, 221-234 for closures written with torch operations: the (i, j) entry of the array
+    is D_x1^i D_x2^j fun contracted with its trailing direction arguments -- checked on a polynomial with known
+    derivatives, then used through DerivativeTerm.evaluate as the reference class uses it."""
+    from lrvb_amd.taylor import append_jvp, generate_two_term_derivative_array, DerivativeTerm, get_taylor_base_terms
+    a = torch.tensor([0.7, -1.2, 0.4], dtype=torch.float64)
+
+    def fun(x1, x2):                                  # vector valued: x1^3 * (a . x2)  +  x1 * x2^2
+        return x1 ** 3 * torch.dot(a, x2) + x1 * x2 ** 2
+    x1 = torch.tensor([0.5, -0.3, 1.1], dtype=torch.float64); x2 = torch.tensor([0.2, 0.9, -0.6], dtype=torch.float64)
+    v = torch.tensor([1.0, 0.5, -0.2], dtype=torch.float64); w = torch.tensor([-0.4, 0.3, 0.8], dtype=torch.float64)
+    arr = generate_two_term_derivative_array(fun, 3)
+    assert len(arr) == 3 and all(len(row) == 4 for row in arr)
+    np.testing.assert_allclose(arr[0][0](x1, x2).numpy(), fun(x1, x2).numpy())
+    np.testing.assert_allclose(arr[1][0](x1, x2, v).numpy(), (3 * x1 ** 2 * v * torch.dot(a, x2) + v * x2 ** 2).numpy(), rtol=1e-13)
+    np.testing.assert_allclose(arr[0][1](x1, x2, w).numpy(), (x1 ** 3 * torch.dot(a, w) + 2 * x1 * x2 * w).numpy(), rtol=1e-13)
+    np.testing.assert_allclose(arr[1][1](x1, x2, v, w).numpy(), (3 * x1 ** 2 * v * torch.dot(a, w) + 2 * v * x2 * w).numpy(), rtol=1e-13)
+    np.testing.assert_allclose(arr[2][0](x1, x2, v, v).numpy(), (6 * x1 * v * v * torch.dot(a, x2)).numpy(), rtol=1e-13)
+    np.testing.assert_allclose(arr[0][2](x1, x2, w, w).numpy(), (2 * x1 * w * w).numpy(), rtol=1e-13)
+    jv = append_jvp(fun, num_base_args=2, argnum=0)
+    np.testing.assert_allclose(jv(x1, x2, v).numpy(), arr[1][0](x1, x2, v).numpy(), rtol=1e-14)
+    # the base terms evaluate through the array: d/dt g = D_eps g [d eps] + D_eta g [eta^(1)]
+    terms = get_taylor_base_terms(eval_g_derivs=arr)
+    eta1 = lambda e0, p0, dp: v
+    terms = [DerivativeTerm(t.eps_order, t.eta_orders, t.prefactor, [eta1], arr) for t in terms]
+    total = sum(t.evaluate(x1, x2, w) for t in terms)
+    np.testing.assert_allclose(total.numpy(), (arr[0][1](x1, x2, w) + arr[1][0](x1, x2, v)).numpy(), rtol=1e-13)
+    second = []
+    for t in terms:
+        second += t.differentiate(eval_next_eta_deriv=lambda e0, p0, dp: w)
+    assert all(len(t.eval_eta_derivs) == 2 for t in second) and sorted(t.order for t in second) == [2] * len(second)
