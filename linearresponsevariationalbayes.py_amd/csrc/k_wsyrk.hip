@@ -202,7 +202,7 @@ void wsyrk_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
 // nobody reads.  ALL LDS lives in one array (a second __shared__ object next to an LDS-DMA target
 // makes hipcc drain vmcnt(0) before every ds_read).
 constexpr int WS_PANEL = WS_KC * WS_LDS_STRIDE;          // doubles per panel
-constexpr int WS_BUF = 2 * WS_PANEL + 32;                // A panel, B panel, 32 c values
+constexpr int WS_BUF = 2 * WS_PANEL + 64;                // A panel, B panel, 32 c values, 32 (c y) values (Gaussian shortcut)
 
 #define WS_GLDS16(gp, lp) __builtin_amdgcn_global_load_lds( \
     (const __attribute__((address_space(1))) void*)(gp), (__attribute__((address_space(3))) void*)(lp), 16, 0, 0)
@@ -218,8 +218,13 @@ constexpr int WS_BUF = 2 * WS_PANEL + 32;                // A panel, B panel, 32
 __global__ __launch_bounds__(WS_THREADS, 2)
 void wsyrk_glds_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
                        const double* __restrict__ cpad, int n_splits, int nb, i64 rows_per_split,
-                       double* __restrict__ partial)
+                       double* __restrict__ partial,
+                       const double* __restrict__ cypad /* nullable */, double* __restrict__ rpart /* n_splits x nb*128 */)
 {
+    // cypad != NULL: the diagonal-tile workgroups also accumulate r = X^T (c o y) for their 128 columns over their
+    // rows (the panel and c y sit in LDS anyway: 8 FMAs + 12 LDS reads per thread and stage).  With it a Gaussian
+    // loss -- whose curvature w tau does not depend on theta -- needs NO separate pass over X for a Hessian build:
+    // d f / d beta = S beta - r  (lrvb_api.hip: hessian_partial).
     __shared__ double lds[2 * WS_BUF];
 
     const int tid = threadIdx.x;
@@ -306,6 +311,8 @@ void wsyrk_glds_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
         }
         if (wave == 0)       // 64 dwords = c[n0 .. n0+31]; reads past N hit the zero padding
             WS_GLDS4_S(reinterpret_cast<const char*>(cpad + n0), voffC, base + (unsigned)(2 * WS_PANEL) * 8u);
+        if (wave == 1 && diag && cypad)
+            WS_GLDS4_S(reinterpret_cast<const char*>(cypad + n0), voffC, base + (unsigned)(2 * WS_PANEL + 32) * 8u);
     };
 
     if (nch > 0) issue_stage(0, 0);
@@ -376,6 +383,7 @@ void wsyrk_glds_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
                     out[(32 * wave + 2 * (l4 + 4 * r) + m) * WS_TILE + 32 * (n >> 1) + 2 * l15 + (n & 1)] = acc[m * 8 + n][r];
     } else {
         const int rb0 = wave, rb1 = 7 - wave;        // this wave's two 16-row blocks
+        d2 racc = (d2){0.0, 0.0};
         const double* row_base = lds + l4 * WS_LDS_STRIDE + l15;       // loop-invariant LDS addresses, as above
         const double* c_base = lds + 2 * WS_PANEL + l4;
         auto stage = [&](auto buf_tag) {
@@ -405,6 +413,15 @@ void wsyrk_glds_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
                     if (n <= rb1) acc[4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(s1, bf[set][n], acc[4 + n], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (cypad) {                 // r[2 cp .. 2 cp + 1] += sum over this wave's 4 rows of (c y)_row x[row][.]: 6 LDS reads, 8 FMAs
+                const double* xs = lds + BUF * WS_BUF + wave * 4 * WS_LDS_STRIDE + 2 * lane;
+                const d2* cys = reinterpret_cast<const d2*>(lds + BUF * WS_BUF + 2 * WS_PANEL + 32 + wave * 4);
+                const d2 cy01 = cys[0], cy23 = cys[1];
+                const d2 x0 = *reinterpret_cast<const d2*>(xs), x1 = *reinterpret_cast<const d2*>(xs + WS_LDS_STRIDE);
+                const d2 x2 = *reinterpret_cast<const d2*>(xs + 2 * WS_LDS_STRIDE), x3 = *reinterpret_cast<const d2*>(xs + 3 * WS_LDS_STRIDE);
+                racc[0] += cy01[0] * x0[0] + cy01[1] * x1[0] + cy23[0] * x2[0] + cy23[1] * x3[0];
+                racc[1] += cy01[0] * x0[1] + cy01[1] * x1[1] + cy23[0] * x2[1] + cy23[1] * x3[1];
+            }
             __builtin_amdgcn_s_waitcnt(0x0F70); __syncthreads();
         };
         for (int ch = 0; ch < nch; ch += 2) {
@@ -414,6 +431,13 @@ void wsyrk_glds_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
                 if (ch + 2 < nch) issue_stage(ch + 2, 0);
                 stage(std::integral_constant<int, 1>{});
             }
+        }
+        if (cypad) {                                           // the two row halves meet in LDS (the stage buffers are idle now)
+            lds[wave * WS_TILE + 2 * lane] = racc[0];
+            lds[wave * WS_TILE + 2 * lane + 1] = racc[1];
+            __syncthreads();
+            if (tid < 128)
+                rpart[((i64)split * nb + bi) * WS_TILE + tid] = (lds[tid] + lds[WS_TILE + tid]) + (lds[2 * WS_TILE + tid] + lds[3 * WS_TILE + tid]);
         }
         // lower-triangle blocks get the sums, the rest of the two block rows is zeroed (never read,
         // but kept finite for the split reduction / all-reduce)
@@ -1008,7 +1032,27 @@ void wsyrk_reduce_kernel(const double* __restrict__ partial, int n_splits, i64 t
     *reinterpret_cast<double2*>(tiles + e2) = make_double2(s0, s1);
 }
 
+// r[p] = sum_s rpart[s][p] (fixed order)
+__global__ void rpart_reduce_kernel(const double* __restrict__ rpart, int n_splits, i64 width, i64 P, double* __restrict__ r)
+{
+    const i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    double s = 0.0;
+    for (int k = 0; k < n_splits; ++k) s += rpart[(i64)k * width + p];
+    r[p] = s;
+}
+
+bool wsyrk_fast_path(const lrvb_ctx* c) {
+    return c->P > 64 && (c->P % 2) == 0 && ((((uintptr_t)c->X.p) & 15) == 0) && !c->force_generic_wsyrk;
+}
+
 int launch_wsyrk(lrvb_ctx* c, const double* cvec_dev, double* tiles_out_dev) {
+    return launch_wsyrk_r(c, cvec_dev, tiles_out_dev, nullptr, nullptr);
+}
+
+// cy_dev / r_out_dev non-null (fast path only): additionally r = X^T cy (P doubles), accumulated by the diagonal tiles
+int launch_wsyrk_r(lrvb_ctx* c, const double* cvec_dev, double* tiles_out_dev, const double* cy_dev, double* r_out_dev) {
+    if (cy_dev && !wsyrk_fast_path(c)) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "the column sums ride on the LDS-DMA SYRK kernel only");
     if (c->P <= 64 && !c->force_generic_wsyrk)       // cvec_dev carries zero padding past N (reserve_obs_vec)
         return launch_gram_small(c, cvec_dev, tiles_out_dev);
     const int T = wsyrk_num_tiles(c->P);
@@ -1017,14 +1061,17 @@ int launch_wsyrk(lrvb_ctx* c, const double* cvec_dev, double* tiles_out_dev) {
     rps = ((rps + WS_KC - 1) / WS_KC) * WS_KC;
     if (rps < WS_KC) rps = WS_KC;
     const i64 tile_elems = (i64)T * WS_TILE * WS_TILE;
-    LRVB_TRY(buf_reserve(c, c->tile_part, (size_t)(tile_elems * S)));
+    const int nbt = (int)((c->P + WS_TILE - 1) / WS_TILE);
+    const i64 rwidth = (i64)nbt * WS_TILE;
+    LRVB_TRY(buf_reserve(c, c->tile_part, (size_t)(tile_elems * S) + (size_t)(rwidth * S)));
+    double* rpart = c->tile_part.p + tile_elems * S;
     const i64 ldx = c->P;
     const int vec_ok = ((ldx % 2) == 0) && ((((uintptr_t)c->X.p) & 15) == 0);
     const int grid = S * T;
     if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
     if (vec_ok && c->P >= 2 && !c->force_generic_wsyrk)     // cvec_dev carries >= 32 zeros past N (reserve_obs_vec)
         hipLaunchKernelGGL(wsyrk_glds_kernel, dim3(grid), dim3(WS_THREADS), 0, c->stream,
-                           c->X.p, ldx, c->N, (int)c->P, cvec_dev, S, (int)((c->P + WS_TILE - 1) / WS_TILE), rps, c->tile_part.p);
+                           c->X.p, ldx, c->N, (int)c->P, cvec_dev, S, nbt, rps, c->tile_part.p, cy_dev, rpart);
     else if (vec_ok)
         hipLaunchKernelGGL(wsyrk_kernel<true>, dim3(grid), dim3(WS_THREADS), 0, c->stream,
                            c->X.p, ldx, c->N, (int)c->P, cvec_dev, S, T, rps, c->tile_part.p);
@@ -1037,6 +1084,11 @@ int launch_wsyrk(lrvb_ctx* c, const double* cvec_dev, double* tiles_out_dev) {
     hipLaunchKernelGGL(wsyrk_reduce_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, c->stream,
                        c->tile_part.p, S, tile_elems, tiles_out_dev);
     HIP_TRY(hipGetLastError());
+    if (cy_dev && r_out_dev) {
+        hipLaunchKernelGGL(rpart_reduce_kernel, dim3((unsigned)((c->P + 255) / 256)), dim3(256), 0, c->stream,
+                           rpart, S, rwidth, c->P, r_out_dev);
+        HIP_TRY(hipGetLastError());
+    }
     if (c->prof_on) {
         c->prof.wsyrk_flops = (double)c->N * (double)c->P * (double)(c->P + 1);
         c->prof.wsyrk_bytes = 8.0 * ((double)c->N * (double)(c->P + 1)) + 8.0 * 0.5 * (double)c->P * (double)(c->P + 1);

@@ -58,6 +58,7 @@ struct lrvb_ctx {
     // per-evaluation state (device)
     DevBuf theta, eta, j1, j2, vtmp, vtmp2, vtmp3, g_eta, g_free;
     DevBuf lp, cw, zbuf;            // per-observation: loss', w*loss'', linear predictor
+    DevBuf cyv, rvec;               // Gaussian shortcut: (c o y) per observation, r = X^T (c o y)
     DevBuf part_vec, part_val;     // fused-pass block partials
     DevBuf stats;                  // [value | g_glm (P) | S tiles]
     DevBuf tile_part;              // weighted-SYRK split partials
@@ -127,6 +128,8 @@ int launch_obs_grad(lrvb_ctx* c, i64 n0, i64 n1, double* G_dev, int mode, const 
 int  wsyrk_num_tiles(i64 P);
 int  wsyrk_auto_splits(const lrvb_ctx* c);
 int  launch_wsyrk(lrvb_ctx* c, const double* cvec_dev, double* tiles_out_dev /* T*128*128 */);
+bool wsyrk_fast_path(const lrvb_ctx* c);
+int  launch_wsyrk_r(lrvb_ctx* c, const double* cvec_dev, double* tiles_out_dev, const double* cy_dev /* nullable */, double* r_out_dev /* P */);
 int  launch_gram_small_on(lrvb_ctx* c, const double* Z, i64 N, i64 P, const double* cvec_dev, double* tiles_out_dev);
 int  launch_mixture_rows(lrvb_ctx* c, int K, const double* theta_z_dev, const double* lam_dev,
                          double* Amat_dev, i64 lda, double* U_dev, double* gfree_dev, double* val2_dev, int* bad_dev);

@@ -308,6 +308,53 @@ def test_sharded_engine_single_rank_matches_direct_build(vb):
     assert rel_err(unpack_tiles(st[o_t:], P), x.T @ ((w * l2)[:, None] * x)) < TOL
 
 
+@pytest.mark.parametrize('N,P', [(5000, 300), (777, 130), (40000, 1024)])
+def test_gaussian_build_reads_x_once(vb, N, P):
+    """Gaussian loss: the curvature w tau does not depend on theta, so the build forms the gradient of the data term
+    from the SYRK's own sums, d f / d beta = S beta - X^T (c o y) (the column sums ride on the diagonal tiles), and runs
+    NO separate pass over X.  The statistics buffer [value | gradient | tiles] must equal the oracle's sums, the pass
+    route (forced through the register-staged kernel, tuning bit 0) must give the same Hessian, and the profile must
+    show zero pass launches for the Gaussian build and one for a logistic build."""
+    import torch
+    from lrvb_amd.distributed import DeviceEngine, unpack_tiles, stats_layout
+    rng = np.random.default_rng(N + P)
+    p1 = P // 3
+    spec = [('box', 'u', P - p1, -np.inf, np.inf), ('box', 'pos', p1, 0.0, np.inf)]
+    par, lay = make_par(vb, spec)
+    x, y, w = glm_data(rng, N, P, om.GAUSSIAN)
+    y = x @ rng.normal(size=P) + 0.3 * rng.normal(size=N)          # a response the model fits: S beta and r nearly cancel
+    fun = vb.GLMObjective(par, x, y, loss='gaussian', lik_info=1.7, prior_info=0.3, weights=w)
+    model = om.DeclaredModel(lay, loss=om.GAUSSIAN, x=x, y=y, w=w, lik_info=1.7, quad_A=np.full(P, 0.3))
+    theta = rng.normal(size=P) * 0.2
+    dev = torch.device('cuda', 0)
+    th = torch.tensor(theta, device=dev)
+    ctx = fun.ctx
+    ctx.profile_enable(True); ctx.profile_reset()
+    st = DeviceEngine(ctx, dev).partial(th).cpu().numpy()
+    ctx.set_stream(None)
+    assert ctx.profile_get()['pass_calls'] == 0 and ctx.profile_get()['wsyrk_calls'] == 1
+    o_val, o_g, o_t, total = stats_layout(P)
+    eta = lay.constrain(theta)
+    l0, l1, l2 = om.loss_terms(om.GAUSSIAN, y, x @ eta, 1.7)
+    S = x.T @ ((w * l2)[:, None] * x)
+    assert rel_err(unpack_tiles(st[o_t:], P), S) < TOL
+    # the gradient is a difference of two O(N) sums: tolerance relative to the sums, not to the (small) difference
+    scale = max(np.max(np.abs(S @ eta)), np.max(np.abs(x.T @ (w * 1.7 * y))))
+    assert np.max(np.abs(st[o_g:o_t] - x.T @ (w * l1))) < 1e-12 * scale
+    assert abs(st[o_val] - np.sum(w * l0)) < 1e-11 * np.sum(w * 1.7 * y * y)
+    H = ctx.hessian(theta)
+    assert rel_err(H, model.hessian(theta)) < TOL
+    ctx.set_tuning(0, 1)                                            # register-staged SYRK: the pass route
+    ctx.profile_reset()
+    H_pass = ctx.hessian(theta)
+    assert ctx.profile_get()['pass_calls'] == 1
+    ctx.set_tuning(0, 0)
+    ctx.profile_enable(False)
+    assert rel_err(H, H_pass) < 1e-12
+    obj = vb.Objective(par, fun)
+    assert rel_err(obj.fun_free_grad(theta), model.grad(theta)) < TOL     # the gradient entry point still runs the pass
+
+
 def test_full_size_properties_headline_shape(vb):
     """Size-independent properties at the BASELINE.json shape (D = 1024) with N reduced to what the
     oracle-free checks need: symmetry, linearity in the weights, H v == HVP, G^T G PSD, and the

@@ -33,7 +33,7 @@ for s, flags in [(s, f) for s in splits for f in flag_list]:
     print('flags=0x%x ' % flags, end='')
     print('splits=%d build %.3f ms  wsyrk %.3f ms (%.1f TF/s, %.1f%% of 78.6)  pass %.3f ms (%.2f TB/s)' % (
         s, (t1 - t0) / K * 1e3, ws, p['wsyrk_flops'] / ws / 1e9, p['wsyrk_flops'] / ws / 1e9 / 78.6 * 100, ps,
-        p['pass_bytes'] / ps / 1e9), flush=True)
+        (p['pass_bytes'] / ps / 1e9) if ps > 0 else 0.0), flush=True)
 ctx.set_tuning(0, 0)
 ctx.hessian_dev(theta.data_ptr(), H.data_ptr(), P); ctx.sync()
 # hvp timing
