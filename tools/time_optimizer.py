@@ -28,3 +28,19 @@ for rep in range(2):
 print('scipy + device callbacks: %.1f ms, nit %d, nfev %d, njev %d, nhev %d, f = %.6f' % ((t1 - t0) * 1e3, res.nit, res.nfev, res.njev, res.nhev, res.fun))
 print('device loop:              %.1f ms, nit %d, nfev %d, njev %d, nhev %d, f = %.6f' % ((t2 - t1) * 1e3, info['nit'], info['nfev'], info['njev'], info['nhev'], info['fun']))
 print('max |x_dev - x_scipy| = %.2e' % np.max(np.abs(xd - res.x)))
+# the preconditioned route of the reference (`set_objective_preconditioner` + the `_cond` family, LRVB/OptimizationUtils.py:25-41,
+# SparseObjectives.py:202-240, restarted as `repeatedly_optimize` does, :114-162): a few plain iterations, then A = H^-1/2 from ONE
+# device Hessian at that point (eigenvalues clamped from below), then the same device loop in y-coordinates (x = A y)
+t3 = time.perf_counter()
+_, x1, info1 = ctx.minimize_trust_ncg(x0, gtol=1e-4, maxiter=8)
+t4 = time.perf_counter()
+H1 = ctx.hessian(x1)
+lam, Q = np.linalg.eigh(0.5 * (H1 + H1.T))
+lam = np.clip(lam, 1e-3 * lam.max(), None)
+A = (Q / np.sqrt(lam)) @ Q.T
+t5 = time.perf_counter()
+yc, xc, infoc = ctx.minimize_trust_ncg(np.linalg.solve(A, x1), precond=A, gtol=1e-4, maxiter=100)
+t6 = time.perf_counter()
+print('restarted with a preconditioner: 8 plain iterations %.1f ms (nhev %d) + Hessian and eigh (host) %.1f ms + preconditioned fit %.1f ms '
+      '(nit %d, nhev %d), f = %.6f, max |x - x_plain| = %.2e'
+      % ((t4 - t3) * 1e3, info1['nhev'], (t5 - t4) * 1e3, (t6 - t5) * 1e3, infoc['nit'], infoc['nhev'], infoc['fun'], np.max(np.abs(xc - xd))))
