@@ -673,18 +673,22 @@ void atb_glds_kernel(const double* __restrict__ A, i64 lda, int PA, const double
     int ca = bi * WS_TILE + 2 * lane; if (ca > PA - 2) ca = PA - 2;
     int cb = bj * WS_TILE + 2 * lane; if (cb > PB - 2) cb = PB - 2;
 
+    // scalar row bases + constant 32-bit lane offsets, as in wsyrk_glds_kernel: a stage issues no VALU instruction
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) double*)lds;
+    const unsigned voffA = (unsigned)ca * 8u, voffB = (unsigned)cb * 8u, voffC = (unsigned)lane * 4u;
     auto issue_stage = [&](int ch, int buf) {
-        double* base = lds + buf * WS_BUF;
+        const unsigned base = lds0 + (unsigned)(buf * WS_BUF) * 8u;
         const i64 n0 = r0 + (i64)ch * WS_KC;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = wave + 4 * i;
-            i64 n = n0 + row; if (n > N - 1) n = N - 1;
-            WS_GLDS16(A + n * lda + ca, base + row * WS_LDS_STRIDE);
-            WS_GLDS16(B + n * ldb + cb, base + WS_PANEL + row * WS_LDS_STRIDE);
+            i64 n = n0 + row; if (n > N - 1) n = N - 1;                 // wave-uniform clamp (scalar)
+            const unsigned la = base + (unsigned)(row * WS_LDS_STRIDE) * 8u;
+            WS_GLDS16_S(reinterpret_cast<const char*>(A + n * lda), voffA, la);
+            WS_GLDS16_S(reinterpret_cast<const char*>(B + n * ldb), voffB, la + (unsigned)WS_PANEL * 8u);
         }
         if (wave == 0)
-            WS_GLDS4(reinterpret_cast<const float*>(cpad + n0) + lane, base + 2 * WS_PANEL);
+            WS_GLDS4_S(reinterpret_cast<const char*>(cpad + n0), voffC, base + (unsigned)(2 * WS_PANEL) * 8u);
     };
     if (nch > 0) issue_stage(0, 0);
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): LDS-DMA of the stage has landed
@@ -697,10 +701,65 @@ void atb_glds_kernel(const double* __restrict__ A, i64 lda, int PA, const double
     int mt_b = (PB - bj * WS_TILE - wc * 64 + 15) / 16; mt_b = mt_b < 0 ? 0 : (mt_b > 4 ? 4 : mt_b);
     mt_a = __builtin_amdgcn_readfirstlane(mt_a); mt_b = __builtin_amdgcn_readfirstlane(mt_b);
     const bool full = (mt_a == 4) && (mt_b == 4);
-    // the chunk loop exists twice: interior workgroups run the unguarded copy (guards inside one loop made hipcc
-    // spill the accumulators)
-    auto run = [&](auto edge_tag) {
-    constexpr bool EDGE = decltype(edge_tag)::value;
+    double* out = partial + ((i64)split * T + t) * (i64)(WS_TILE * WS_TILE);
+    if (full) {
+        // interior tile: the loop of wsyrk_glds_kernel's off-diagonal tiles -- wave w owns rows [32 w, 32 w + 32) x all 128
+        // columns (2 scaling multiplies per k-step), 16-byte LDS reads, stage loop unrolled over the two buffers with
+        // loop-invariant addresses
+        const double* a_base = lds + l4 * WS_LDS_STRIDE + 32 * wave + 2 * l15;
+        const double* b_base = lds + WS_PANEL + l4 * WS_LDS_STRIDE + 2 * l15;
+        const double* c_base = lds + 2 * WS_PANEL + l4;
+        auto stage = [&](auto buf_tag) {
+            constexpr int BUF = decltype(buf_tag)::value;
+            double af[2][2], bf[2][8], cv[2];
+            auto read_frags = [&](int kk, int set) {
+                const int o = BUF * WS_BUF + kk * 4 * WS_LDS_STRIDE;
+                cv[set] = c_base[BUF * WS_BUF + kk * 4];
+                const d2 va = *reinterpret_cast<const d2*>(a_base + o);
+                af[set][0] = va[0]; af[set][1] = va[1];
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const d2 vb = *reinterpret_cast<const d2*>(b_base + o + 32 * h);
+                    bf[set][2 * h] = vb[0]; bf[set][2 * h + 1] = vb[1];
+                }
+            };
+            read_frags(0, 0);
+#pragma unroll
+            for (int kk = 0; kk < WS_KC / 4; ++kk) {
+                const int set = kk & 1;
+                const double as0 = af[set][0] * cv[set], as1 = af[set][1] * cv[set];
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk + 1 < WS_KC / 4) read_frags(kk + 1, set ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(as0, bf[set][n], acc[n], 0, 0, 0);
+                    acc[8 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(as1, bf[set][n], acc[8 + n], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70); __syncthreads();
+        };
+        for (int ch = 0; ch < nch; ch += 2) {
+            if (ch + 1 < nch) issue_stage(ch + 1, 1);
+            stage(std::integral_constant<int, 0>{});
+            if (ch + 1 < nch) {
+                if (ch + 2 < nch) issue_stage(ch + 2, 0);
+                stage(std::integral_constant<int, 1>{});
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 8; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    out[(32 * wave + 2 * (l4 + 4 * r) + m) * WS_TILE + 32 * (n >> 1) + 2 * l15 + (n & 1)] = acc[m * 8 + n][r];
+        return;
+    }
+    // ragged edge of the operand widths (e.g. 528 = 4 x 128 + 16 columns): 64 x 64 wave tiles in plain 16-column blocks,
+    // MFMA tiles that lie wholly past the last column are skipped (wave-uniform), so an edge workgroup costs its loads
+    // and little else (the paired-column mapping of the interior loop would keep twice as many tiles alive here)
     int buf = 0;
     for (int ch = 0; ch < nch; ++ch) {
         if (ch + 1 < nch) issue_stage(ch + 1, buf ^ 1);
@@ -726,31 +785,18 @@ void atb_glds_kernel(const double* __restrict__ A, i64 lda, int PA, const double
             __builtin_amdgcn_sched_barrier(0);
             if (kk + 1 < WS_KC / 4) read_frags(kk + 1, set ^ 1);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!EDGE) {
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < 4; ++m)
 #pragma unroll
-                    for (int n = 0; n < 4; ++n)
+                for (int n = 0; n < 4; ++n)
+                    if (m < mt_a && n < mt_b)
                         acc[m * 4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[m], bf[set][n], acc[m * 4 + n], 0, 0, 0);
-            } else {
-                // ragged edge of the operand widths (e.g. 528 = 4 x 128 + 16 columns): MFMA tiles that lie wholly past
-                // the last column are skipped (wave-uniform), so an edge workgroup costs its loads and little else
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int n = 0; n < 4; ++n)
-                        if (m < mt_a && n < mt_b)
-                            acc[m * 4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[m], bf[set][n], acc[m * 4 + n], 0, 0, 0);
-            }
             __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): LDS-DMA of the stage has landed
         __syncthreads();
         buf ^= 1;
     }
-    };
-    if (full) run(std::false_type{}); else run(std::true_type{});
-    double* out = partial + ((i64)split * T + t) * (i64)(WS_TILE * WS_TILE);
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
