@@ -446,11 +446,19 @@ def main(args):
         ctx.set_tuning(args.n_splits)
 
     H = torch.empty((D, D), dtype=torch.float64, device=dev)
-    engine = DeviceEngine(ctx, dev) if use_dist else None
-    sharded = ShardedHessian(engine) if use_dist else None
+    # LRVB_BENCH_NATIVE_RCCL=1: the exchange runs inside the library (lrvb_comm_init: its own RCCL communicator, the id
+    # carried by the process group) and a step is the single call lrvb_hessian_dev; default: torch.distributed's
+    # all-reduce of the statistics buffer between lrvb_hessian_partial_dev and lrvb_hessian_finish_dev
+    native = use_dist and backend == 'nccl' and os.environ.get('LRVB_BENCH_NATIVE_RCCL', '0') == '1'
+    if native:
+        from lrvb_amd.distributed import native_comm_init
+        ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        native_comm_init(ctx)
+    engine = DeviceEngine(ctx, dev) if (use_dist and not native) else None
+    sharded = ShardedHessian(engine) if (use_dist and not native) else None
 
     def step():
-        if not use_dist:
+        if not use_dist or native:
             ctx.hessian_dev(theta.data_ptr(), H.data_ptr(), D)
             return H
         return sharded.build(theta)
@@ -512,7 +520,7 @@ def main(args):
                                'Hessian build'.format(args.loss, N_total, D, n_pos),
                    'n_obs_total': N_total, 'n_obs_per_gpu': n_local, 'n_free': D,
                    'ranks_seen': dist.get_world_size() if use_dist else 1,
-                   'backend': backend if use_dist else 'none (single process)',
+                   'backend': (backend + (' (in-library communicator)' if native else '')) if use_dist else 'none (single process)',
                    'parallelism': 'observation shards x{} + 1 sum all-reduce per build'.format(world)},
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP64_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': achieved / PEAK_FP64_MFMA_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_src,

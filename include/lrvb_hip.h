@@ -345,6 +345,18 @@ int lrvb_hessian_dev(lrvb_ctx* ctx, const double* free_dev, double* H_dev, int64
  * fn == NULL removes the hook.                                                                                */
 typedef int (*lrvb_reduce_fn)(void* user, double* buf_dev, int64_t n, void* hip_stream);
 int lrvb_set_reduce_hook(lrvb_ctx* ctx, lrvb_reduce_fn fn, void* user);
+
+/* In-library collective (lrvb_comm_init / lrvb_allreduce_hessian), one process per GPU:
+ * rank 0 obtains an id with lrvb_comm_unique_id and hands the 128 bytes to the other ranks by any channel; every rank
+ * calls lrvb_comm_init(ctx, world_size, rank, &id) (collective: returns when all ranks have joined), which creates its
+ * rank of ONE RCCL communicator on the context's device and installs it as the sum-over-ranks hook above (in-place
+ * ncclAllReduce of doubles on the context's stream, RCCL over xGMI).  lrvb_allreduce_hessian sums a statistics buffer
+ * of lrvb_hessian_partial_dev explicitly.  librccl is loaded at run time (dlopen), not linked.                     */
+typedef struct lrvb_comm_id { char bytes[128]; } lrvb_comm_id;
+int lrvb_comm_unique_id(lrvb_comm_id* id_out);
+int lrvb_comm_init(lrvb_ctx* ctx, int world_size, int rank, const lrvb_comm_id* id);
+int lrvb_comm_destroy(lrvb_ctx* ctx);
+int lrvb_allreduce_hessian(lrvb_ctx* ctx, double* stats_dev, int64_t n_doubles);
 int lrvb_hvp_dev    (lrvb_ctx* ctx, const double* free_dev, const double* v_dev, double* out_dev);
 int lrvb_gram_dev   (lrvb_ctx* ctx, const double* free_dev, double* GtG_dev, int64_t ld);
 

@@ -115,6 +115,10 @@ _SIGNATURES = {
     'lrvb_profile_reset': [_VP],
     'lrvb_set_tuning': [_VP, ctypes.c_int, ctypes.c_int],
     'lrvb_set_reduce_hook': [_VP, _VP, _VP],
+    'lrvb_comm_unique_id': [_VP],
+    'lrvb_comm_init': [_VP, ctypes.c_int, ctypes.c_int, _VP],
+    'lrvb_comm_destroy': [_VP],
+    'lrvb_allreduce_hessian': [_VP, _VP, c_i64],
 }
 
 # lrvb_reduce_fn of include/lrvb_hip.h: int fn(void* user, double* buf_dev, int64_t n, void* hip_stream)

@@ -52,6 +52,8 @@ void buf_free(DevBuf& b) {
     b.p = nullptr; b.n = 0; b.owned = true;
 }
 
+static void comm_release(lrvb_ctx* c);      // destroys the context's RCCL communicator, if any (defined with the RCCL loader)
+
 static int ctx_bind(lrvb_ctx* c) {
     if (!c) LRVB_FAIL(LRVB_ERR_INVALID, "null context");
     c->hvp_pt_valid = false;
@@ -168,6 +170,7 @@ extern "C" int lrvb_ctx_destroy(lrvb_ctx* c) {
     if (!c) return LRVB_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    comm_release(c);
     DevBuf* all[] = { &c->X, &c->y, &c->w, &c->quadA, &c->quadM, &c->quadB, &c->theta, &c->eta, &c->j1, &c->j2,
                       &c->vtmp, &c->vtmp2, &c->vtmp3, &c->g_eta, &c->g_free, &c->lp, &c->cw, &c->zbuf,
                       &c->part_vec, &c->part_val, &c->stats, &c->tile_part, &c->Heta, &c->Hfree, &c->Jdense,
@@ -359,6 +362,86 @@ extern "C" int lrvb_set_reduce_hook(lrvb_ctx* c, lrvb_reduce_fn fn, void* user) 
     if (!c) LRVB_FAIL(LRVB_ERR_INVALID, "null context");
     c->hvp_pt_valid = false;
     c->reduce_fn = fn; c->reduce_user = fn ? user : nullptr;
+    return LRVB_OK;
+}
+
+// ---- in-library collective: RCCL, loaded at run time --------------------------------------------------------------
+// One process per GPU; the ranks of the job exchange a 128-byte id out of band (any channel: the Python layer uses
+// torch.distributed's store) and each creates its rank of ONE RCCL communicator here.  The communicator then serves
+// as the native sum-over-ranks hook (ncclAllReduce on the context's stream, in place) and behind
+// lrvb_allreduce_hessian.  librccl is dlopen'ed by soname -- if the process has already mapped a copy (torch's), that
+// copy is used -- so liblrvb_hip.so keeps its single link dependency (libamdhip64).
+#include <dlfcn.h>
+namespace {
+struct RcclApi {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, lrvb_comm_id, int) = nullptr;      // ncclUniqueId is a 128-byte struct passed by value
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+int rccl_load() {
+    if (g_rccl.lib) return LRVB_OK;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "librccl.so.1 cannot be loaded: %s", dlerror());
+    g_rccl.GetUniqueId = (int (*)(void*))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (int (*)(void**, int, lrvb_comm_id, int))dlsym(h, "ncclCommInitRank");
+    g_rccl.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+    g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclAllReduce");
+    g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce)
+        LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "librccl lacks an expected entry point");
+    g_rccl.lib = h;
+    return LRVB_OK;
+}
+#define RCCL_TRY(expr) do { int r_ = (expr); if (r_ != 0) { \
+    lrvb_set_error("%s failed: %s", #expr, g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "rccl error"); return LRVB_ERR_HIP; } } while (0)
+int native_reduce(void* user, double* buf, int64_t n, void* stream) {
+    lrvb_ctx* c = static_cast<lrvb_ctx*>(user);
+    // ncclSum = 0, ncclDouble = 8 (rccl.h)
+    return g_rccl.AllReduce(buf, buf, (size_t)n, 8, 0, c->comm, (hipStream_t)stream);
+}
+}  // namespace
+
+static void comm_release(lrvb_ctx* c) {
+    if (c->comm && g_rccl.CommDestroy) { (void)g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
+}
+
+extern "C" int lrvb_comm_unique_id(lrvb_comm_id* id_out) {
+    if (!id_out) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    LRVB_TRY(rccl_load());
+    RCCL_TRY(g_rccl.GetUniqueId(id_out));
+    return LRVB_OK;
+}
+extern "C" int lrvb_comm_init(lrvb_ctx* c, int world_size, int rank, const lrvb_comm_id* id) {
+    LRVB_TRY(ctx_bind(c));
+    if (!id || world_size < 1 || rank < 0 || rank >= world_size) LRVB_FAIL(LRVB_ERR_INVALID, "bad communicator arguments");
+    if (c->comm) LRVB_FAIL(LRVB_ERR_STATE, "this context already has a communicator");
+    LRVB_TRY(rccl_load());
+    RCCL_TRY(g_rccl.CommInitRank(&c->comm, world_size, *id, rank));
+    c->comm_world = world_size; c->comm_rank = rank;
+    c->reduce_fn = native_reduce; c->reduce_user = c;              // every observation sum now goes through RCCL
+    return LRVB_OK;
+}
+extern "C" int lrvb_comm_destroy(lrvb_ctx* c) {
+    if (!c) LRVB_FAIL(LRVB_ERR_INVALID, "null context");
+    if (!c->comm) return LRVB_OK;
+    (void)hipSetDevice(c->device);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->reduce_fn == native_reduce) { c->reduce_fn = nullptr; c->reduce_user = nullptr; }
+    RCCL_TRY(g_rccl.CommDestroy(c->comm));
+    c->comm = nullptr; c->comm_world = 1; c->comm_rank = 0;
+    c->hvp_pt_valid = false;
+    return LRVB_OK;
+}
+extern "C" int lrvb_allreduce_hessian(lrvb_ctx* c, double* stats_dev, int64_t n) {
+    LRVB_TRY(ctx_bind(c));
+    if (!stats_dev || n < 0) LRVB_FAIL(LRVB_ERR_INVALID, "bad argument");
+    if (!c->comm) LRVB_FAIL(LRVB_ERR_STATE, "no communicator: call lrvb_comm_init first");
+    RCCL_TRY(native_reduce(c, stats_dev, n, (void*)c->stream));
     return LRVB_OK;
 }
 

@@ -50,6 +50,7 @@ struct lrvb_ctx {
 
     // sum-over-ranks hook (lrvb_set_reduce_hook): null = single process
     lrvb_reduce_fn reduce_fn = nullptr; void* reduce_user = nullptr;
+    void* comm = nullptr; int comm_world = 1, comm_rank = 0;          // RCCL communicator of lrvb_comm_init (ncclComm_t)
 
     // resident data
     DevBuf X, y, w, quadA, quadM, quadB;

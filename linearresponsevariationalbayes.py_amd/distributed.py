@@ -96,6 +96,19 @@ def torch_reduce_hook(torch_device, group=None):
     return hook
 
 
+def native_comm_init(ctx, group=None):
+    """Create this rank's part of an in-library RCCL communicator for `ctx` (lrvb_comm_init): rank 0 draws the id, the
+    process group (any backend) carries its 128 bytes to the other ranks.  Afterwards every observation sum of the
+    declared-objective entry points is all-reduced inside the library, with no torch tensor in the data path."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    box = [type(ctx).comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    ctx.comm_init(world, rank, box[0])
+    return world, rank
+
+
 class ShardedObjective(object):
     """Value, gradient, Hessian-vector products, CG solves and trust-ncg fits of an objective whose observations
     are sharded over the ranks of a process group ("one D-vector all-reduce per CG

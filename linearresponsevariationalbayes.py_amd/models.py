@@ -110,6 +110,28 @@ class DeviceContext(object):
         self._hook_cb = _hip.REDUCE_FN(trampoline)      # keep the callback object alive as long as it is installed
         self._check(self._lib.lrvb_set_reduce_hook(self._h, ctypes.cast(self._hook_cb, ctypes.c_void_p), None))
 
+    # -- in-library RCCL communicator (one process per GPU) ------------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes naming a new communicator (rank 0 creates them, every rank passes the same bytes to comm_init)."""
+        buf = ctypes.create_string_buffer(128)
+        _hip.check(_hip.load().lrvb_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p)))
+        return buf.raw
+
+    def comm_init(self, world_size, rank, comm_id):
+        """Join the communicator (collective) and make it this context's sum-over-ranks hook."""
+        if len(comm_id) != 128:
+            raise ValueError('a communicator id has 128 bytes')
+        buf = ctypes.create_string_buffer(bytes(comm_id), 128)
+        self._hook_cb = None
+        self._check(self._lib.lrvb_comm_init(self._h, int(world_size), int(rank), ctypes.cast(buf, ctypes.c_void_p)))
+
+    def comm_destroy(self):
+        self._check(self._lib.lrvb_comm_destroy(self._h))
+
+    def allreduce_hessian(self, stats_ptr, n):
+        self._check(self._lib.lrvb_allreduce_hessian(self._h, ctypes.c_void_p(stats_ptr), int(n)))
+
     def _check(self, status):
         """_hip.check, re-raising an exception that the reduce hook raised inside the call."""
         err = getattr(self, '_hook_error', None)

@@ -181,6 +181,53 @@ def test_hook_over_a_one_rank_group_and_hook_errors(tmp_path):
             dist.destroy_process_group()
 
 
+def test_in_library_rccl_communicator_one_rank():
+    """lrvb_comm_unique_id / lrvb_comm_init / lrvb_allreduce_hessian / lrvb_comm_destroy: the RCCL communicator inside the
+    library (librccl dlopen'ed, no torch tensor in the data path).  RCCL refuses two ranks on one device, so this box can
+    only run a ONE-rank communicator: every collective really is launched on the context's stream (ncclAllReduce in place,
+    identity for one rank), results equal the unsharded oracle, and the error paths hold."""
+    import torch
+    import lrvb_amd as vb
+    N, P, x, y, w, theta, v, B = _problem()
+    par = vb.ModelParamsDict('par')
+    par.push_param(vb.VectorParam('u', 100)); par.push_param(vb.VectorParam('pos', P - 100, lb=0.0))
+    fun = vb.DeviceObjective(par, x=x, y=y, loss='logistic', quad_A=np.full(P, 0.9), weights=w)
+    fun._push_state()
+    ctx = fun.ctx
+    full = om.DeclaredModel(_layout(P), loss=om.LOGISTIC, x=x, y=y, w=w, quad_A=np.full(P, 0.9))
+    with pytest.raises(RuntimeError):                         # no communicator yet
+        ctx.allreduce_hessian(0, 1)
+    cid = vb.DeviceContext.comm_unique_id()
+    assert len(cid) == 128 and any(cid)
+    ctx.comm_init(1, 0, cid)
+    with pytest.raises(RuntimeError):
+        ctx.comm_init(1, 0, cid)                              # one communicator per context
+    with pytest.raises(ValueError):
+        ctx.comm_init(2, 5, cid)
+    H = full.hessian(theta)
+    assert abs(ctx.value(theta) - full.value(theta)) < 1e-12 * abs(full.value(theta))
+    np.testing.assert_allclose(ctx.hvp(theta, v), H @ v, rtol=1e-11, atol=1e-12)
+    assert np.max(np.abs(ctx.hessian(theta) - H)) < 1e-11 * np.max(np.abs(H))
+    sol, info, _ = ctx.cg_solve(theta, B[0], tol=1e-10)
+    assert info == 0
+    np.testing.assert_allclose(sol, np.linalg.solve(H, B[0]), rtol=1e-7, atol=1e-9)
+    # the explicit form on a statistics buffer: partial -> lrvb_allreduce_hessian -> finish
+    dev = torch.device('cuda', 0)
+    th = torch.tensor(theta, device=dev)
+    stats = torch.empty(ctx.stats_size(), dtype=torch.float64, device=dev)
+    Hd = torch.empty((P, P), dtype=torch.float64, device=dev)
+    ctx.hessian_partial_dev(th.data_ptr(), stats.data_ptr())
+    before = stats.clone()
+    ctx.allreduce_hessian(stats.data_ptr(), stats.numel())
+    ctx.hessian_finish_dev(th.data_ptr(), stats.data_ptr(), Hd.data_ptr(), P)
+    ctx.sync()
+    assert torch.equal(stats, before)                         # one rank: the sum over ranks is the buffer itself
+    assert np.max(np.abs(Hd.cpu().numpy() - H)) < 1e-11 * np.max(np.abs(H))
+    ctx.comm_destroy()
+    ctx.comm_destroy()                                        # idempotent
+    np.testing.assert_allclose(ctx.grad(theta), full.grad(theta), rtol=1e-11, atol=1e-12)
+
+
 def _bench_line(extra_args, env_extra):
     env = dict(os.environ, **env_extra)
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + extra_args, env=env, capture_output=True,
