@@ -195,8 +195,12 @@ def test_in_library_rccl_communicator_one_rank():
     fun._push_state()
     ctx = fun.ctx
     full = om.DeclaredModel(_layout(P), loss=om.LOGISTIC, x=x, y=y, w=w, quad_A=np.full(P, 0.9))
+    dev = torch.device('cuda', 0)
+    probe = torch.zeros(4, dtype=torch.float64, device=dev)
+    with pytest.raises(ValueError):
+        ctx.allreduce_hessian(0, 1)                           # null buffer
     with pytest.raises(RuntimeError):                         # no communicator yet
-        ctx.allreduce_hessian(0, 1)
+        ctx.allreduce_hessian(probe.data_ptr(), 4)
     cid = vb.DeviceContext.comm_unique_id()
     assert len(cid) == 128 and any(cid)
     ctx.comm_init(1, 0, cid)
@@ -212,7 +216,6 @@ def test_in_library_rccl_communicator_one_rank():
     assert info == 0
     np.testing.assert_allclose(sol, np.linalg.solve(H, B[0]), rtol=1e-7, atol=1e-9)
     # the explicit form on a statistics buffer: partial -> lrvb_allreduce_hessian -> finish
-    dev = torch.device('cuda', 0)
     th = torch.tensor(theta, device=dev)
     stats = torch.empty(ctx.stats_size(), dtype=torch.float64, device=dev)
     Hd = torch.empty((P, P), dtype=torch.float64, device=dev)
