@@ -223,6 +223,50 @@ void pass_reduce_kernel(const double* __restrict__ part_vec, const double* __res
     }
 }
 
+// First level for many block partials: workgroup g adds the ROWS [16 g, 16 g + 16) of part_vec, all P columns -- every
+// load a contiguous run of the row (the column-strided walk of pass_reduce_kernel over 2048 rows of 8 KiB touched a new
+// page with every load: 32 us for 16 MB, whatever the number of workgroups).  scratch[g][P]; fixed order.
+__global__ __launch_bounds__(512)
+void pass_reduce_rows_kernel(const double* __restrict__ part_vec, int nblk, int P, double* __restrict__ scratch)
+{
+    const int b0 = blockIdx.x * 16;
+    for (int col = threadIdx.x; col < P; col += 512) {
+        double v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = (b0 + k < nblk) ? part_vec[(i64)(b0 + k) * P + col] : 0.0;
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += v[k];
+        scratch[(i64)blockIdx.x * P + col] = s;
+    }
+}
+
+// the fixed-order reduction of nblk block partials (vector part: P columns; value part: out_val != NULL)
+static int launch_pass_reduce(lrvb_ctx* c, int nblk, int P, double* out_vec, double* out_val) {
+    const int nbx = P > 0 ? (P + 63) / 64 : 1;
+    if (P > 0 && nblk >= 256) {
+        const int ng = (nblk + 15) / 16;
+        LRVB_TRY(buf_reserve(c, c->red_scratch, (size_t)ng * (size_t)P));
+        hipLaunchKernelGGL(pass_reduce_rows_kernel, dim3((unsigned)ng), dim3(512), 0, c->stream,
+                           (const double*)c->part_vec.p, nblk, P, c->red_scratch.p);
+        HIP_TRY(hipGetLastError());
+        // second level over the ng group sums; the value partials (one per ORIGINAL block) are summed by its first workgroup
+        hipLaunchKernelGGL(pass_reduce_kernel, dim3((unsigned)nbx), dim3(512), 0, c->stream,
+                           (const double*)c->red_scratch.p, (const double*)c->part_val.p, ng, P, out_vec, (double*)nullptr);
+        HIP_TRY(hipGetLastError());
+        if (out_val) {
+            hipLaunchKernelGGL(pass_reduce_kernel, dim3(1), dim3(512), 0, c->stream,
+                               (const double*)c->part_vec.p, (const double*)c->part_val.p, nblk, 0, out_vec, out_val);
+            HIP_TRY(hipGetLastError());
+        }
+        return LRVB_OK;
+    }
+    hipLaunchKernelGGL(pass_reduce_kernel, dim3((unsigned)nbx), dim3(512), 0, c->stream,
+                       (const double*)c->part_vec.p, (const double*)c->part_val.p, nblk, P, out_vec, out_val);
+    HIP_TRY(hipGetLastError());
+    return LRVB_OK;
+}
+
 template <int NIT>
 static int launch_pass_nit(lrvb_ctx* c, PassMode mode, const double* beta, const double* u,
                            int grid, int vec_ok, int store_obs) {
@@ -352,14 +396,9 @@ static int launch_glm_pass_wide(lrvb_ctx* c, PassMode mode, const double* beta, 
     if (c->prof_on && mode == PASS_GRAD) LRVB_TRY(prof_mark(c, PROF_PASS));
     // the value partials are per block of the FIRST kernel, the vector partials per row block of the second:
     // two calls of the fixed-order reduction
-    hipLaunchKernelGGL(pass_reduce_kernel, dim3((unsigned)((c->P + 63) / 64)), dim3(512), 0, c->stream,
-                       c->part_vec.p, c->part_val.p, (int)nblk, (int)c->P, out_vec_P, (double*)nullptr);
-    HIP_TRY(hipGetLastError());
-    if (mode == PASS_GRAD && value_out_dev) {
-        hipLaunchKernelGGL(pass_reduce_kernel, dim3(1), dim3(512), 0, c->stream,
-                           c->part_vec.p, c->part_val.p, (int)grid1, 0, out_vec_P, value_out_dev);
-        HIP_TRY(hipGetLastError());
-    }
+    LRVB_TRY(launch_pass_reduce(c, (int)nblk, (int)c->P, out_vec_P, nullptr));
+    if (mode == PASS_GRAD && value_out_dev)
+        LRVB_TRY(launch_pass_reduce(c, (int)grid1, 0, out_vec_P, value_out_dev));
     if (c->prof_on && mode == PASS_GRAD) c->prof.pass_bytes = 2.0 * 8.0 * (double)c->N * (double)(c->P + 3);
     return LRVB_OK;
 }
@@ -387,10 +426,7 @@ int launch_glm_pass(lrvb_ctx* c, PassMode mode, const double* beta_dev, const do
     else                  st = launch_pass_nit<8>(c, mode, beta_dev, u_dev, (int)grid, vec_ok, so);
     LRVB_TRY(st);
     if (c->prof_on && mode == PASS_GRAD) LRVB_TRY(prof_mark(c, PROF_PASS));
-    hipLaunchKernelGGL(pass_reduce_kernel, dim3((unsigned)((c->P + 63) / 64)), dim3(512), 0, c->stream,
-                       c->part_vec.p, c->part_val.p, (int)grid, (int)c->P, out_vec_P,
-                       (mode == PASS_GRAD) ? value_out_dev : (double*)nullptr);
-    HIP_TRY(hipGetLastError());
+    LRVB_TRY(launch_pass_reduce(c, (int)grid, (int)c->P, out_vec_P, (mode == PASS_GRAD) ? value_out_dev : nullptr));
     if (c->prof_on && mode == PASS_GRAD) {
         c->prof.pass_bytes = 8.0 * (double)c->N * (double)(c->P + 3);
     }

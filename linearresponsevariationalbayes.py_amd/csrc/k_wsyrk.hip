@@ -1078,14 +1078,28 @@ void wsyrk_reduce_kernel(const double* __restrict__ partial, int n_splits, i64 t
     *reinterpret_cast<double2*>(tiles + e2) = make_double2(s0, s1);
 }
 
-// r[p] = sum_s rpart[s][p] (fixed order)
-__global__ void rpart_reduce_kernel(const double* __restrict__ rpart, int n_splits, i64 width, i64 P, double* __restrict__ r)
+// r[p] = sum_s rpart[s][p]: eight row groups of the block sum every eighth split, then the groups are added in group
+// order (a fixed order; one thread per column walking all splits was a 27 us latency chain at 64 splits)
+__global__ __launch_bounds__(512)
+void rpart_reduce_kernel(const double* __restrict__ rpart, int n_splits, i64 width, i64 P, double* __restrict__ r)
 {
-    const i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= P) return;
-    double s = 0.0;
-    for (int k = 0; k < n_splits; ++k) s += rpart[(i64)k * width + p];
-    r[p] = s;
+    __shared__ double sh[8][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const i64 p = (i64)blockIdx.x * 64 + cx;
+    double s0 = 0.0, s1 = 0.0;
+    if (p < P) {
+        int k = ry;
+        for (; k + 8 < n_splits; k += 16) { s0 += rpart[(i64)k * width + p]; s1 += rpart[(i64)(k + 8) * width + p]; }
+        for (; k < n_splits; k += 8) s0 += rpart[(i64)k * width + p];
+    }
+    sh[ry][cx] = s0 + s1;
+    __syncthreads();
+    if (ry == 0 && p < P) {
+        double t = sh[0][cx];
+#pragma unroll
+        for (int g = 1; g < 8; ++g) t += sh[g][cx];
+        r[p] = t;
+    }
 }
 
 bool wsyrk_fast_path(const lrvb_ctx* c) {
@@ -1131,7 +1145,7 @@ int launch_wsyrk_r(lrvb_ctx* c, const double* cvec_dev, double* tiles_out_dev, c
                        c->tile_part.p, S, tile_elems, tiles_out_dev);
     HIP_TRY(hipGetLastError());
     if (cy_dev && r_out_dev) {
-        hipLaunchKernelGGL(rpart_reduce_kernel, dim3((unsigned)((c->P + 255) / 256)), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(rpart_reduce_kernel, dim3((unsigned)((c->P + 63) / 64)), dim3(512), 0, c->stream,
                            rpart, S, rwidth, c->P, r_out_dev);
         HIP_TRY(hipGetLastError());
     }

@@ -174,7 +174,7 @@ extern "C" int lrvb_ctx_destroy(lrvb_ctx* c) {
     DevBuf* all[] = { &c->X, &c->y, &c->w, &c->quadA, &c->quadM, &c->quadB, &c->theta, &c->eta, &c->j1, &c->j2,
                       &c->vtmp, &c->vtmp2, &c->vtmp3, &c->g_eta, &c->g_free, &c->lp, &c->cw, &c->zbuf,
                       &c->part_vec, &c->part_val, &c->stats, &c->tile_part, &c->Heta, &c->Hfree, &c->Jdense,
-                      &c->Tdense, &c->work1, &c->chol, &c->cholW, &c->cgH, &c->groups, &c->mx_theta, &c->mx_lam, &c->mx_A, &c->mx_U, &c->mx_g, &c->mx_Xk, &c->mx_R, &c->cgT, &c->ones, &c->cgm[0], &c->cgm[1], &c->cgm[2], &c->cgm[3], &c->cgm[4], &c->cgm[5], &c->cgm[6], &c->cgm[7], &c->cgm[8], &c->rhs, &c->cgx, &c->cgr, &c->cgp, &c->cgq, &c->cgz, &c->scal, &c->opt, &c->dkw, &c->cyv, &c->rvec };
+                      &c->Tdense, &c->work1, &c->chol, &c->cholW, &c->cgH, &c->groups, &c->mx_theta, &c->mx_lam, &c->mx_A, &c->mx_U, &c->mx_g, &c->mx_Xk, &c->mx_R, &c->cgT, &c->ones, &c->cgm[0], &c->cgm[1], &c->cgm[2], &c->cgm[3], &c->cgm[4], &c->cgm[5], &c->cgm[6], &c->cgm[7], &c->cgm[8], &c->rhs, &c->cgx, &c->cgr, &c->cgp, &c->cgq, &c->cgz, &c->scal, &c->opt, &c->dkw, &c->cyv, &c->rvec, &c->red_scratch };
     for (DevBuf* b : all) buf_free(*b);
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
     for (int k = 0; k < 3; ++k) for (hipEvent_t e : c->ev_pool[k]) (void)hipEventDestroy(e);
@@ -557,10 +557,10 @@ void gauss_coef_kernel(i64 n, double tau, const double* __restrict__ w, const do
 // wave w takes rows w, w + 4, ...; the row dot products are the tile's share of (S beta) in block row bi, and -- off
 // the diagonal, or below it inside a diagonal tile -- the same loaded values accumulate the share of block row bj
 // (the transposed tile).  part: [2 nb][nb * 128], zeroed by the caller; slot [bj] holds row shares, [nb + bi] column shares.
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(1024)
 void tiles_symv_kernel(const double* __restrict__ tiles, int nb, i64 P, const double* __restrict__ beta, double* __restrict__ part)
 {
-    __shared__ double colsh[4][128];
+    __shared__ double colsh[16][128];         // sixteen waves: eight rows of the tile each (four waves were a 32-step latency chain)
     const int t = blockIdx.x;
     int bi = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
     while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
@@ -573,7 +573,7 @@ void tiles_symv_kernel(const double* __restrict__ tiles, int nb, i64 P, const do
     const i64 j0 = (i64)bj * WS_TILE + lane, j1 = j0 + 64;
     const double b0 = j0 < P ? beta[j0] : 0.0, b1 = j1 < P ? beta[j1] : 0.0;
     double c0 = 0.0, c1 = 0.0;
-    for (int ii = wave; ii < WS_TILE; ii += 4) {
+    for (int ii = wave; ii < WS_TILE; ii += 16) {
         const i64 i = (i64)bi * WS_TILE + ii;
         double s0 = tile[ii * WS_TILE + lane], s1 = tile[ii * WS_TILE + lane + 64];
         if (i >= P) { s0 = 0.0; s1 = 0.0; }
@@ -591,7 +591,12 @@ void tiles_symv_kernel(const double* __restrict__ tiles, int nb, i64 P, const do
     __syncthreads();
     if (threadIdx.x < 128) {
         const i64 j = (i64)bj * WS_TILE + threadIdx.x;
-        if (j < P) part[(i64)(nb + bi) * width + j] = colsh[0][threadIdx.x] + colsh[1][threadIdx.x] + colsh[2][threadIdx.x] + colsh[3][threadIdx.x];
+        if (j < P) {
+            double cs = colsh[0][threadIdx.x];
+#pragma unroll
+            for (int g = 1; g < 16; ++g) cs += colsh[g][threadIdx.x];
+            part[(i64)(nb + bi) * width + j] = cs;
+        }
     }
 }
 // one block: g = S beta - r from the shares, value = 1/2 beta^T S beta - beta^T r + 1/2 sum c y^2
@@ -637,7 +642,7 @@ static int hessian_partial(lrvb_ctx* c, const double* point_dev, bool is_free, d
         LRVB_TRY(launch_wsyrk_r(c, c->cw.p, stats_dev + 1 + c->P, c->cyv.p, c->rvec.p));
         HIP_TRY(hipMemsetAsync(c->work1.p, 0, npart * sizeof(double), c->stream));
         const double* beta = c->eta.p + c->glm_off;
-        hipLaunchKernelGGL(tiles_symv_kernel, dim3((unsigned)(nb * (nb + 1) / 2)), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(tiles_symv_kernel, dim3((unsigned)(nb * (nb + 1) / 2)), dim3(1024), 0, c->stream,
                            (const double*)(stats_dev + 1 + c->P), nb, c->P, beta, c->work1.p);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(gauss_finish_kernel, dim3(1), dim3(1024), 0, c->stream, (const double*)c->work1.p, nb, c->P,

@@ -61,6 +61,7 @@ struct lrvb_ctx {
     DevBuf lp, cw, zbuf;            // per-observation: loss', w*loss'', linear predictor
     DevBuf cyv, rvec;               // Gaussian shortcut: (c o y) per observation, r = X^T (c o y)
     DevBuf part_vec, part_val;     // fused-pass block partials
+    DevBuf red_scratch;            // first level of the block-partial reduction: sums of 16 rows each (pass_reduce_rows_kernel)
     DevBuf stats;                  // [value | g_glm (P) | S tiles]
     DevBuf tile_part;              // weighted-SYRK split partials
     DevBuf Heta, Hfree, Jdense, Tdense, work1;   // dense V x V / D x D scratch
