@@ -644,7 +644,16 @@ __global__ void wsyrk_reduce_kernel(const double* __restrict__ partial, int n_sp
 // A is N x PA, B is N x PB (both row-major, even widths, 16-byte aligned): every 128 x 128 tile of the
 // PA x PB result is an "off-diagonal" tile of the scheme above.  Used for the Schur complement of the
 // mixture model (config 3): sum_n (x~_n (x) x~_n) vec(A_n)^T.  Output: row-major tiles [ta][tb].
-template <int DUMMY>
+// SLIVER = 1 (PA = PB = 4 x 128 + 16: the 528 x 528 Schur operand of the K = 32, V = 31 mixture): only the 16 interior
+// tiles are workgroups.  The 16-column slivers of A and B are never staged: every workgroup keeps ONE k-step of each in
+// registers (A sliver: the k-step bi of a stage, B sliver: k-step bj; plain global loads one stage ahead) and adds
+//   its rows of A_panel(bi)^T c B_sliver   over the k-steps bj   (2 MFMAs per wave and stage, A operand re-read from LDS),
+//   its columns of A_sliver^T c B_panel(bj) over the k-steps bi  (2 MFMAs),   and, if bi == bj, the corner (1 MFMA, wave 0):
+// the four workgroups of a tile row / column each cover a quarter of the k axis, their partial sums go to separate
+// 16-wide groups of the edge tile's slot and are added when the tiles are unpacked.  With the edge tiles as workgroups
+// of their own (SLIVER = 0) nine of 25 workgroups per split paid a full stage of loads and barriers for 1/8 of the MFMAs:
+// 10.65 ms for 5.6e11 flops.  The caller guarantees 16 readable, finite rows past N in A and B.
+template <int SLIVER>
 __global__ __launch_bounds__(WS_THREADS, 2)
 void atb_glds_kernel(const double* __restrict__ A, i64 lda, int PA, const double* __restrict__ B, i64 ldb, int PB,
                      i64 N, const double* __restrict__ cpad, int n_splits, int nba, int nbb, i64 rows_per_split,
@@ -656,10 +665,12 @@ void atb_glds_kernel(const double* __restrict__ A, i64 lda, int PA, const double
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int xcd = blockIdx.x & 7;
     const int qpos = blockIdx.x >> 3;
-    const int T = nba * nbb;
-    const int split_local = qpos / T;
-    const int t = qpos - split_local * T;
-    const int bi = t / nbb, bj = t - bi * nbb;
+    const int T = nba * nbb;                      // tile slots of the partial buffer (5 x 5 with SLIVER)
+    const int TW = SLIVER ? 16 : T;               // workgroups per split
+    const int split_local = qpos / TW;
+    const int tw = qpos - split_local * TW;
+    const int bi = SLIVER ? (tw >> 2) : tw / nbb, bj = SLIVER ? (tw & 3) : tw - bi * nbb;
+    const int t = bi * nbb + bj;
     const int split = split_local * 8 + xcd;
     i64 r0 = (i64)split * rows_per_split;
     i64 r1 = r0 + rows_per_split;
@@ -709,9 +720,37 @@ void atb_glds_kernel(const double* __restrict__ A, i64 lda, int PA, const double
         const double* a_base = lds + l4 * WS_LDS_STRIDE + 32 * wave + 2 * l15;
         const double* b_base = lds + WS_PANEL + l4 * WS_LDS_STRIDE + 2 * l15;
         const double* c_base = lds + 2 * WS_PANEL + l4;
-        auto stage = [&](auto buf_tag) {
+        // sliver mode: the k-step of the stage is part of the ADDRESS (LDS pointers below, row offsets of the global loads)
+        const double* a_base_s = a_base + bj * 4 * WS_LDS_STRIDE;                   // A panel rows of k-step bj (pairs with the B sliver)
+        const double* b_base_s = b_base + bi * 4 * WS_LDS_STRIDE + 32 * wave;       // B panel blocks (2 w, 2 w + 1) of k-step bi (A sliver)
+        const double* c_base_i = c_base + bj * 4;
+        const double* c_base_ii = c_base + bi * 4;
+        const unsigned voffSA = (unsigned)(((i64)(4 * bi + l4) * lda + 4 * WS_TILE + l15) * 8);
+        const unsigned voffSB = (unsigned)(((i64)(4 * bj + l4) * ldb + 4 * WS_TILE + l15) * 8);
+        double asl[2] = {0.0, 0.0}, bsl[2] = {0.0, 0.0};
+        d4 acc_i0 = (d4){0.0, 0.0, 0.0, 0.0}, acc_i1 = acc_i0, acc_ii0 = acc_i0, acc_ii1 = acc_i0, acc_c = acc_i0;
+        const bool corner = SLIVER && (bi == bj) && (wave == 0);                    // wave-uniform
+        auto load_sliver = [&](int ch, double& a, double& b) {
+            const i64 n0 = r0 + (i64)ch * WS_KC;
+            asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(a) : "v"(voffSA), "s"(A + n0 * lda) : "memory");
+            asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(b) : "v"(voffSB), "s"(B + n0 * ldb) : "memory");
+        };
+        if (SLIVER) {
+            load_sliver(0, asl[0], bsl[0]);
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            asm volatile("" : "+v"(asl[0]), "+v"(bsl[0]));
+        }
+        auto stage = [&](auto buf_tag, int ch) {
             constexpr int BUF = decltype(buf_tag)::value;
             double af[2][2], bf[2][8], cv[2];
+            if (SLIVER) load_sliver(ch + 1 < nch ? ch + 1 : ch, asl[BUF ^ 1], bsl[BUF ^ 1]);     // no branch around the asm loads
+            d2 ax = (d2){0.0, 0.0}, bx = (d2){0.0, 0.0};
+            double cxi = 0.0, cxii = 0.0;
+            if (SLIVER) {
+                ax = *reinterpret_cast<const d2*>(a_base_s + BUF * WS_BUF);
+                bx = *reinterpret_cast<const d2*>(b_base_s + BUF * WS_BUF);
+                cxi = c_base_i[BUF * WS_BUF]; cxii = c_base_ii[BUF * WS_BUF];
+            }
             auto read_frags = [&](int kk, int set) {
                 const int o = BUF * WS_BUF + kk * 4 * WS_LDS_STRIDE;
                 cv[set] = c_base[BUF * WS_BUF + kk * 4];
@@ -736,16 +775,26 @@ void atb_glds_kernel(const double* __restrict__ A, i64 lda, int PA, const double
                     acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(as0, bf[set][n], acc[n], 0, 0, 0);
                     acc[8 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(as1, bf[set][n], acc[8 + n], 0, 0, 0);
                 }
+                if (SLIVER && kk == 1) {          // the sliver products of this stage, behind the second MFMA block
+                    const double sa = asl[BUF] * cxii;
+                    acc_i0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[0] * cxi, bsl[BUF], acc_i0, 0, 0, 0);
+                    acc_i1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[1] * cxi, bsl[BUF], acc_i1, 0, 0, 0);
+                    acc_ii0 = __builtin_amdgcn_mfma_f64_16x16x4f64(sa, bx[0], acc_ii0, 0, 0, 0);
+                    acc_ii1 = __builtin_amdgcn_mfma_f64_16x16x4f64(sa, bx[1], acc_ii1, 0, 0, 0);
+                    if (corner) acc_c = __builtin_amdgcn_mfma_f64_16x16x4f64(sa, bsl[BUF], acc_c, 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_s_waitcnt(0x0F70); __syncthreads();
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            if (SLIVER) asm volatile("" : "+v"(asl[BUF ^ 1]), "+v"(bsl[BUF ^ 1]));      // consumers stay behind the wait
+            __syncthreads();
         };
         for (int ch = 0; ch < nch; ch += 2) {
             if (ch + 1 < nch) issue_stage(ch + 1, 1);
-            stage(std::integral_constant<int, 0>{});
+            stage(std::integral_constant<int, 0>{}, ch);
             if (ch + 1 < nch) {
                 if (ch + 2 < nch) issue_stage(ch + 2, 0);
-                stage(std::integral_constant<int, 1>{});
+                stage(std::integral_constant<int, 1>{}, ch + 1);
             }
         }
 #pragma unroll
@@ -755,6 +804,24 @@ void atb_glds_kernel(const double* __restrict__ A, i64 lda, int PA, const double
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     out[(32 * wave + 2 * (l4 + 4 * r) + m) * WS_TILE + 32 * (n >> 1) + 2 * l15 + (n & 1)] = acc[m * 8 + n][r];
+        if (SLIVER) {
+            // edge tile slots: (bi, 4) takes this workgroup's quarter of A_panel(bi)^T c B_sliver in the column group bj,
+            // (4, bj) its quarter of A_sliver^T c B_panel(bj) in the row group bi, (4, 4) the corner quarter in row group bi
+            double* oe = partial + ((i64)split * T + (bi * nbb + 4)) * (i64)(WS_TILE * WS_TILE);
+            double* of = partial + ((i64)split * T + (4 * nbb + bj)) * (i64)(WS_TILE * WS_TILE);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                oe[(32 * wave + 2 * (l4 + 4 * r)) * WS_TILE + 16 * bj + l15] = acc_i0[r];
+                oe[(32 * wave + 2 * (l4 + 4 * r) + 1) * WS_TILE + 16 * bj + l15] = acc_i1[r];
+                of[(16 * bi + l4 + 4 * r) * WS_TILE + 32 * wave + 2 * l15] = acc_ii0[r];
+                of[(16 * bi + l4 + 4 * r) * WS_TILE + 32 * wave + 2 * l15 + 1] = acc_ii1[r];
+            }
+            if (corner) {
+                double* oc = partial + ((i64)split * T + (4 * nbb + 4)) * (i64)(WS_TILE * WS_TILE);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) oc[(16 * bi + l4 + 4 * r) * WS_TILE + l15] = acc_c[r];
+            }
+        }
         return;
     }
     // ragged edge of the operand widths (e.g. 528 = 4 x 128 + 16 columns): 64 x 64 wave tiles in plain 16-column blocks,
@@ -807,23 +874,32 @@ void atb_glds_kernel(const double* __restrict__ A, i64 lda, int PA, const double
 }
 
 __global__ __launch_bounds__(256)
-void atb_tiles_to_dense_kernel(const double* __restrict__ tiles, int nbb, i64 PA, i64 PB, double* __restrict__ C, i64 ldc)
+void atb_tiles_to_dense_kernel(const double* __restrict__ tiles, int nbb, i64 PA, i64 PB, double* __restrict__ C, i64 ldc, int sliver)
 {
     const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     const i64 i = blockIdx.y;
     if (j >= PB || i >= PA) return;
-    const i64 t = (i / WS_TILE) * nbb + (j / WS_TILE);
-    C[i * ldc + j] = tiles[t * (WS_TILE * WS_TILE) + (i % WS_TILE) * WS_TILE + (j % WS_TILE)];
+    const i64 ti = i / WS_TILE, tj = j / WS_TILE, li = i % WS_TILE, lj = j % WS_TILE;
+    const double* tile = tiles + (ti * nbb + tj) * (WS_TILE * WS_TILE);
+    if (!sliver || (ti < 4 && tj < 4)) { C[i * ldc + j] = tile[li * WS_TILE + lj]; return; }
+    // sliver mode: the edge slots hold four k-quarters side by side (atb_glds_kernel<1>); added in a fixed order
+    double s = 0.0;
+    if (ti < 4)      for (int g = 0; g < 4; ++g) s += tile[li * WS_TILE + 16 * g + lj];            // (bi, 4): column groups
+    else             for (int g = 0; g < 4; ++g) s += tile[(16 * g + li) * WS_TILE + lj];          // (4, bj) and the corner: row groups
+    C[i * ldc + j] = s;
 }
 
 // C (PA x PB, row-major, ld = PB) = A^T diag(c) B;  cvec_dev carries zero padding past N.
 int launch_atb(lrvb_ctx* c, const double* A, i64 PA, const double* B, i64 PB, i64 N,
-               const double* cvec_dev, double* C_dev) {
+               const double* cvec_dev, double* C_dev, bool rows_padded) {
     if ((PA % 2) || (PB % 2) || (((uintptr_t)A) & 15) || (((uintptr_t)B) & 15))
         LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "atb: operands must have even widths and 16-byte aligned rows");
     const int nba = (int)((PA + WS_TILE - 1) / WS_TILE), nbb = (int)((PB + WS_TILE - 1) / WS_TILE);
     const int T = nba * nbb;
-    i64 S = (4608 + T / 2) / T;
+    // 4 x 128 + 16 columns on both sides, 16 finite rows past N: the slivers ride on the 16 interior workgroups
+    const bool sliver = rows_padded && PA == 4 * WS_TILE + 16 && PB == 4 * WS_TILE + 16;
+    const int TW = sliver ? 16 : T;
+    i64 S = (4608 + TW / 2) / TW;
     S = ((S + 7) / 8) * 8;
     i64 max_by_rows = (N / 256 / 8) * 8;
     if (S > max_by_rows) S = max_by_rows;
@@ -836,15 +912,19 @@ int launch_atb(lrvb_ctx* c, const double* A, i64 PA, const double* B, i64 PB, i6
     double* part = c->tile_part.p;
     double* tiles = c->tile_part.p + tile_elems * S;
     if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
-    hipLaunchKernelGGL(atb_glds_kernel<0>, dim3((unsigned)(S * T)), dim3(WS_THREADS), 0, c->stream,
-                       A, PA, (int)PA, B, PB, (int)PB, N, cvec_dev, (int)S, nba, nbb, rps, part);
+    if (sliver)
+        hipLaunchKernelGGL(atb_glds_kernel<1>, dim3((unsigned)(S * 16)), dim3(WS_THREADS), 0, c->stream,
+                           A, PA, (int)PA, B, PB, (int)PB, N, cvec_dev, (int)S, nba, nbb, rps, part);
+    else
+        hipLaunchKernelGGL(atb_glds_kernel<0>, dim3((unsigned)(S * T)), dim3(WS_THREADS), 0, c->stream,
+                           A, PA, (int)PA, B, PB, (int)PB, N, cvec_dev, (int)S, nba, nbb, rps, part);
     HIP_TRY(hipGetLastError());
     if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
     hipLaunchKernelGGL(wsyrk_reduce_kernel, dim3((unsigned)((tile_elems / 2 + 255) / 256)), dim3(256), 0, c->stream,
                        part, (int)S, tile_elems, tiles);
     HIP_TRY(hipGetLastError());
     dim3 grid((unsigned)((PB + 255) / 256), (unsigned)PA);
-    hipLaunchKernelGGL(atb_tiles_to_dense_kernel, grid, dim3(256), 0, c->stream, tiles, nbb, PA, PB, C_dev, PB);
+    hipLaunchKernelGGL(atb_tiles_to_dense_kernel, grid, dim3(256), 0, c->stream, tiles, nbb, PA, PB, C_dev, PB, sliver ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return LRVB_OK;
 }

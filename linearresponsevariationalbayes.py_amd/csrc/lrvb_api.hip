@@ -1262,7 +1262,7 @@ extern "C" int lrvb_mixture_rows(lrvb_ctx* c, int32_t K, const double* theta_z, 
     c->mx_res_K = c->mx_res_q = 0;
     int st = buf_reserve(c, thz, (size_t)(N * KM));
     if (st == LRVB_OK) st = buf_reserve(c, lam, (size_t)((V + 1) * K));
-    if (st == LRVB_OK) st = buf_reserve(c, Amat, (size_t)(N * lda));
+    if (st == LRVB_OK) st = buf_reserve(c, Amat, (size_t)((N + 16) * lda));      // + 16 rows of zeros: the sliver loads of launch_atb run past N
     if (st == LRVB_OK) st = buf_reserve(c, U, (size_t)(N * 64));
     if (st == LRVB_OK) st = buf_reserve(c, gfr, (size_t)(N * KM));
     if (st == LRVB_OK && theta_z) { c->mx_theta_n = 0; st = h2d(c, thz.p, theta_z, (size_t)(N * KM)); if (st == LRVB_OK) c->mx_theta_n = N * KM; }
@@ -1286,11 +1286,15 @@ extern "C" int lrvb_mixture_rows(lrvb_ctx* c, int32_t K, const double* theta_z, 
     if (st == LRVB_OK) st = d2h(c, S64_out, c->Hfree.p, 64 * 64);
     if (st == LRVB_OK && R_out) {
         if (hbad) { lrvb_set_error("a local (simplex) Hessian block is not positive definite: the Schur complement is undefined at this point"); st = LRVB_ERR_NOT_POSDEF; }
-        if (st == LRVB_OK) st = buf_reserve(c, Xk, (size_t)(N * ldk));
+        if (st == LRVB_OK) st = buf_reserve(c, Xk, (size_t)((N + 16) * ldk));
         if (st == LRVB_OK) st = launch_kron_rows(c, Xk.p, ldk);
         if (st == LRVB_OK) st = buf_reserve(c, Rd, (size_t)(ldk * lda));
         if (st == LRVB_OK) { EW(fill_kernel, N, 1.0, c->zbuf.p); }
-        if (st == LRVB_OK) st = launch_atb(c, Xk.p, ldk, Amat.p, lda, N, c->zbuf.p, Rd.p);
+        if (st == LRVB_OK && (hipMemsetAsync(Xk.p + N * ldk, 0, (size_t)(16 * ldk) * sizeof(double), c->stream) != hipSuccess ||
+                              hipMemsetAsync(Amat.p + N * lda, 0, (size_t)(16 * lda) * sizeof(double), c->stream) != hipSuccess)) {
+            lrvb_set_error("memset failed"); st = LRVB_ERR_HIP;
+        }
+        if (st == LRVB_OK) st = launch_atb(c, Xk.p, ldk, Amat.p, lda, N, c->zbuf.p, Rd.p, true);
         // Amat is dead now: reuse it for the expanded (V+1)^2 x K^2 result
         if (st == LRVB_OK) st = buf_reserve(c, Amat, (size_t)(QQ * KK));
         if (st == LRVB_OK) st = launch_mixture_expand(c, Rd.p, lda, V + 1, K, Amat.p);
