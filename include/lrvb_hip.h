@@ -229,6 +229,24 @@ int lrvb_cross_hessian_tilt(lrvb_ctx* ctx, const double* free_in, int64_t D, dou
  * and never materialised.                                                                   */
 int lrvb_gram(lrvb_ctx* ctx, const double* free_in, int64_t D, double* GtG_out, int64_t ld);
 
+/* ---- the non-conjugate logistic term (LRVB/Modeling.py) -----------------------------------
+ * Per element i: phi_i = sum_k gh_w[k] log(1 + exp(z_mean[i] + sqrt(2) z_sd[i] gh_x[k])) / sqrt(pi), the Gauss-Hermite
+ * value of E log(1 + e^z), z ~ N(z_mean, z_sd^2): get_e_logistic_term_guass_hermite(..., aggregate_all=False),
+ * LRVB/Modeling.py:36-52 (log(1 + e^t) in the overflow-free form; the reference's log1p(exp(t)) is inf past t = 709).
+ * order >= 1: d1 (n x 2) = [d/dz_mean, d/dz_sd]; order >= 2: d2 (n x 3) = [mean mean, mean sd, sd sd] -- derivatives of
+ * the quadrature SUM, i.e. what autograd returns for the reference's expression.  1 <= n_nodes <= 128.
+ * get_e_logistic_term (:16-32) is the same sum with nodes draws / sqrt(2) and weights sqrt(pi) / n_draws.             */
+int lrvb_gh_logistic(lrvb_ctx* ctx, int64_t n, const double* z_mean, const double* z_sd, const double* gh_x,
+                     const double* gh_w, int32_t n_nodes, int32_t order, double* val, double* d1, double* d2);
+/* The model that expectation is written for: logistic regression with q(beta_j) = N(mean_j, var_j).  Data term
+ *   sum_n w_n ( phi(x_n . mean, sqrt(x_n^2 . var)) - y_n x_n . mean )
+ * of the context's X (n_obs x n_cols = P), y and weights, in the coordinates (mean, var): value, gradient (2 P, nullable)
+ * and the three P x P blocks [d2/dmean2 | d2/dmean dvar | d2/dvar2] of the Hessian (3 P^2, row-major, nullable):
+ * X^T D11 X, X^T D12 (X o X), (X o X)^T D22 (X o X) on the fp64 matrix cores with the per-observation second
+ * derivatives of the quadrature sum as weights.  The context must hold X and y (any GLM loss).                       */
+int lrvb_logitnormal_terms(lrvb_ctx* ctx, const double* mean, const double* var, int64_t P, const double* gh_x,
+                           const double* gh_w, int32_t n_nodes, double* value_out, double* grad_out, double* H_blocks_out);
+
 /* ---- objectives that are quadratic in the data ------------------------------------------
  * S = Z^T diag(w) Z (n_cols x n_cols, both triangles) with the context's current weights: the
  * weighted sufficient statistics sum_n w_n z_n z_n^T that `np.einsum('ni,ij,nj,n', ...)` at

@@ -26,7 +26,7 @@ from .sensitivity import (ParametricSensitivityLinearApproximation, Hyperparamet
                           get_kl_hessian, get_lrvb_cov)
 from .taylor import ParametricSensitivityTaylorExpansion
 from .cg import ConjugateGradientSolver
-from .models import (DeviceContext, DeviceObjective, GLMObjective, QuadraticObjective, LinearMoments)
+from .models import (DeviceContext, DeviceObjective, GLMObjective, QuadraticObjective, LinearMoments, scratch_context)
 from .quadform import (QuadraticDataObjective, NormalRegressionObjective, MVNRegressionObjective,
                        WishartMVNObjective)
 
@@ -43,6 +43,7 @@ from . import expfam as ExponentialFamilies
 from . import families as NormalParams
 from .hierarchical import LMMObjective
 from .mixture import MixtureObjective
+from .logitnormal import LogitNormalRegressionObjective
 from . import regression as regression_utils
 from . import packing as ProjectionParams
 from . import families as GammaParams

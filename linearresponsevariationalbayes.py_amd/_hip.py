@@ -74,6 +74,8 @@ _SIGNATURES = {
     'lrvb_obs_grad': [_VP, _VP, c_i64, c_i64, c_i64, _VP],
     'lrvb_obs_grad_vec': [_VP, _VP, c_i64, c_i64, c_i64, _VP],
     'lrvb_obs_loss': [_VP, _VP, c_i64, ctypes.c_int, c_i64, c_i64, _VP],
+    'lrvb_gh_logistic': [_VP, c_i64, _VP, _VP, _VP, _VP, ctypes.c_int32, ctypes.c_int32, _VP, _VP, _VP],
+    'lrvb_logitnormal_terms': [_VP, _VP, _VP, c_i64, _VP, _VP, ctypes.c_int32, _VP, _VP, _VP],
     'lrvb_hvec_begin': [_VP],
     'lrvb_hvec_add_block': [_VP, _VP, c_i64, c_i64, c_i64, c_i64, ctypes.c_int],
     'lrvb_hvec_add_symkron': [_VP, _VP, _VP, c_i64, ctypes.c_double, c_i64, c_i64, ctypes.c_int],

@@ -418,10 +418,74 @@ void gemv_kernel(int trans, i64 M, i64 N, double alpha, const double* __restrict
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
     if (lane == 0) y[o] = alpha * s + (beta == 0.0 ? 0.0 : beta * y[o]);
 }
+// Transposed product of a TALL matrix (M rows >> N columns): y[j] = alpha sum_k A[k][j] x[k] + beta y[j].  One wave per
+// output walking a column touches a new cache line with every element (8.9 ms for 1e6 x 256); here a workgroup owns a
+// range of rows, its four waves read whole 512-byte row pieces, and the workgroup partials are added in a fixed order.
+__global__ __launch_bounds__(256)
+void gemv_t_tall_kernel(i64 M, i64 N, const double* __restrict__ A, i64 lda, const double* __restrict__ x,
+                        i64 rows_per_block, double* __restrict__ part /* [gridDim.x][N] */)
+{
+    __shared__ double sh[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const i64 r0 = (i64)blockIdx.x * rows_per_block;
+    i64 r1 = r0 + rows_per_block; if (r1 > M) r1 = M;
+    for (i64 j0 = 0; j0 < N; j0 += 64) {
+        const i64 col = j0 + tx;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        if (col < N) {
+            i64 k = r0 + ty;
+            for (; k + 12 < r1; k += 16) {
+                s0 += A[k * lda + col] * x[k];
+                s1 += A[(k + 4) * lda + col] * x[k + 4];
+                s2 += A[(k + 8) * lda + col] * x[k + 8];
+                s3 += A[(k + 12) * lda + col] * x[k + 12];
+            }
+            for (; k < r1; k += 4) s0 += A[k * lda + col] * x[k];
+        }
+        sh[ty][tx] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (ty == 0 && col < N) part[(i64)blockIdx.x * N + col] = (sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx]);
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(512)
+void gemv_t_tall_reduce_kernel(const double* __restrict__ part, int nblk, i64 N, double alpha, double beta, double* __restrict__ y)
+{
+    __shared__ double sh[8][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const i64 col = (i64)blockIdx.x * 64 + cx;
+    double s0 = 0.0, s1 = 0.0;
+    if (col < N) {
+        int b = ry;
+        for (; b + 8 < nblk; b += 16) { s0 += part[(i64)b * N + col]; s1 += part[(i64)(b + 8) * N + col]; }
+        for (; b < nblk; b += 8) s0 += part[(i64)b * N + col];
+    }
+    sh[ry][cx] = s0 + s1;
+    __syncthreads();
+    if (ry == 0 && col < N) {
+        double t = sh[0][cx];
+#pragma unroll
+        for (int g = 1; g < 8; ++g) t += sh[g][cx];
+        y[col] = alpha * t + (beta == 0.0 ? 0.0 : beta * y[col]);
+    }
+}
+
 int launch_gemv(lrvb_ctx* c, bool trans, i64 M, i64 Nn, double alpha, const double* A, i64 lda,
                 const double* x, double beta, double* y) {
     const i64 nout = trans ? Nn : M;
     if (nout <= 0) return LRVB_OK;
+    if (trans && M >= 8192 && Nn <= 4096) {
+        i64 nblk = (M + 255) / 256; if (nblk > 1024) nblk = 1024;
+        const i64 rpb = (M + nblk - 1) / nblk;
+        nblk = (M + rpb - 1) / rpb;
+        LRVB_TRY(buf_reserve(c, c->red_scratch, (size_t)(nblk * Nn)));
+        hipLaunchKernelGGL(gemv_t_tall_kernel, dim3((unsigned)nblk), dim3(256), 0, c->stream, M, Nn, A, lda, x, rpb, c->red_scratch.p);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(gemv_t_tall_reduce_kernel, dim3((unsigned)((Nn + 63) / 64)), dim3(512), 0, c->stream,
+                           (const double*)c->red_scratch.p, (int)nblk, Nn, alpha, beta, y);
+        HIP_TRY(hipGetLastError());
+        return LRVB_OK;
+    }
     hipLaunchKernelGGL(gemv_kernel, dim3((unsigned)((nout + 3) / 4)), dim3(256), 0, c->stream,
                        trans ? 1 : 0, M, Nn, alpha, A, lda, x, beta, y);
     HIP_TRY(hipGetLastError());

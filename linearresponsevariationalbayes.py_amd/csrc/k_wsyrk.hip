@@ -711,7 +711,9 @@ void atb_glds_kernel(const double* __restrict__ A, i64 lda, int PA, const double
     int mt_a = (PA - bi * WS_TILE - wr * 64 + 15) / 16; mt_a = mt_a < 0 ? 0 : (mt_a > 4 ? 4 : mt_a);
     int mt_b = (PB - bj * WS_TILE - wc * 64 + 15) / 16; mt_b = mt_b < 0 ? 0 : (mt_b > 4 ? 4 : mt_b);
     mt_a = __builtin_amdgcn_readfirstlane(mt_a); mt_b = __builtin_amdgcn_readfirstlane(mt_b);
-    const bool full = (mt_a == 4) && (mt_b == 4);
+    // interior = the WHOLE 128 x 128 tile holds real columns (the same answer in every wave: the two loops below tile the
+    // workgroup differently and both contain barriers)
+    const bool full = (PA - bi * WS_TILE >= WS_TILE) && (PB - bj * WS_TILE >= WS_TILE);
     double* out = partial + ((i64)split * T + t) * (i64)(WS_TILE * WS_TILE);
     if (full) {
         // interior tile: the loop of wsyrk_glds_kernel's off-diagonal tiles -- wave w owns rows [32 w, 32 w + 32) x all 128

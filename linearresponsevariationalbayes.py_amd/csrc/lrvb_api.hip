@@ -244,7 +244,7 @@ extern "C" int lrvb_set_data(lrvb_ctx* c, int slot, const double* host, int64_t 
     if (!b->owned) { b->p = nullptr; b->n = 0; b->owned = true; }
     LRVB_TRY(buf_reserve(c, *b, n));
     LRVB_TRY(h2d(c, b->p, host, n));
-    if (slot == LRVB_SLOT_X) c->have_X = true;
+    if (slot == LRVB_SLOT_X) { c->have_X = true; c->x2_ready = false; }
     if (slot == LRVB_SLOT_Y) c->have_y = true;
     return LRVB_OK;
 }
@@ -256,7 +256,7 @@ extern "C" int lrvb_set_data_dev(lrvb_ctx* c, int slot, const double* data_dev, 
     LRVB_TRY(slot_shape_check(c, slot, rows, cols, &b, &n));
     if (b->p && b->owned) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(b->p)); }
     b->p = const_cast<double*>(data_dev); b->n = n; b->owned = false;
-    if (slot == LRVB_SLOT_X) c->have_X = true;
+    if (slot == LRVB_SLOT_X) { c->have_X = true; c->x2_ready = false; }
     if (slot == LRVB_SLOT_Y) c->have_y = true;
     return LRVB_OK;
 }
@@ -1259,6 +1259,7 @@ extern "C" int lrvb_mixture_rows(lrvb_ctx* c, int32_t K, const double* theta_z, 
     const i64 KP = (i64)K * (K + 1) / 2, QP = (i64)(V + 1) * (V + 2) / 2;
     const i64 lda = KP + (KP & 1), ldk = QP + (QP & 1);
     DevBuf &thz = c->mx_theta, &lam = c->mx_lam, &Amat = c->mx_A, &U = c->mx_U, &gfr = c->mx_g, &Xk = c->mx_Xk, &Rd = c->mx_R;
+    c->x2_ready = false;
     c->mx_res_K = c->mx_res_q = 0;
     int st = buf_reserve(c, thz, (size_t)(N * KM));
     if (st == LRVB_OK) st = buf_reserve(c, lam, (size_t)((V + 1) * K));
@@ -1336,6 +1337,7 @@ extern "C" int lrvb_mixture_schur(lrvb_ctx* c, int32_t K, int32_t q, const doubl
     if (K < 1 || q < 1 || (i64)K * q > 8192) LRVB_FAIL(LRVB_ERR_INVALID, "K, q out of range");
     const i64 n = (i64)K * q, nn = n * n;
     DevBuf &Rfull = c->mx_A, &Rm = c->mx_Xk, &Jd = c->mx_U, &T = c->mx_R, &Hd = c->mx_g;
+    c->x2_ready = false;
     if (R) {
         LRVB_TRY(buf_reserve(c, Rfull, (size_t)nn));
         LRVB_TRY(h2d(c, Rfull.p, R, (size_t)nn));
@@ -1832,6 +1834,158 @@ extern "C" int lrvb_obs_loss(lrvb_ctx* c, const double* point, int64_t n_in, int
     }
     EW(obs_loss_kernel, rows, (int)c->loss, c->lik_info, (const double*)(c->y.p + n0), (const double*)z, lv);
     return d2h(c, out, lv, (size_t)rows);
+}
+
+// ---- non-conjugate logistic term by Gauss-Hermite quadrature (LRVB/Modeling.py:36-52) ------------------------------------
+// phi(m, s) = sum_k w_k log(1 + exp(m + sqrt(2) s x_k)) / sqrt(pi) and the derivatives of THIS SUM with respect to (m, s)
+// (what autograd forms from the reference's expression), up to second order.  log(1 + e^t) in the overflow-free form.
+__device__ __forceinline__ void gh_logistic_point(double m, double sd, const double* __restrict__ gx, const double* __restrict__ gw, int K,
+                                                  double& v, double& dm, double& ds, double& dmm, double& dms, double& dss) {
+    const double r2 = 1.4142135623730951, ispi = 0.5641895835477563;     // sqrt(2), 1 / sqrt(pi)
+    v = dm = ds = dmm = dms = dss = 0.0;
+    for (int k = 0; k < K; ++k) {
+        const double xk = r2 * gx[k], wk = gw[k] * ispi;
+        const double t = m + sd * xk;
+        const double e = exp(-fabs(t));
+        const double sp = (t > 0.0 ? t : 0.0) + log1p(e);                // log(1 + e^t)
+        const double sg = t >= 0.0 ? 1.0 / (1.0 + e) : e / (1.0 + e);     // sigmoid(t)
+        const double s2 = sg * (1.0 - sg);
+        v += wk * sp; dm += wk * sg; ds += wk * sg * xk;
+        dmm += wk * s2; dms += wk * s2 * xk; dss += wk * s2 * xk * xk;
+    }
+}
+__global__ __launch_bounds__(256)
+void gh_logistic_kernel(i64 n, const double* __restrict__ zm, const double* __restrict__ zs, const double* __restrict__ gx,
+                        const double* __restrict__ gw, int K, int order, double* __restrict__ val, double* __restrict__ d1, double* __restrict__ d2)
+{
+    __shared__ double sx[128], sw[128];
+    if ((int)threadIdx.x < K) { sx[threadIdx.x] = gx[threadIdx.x]; sw[threadIdx.x] = gw[threadIdx.x]; }
+    __syncthreads();
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double v, dm, ds, dmm, dms, dss;
+    gh_logistic_point(zm[i], zs[i], sx, sw, K, v, dm, ds, dmm, dms, dss);
+    val[i] = v;
+    if (order >= 1) { d1[2 * i] = dm; d1[2 * i + 1] = ds; }
+    if (order >= 2) { d2[3 * i] = dmm; d2[3 * i + 1] = dms; d2[3 * i + 2] = dss; }
+}
+
+extern "C" int lrvb_gh_logistic(lrvb_ctx* c, int64_t n, const double* z_mean, const double* z_sd, const double* gh_x, const double* gh_w,
+                                int32_t n_nodes, int32_t order, double* val, double* d1, double* d2) {
+    LRVB_TRY(ctx_bind(c));
+    if (n < 0 || !z_mean || !z_sd || !gh_x || !gh_w || !val) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    if (n_nodes < 1 || n_nodes > 128) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "1 to 128 quadrature nodes");
+    if (order < 0 || order > 2 || (order >= 1 && !d1) || (order >= 2 && !d2)) LRVB_FAIL(LRVB_ERR_INVALID, "order 0..2 with its output arrays");
+    if (n == 0) return LRVB_OK;
+    LRVB_TRY(buf_reserve(c, c->work1, (size_t)n * 8 + 256));
+    double* zm = c->work1.p; double* zs = zm + n; double* v = zs + n; double* o1 = v + n; double* o2 = o1 + 2 * n; double* g = o2 + 3 * n;
+    LRVB_TRY(h2d(c, zm, z_mean, (size_t)n));
+    LRVB_TRY(h2d(c, zs, z_sd, (size_t)n));
+    LRVB_TRY(h2d(c, g, gh_x, (size_t)n_nodes));
+    LRVB_TRY(h2d(c, g + 128, gh_w, (size_t)n_nodes));
+    EW(gh_logistic_kernel, n, (const double*)zm, (const double*)zs, (const double*)g, (const double*)(g + 128), (int)n_nodes, (int)order, v, o1, o2);
+    LRVB_TRY(d2h(c, val, v, (size_t)n));
+    if (order >= 1) LRVB_TRY(d2h(c, d1, o1, (size_t)n * 2));
+    if (order >= 2) LRVB_TRY(d2h(c, d2, o2, (size_t)n * 3));
+    return LRVB_OK;
+}
+
+// ---- logistic regression with a mean-field Gaussian variational posterior (the model that expectation is written for) -------
+// z_n ~ N(mu_n, v_n), mu = X mean, v = (X o X) var.  Per observation psi(mu, v) = phi(mu, sqrt(v)) - y mu; this kernel turns
+// (mu, v) into the weighted coefficient vectors of the gradient and of the three Hessian products, and block sums of w psi.
+__global__ __launch_bounds__(256)
+void logitnormal_coef_kernel(i64 n, const double* __restrict__ mu, const double* __restrict__ vv, const double* __restrict__ y,
+                             const double* __restrict__ w, const double* __restrict__ gx, const double* __restrict__ gw, int K,
+                             double* __restrict__ a1, double* __restrict__ a2, double* __restrict__ c11, double* __restrict__ c12,
+                             double* __restrict__ c22, double* __restrict__ vpart)
+{
+    __shared__ double sx[128], sw[128], red[4];
+    if ((int)threadIdx.x < K) { sx[threadIdx.x] = gx[threadIdx.x]; sw[threadIdx.x] = gw[threadIdx.x]; }
+    __syncthreads();
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    double contrib = 0.0;
+    if (i < n) {
+        const double m = mu[i], var = vv[i], sd = sqrt(var), wi = w[i];
+        double v, dm, ds, dmm, dms, dss;
+        gh_logistic_point(m, sd, sx, sw, K, v, dm, ds, dmm, dms, dss);
+        // chain sd = sqrt(var): sd' = 1 / (2 sd), sd'' = -1 / (4 sd^3)
+        const double s1 = 0.5 / sd, s2 = -0.25 / (sd * var);
+        contrib = wi * (v - y[i] * m);
+        a1[i] = wi * (dm - y[i]);
+        a2[i] = wi * ds * s1;
+        c11[i] = wi * dmm;
+        c12[i] = wi * dms * s1;
+        c22[i] = wi * (dss * s1 * s1 + ds * s2);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) contrib += __shfl_xor(contrib, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = contrib;
+    __syncthreads();
+    if (threadIdx.x == 0) vpart[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void rowscale_kernel(i64 n, i64 P, const double* __restrict__ cvec, const double* __restrict__ B, double* __restrict__ o) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = cvec[i / P] * B[i];
+}
+// C (P x P) = A^T diag(cvec) B over N rows: the LDS-DMA MFMA kernel when the operands allow, the generic tile GEMM on a
+// row-scaled copy otherwise
+static int weighted_tn(lrvb_ctx* c, const double* A, const double* B, i64 P, i64 N, const double* cvec_padded, double* C, DevBuf& scratch) {
+    const bool fast = !(P % 2) && !(((uintptr_t)A) & 15) && !(((uintptr_t)B) & 15) && P >= 2;
+    if (fast) return launch_atb(c, A, P, B, P, N, cvec_padded, C);
+    LRVB_TRY(buf_reserve(c, scratch, (size_t)(N * P)));
+    EW(rowscale_kernel, N * P, P, cvec_padded, B, scratch.p);
+    return launch_gemm(c, true, false, P, P, N, 1.0, A, P, scratch.p, P, 0.0, C, P);
+}
+
+extern "C" int lrvb_logitnormal_terms(lrvb_ctx* c, const double* mean, const double* var, int64_t P_in, const double* gh_x,
+                                      const double* gh_w, int32_t n_nodes, double* value_out, double* grad_out, double* H_blocks_out) {
+    LRVB_TRY(ctx_bind(c));
+    if (!mean || !var || !gh_x || !gh_w || !value_out) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    if (n_nodes < 1 || n_nodes > 128) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "1 to 128 quadrature nodes");
+    if (c->loss == LRVB_LOSS_NONE || c->data_only || !(c->have_X && c->have_y))
+        LRVB_FAIL(LRVB_ERR_STATE, "the context needs a design matrix and responses: lrvb_set_data for LRVB_SLOT_X and LRVB_SLOT_Y");
+    const i64 N = c->N, P = c->P;
+    LRVB_TRY(check_len(P_in, P, "mean / var"));
+    for (i64 j = 0; j < P; ++j) if (!(var[j] > 0.0)) LRVB_FAIL(LRVB_ERR_INVALID, "var[%lld] is not positive", (long long)j);
+    // device scratch: X o X, the parameter vectors and nodes, (mu, v), five coefficient vectors (zero-padded past N), block sums
+    DevBuf& X2 = c->mx_Xk;
+    if (!c->x2_ready || X2.n < (size_t)(N * P)) {
+        LRVB_TRY(buf_reserve(c, X2, (size_t)(N * P)));
+        EW(square_kernel, N * P, (const double*)c->X.p, X2.p);
+        c->x2_ready = true;
+    }
+    const i64 nblk = (N + 255) / 256, NP = N + 64;
+    LRVB_TRY(buf_reserve(c, c->work1, (size_t)(2 * P + 256 + 2 * N + 5 * NP + nblk + 2 * P)));
+    double* dm = c->work1.p; double* dv = dm + P; double* g = dv + P; double* mu = g + 256; double* vv = mu + N;
+    double* a1 = vv + N; double* a2 = a1 + NP; double* c11 = a2 + NP; double* c12 = c11 + NP; double* c22 = c12 + NP;
+    double* vpart = c22 + NP; double* gout = vpart + nblk;
+    LRVB_TRY(h2d(c, dm, mean, (size_t)P));
+    LRVB_TRY(h2d(c, dv, var, (size_t)P));
+    LRVB_TRY(h2d(c, g, gh_x, (size_t)n_nodes));
+    LRVB_TRY(h2d(c, g + 128, gh_w, (size_t)n_nodes));
+    HIP_TRY(hipMemsetAsync(a1, 0, (size_t)(5 * NP) * sizeof(double), c->stream));
+    LRVB_TRY(launch_gemv(c, false, N, P, 1.0, c->X.p, P, dm, 0.0, mu));
+    LRVB_TRY(launch_gemv(c, false, N, P, 1.0, X2.p, P, dv, 0.0, vv));
+    EW(logitnormal_coef_kernel, N, (const double*)mu, (const double*)vv, (const double*)c->y.p, (const double*)c->w.p, (const double*)g,
+       (const double*)(g + 128), (int)n_nodes, a1, a2, c11, c12, c22, vpart);
+    std::vector<double> hpart((size_t)nblk);
+    LRVB_TRY(d2h(c, hpart.data(), vpart, (size_t)nblk));
+    double val = 0.0;
+    for (i64 b = 0; b < nblk; ++b) val += hpart[(size_t)b];                   // fixed order
+    *value_out = val;
+    if (grad_out) {
+        LRVB_TRY(launch_gemv(c, true, N, P, 1.0, c->X.p, P, a1, 0.0, gout));
+        LRVB_TRY(launch_gemv(c, true, N, P, 1.0, X2.p, P, a2, 0.0, gout + P));
+        LRVB_TRY(d2h(c, grad_out, gout, (size_t)(2 * P)));
+    }
+    if (H_blocks_out) {
+        LRVB_TRY(buf_reserve(c, c->Hfree, (size_t)(3 * P * P)));
+        LRVB_TRY(weighted_tn(c, c->X.p, c->X.p, P, N, c11, c->Hfree.p, c->mx_A));
+        LRVB_TRY(weighted_tn(c, c->X.p, X2.p, P, N, c12, c->Hfree.p + P * P, c->mx_A));
+        LRVB_TRY(weighted_tn(c, X2.p, X2.p, P, N, c22, c->Hfree.p + 2 * P * P, c->mx_A));
+        LRVB_TRY(d2h(c, H_blocks_out, c->Hfree.p, (size_t)(3 * P * P)));
+    }
+    return LRVB_OK;
 }
 
 extern "C" int lrvb_dk_grad_vec(lrvb_ctx* c, const double* vec_in, int64_t V, int32_t order, const double* U,

@@ -55,6 +55,7 @@ struct lrvb_ctx {
     // resident data
     DevBuf X, y, w, quadA, quadM, quadB;
     bool have_X = false, have_y = false;
+    bool x2_ready = false;          // mx_Xk holds X o X of the current design (lrvb_logitnormal_terms)
 
     // per-evaluation state (device)
     DevBuf theta, eta, j1, j2, vtmp, vtmp2, vtmp3, g_eta, g_free;

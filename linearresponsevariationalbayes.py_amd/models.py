@@ -37,6 +37,15 @@ def _block_array(blocks):
     return arr, fo, vo
 
 
+def scratch_context(device=0):
+    """A minimal context (one unconstrained parameter, unit quadratic term) for the element-wise device utilities that
+    need a device and a stream but no model: `DeviceContext.gh_logistic`, the `ctx=` argument of the Modeling functions."""
+    ctx = DeviceContext([dict(kind=_hip.BLOCK_BOX, free_size=1, vec_size=1, dim0=1, dim1=0, lb=-np.inf, ub=np.inf)],
+                        loss=None, quad_kind=_hip.QUAD_DIAG, device=device)
+    ctx.set_data(_hip.SLOT_QUAD_A, np.ones(1))
+    return ctx
+
+
 class DeviceContext(object):
     """Owns one lrvb_ctx (one HIP device + stream).  Thin, typed wrappers over the C ABI."""
 
@@ -233,6 +242,43 @@ class DeviceContext(object):
         out = np.empty(max(n1 - n0, 0))
         self._check(self._lib.lrvb_obs_loss(self._h, _hip.ptr(x), x.size, 1 if is_free else 0, n0, n1, _hip.ptr(out)))
         return out
+
+    def gh_logistic(self, z_mean, z_sd, gh_x, gh_w, order=0):
+        """Gauss-Hermite value of E log(1 + e^z), z ~ N(z_mean, z_sd^2), per element (LRVB/Modeling.py:36-52), and
+        with order 1 / 2 the first (n x 2: mean, sd) and second (n x 3: mean-mean, mean-sd, sd-sd) derivatives of that sum."""
+        zm, zs = _hip.as_f64(z_mean), _hip.as_f64(z_sd)
+        if zm.shape != zs.shape:
+            raise ValueError('z_mean and z_sd must have one shape')
+        gx, gw = _hip.as_f64(gh_x).ravel(), _hip.as_f64(gh_w).ravel()
+        if gx.size != gw.size:
+            raise ValueError('as many quadrature weights as nodes')
+        n = zm.size
+        val = np.empty(n)
+        d1 = np.empty((n, 2)) if order >= 1 else None
+        d2 = np.empty((n, 3)) if order >= 2 else None
+        self._check(self._lib.lrvb_gh_logistic(self._h, n, _hip.ptr(zm.ravel()), _hip.ptr(zs.ravel()), _hip.ptr(gx), _hip.ptr(gw),
+                                              gx.size, int(order), _hip.ptr(val), _hip.ptr(d1), _hip.ptr(d2)))
+        out = [val.reshape(zm.shape)]
+        if order >= 1:
+            out.append(d1.reshape(zm.shape + (2,)))
+        if order >= 2:
+            out.append(d2.reshape(zm.shape + (3,)))
+        return out[0] if order == 0 else tuple(out)
+
+    def logitnormal_terms(self, mean, var, gh_x, gh_w, want_grad=True, want_hess=True):
+        """Data term of logistic regression under q(beta_j) = N(mean_j, var_j) in the coordinates (mean, var):
+        value, gradient (2 P) and the Hessian blocks (H_mm, H_mv, H_vv), each P x P (lrvb_logitnormal_terms)."""
+        m, v = _hip.as_f64(mean).ravel(), _hip.as_f64(var).ravel()
+        gx, gw = _hip.as_f64(gh_x).ravel(), _hip.as_f64(gh_w).ravel()
+        P = self.n_cols
+        if m.size != P or v.size != P or gx.size != gw.size:
+            raise ValueError('expected mean and var of length {} and as many weights as nodes'.format(P))
+        val = np.empty(1)
+        g = np.empty(2 * P) if want_grad else None
+        Hb = np.empty((3, P, P)) if want_hess else None
+        self._check(self._lib.lrvb_logitnormal_terms(self._h, _hip.ptr(m), _hip.ptr(v), P, _hip.ptr(gx), _hip.ptr(gw), gx.size,
+                                                    _hip.ptr(val), _hip.ptr(g), _hip.ptr(Hb)))
+        return float(val[0]), g, (None if Hb is None else (Hb[0], Hb[1], Hb[2]))
 
     def obs_influence(self, x, moment_jac, n0=0, n1=None, is_free=True):
         """d moments / d weights for observations n0..n1 ((n1 - n0) x Q), from the resident factor."""

@@ -75,7 +75,7 @@ def test_schur_complement_matches_ad(vb, N, V, K):
     assert rel_err(fun.global_cov(theta, M), M @ np.linalg.inv(HS_ad) @ M.T) < 1e-6
 
 
-@pytest.mark.parametrize('K,q', [(2, 3), (3, 5), (5, 4), (8, 16), (32, 32)])
+@pytest.mark.parametrize('K,q', [(2, 3), (3, 5), (5, 4), (8, 16), (6, 32), (32, 32)])      # (6, 32): 192 = 128 + 64 columns, an edge tile half full
 def test_device_schur_assembly_matches_oracle(vb, K, q):
     """lrvb_mixture_schur against oracle.mixture_schur: odd sizes take the generic GEMM, (8, 16) and (32, 32)
     the LDS-DMA MFMA kernel; R from the host and R left on the device by lrvb_mixture_rows."""
