@@ -212,6 +212,10 @@ constexpr int WS_BUF = 2 * WS_PANEL + 64;                // A panel, B panel, 32
 // destination base travels in M0 (the hardware adds lane * size)
 #define WS_GLDS16_S(sbase, voff, ldsaddr) asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" \
     :: "v"(voff), "s"(sbase), "s"(ldsaddr) : "memory")
+// the same with the streaming cache policy (sc1 nt): the diagonal tiles are the only readers of their panel, so their lines
+// need not displace what the off-diagonal readers share in L2 (14.97 against 15.07 ms over six alternating runs)
+#define WS_GLDS16_S_NT(sbase, voff, ldsaddr) asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1 sc1 nt" \
+    :: "v"(voff), "s"(sbase), "s"(ldsaddr) : "memory")
 #define WS_GLDS4_S(sbase, voff, ldsaddr) asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dword %0, %1" \
     :: "v"(voff), "s"(sbase), "s"(ldsaddr) : "memory")
 
@@ -295,7 +299,7 @@ void wsyrk_glds_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const unsigned la = base + (unsigned)((wave + 4 * i) * WS_LDS_STRIDE) * 8u;
-                WS_GLDS16_S(sb, voffA[i], la);
+                if (diag) WS_GLDS16_S_NT(sb, voffA[i], la); else WS_GLDS16_S(sb, voffA[i], la);
                 if (!diag) WS_GLDS16_S(sb, voffB[i], la + (unsigned)WS_PANEL * 8u);
             }
         } else {                                                 // last rows of the matrix: clamp to a readable row
