@@ -25,7 +25,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
     (const __attribute__((address_space(1))) void*)(gp), (__attribute__((address_space(3))) void*)(lp), 16, 0, 0)
 
 // scalar-base form: global address = sbase (SGPR pair) + voff (32-bit per-lane byte offset), LDS destination base in M0
-#define HM_GLDS16_S(sbase, voff, ldsaddr) asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" \
+#define HM_GLDS16_S(sbase, voff, ldsaddr) asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1 nt" \
     :: "v"(voff), "s"(sbase), "s"(ldsaddr) : "memory")
 
 constexpr int HM_ROWS = 8;               // observations per chunk

@@ -412,7 +412,7 @@ void gemv_kernel(int trans, i64 M, i64 N, double alpha, const double* __restrict
     const i64 nout = trans ? N : M;
     if (o >= nout) return;
     double s = 0.0;
-    if (!trans) { for (i64 k = lane; k < N; k += 64) s += A[o * lda + k] * x[k]; }
+    if (!trans) { for (i64 k = lane; k < N; k += 64) s += __builtin_nontemporal_load(A + o * lda + k) * x[k]; }
     else        { for (i64 k = lane; k < M; k += 64) s += A[k * lda + o] * x[k]; }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
@@ -435,12 +435,12 @@ void gemv_t_tall_kernel(i64 M, i64 N, const double* __restrict__ A, i64 lda, con
         if (col < N) {
             i64 k = r0 + ty;
             for (; k + 12 < r1; k += 16) {
-                s0 += A[k * lda + col] * x[k];
-                s1 += A[(k + 4) * lda + col] * x[k + 4];
-                s2 += A[(k + 8) * lda + col] * x[k + 8];
-                s3 += A[(k + 12) * lda + col] * x[k + 12];
+                s0 += __builtin_nontemporal_load(A + k * lda + col) * x[k];
+                s1 += __builtin_nontemporal_load(A + (k + 4) * lda + col) * x[k + 4];
+                s2 += __builtin_nontemporal_load(A + (k + 8) * lda + col) * x[k + 8];
+                s3 += __builtin_nontemporal_load(A + (k + 12) * lda + col) * x[k + 12];
             }
-            for (; k < r1; k += 4) s0 += A[k * lda + col] * x[k];
+            for (; k < r1; k += 4) s0 += __builtin_nontemporal_load(A + k * lda + col) * x[k];
         }
         sh[ty][tx] = (s0 + s1) + (s2 + s3);
         __syncthreads();

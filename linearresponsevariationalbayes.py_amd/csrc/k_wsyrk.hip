@@ -503,8 +503,9 @@ void gram_small_kernel(const double* __restrict__ Z, i64 ldz, i64 N, int P,
 #pragma unroll
             for (int m = 0; m < NPAIR; ++m) {
                 if (aligned16) {
-                    const double2 t = *reinterpret_cast<const double2*>(rowp + colp[m]);
-                    x[ks][m][0] = t.x; x[ks][m][1] = t.y;
+                    typedef double v2d __attribute__((ext_vector_type(2)));       // streamed once: non-temporal
+                    const v2d t = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(rowp + colp[m]));
+                    x[ks][m][0] = t[0]; x[ks][m][1] = t[1];
                 } else {
                     x[ks][m][0] = rowp[colp[m]]; x[ks][m][1] = rowp[colp[m] + (P >= 2 ? 1 : 0)];
                 }
