@@ -1158,9 +1158,10 @@ void wsyrk_reduce_kernel(const double* __restrict__ partial, int n_splits, i64 t
     const i64 e2 = ((i64)blockIdx.x * blockDim.x + threadIdx.x) * 2;
     if (e2 >= tile_elems_total) return;
     double s0 = 0.0, s1 = 0.0;
-    for (int s = 0; s < n_splits; ++s) {
-        const double2 v = *reinterpret_cast<const double2*>(partial + (i64)s * tile_elems_total + e2);
-        s0 += v.x; s1 += v.y;
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    for (int s = 0; s < n_splits; ++s) {                       // every partial is read exactly once: streaming loads
+        const v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(partial + (i64)s * tile_elems_total + e2));
+        s0 += v[0]; s1 += v[1];
     }
     *reinterpret_cast<double2*>(tiles + e2) = make_double2(s0, s1);
 }
