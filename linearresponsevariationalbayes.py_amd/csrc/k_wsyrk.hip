@@ -658,6 +658,11 @@ __global__ void wsyrk_reduce_kernel(const double* __restrict__ partial, int n_sp
 // 16-wide groups of the edge tile's slot and are added when the tiles are unpacked.  With the edge tiles as workgroups
 // of their own (SLIVER = 0) nine of 25 workgroups per split paid a full stage of loads and barriers for 1/8 of the MFMAs:
 // 10.65 ms for 5.6e11 flops.  The caller guarantees 16 readable, finite rows past N in A and B.
+// SLIVER = 2: the same with the A operand GENERATED ON CHIP.  A is then the N x 31 data matrix X of the mixture (lda = 31) and
+// the virtual operand row is the packed lower triangle of x~ x~^T, x~ = [1, x] (528 products of 32 numbers): a stage DMAs
+// the 16 rows of X (4 KB instead of the 16 KB panel), and a fragment element is the product of two LDS reads whose
+// addresses (the pair (a, b) of its packed column) are computed once per lane.  kron_rows_kernel and its 4.2 GB operand
+// (0.9 ms to write, as much to read back) disappear.
 template <int SLIVER>
 __global__ __launch_bounds__(WS_THREADS, 2)
 void atb_glds_kernel(const double* __restrict__ A, i64 lda, int PA, const double* __restrict__ B, i64 ldb, int PB,
@@ -692,6 +697,7 @@ void atb_glds_kernel(const double* __restrict__ A, i64 lda, int PA, const double
     // scalar row bases + constant 32-bit lane offsets, as in wsyrk_glds_kernel: a stage issues no VALU instruction
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) double*)lds;
     const unsigned voffA = (unsigned)ca * 8u, voffB = (unsigned)cb * 8u, voffC = (unsigned)lane * 4u;
+    const unsigned voffX = (unsigned)(lane < 62 ? lane : 61) * 4u;
     auto issue_stage = [&](int ch, int buf) {
         const unsigned base = lds0 + (unsigned)(buf * WS_BUF) * 8u;
         const i64 n0 = r0 + (i64)ch * WS_KC;
@@ -700,12 +706,19 @@ void atb_glds_kernel(const double* __restrict__ A, i64 lda, int PA, const double
             const int row = wave + 4 * i;
             i64 n = n0 + row; if (n > N - 1) n = N - 1;                 // wave-uniform clamp (scalar)
             const unsigned la = base + (unsigned)(row * WS_LDS_STRIDE) * 8u;
-            WS_GLDS16_S(reinterpret_cast<const char*>(A + n * lda), voffA, la);
+            if (SLIVER == 2)      // row n of X: 31 doubles = 62 dwords behind the constant slot 0 (lanes 62, 63 repeat lane 61's dword into the pad)
+                WS_GLDS4_S(reinterpret_cast<const char*>(A + n * lda), voffX, la + 8u);
+            else
+                WS_GLDS16_S(reinterpret_cast<const char*>(A + n * lda), voffA, la);
             WS_GLDS16_S(reinterpret_cast<const char*>(B + n * ldb), voffB, la + (unsigned)WS_PANEL * 8u);
         }
         if (wave == 0)
             WS_GLDS4_S(reinterpret_cast<const char*>(cpad + n0), voffC, base + (unsigned)(2 * WS_PANEL) * 8u);
     };
+    if (SLIVER == 2) {            // x~_0 = 1 in slot 0 of the 16 rows of both buffers; the DMA never writes there
+        if (tid < 32) lds[(tid >> 4) * WS_BUF + (tid & 15) * WS_LDS_STRIDE] = 1.0;
+        __syncthreads();
+    }
     if (nch > 0) issue_stage(0, 0);
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): LDS-DMA of the stage has landed
     __syncthreads();
@@ -736,10 +749,26 @@ void atb_glds_kernel(const double* __restrict__ A, i64 lda, int PA, const double
         const unsigned voffSB = (unsigned)(((i64)(4 * bj + l4) * ldb + 4 * WS_TILE + l15) * 8);
         double asl[2] = {0.0, 0.0}, bsl[2] = {0.0, 0.0};
         d4 acc_i0 = (d4){0.0, 0.0, 0.0, 0.0}, acc_i1 = acc_i0, acc_ii0 = acc_i0, acc_ii1 = acc_i0, acc_c = acc_i0;
+        // SLIVER = 2: packed column v = a (a + 1) / 2 + b (b <= a) of the virtual operand is x~_a x~_b; this lane's two columns
+        // of the panel and its column of the sliver, as LDS addresses (row l4 of a k-step; slot s of a row holds x~_s)
+        auto pair_of = [](int v, int& a, int& b) {
+            a = (int)((sqrtf(8.f * (float)v + 1.f) - 1.f) * 0.5f);
+            while (a * (a + 1) / 2 > v) --a;
+            while ((a + 1) * (a + 2) / 2 <= v) ++a;
+            b = v - a * (a + 1) / 2;
+        };
+        const double *ga0 = lds, *gb0 = lds, *ga1 = lds, *gb1 = lds, *gas = lds, *gbs = lds;
+        if (SLIVER == 2) {
+            int a, b;
+            pair_of(bi * WS_TILE + 32 * wave + 2 * l15, a, b);     ga0 = lds + l4 * WS_LDS_STRIDE + a; gb0 = lds + l4 * WS_LDS_STRIDE + b;
+            pair_of(bi * WS_TILE + 32 * wave + 2 * l15 + 1, a, b); ga1 = lds + l4 * WS_LDS_STRIDE + a; gb1 = lds + l4 * WS_LDS_STRIDE + b;
+            pair_of(4 * WS_TILE + l15, a, b);
+            gas = lds + (4 * bi + l4) * WS_LDS_STRIDE + a; gbs = lds + (4 * bi + l4) * WS_LDS_STRIDE + b;     // k-step bi, as the register sliver
+        }
         const bool corner = SLIVER && (bi == bj) && (wave == 0);                    // wave-uniform
         auto load_sliver = [&](int ch, double& a, double& b) {
             const i64 n0 = r0 + (i64)ch * WS_KC;
-            asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(a) : "v"(voffSA), "s"(A + n0 * lda) : "memory");
+            if (SLIVER == 1) asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(a) : "v"(voffSA), "s"(A + n0 * lda) : "memory");
             asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(b) : "v"(voffSB), "s"(B + n0 * ldb) : "memory");
         };
         if (SLIVER) {
@@ -749,20 +778,31 @@ void atb_glds_kernel(const double* __restrict__ A, i64 lda, int PA, const double
         }
         auto stage = [&](auto buf_tag, int ch) {
             constexpr int BUF = decltype(buf_tag)::value;
-            double af[2][2], bf[2][8], cv[2];
+            double af[2][2], gf[2][2], bf[2][8], cv[2];
             if (SLIVER) load_sliver(ch + 1 < nch ? ch + 1 : ch, asl[BUF ^ 1], bsl[BUF ^ 1]);     // no branch around the asm loads
             d2 ax = (d2){0.0, 0.0}, bx = (d2){0.0, 0.0};
             double cxi = 0.0, cxii = 0.0;
+            double asg = 0.0;
             if (SLIVER) {
-                ax = *reinterpret_cast<const d2*>(a_base_s + BUF * WS_BUF);
+                if (SLIVER == 2) {
+                    const int os = BUF * WS_BUF + bj * 4 * WS_LDS_STRIDE;
+                    ax = (d2){ga0[os] * gb0[os], ga1[os] * gb1[os]};
+                    asg = gas[BUF * WS_BUF] * gbs[BUF * WS_BUF];
+                } else {
+                    ax = *reinterpret_cast<const d2*>(a_base_s + BUF * WS_BUF);
+                }
                 bx = *reinterpret_cast<const d2*>(b_base_s + BUF * WS_BUF);
                 cxi = c_base_i[BUF * WS_BUF]; cxii = c_base_ii[BUF * WS_BUF];
             }
             auto read_frags = [&](int kk, int set) {
                 const int o = BUF * WS_BUF + kk * 4 * WS_LDS_STRIDE;
                 cv[set] = c_base[BUF * WS_BUF + kk * 4];
-                const d2 va = *reinterpret_cast<const d2*>(a_base + o);
-                af[set][0] = va[0]; af[set][1] = va[1];
+                if (SLIVER == 2) {
+                    af[set][0] = ga0[o]; af[set][1] = ga1[o]; gf[set][0] = gb0[o]; gf[set][1] = gb1[o];
+                } else {
+                    const d2 va = *reinterpret_cast<const d2*>(a_base + o);
+                    af[set][0] = va[0]; af[set][1] = va[1];
+                }
 #pragma unroll
                 for (int h = 0; h < 4; ++h) {
                     const d2 vb = *reinterpret_cast<const d2*>(b_base + o + 32 * h);
@@ -773,7 +813,8 @@ void atb_glds_kernel(const double* __restrict__ A, i64 lda, int PA, const double
 #pragma unroll
             for (int kk = 0; kk < WS_KC / 4; ++kk) {
                 const int set = kk & 1;
-                const double as0 = af[set][0] * cv[set], as1 = af[set][1] * cv[set];
+                const double as0 = (SLIVER == 2 ? af[set][0] * gf[set][0] : af[set][0]) * cv[set];
+                const double as1 = (SLIVER == 2 ? af[set][1] * gf[set][1] : af[set][1]) * cv[set];
                 __builtin_amdgcn_sched_barrier(0);
                 if (kk + 1 < WS_KC / 4) read_frags(kk + 1, set ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
@@ -783,7 +824,7 @@ void atb_glds_kernel(const double* __restrict__ A, i64 lda, int PA, const double
                     acc[8 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(as1, bf[set][n], acc[8 + n], 0, 0, 0);
                 }
                 if (SLIVER && kk == 1) {          // the sliver products of this stage, behind the second MFMA block
-                    const double sa = asl[BUF] * cxii;
+                    const double sa = (SLIVER == 2 ? asg : asl[BUF]) * cxii;
                     acc_i0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[0] * cxi, bsl[BUF], acc_i0, 0, 0, 0);
                     acc_i1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[1] * cxi, bsl[BUF], acc_i1, 0, 0, 0);
                     acc_ii0 = __builtin_amdgcn_mfma_f64_16x16x4f64(sa, bx[0], acc_ii0, 0, 0, 0);
@@ -880,6 +921,8 @@ void atb_glds_kernel(const double* __restrict__ A, i64 lda, int PA, const double
                 out[(wr * 64 + m * 16 + l4 + 4 * r) * WS_TILE + wc * 64 + n * 16 + l15] = acc[m * 4 + n][r];
 }
 
+int launch_atb_kron32(lrvb_ctx* c, const double* X31, const double* B, i64 N, const double* cvec_dev, double* C_dev);
+
 __global__ __launch_bounds__(256)
 void atb_tiles_to_dense_kernel(const double* __restrict__ tiles, int nbb, i64 PA, i64 PB, double* __restrict__ C, i64 ldc, int sliver)
 {
@@ -936,6 +979,36 @@ int launch_atb(lrvb_ctx* c, const double* A, i64 PA, const double* B, i64 PB, i6
     return LRVB_OK;
 }
 
+
+// C (528 x 528) = Xk^T diag(c) B with Xk[n, :] = packed lower triangle of [1, x_n][1, x_n]^T generated on chip from the
+// N x 31 matrix X31 (atb_glds_kernel<2>); B is N x 528 with 16 zero rows past N, its rows 16-byte aligned.
+int launch_atb_kron32(lrvb_ctx* c, const double* X31, const double* B, i64 N, const double* cvec_dev, double* C_dev) {
+    const i64 PA = 4 * WS_TILE + 16, PB = PA;
+    if ((((uintptr_t)B) & 15) || (((uintptr_t)X31) & 7)) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "atb: operand alignment");
+    const int nba = 5, nbb = 5, T = 25;
+    i64 S = 128;
+    i64 max_by_rows = (N / 256 / 8) * 8;
+    if (S > max_by_rows) S = max_by_rows;
+    if (S < 8) S = 8;
+    i64 rps = (N + S - 1) / S;
+    rps = ((rps + WS_KC - 1) / WS_KC) * WS_KC;
+    const i64 tile_elems = (i64)T * WS_TILE * WS_TILE;
+    LRVB_TRY(buf_reserve(c, c->tile_part, (size_t)(tile_elems * (S + 1))));
+    double* part = c->tile_part.p;
+    double* tiles = c->tile_part.p + tile_elems * S;
+    if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
+    hipLaunchKernelGGL(atb_glds_kernel<2>, dim3((unsigned)(S * 16)), dim3(WS_THREADS), 0, c->stream,
+                       X31, (i64)31, (int)PA, B, PB, (int)PB, N, cvec_dev, (int)S, nba, nbb, rps, part);
+    HIP_TRY(hipGetLastError());
+    if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
+    hipLaunchKernelGGL(wsyrk_reduce_kernel, dim3((unsigned)((tile_elems / 2 + 255) / 256)), dim3(256), 0, c->stream,
+                       part, (int)S, tile_elems, tiles);
+    HIP_TRY(hipGetLastError());
+    dim3 grid((unsigned)((PB + 255) / 256), (unsigned)PA);
+    hipLaunchKernelGGL(atb_tiles_to_dense_kernel, grid, dim3(256), 0, c->stream, tiles, nbb, PA, PB, C_dev, PB, 1);
+    HIP_TRY(hipGetLastError());
+    return LRVB_OK;
+}
 
 // ---- Kronecker-row variant: K4 = sum_n c_n (z_n (x) z_n)(z_n (x) z_n)^T ---------------------------
 // The Gram matrix G^T G of per-observation gradients of an objective that is QUADRATIC IN THE DATA

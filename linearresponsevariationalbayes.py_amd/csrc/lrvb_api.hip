@@ -1287,15 +1287,17 @@ extern "C" int lrvb_mixture_rows(lrvb_ctx* c, int32_t K, const double* theta_z, 
     if (st == LRVB_OK) st = d2h(c, S64_out, c->Hfree.p, 64 * 64);
     if (st == LRVB_OK && R_out) {
         if (hbad) { lrvb_set_error("a local (simplex) Hessian block is not positive definite: the Schur complement is undefined at this point"); st = LRVB_ERR_NOT_POSDEF; }
-        if (st == LRVB_OK) st = buf_reserve(c, Xk, (size_t)((N + 16) * ldk));
-        if (st == LRVB_OK) st = launch_kron_rows(c, Xk.p, ldk);
+        const bool onchip = (V == 31 && K == 32);        // 528 x N x 528: the x~ (x) x~ operand is generated inside the GEMM
+        if (st == LRVB_OK && !onchip) st = buf_reserve(c, Xk, (size_t)((N + 16) * ldk));
+        if (st == LRVB_OK && !onchip) st = launch_kron_rows(c, Xk.p, ldk);
         if (st == LRVB_OK) st = buf_reserve(c, Rd, (size_t)(ldk * lda));
         if (st == LRVB_OK) { EW(fill_kernel, N, 1.0, c->zbuf.p); }
-        if (st == LRVB_OK && (hipMemsetAsync(Xk.p + N * ldk, 0, (size_t)(16 * ldk) * sizeof(double), c->stream) != hipSuccess ||
+        if (st == LRVB_OK && ((!onchip && hipMemsetAsync(Xk.p + N * ldk, 0, (size_t)(16 * ldk) * sizeof(double), c->stream) != hipSuccess) ||
                               hipMemsetAsync(Amat.p + N * lda, 0, (size_t)(16 * lda) * sizeof(double), c->stream) != hipSuccess)) {
             lrvb_set_error("memset failed"); st = LRVB_ERR_HIP;
         }
-        if (st == LRVB_OK) st = launch_atb(c, Xk.p, ldk, Amat.p, lda, N, c->zbuf.p, Rd.p, true);
+        if (st == LRVB_OK) st = onchip ? launch_atb_kron32(c, c->X.p, Amat.p, N, c->zbuf.p, Rd.p)
+                                       : launch_atb(c, Xk.p, ldk, Amat.p, lda, N, c->zbuf.p, Rd.p, true);
         // Amat is dead now: reuse it for the expanded (V+1)^2 x K^2 result
         if (st == LRVB_OK) st = buf_reserve(c, Amat, (size_t)(QQ * KK));
         if (st == LRVB_OK) st = launch_mixture_expand(c, Rd.p, lda, V + 1, K, Amat.p);
