@@ -57,14 +57,46 @@ class LogitNormalRegressionObjective(object):
         x = _hip.as_f64(x).ravel()
         return self.ctx.constrain(x) if is_free else x
 
+    # ---- observations sharded over GPUs: the data term is a sum over rows --------------------------------------
+    def local_stats(self, eta):
+        """[value | gradient (2 P) | H_mm, H_mv, H_vv (3 P^2)] of THIS process's rows in the coordinates (mean, var) at the
+        vector-coordinate point eta = [mean | info]: the buffer of the one sum all-reduce per evaluation (SURVEY.md section
+        8(e)); prior, entropy, the chain var = 1 / info and the free conversion are replicated afterwards."""
+        eta = _hip.as_f64(eta).ravel()
+        self._push_state()
+        val, g, Hb = self.ctx.logitnormal_terms(eta[:self.P], 1.0 / eta[self.P:], self.gh_x, self.gh_w)
+        return np.concatenate([[val], g, Hb[0].ravel(), Hb[1].ravel(), Hb[2].ravel()])
+
+    def set_reduced_stats(self, flat, eta=None):
+        """Install statistics summed over all shards for the point eta (None = use this process's own rows again)."""
+        if flat is None:
+            self._external = None
+            return
+        flat = np.asarray(flat, dtype=np.float64).ravel()
+        P = self.P
+        if flat.size != 1 + 2 * P + 3 * P * P or eta is None:
+            raise ValueError('expected {} statistics and the point they were formed at'.format(1 + 2 * P + 3 * P * P))
+        self._external = (np.asarray(eta, dtype=np.float64).copy(), flat.copy())
+        self._h_key = None
+
+    def _data_terms(self, eta, want_grad, want_hess):
+        P = self.P
+        ext = getattr(self, '_external', None)
+        if ext is not None:
+            if not np.array_equal(ext[0], eta):
+                raise ValueError('the installed statistics were formed at another point')
+            f = ext[1]
+            Hb = f[1 + 2 * P:].reshape(3, P, P)
+            return float(f[0]), f[1:1 + 2 * P], (Hb[0], Hb[1], Hb[2])
+        self._push_state()
+        return self.ctx.logitnormal_terms(eta[:P], 1.0 / eta[P:], self.gh_x, self.gh_w, want_grad=want_grad, want_hess=want_hess)
+
     # ---- vector coordinates (mean, info) -------------------------------------------------------------------
     def _terms(self, eta, want_grad=True, want_hess=True):
         P = self.P
         mean, info = eta[:P], eta[P:]
         var = 1.0 / info
-        self._push_state()
-        val, g_mv, Hb = self.ctx.logitnormal_terms(mean, var, self.gh_x, self.gh_w, want_grad=want_grad or want_hess,
-                                                   want_hess=want_hess)
+        val, g_mv, Hb = self._data_terms(eta, want_grad or want_hess, want_hess)
         tau = self.prior_info
         val += 0.5 * tau * (np.sum(mean ** 2) + np.sum(var)) + 0.5 * np.sum(np.log(info))
         if not (want_grad or want_hess):

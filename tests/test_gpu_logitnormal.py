@@ -140,3 +140,25 @@ def test_bad_arguments_fail_loudly(vb):
     par2.push_param(vb.UVNParamVector('beta', length=5))
     with pytest.raises(ValueError):
         vb.LogitNormalRegressionObjective(par2, x, y)                                         # parameter does not match the design
+
+
+def test_statistics_are_additive_over_shards(vb):
+    """The multi-GPU reduction of this model: [value | gradient | Hessian blocks] of row shards add up to the full data term,
+    and a shard object with the summed statistics installed returns the full-data value, gradient and Hessian."""
+    N, P = 5001, 12
+    x, y, w, eta = problem(N, P, seed=9)
+    gx, gw = np.polynomial.hermite.hermgauss(20)
+    _, full = _model(vb, x, y, w)
+    n1 = 1777
+    _, f1 = _model(vb, x[:n1], y[:n1], w[:n1])
+    _, f2 = _model(vb, x[n1:], y[n1:], w[n1:])
+    s_sum = f1.local_stats(eta) + f2.local_stats(eta)
+    assert rel_err(s_sum, full.local_stats(eta)) < 1e-11
+    o_val, o_g, o_H = ol.kl_terms(eta, x, y, w, 0.7, gx, gw)
+    f1.set_reduced_stats(s_sum, eta)
+    assert abs(f1.value(eta, False) - o_val) < 1e-11 * abs(o_val)
+    assert rel_err(f1.grad(eta, False), o_g) < 1e-10 and rel_err(f1.hessian(eta, False), o_H) < 1e-9
+    with pytest.raises(ValueError):
+        f1.value(eta * 1.01, False)                             # statistics of another point
+    f1.set_reduced_stats(None)
+    assert abs(f1.value(eta, False) - o_val) > 1e-3 * abs(o_val)      # back to its own rows
