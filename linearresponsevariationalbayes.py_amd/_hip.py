@@ -213,3 +213,39 @@ def ptr(a):
         return None
     assert a.dtype == np.float64 and a.flags['C_CONTIGUOUS']
     return a.ctypes.data_as(ctypes.c_void_p)
+
+
+# ---- host closed forms -------------------------------------------------------------------------------------------
+# The N-independent algebra of the model classes (a few hundred small products per evaluation) runs through numpy's BLAS.
+# With the library's default pool -- one thread per hardware thread of a 128+-core host -- every small product pays for
+# waking the pool: the LMM step of bench.py --config c4 took 40-68 ms with it and 10.6 ms with 16 threads.
+try:
+    from threadpoolctl import ThreadpoolController as _ThreadpoolController
+except Exception:                                    # not installed: run with the pool as it is
+    _ThreadpoolController = None
+HOST_BLAS_THREADS = int(os.environ.get('LRVB_HOST_BLAS_THREADS', '16'))
+_blas_controller = None
+_blas_depth = 0
+
+
+def host_blas(fn):
+    """Decorator: run the method with the BLAS pool limited to HOST_BLAS_THREADS (0 = leave the pool alone).  The
+    controller (one scan of the loaded libraries) is built once; nested decorated calls do not re-enter it."""
+    if _ThreadpoolController is None:
+        return fn
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **k):
+        global _blas_controller, _blas_depth
+        if HOST_BLAS_THREADS <= 0 or _blas_depth > 0:
+            return fn(*a, **k)
+        if _blas_controller is None:
+            _blas_controller = _ThreadpoolController()
+        _blas_depth += 1
+        try:
+            with _blas_controller.limit(limits=HOST_BLAS_THREADS, user_api='blas'):
+                return fn(*a, **k)
+        finally:
+            _blas_depth -= 1
+    return wrapped

@@ -257,15 +257,18 @@ class LMMObjective(object):
     def __call__(self):
         return self.value(np.asarray(self.par.get_free(), dtype=np.float64), True)
 
+    @_hip.host_blas
     def value(self, x, is_free):
         return self.value_vec(self._eta(x, is_free))
 
+    @_hip.host_blas
     def grad(self, x, is_free):
         g = self._arrow(self._eta(x, is_free))[0]
         return self.ctx.free_to_vector_jac(x).T @ g if is_free else g
 
     jacobian = grad
 
+    @_hip.host_blas
     def hessian(self, x, is_free):
         if self.par.vector_size() > 8192:
             raise MemoryError('dense Hessian of {} parameters: use global_hessian() (Schur complement)'.format(self.par.vector_size()))
@@ -276,6 +279,7 @@ class LMMObjective(object):
         return self.hessian(x, is_free) @ _hip.as_f64(v).ravel()
 
     # ---- arrow structure: sparse export (SparseObjectives.get_sparse_sub_hessian, :587-594) ------------
+    @_hip.host_blas
     def sparse_hessian(self, free_val):
         """The full free-coordinate Hessian as a scipy CSR matrix: dense global block, the cross block
         and the 2G diagonal local entries placed with `get_sparse_sub_matrix` -- the format in which the
@@ -303,6 +307,7 @@ class LMMObjective(object):
         return np.diag(self._gctx.free_to_vector_jac(free_g)).copy()
 
     # ---- arrow structure: Schur complement onto the global block, free coordinates --------------------
+    @_hip.host_blas
     def global_hessian(self, free_val):
         """H_S = H_gg - H_gl diag(H_ll)^-1 H_lg in FREE coordinates (n_global x n_global): the
         matrix whose inverse is the linear-response covariance block of the global parameters."""
