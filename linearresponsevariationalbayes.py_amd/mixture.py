@@ -129,18 +129,27 @@ class MixtureObjective(object):
 
     def _global_terms(self, alpha, beta, C):
         """Value, vector-coordinate gradient (ng,) and Hessian (ng, ng) of everything that depends on
-        the Dirichlet parameters, at FIXED responsibilities; C = sum_n w_n x~_n z_n^T."""
+        the Dirichlet parameters, at FIXED responsibilities; C = sum_n w_n x~_n z_n^T.  The K columns of phi are K
+        independent Dirichlets: their terms (`_dirichlet_terms`, one column at a time) are evaluated for all columns at once."""
         V, K, ng = self.V, self.K, self.n_global
         g = np.zeros(ng)
         H = np.zeros((ng, ng))
         val, gp, Hp = _dirichlet_terms(alpha, C[0] + self.a0 - 1.0)
         g[self._ipi] = gp
         H[np.ix_(self._ipi, self._ipi)] = Hp
-        for k in range(K):
-            vk, gk, Hk = _dirichlet_terms(beta[:, k], C[1:, k] + self.b0[:, k] - 1.0)
-            val += vk
-            g[self._iphi[:, k]] = gk
-            H[np.ix_(self._iphi[:, k], self._iphi[:, k])] = Hk
+        d = C[1:] + self.b0 - 1.0                                   # (V, K)
+        b0 = np.sum(beta, axis=0)                                    # (K,)
+        dg, dg0 = special.digamma(beta), special.digamma(b0)
+        ent = (np.sum(special.gammaln(beta), axis=0) - special.gammaln(b0) + (b0 - V) * dg0 - np.sum((beta - 1.0) * dg, axis=0))
+        e = beta - 1.0 - d
+        es = np.sum(e, axis=0)
+        p1, p2 = special.polygamma(1, beta), special.polygamma(2, beta)
+        p10, p20 = special.polygamma(1, b0), special.polygamma(2, b0)
+        val += -np.sum(d * (dg - dg0)) - np.sum(ent)
+        g[self._iphi] = e * p1 - es * p10
+        idx = self._iphi.T                                           # (K, V): the parameters of column k
+        blocks = (-p10 - es * p20)[:, None, None] + np.eye(V)[None] * (p1 + e * p2).T[:, :, None]
+        H[idx[:, :, None], idx[:, None, :]] = blocks
         return val, g, H
 
     def _dlam(self, alpha, beta):
@@ -148,10 +157,11 @@ class MixtureObjective(object):
         V, K, ng = self.V, self.K, self.n_global
         DL = np.zeros(((V + 1) * K, ng))
         DL[np.ix_(np.arange(K), self._ipi)] = np.diag(special.polygamma(1, alpha)) - special.polygamma(1, np.sum(alpha))
-        for k in range(K):
-            rows = (np.arange(V) + 1) * K + k
-            DL[np.ix_(rows, self._iphi[:, k])] = (np.diag(special.polygamma(1, beta[:, k]))
-                                                   - special.polygamma(1, np.sum(beta[:, k])))
+        rows = ((np.arange(V) + 1) * K)[None, :] + np.arange(K)[:, None]          # (K, V): rows (j + 1) K + k of column k
+        idx = self._iphi.T
+        p1 = special.polygamma(1, beta)                                          # (V, K)
+        p10 = special.polygamma(1, np.sum(beta, axis=0))
+        DL[rows[:, :, None], idx[:, None, :]] = np.eye(V)[None] * p1.T[:, :, None] - p10[:, None, None]
         return DL
 
     def _rows(self, free_val, want_grad, want_schur):
