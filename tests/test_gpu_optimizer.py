@@ -107,7 +107,10 @@ def test_general_layout_and_quadratic_model(vb):
     xh, rh = vb.OptimizationUtils.minimize_objective_trust_ncg(obj, x0, False, maxiter=300, gtol=1e-8, disp=False)
     xd, rd = vb.OptimizationUtils.minimize_objective_trust_ncg(obj, x0, False, maxiter=300, gtol=1e-8, disp=False, on_device=True)
     assert rd.status == rh.status and rd.nit == rh.nit
-    assert rel_err(xd, xh) < 1e-7
+    # both runs stop at |grad| < 1e-8; along the flattest direction of this layout (a simplex logit near -10) that leaves
+    # ~1e-6 of freedom in x, and the two routes sum their reductions in different orders
+    assert rel_err(xd, xh) < 1e-5
+    assert np.max(np.abs(obj.fun_free_grad(xd))) < 1e-7
     # quadratic model: f(x) = 1/2 (x - t)^T Q (x - t), optimum t, reached exactly
     D = 9
     Q = rng.normal(size=(D, D)); Q = Q @ Q.T + np.eye(D)
