@@ -162,3 +162,17 @@ def test_statistics_are_additive_over_shards(vb):
         f1.value(eta * 1.01, False)                             # statistics of another point
     f1.set_reduced_stats(None)
     assert abs(f1.value(eta, False) - o_val) > 1e-3 * abs(o_val)      # back to its own rows
+
+
+@pytest.mark.parametrize('P', [62, 66, 126, 128, 190, 192, 194, 254, 256, 258, 320, 382])
+def test_hessian_blocks_over_tile_edge_shapes(vb, P):
+    """The three Hessian products run on the two-operand LDS-DMA MFMA kernel for every even P: widths just below, at and
+    above the 128-column tile and its 64-column half (an edge tile whose real columns end inside it, a full tile next to a
+    sliver, ...), and row counts that end inside a 16-row stage and inside a split."""
+    N = 1000 + 37 * (P % 13)
+    x, y, w, eta = problem(N, P, seed=P)
+    gx, gw = np.polynomial.hermite.hermgauss(12)
+    par, fun = _model(vb, x, y, w, deg=12)
+    o_val, o_g, o_H = ol.kl_terms(eta, x, y, w, 0.7, gx, gw)
+    assert rel_err(fun.grad(eta, False), o_g) < 1e-10
+    assert rel_err(fun.hessian(eta, False), o_H) < 1e-9
