@@ -2301,6 +2301,17 @@ static int hvp_apply_multi(lrvb_ctx* c, i64 Q, const double* Vb, double* Out) {
     return launch_gemm(c, false, false, Q, D, D, 1.0, Vb, D, c->Tdense.p, D, 1.0, Out, D);        // + Vb T (T symmetric)
 }
 
+// step lengths of the blocked CG on the device: alpha_q = (r.z)_q / (p.Hp)_q for the systems still running (the ones whose
+// direction was updated in this iteration: z coefficient 1), 0 for the frozen ones; the coefficient rows of the two updates
+// x += alpha p, r -= alpha q are written in place.  Saves the second host round trip of every iteration.
+__global__ void cg_multi_alpha_kernel(int Q, double* __restrict__ s) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    const bool act = s[4 * Q + q] != 0.0;
+    const double alpha = act ? s[2 * Q + q] / s[3 * Q + q] : 0.0;
+    s[4 * Q + q] = alpha; s[5 * Q + q] = 1.0; s[6 * Q + q] = -alpha; s[7 * Q + q] = 1.0;
+}
+
 extern "C" int lrvb_cg_solve_multi(lrvb_ctx* c, const double* free_in, const double* B, const double* X0,
                                    const double* Minv, double tol, int64_t maxiter, int64_t D, int64_t Q,
                                    double* X_out, int* info_out, int64_t* iters_out) {
@@ -2372,13 +2383,9 @@ extern "C" int lrvb_cg_solve_multi(lrvb_ctx* c, const double* free_in, const dou
         LRVB_TRY(hvp_apply_multi(c, Q, Pd, Qd));
         hipLaunchKernelGGL(rows_dot_kernel, dim3((unsigned)Q), dim3(256), 0, c->stream, Q, D, Pd, Qd, s + 3 * Q);
         HIP_TRY(hipGetLastError());
-        LRVB_TRY(d2h(c, hs.data() + 2 * Q, s + 3 * Q, (size_t)Q));
-        for (i64 q = 0; q < Q; ++q) {
-            const double alpha = active[q] ? rho_prev[q] / hs[2 * Q + q] : 0.0;
-            coef[q] = alpha; coef[Q + q] = 1.0; coef[2 * Q + q] = -alpha; coef[3 * Q + q] = 1.0;
-            if (active[q]) iters[q] = it + 1;
-        }
-        LRVB_TRY(h2d(c, s + 4 * Q, coef.data(), (size_t)(4 * Q)));
+        hipLaunchKernelGGL(cg_multi_alpha_kernel, dim3((unsigned)((Q + 63) / 64)), dim3(64), 0, c->stream, (int)Q, s);
+        HIP_TRY(hipGetLastError());
+        for (i64 q = 0; q < Q; ++q) if (active[q]) iters[q] = it + 1;
         EW(rows_axpby_kernel, (i64)qd, D, s + 4 * Q, Pd, s + 5 * Q, Xd);          // x += alpha p
         EW(rows_axpby_kernel, (i64)qd, D, s + 6 * Q, Qd, s + 7 * Q, Rd);          // r -= alpha q
     }
