@@ -77,6 +77,13 @@ static int h2d(lrvb_ctx* c, double* dst, const double* src, size_t n) {
 }
 static int d2h(lrvb_ctx* c, double* dst, const double* src, size_t n) {
     if (n == 0) return LRVB_OK;
+    if (n <= 4096) {          // scalars of the iterative solvers: through the context's pinned page (no pageable staging in the runtime)
+        LRVB_TRY(pinned_reserve(c, 4096));
+        HIP_TRY(hipMemcpyAsync(c->host_pinned, src, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        memcpy(dst, c->host_pinned, n * sizeof(double));
+        return LRVB_OK;
+    }
     HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return LRVB_OK;
