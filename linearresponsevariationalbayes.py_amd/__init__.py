@@ -13,7 +13,8 @@ Reference module names are importable as attributes for drop-in code
 (`vb.SparseObjectives.Objective`, `vb.ModelSensitivity...`, `vb.ConjugateGradient...`,
 `vb.OptimizationUtils...`, `vb.ExponentialFamilies...`, `vb.Parameters...`).
 """
-__version__ = '0.1.0'
+from .version import __version__
+from . import version
 
 from .packing import (ScalarParam, VectorParam, ArrayParam, PosDefMatrixParam, PosDefMatrixParamVector,
                       PosDefMatrixParamArray, SimplexParam, SubspaceVectorParam,

@@ -19,6 +19,8 @@ def test_reference_style_module_imports():
     assert obj_lib.Objective is vb.Objective
     assert ef.get_e_fun_normal is vb.ExponentialFamilies.get_e_fun_normal
     assert modeling.get_standard_draws is vb.Modeling.get_standard_draws
+    import lrvb_amd.version as version
+    assert version.__version__ == vb.__version__ and vb.version is version
     assert ProjectionParams.SubspaceVectorParam is vb.SubspaceVectorParam
     assert ConjugateGradient.ConjugateGradientSolver is vb.ConjugateGradientSolver
 
