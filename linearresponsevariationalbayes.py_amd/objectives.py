@@ -157,6 +157,19 @@ class Objective(object):
             self.par.set_vector(val)
         return result
 
+    def cache_free_and_eval(self, diff_fun, free_val, *argv, **argk):
+        """Evaluate `diff_fun(free_val, ...)` and leave `par` at free_val: the side-effect contract every derivative
+        method of the reference goes through (LRVB/SparseObjectives.py:142-145)."""
+        result = diff_fun(free_val, *argv, **argk)
+        self.par.set_free(free_val)
+        return result
+
+    def cache_vector_and_eval(self, diff_fun, vec_val, *argv, **argk):
+        """LRVB/SparseObjectives.py:147-150."""
+        result = diff_fun(vec_val, *argv, **argk)
+        self.par.set_vector(vec_val)
+        return result
+
     def fun_free_grad(self, free_val, *argv, **argk):
         return self._eval('grad', free_val, True, *argv, **argk)
 
@@ -235,6 +248,23 @@ class ParameterConverter(object):
         set_par(self.par_in, val_in, in_is_free)
         self.converter()
         return self.par_out.get_free() if out_is_free else self.par_out.get_vector()
+
+    def cache_free_and_eval(self, diff_fun, free_val_in):
+        """Evaluate `diff_fun(free_val_in)`, then leave par_in at free_val_in and par_out where it was
+        (LRVB/SparseObjectives.py:280-285)."""
+        vec_val_out = self.par_out.get_vector()
+        result = diff_fun(free_val_in)
+        self.par_in.set_free(free_val_in)
+        self.par_out.set_vector(vec_val_out)
+        return result
+
+    def cache_vector_and_eval(self, diff_fun, vec_val_in):
+        """LRVB/SparseObjectives.py:287-292."""
+        vec_val_out = self.par_out.get_vector()
+        result = diff_fun(vec_val_in)
+        self.par_in.set_vector(vec_val_in)
+        self.par_out.set_vector(vec_val_out)
+        return result
 
     def converter_free_to_vec(self, free_par_in):
         return self._convert(free_par_in, True, False)
@@ -351,6 +381,14 @@ class TwoParameterObjective(object):
         self.par1 = par1
         self.par2 = par2
         self.fun = fun
+
+    def cache_and_eval(self, diff_fun, val1, val2, val1_is_free, val2_is_free, *argv, **argk):
+        """Evaluate `diff_fun(val1, val2, val1_is_free, val2_is_free, ...)` and leave both parameters at the
+        evaluation point (LRVB/SparseObjectives.py:341-351)."""
+        result = diff_fun(val1, val2, val1_is_free, val2_is_free, *argv, **argk)
+        set_par(self.par1, val1, val1_is_free)
+        set_par(self.par2, val2, val2_is_free)
+        return result
 
     def eval_fun(self, val1, val2, val1_is_free, val2_is_free, *argv, **argk):
         set_par(self.par1, val1, val1_is_free)
@@ -518,3 +556,9 @@ def json_unpack_csr_matrix(sp_mat_dict):
                                  np.asarray(sp_mat_dict['indices'], dtype=np.int64),
                                  np.asarray(sp_mat_dict['indptr'], dtype=np.int64)),
                                 shape=tuple(sp_mat_dict['shape']))
+
+
+def get_sym_matrix_inv_sqrt(block_hessian, ev_min=None, ev_max=None):
+    """Deprecated in the reference as well (LRVB/SparseObjectives.py:662-664): it raises and points at
+    `OptimizationUtils.get_sym_matrix_inv_sqrt`."""
+    raise DeprecationWarning('Deprecated.  Use OptimizationUtils.get_sym_matrix_inv_sqrt instead.')

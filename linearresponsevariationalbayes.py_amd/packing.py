@@ -991,3 +991,16 @@ def convert_vector_to_free_hessian(param, free_val, vector_grad, vector_hess):
         cols.append(h.col)
     third = coo_matrix((np.hstack(vals), (np.hstack(rows), np.hstack(cols))), (D, D))
     return third + J.T * vector_hess * J
+
+
+def unvectorize_ld_matrix_vjp(g):
+    """Cotangent of `unvectorize_ld_matrix`: the lower-triangle entries of g in packed order
+    (LRVB/MatrixParameters.py:70-72; the map is linear, so its vector-Jacobian product is the packing itself)."""
+    g = np.asarray(g)
+    assert g.shape[0] == g.shape[1]
+    return vectorize_ld_matrix(g)
+
+
+def unvectorize_ld_matrix_jvp(g):
+    """Tangent of `unvectorize_ld_matrix` (LRVB/MatrixParameters.py:77-78): the map applied to the tangent."""
+    return unvectorize_ld_matrix(g)

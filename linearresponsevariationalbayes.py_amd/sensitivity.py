@@ -165,3 +165,8 @@ def get_lrvb_cov(objective, free_val, moment_jac, kl_hessian=None):
 # the k-th order class and its term algebra live in taylor.py; the reference keeps them in this module
 from .taylor import (ParametricSensitivityTaylorExpansion, DerivativeTerm, get_taylor_base_terms,   # noqa: E402,F401
                      consolidate_terms, differentiate_terms)
+
+
+# LRVB/ModelSensitivity.py holds the Taylor-expansion machinery too: same names under this module
+from .taylor import (DerivativeTerm, ParametricSensitivityTaylorExpansion, append_jvp, generate_two_term_derivative_array,  # noqa: E402,F401
+                     consolidate_terms, differentiate_terms, evaluate_terms, evaluate_dketa_depsk, get_taylor_base_terms)

@@ -166,6 +166,26 @@ def differentiate_terms(terms, eval_next_eta_deriv=None):
     return consolidate_terms(out)
 
 
+def evaluate_terms(dterms, eta0, eps0, deps, include_highest_eta_order=True):
+    """Sum of `term.evaluate(eta0, eps0, deps)` over the terms (those without the highest eta derivative if asked):
+    LRVB/ModelSensitivity.py:274-282.  The terms must carry callables (`eval_eta_derivs`, `eval_g_derivs`), as the
+    reference's do; the terms this package's Taylor class builds for DECLARED objectives carry orders only and are
+    evaluated by the class on the device (`evaluate_dkinput_dhyperk`)."""
+    vec = None
+    for term in dterms:
+        if include_highest_eta_order or (term.eta_orders[-1] == 0):
+            val = term.evaluate(eta0, eps0, deps)
+            vec = val if vec is None else vec + val
+    return vec
+
+
+def evaluate_dketa_depsk(hess0, dterms, eta0, eps0, deps):
+    """d^k eta / d eps^k [deps] = -H^-1 (terms that do not contain it): LRVB/ModelSensitivity.py:312-316."""
+    vec = evaluate_terms(dterms, eta0, eps0, deps, include_highest_eta_order=False)
+    assert vec is not None
+    return -1 * np.linalg.solve(hess0, vec)
+
+
 def _set_partitions(items):
     """All partitions of a list into non-empty blocks."""
     if not items:
@@ -327,6 +347,39 @@ class ParametricSensitivityTaylorExpansion(object):
         self.objective = Objective(self.input_par, self.objective_functor)
         self.set_base_values(input_val0, hyper_val0, hess0=hess0)
         self.set_order(order)
+
+    # ---- reference helper methods (LRVB/ModelSensitivity.py:412-450) ---------------------------------------------
+    def cache_and_eval(self, diff_fun, *argv, **argk):
+        """Evaluate and put the parameters back to the base values (:412-415)."""
+        result = diff_fun(*argv, **argk)
+        self.set_par_to_base_values()
+        return result
+
+    def objective_gradient(self, input_val, hyper_val, *argv, **argk):
+        """Gradient of the objective in the input parameter at (input_val, hyper_val): the function whose Taylor
+        expansion the class forms (:430-433), evaluated on the device."""
+        from .objectives import TwoParameterObjective
+        fun = self.hyper_par_objective_functor
+        two = TwoParameterObjective(self.input_par, self.hyper_par, fun)
+        out = two.fun_grad1(input_val, hyper_val, self.input_is_free, self.hyper_is_free, *argv, **argk)
+        self.set_par_to_base_values()
+        return out
+
+    def get_dkinput_dhyperk_from_terms(self, dterms):
+        """A function (input_val, hyper_val, dhyper, tolerance) -> next derivative from the terms, checked to be asked
+        for at the base point (:436-444); the evaluation is this class's device recursion for the order of `dterms`."""
+        k = max(sum(t.eta_orders[i] * (i + 1) for i in range(len(t.eta_orders))) + t.eps_order for t in dterms)
+
+        def dkinput_dhyperk(input_val, hyper_val, dhyper, tolerance=1e-8):
+            if tolerance is not None:
+                assert np.max(np.abs(np.asarray(input_val) - self.input_val0)) <= tolerance
+                assert np.max(np.abs(np.asarray(hyper_val) - self.hyper_val0)) <= tolerance
+            return self.evaluate_dkinput_dhyperk(dhyper, k)
+        return dkinput_dhyperk
+
+    def differentiate_terms(self, dterms, eval_next_eta_deriv=None):
+        """:446-450."""
+        return differentiate_terms(dterms, eval_next_eta_deriv)
 
     # ---- base point ------------------------------------------------------------------------------------------
     def set_par_to_base_values(self):

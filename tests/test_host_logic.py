@@ -377,3 +377,75 @@ def test_index_param_and_sparse_sub_matrix_helpers():
                               vb.SparseObjectives.json_unpack_csr_matrix)]:
         back = unpacker(packer(full))
         assert (back != full).nnz == 0 and back.shape == full.shape
+
+
+def test_every_reference_name_resolves():
+    """Name-level drop-in check: every module, class, method and function of the reference package (inventory in
+    tests/golden/reference_api_names.json, made by tests/golden/make_api_names.py) exists under the same name here."""
+    import json
+    import os
+    import lrvb_amd as vb
+    names = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_api_names.json')))
+    missing = []
+    for mod_name, content in names.items():
+        mod = getattr(vb, mod_name, None)
+        if mod is None:
+            missing.append(mod_name)
+            continue
+        for fn in content['functions']:
+            if not hasattr(mod, fn):
+                missing.append(mod_name + '.' + fn)
+        for cls_name, methods in content['classes'].items():
+            cls = getattr(mod, cls_name, None)
+            if cls is None:
+                missing.append(mod_name + '.' + cls_name)
+                continue
+            missing += [mod_name + '.' + cls_name + '.' + m for m in methods if not hasattr(cls, m)]
+    assert missing == []
+
+
+def test_cache_and_eval_contracts():
+    """`cache_free_and_eval` / `cache_vector_and_eval` / `cache_and_eval` (LRVB/SparseObjectives.py:142-150, 280-292, 341-351):
+    evaluate, then leave the parameters at the evaluation point (and an output parameter where it was)."""
+    import lrvb_amd as vb
+    par = vb.VectorParam('x', 3, lb=0.0)
+    obj = vb.Objective(par, lambda: float(np.sum(par.get() ** 2)))
+    free = np.array([0.1, -0.2, 0.3])
+    assert obj.cache_free_and_eval(lambda f: 7.0, free) == 7.0
+    np.testing.assert_allclose(par.get_free(), free)
+    vec = np.array([1.0, 2.0, 3.0])
+    assert obj.cache_vector_and_eval(lambda v: float(v.sum()), vec) == 6.0
+    np.testing.assert_allclose(par.get_vector(), vec)
+    par2 = vb.VectorParam('y', 2)
+    two = vb.TwoParameterObjective(par, par2, lambda: 0.0)
+    out = two.cache_and_eval(lambda a, b, fa, fb: (a.sum(), b.sum(), fa, fb), free, np.array([4.0, 5.0]), True, False)
+    assert out[2] is True and out[3] is False
+    np.testing.assert_allclose(par.get_free(), free)
+    np.testing.assert_allclose(par2.get_vector(), [4.0, 5.0])
+    conv = vb.ParameterConverter(par, par2, vb.LinearConverter(par, par2, np.ones((2, 3))))
+    par2.set_vector(np.array([9.0, 8.0]))
+    assert conv.cache_free_and_eval(lambda f: 1.5, free) == 1.5
+    np.testing.assert_allclose(par.get_free(), free)
+    np.testing.assert_allclose(par2.get_vector(), [9.0, 8.0])
+    with pytest.raises(DeprecationWarning):
+        vb.SparseObjectives.get_sym_matrix_inv_sqrt(np.eye(2))
+    # tangent / cotangent helpers of the (linear) log-Cholesky unpacking map
+    g = np.arange(9.0).reshape(3, 3)
+    np.testing.assert_allclose(vb.MatrixParameters.unvectorize_ld_matrix_vjp(g), vb.MatrixParameters.vectorize_ld_matrix(g))
+    v = np.arange(6.0)
+    np.testing.assert_allclose(vb.MatrixParameters.unvectorize_ld_matrix_jvp(v), vb.MatrixParameters.unvectorize_ld_matrix(v))
+
+
+def test_evaluate_terms_with_callable_terms():
+    """`evaluate_terms` / `evaluate_dketa_depsk` (LRVB/ModelSensitivity.py:274-316) on terms that carry callables, for the
+    quadratic-plus-tilt objective g(eta, eps) = A eta + eps whose first sensitivity is -A^-1 deps."""
+    import lrvb_amd as vb
+    ms = vb.ModelSensitivity
+    A = np.array([[2.0, 0.3], [0.3, 1.0]])
+    # d g / d eps [deps] = deps; d g / d eta [v] = A v
+    g_derivs = [[None, lambda eta, eps, d: d], [lambda eta, eps, v: A @ v, None]]
+    t_eps = ms.DerivativeTerm(eps_order=1, eta_orders=[0], prefactor=1.0, eval_eta_derivs=[], eval_g_derivs=g_derivs)
+    deps = np.array([0.5, -1.0])
+    vec = ms.evaluate_terms([t_eps], np.zeros(2), np.zeros(2), deps, include_highest_eta_order=False)
+    np.testing.assert_allclose(vec, deps)
+    np.testing.assert_allclose(ms.evaluate_dketa_depsk(A, [t_eps], np.zeros(2), np.zeros(2), deps), -np.linalg.solve(A, deps))
