@@ -98,6 +98,21 @@ def test_taylor_expansion_on_the_reference_test_model(vb):
         with pytest.raises(ValueError):
             tay.evaluate_taylor_series(d, max_order=bad)
     tay.print_terms(2)
+    # the reference class's helper methods (LRVB/ModelSensitivity.py:412-450) on the device path: the gradient being expanded
+    # vanishes at the base point and equals d f / d phi elsewhere; the derivative function made from a term list is the
+    # class's own k-th derivative, checked to be asked for at the base point; both leave the parameters at the base values
+    assert np.max(np.abs(tay.objective_gradient(phi0, lam0))) < 1e-10
+    g_shift = tay.objective_gradient(phi0 + 0.1, lam0)
+    th = np.exp(phi0 + 0.1) - 10.0
+    np.testing.assert_allclose(g_shift, (M @ th + lam0) * np.exp(phi0 + 0.1), rtol=1e-12)
+    for k in (1, 2, 3):
+        fk = tay.get_dkinput_dhyperk_from_terms(tay.taylor_terms_list[k - 1])
+        np.testing.assert_allclose(fk(phi0, lam0, d), tay.evaluate_dkinput_dhyperk(d, k), rtol=1e-13)
+    with pytest.raises(AssertionError):
+        tay.get_dkinput_dhyperk_from_terms(tay.taylor_terms_list[0])(phi0 + 1e-3, lam0, d)
+    assert tay.cache_and_eval(lambda a: a + 1, 2) == 3
+    assert len(tay.differentiate_terms(tay.taylor_terms_list[0])) == len(tay.taylor_terms_list[1])
+    np.testing.assert_allclose(param.get_free(), phi0, rtol=1e-15)
     # vector coordinates: the optimum is linear in lambda, every higher derivative vanishes
     tv = vb.ParametricSensitivityTaylorExpansion(fun, param, fun.tilt_par, theta0, lam0, 3, input_is_free=False)
     assert rel_err(tv.evaluate_dkinput_dhyperk(d, 1), b) < 1e-12
