@@ -157,16 +157,16 @@ class Objective(object):
             self.par.set_vector(val)
         return result
 
-    def cache_free_and_eval(self, diff_fun, free_val, *argv, **argk):
-        """Evaluate `diff_fun(free_val, ...)` and leave `par` at free_val: the side-effect contract every derivative
+    def cache_free_and_eval(self, autograd_fun, free_val, *argv, **argk):
+        """Evaluate `autograd_fun(free_val, ...)` and leave `par` at free_val: the side-effect contract every derivative
         method of the reference goes through (LRVB/SparseObjectives.py:142-145)."""
-        result = diff_fun(free_val, *argv, **argk)
+        result = autograd_fun(free_val, *argv, **argk)
         self.par.set_free(free_val)
         return result
 
-    def cache_vector_and_eval(self, diff_fun, vec_val, *argv, **argk):
+    def cache_vector_and_eval(self, autograd_fun, vec_val, *argv, **argk):
         """LRVB/SparseObjectives.py:147-150."""
-        result = diff_fun(vec_val, *argv, **argk)
+        result = autograd_fun(vec_val, *argv, **argk)
         self.par.set_vector(vec_val)
         return result
 
@@ -249,19 +249,19 @@ class ParameterConverter(object):
         self.converter()
         return self.par_out.get_free() if out_is_free else self.par_out.get_vector()
 
-    def cache_free_and_eval(self, diff_fun, free_val_in):
-        """Evaluate `diff_fun(free_val_in)`, then leave par_in at free_val_in and par_out where it was
+    def cache_free_and_eval(self, autograd_fun, free_val_in):
+        """Evaluate `autograd_fun(free_val_in)`, then leave par_in at free_val_in and par_out where it was
         (LRVB/SparseObjectives.py:280-285)."""
         vec_val_out = self.par_out.get_vector()
-        result = diff_fun(free_val_in)
+        result = autograd_fun(free_val_in)
         self.par_in.set_free(free_val_in)
         self.par_out.set_vector(vec_val_out)
         return result
 
-    def cache_vector_and_eval(self, diff_fun, vec_val_in):
+    def cache_vector_and_eval(self, autograd_fun, vec_val_in):
         """LRVB/SparseObjectives.py:287-292."""
         vec_val_out = self.par_out.get_vector()
-        result = diff_fun(vec_val_in)
+        result = autograd_fun(vec_val_in)
         self.par_in.set_vector(vec_val_in)
         self.par_out.set_vector(vec_val_out)
         return result
@@ -382,10 +382,10 @@ class TwoParameterObjective(object):
         self.par2 = par2
         self.fun = fun
 
-    def cache_and_eval(self, diff_fun, val1, val2, val1_is_free, val2_is_free, *argv, **argk):
-        """Evaluate `diff_fun(val1, val2, val1_is_free, val2_is_free, ...)` and leave both parameters at the
+    def cache_and_eval(self, autograd_fun, val1, val2, val1_is_free, val2_is_free, *argv, **argk):
+        """Evaluate `autograd_fun(val1, val2, val1_is_free, val2_is_free, ...)` and leave both parameters at the
         evaluation point (LRVB/SparseObjectives.py:341-351)."""
-        result = diff_fun(val1, val2, val1_is_free, val2_is_free, *argv, **argk)
+        result = autograd_fun(val1, val2, val1_is_free, val2_is_free, *argv, **argk)
         set_par(self.par1, val1, val1_is_free)
         set_par(self.par2, val2, val2_is_free)
         return result

@@ -10,11 +10,11 @@ form; they act on small batched arrays on the host (the same X^T Lambda X contra
 import numpy as np
 
 
-def mat_mul_last2dims(x, y):
-    """x[..., n, m] @ y[..., m, p] with broadcasting of the leading dimensions of the smaller one."""
-    x, y = np.asarray(x), np.asarray(y)
-    assert x.shape[-1] == y.shape[-2]
-    return np.matmul(x, y)
+def mat_mul_last2dims(x1, x2):
+    """x1[..., n, m] @ x2[..., m, p] with broadcasting of the leading dimensions of the smaller one."""
+    x1, x2 = np.asarray(x1), np.asarray(x2)
+    assert x1.shape[-1] == x2.shape[-2]
+    return np.matmul(x1, x2)
 
 
 def matvec_mul_last2dims(x, y):

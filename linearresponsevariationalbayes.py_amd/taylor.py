@@ -150,20 +150,32 @@ def _append_x2(f, n_x1_dirs):
     return g
 
 
-def consolidate_terms(terms):
+def consolidate_terms(dterms):
     """Sum the prefactors of terms with equal orders, first-seen order kept (:255-266)."""
     merged = {}
-    for t in terms:
+    for t in dterms:
         k = t.key()
         merged[k] = merged[k].combine_with(t) if k in merged else t
     return list(merged.values())
 
 
-def differentiate_terms(terms, eval_next_eta_deriv=None):
+def _differentiate_terms(dterms, eval_next_eta_deriv=None):
     out = []
-    for t in terms:
+    for t in dterms:
         out += t.differentiate(eval_next_eta_deriv)
     return consolidate_terms(out)
+
+
+def differentiate_terms(hess0, dterms):
+    """Derivatives of the terms with respect to the hyper-parameter, the next eta derivative being
+    -hess0^-1 (terms without it): the module-level function of LRVB/ModelSensitivity.py:327-335 (the terms must carry
+    evaluators; `hess0 = None` differentiates the orders only)."""
+    if hess0 is None:
+        return _differentiate_terms(dterms)
+
+    def eval_next_eta_deriv(eta, eps, deps):
+        return evaluate_dketa_depsk(hess0, dterms, eta, eps, deps)
+    return _differentiate_terms(dterms, eval_next_eta_deriv)
 
 
 def evaluate_terms(dterms, eta0, eps0, deps, include_highest_eta_order=True):
@@ -379,7 +391,7 @@ class ParametricSensitivityTaylorExpansion(object):
 
     def differentiate_terms(self, dterms, eval_next_eta_deriv=None):
         """:446-450."""
-        return differentiate_terms(dterms, eval_next_eta_deriv)
+        return _differentiate_terms(dterms, eval_next_eta_deriv)
 
     # ---- base point ------------------------------------------------------------------------------------------
     def set_par_to_base_values(self):
@@ -513,7 +525,7 @@ class ParametricSensitivityTaylorExpansion(object):
         self.order = int(order)
         self.taylor_terms_list = [get_taylor_base_terms()]
         for _ in range(self.order - 1):
-            self.taylor_terms_list.append(differentiate_terms(self.taylor_terms_list[-1]))
+            self.taylor_terms_list.append(_differentiate_terms(self.taylor_terms_list[-1]))
 
     def _eta_derivatives(self, dhyper, k):
         """[eta^(1), ..., eta^(k)] along dhyper: eta^(j) = -H^-1 (terms of order j that do not contain eta^(j))."""

@@ -386,22 +386,41 @@ def test_every_reference_name_resolves():
     import os
     import lrvb_amd as vb
     names = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_api_names.json')))
-    missing = []
+    import inspect
+    missing, differ = [], []
+
+    def check(label, obj, ref_args):
+        # the reference's positional parameter names must be the leading positional parameter names here (extra
+        # trailing parameters with defaults are additions, not breaks)
+        try:
+            mine = [p.name for p in inspect.signature(obj).parameters.values()
+                    if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD)]
+        except (TypeError, ValueError):
+            return
+        if mine[:len(ref_args)] != ref_args:
+            differ.append((label, ref_args, mine))
     for mod_name, content in names.items():
         mod = getattr(vb, mod_name, None)
         if mod is None:
             missing.append(mod_name)
             continue
-        for fn in content['functions']:
+        for fn, ref_args in content['functions'].items():
             if not hasattr(mod, fn):
                 missing.append(mod_name + '.' + fn)
+            else:
+                check(mod_name + '.' + fn, getattr(mod, fn), ref_args)
         for cls_name, methods in content['classes'].items():
             cls = getattr(mod, cls_name, None)
             if cls is None:
                 missing.append(mod_name + '.' + cls_name)
                 continue
-            missing += [mod_name + '.' + cls_name + '.' + m for m in methods if not hasattr(cls, m)]
+            for m, ref_args in methods.items():
+                if not hasattr(cls, m):
+                    missing.append(mod_name + '.' + cls_name + '.' + m)
+                else:
+                    check(mod_name + '.' + cls_name + '.' + m, getattr(cls, m), ref_args)
     assert missing == []
+    assert differ == []
 
 
 def test_cache_and_eval_contracts():
@@ -436,6 +455,11 @@ def test_cache_and_eval_contracts():
     np.testing.assert_allclose(vb.MatrixParameters.unvectorize_ld_matrix_jvp(v), vb.MatrixParameters.unvectorize_ld_matrix(v))
 
 
+def taylor_orders(terms):
+    from lrvb_amd import taylor
+    return taylor._differentiate_terms(terms)
+
+
 def test_evaluate_terms_with_callable_terms():
     """`evaluate_terms` / `evaluate_dketa_depsk` (LRVB/ModelSensitivity.py:274-316) on terms that carry callables, for the
     quadratic-plus-tilt objective g(eta, eps) = A eta + eps whose first sensitivity is -A^-1 deps."""
@@ -449,3 +473,6 @@ def test_evaluate_terms_with_callable_terms():
     vec = ms.evaluate_terms([t_eps], np.zeros(2), np.zeros(2), deps, include_highest_eta_order=False)
     np.testing.assert_allclose(vec, deps)
     np.testing.assert_allclose(ms.evaluate_dketa_depsk(A, [t_eps], np.zeros(2), np.zeros(2), deps), -np.linalg.solve(A, deps))
+    # the module-level differentiate_terms(hess0, dterms) of the reference: same orders as the order-only recursion
+    base = ms.get_taylor_base_terms()
+    assert sorted(t.key() for t in ms.differentiate_terms(None, base)) == sorted(t.key() for t in taylor_orders(base))

@@ -20,17 +20,17 @@ def test_term_algebra_matches_the_known_expansions():
     the comments of LRVB/ModelSensitivity.py:320-345)."""
     t1 = taylor.get_taylor_base_terms()
     assert sorted((t.key(), t.prefactor) for t in t1) == [((0, (1,)), 1.0), ((1, (0,)), 1.0)]
-    t2 = taylor.differentiate_terms(t1)
+    t2 = taylor.differentiate_terms(None, t1)
     assert dict((t.key(), t.prefactor) for t in t2) == {(2, (0, 0)): 1.0, (1, (1, 0)): 2.0, (0, (2, 0)): 1.0, (0, (0, 1)): 1.0}
-    t3 = taylor.differentiate_terms(t2)
+    t3 = taylor.differentiate_terms(None, t2)
     assert dict((t.key(), t.prefactor) for t in t3) == {
         (3, (0, 0, 0)): 1.0, (2, (1, 0, 0)): 3.0, (1, (2, 0, 0)): 3.0, (1, (0, 1, 0)): 3.0,
         (0, (3, 0, 0)): 1.0, (0, (1, 1, 0)): 3.0, (0, (0, 0, 1)): 1.0}
-    for k, terms in enumerate([t1, t2, t3, taylor.differentiate_terms(t3)], start=1):
+    for k, terms in enumerate([t1, t2, t3, taylor.differentiate_terms(None, t3)], start=1):
         assert all(t.order == k for t in terms)
         assert sum(1 for t in terms if t.eta_orders[-1] == 1) == 1          # exactly one term carries eta^(k): H eta^(k)
     # the pure-eta terms of order k count the set partitions of k elements (Faa di Bruno): Bell numbers 1, 2, 5, 15
-    t4 = taylor.differentiate_terms(t3)
+    t4 = taylor.differentiate_terms(None, t3)
     for terms, bell in ((t1, 1), (t2, 2), (t3, 5), (t4, 15)):
         assert sum(t.prefactor for t in terms if t.eps_order == 0) == bell
     with pytest.raises(AssertionError):
