@@ -124,3 +124,15 @@ def test_entropies_and_moments_against_scipy_stats():
     np.testing.assert_allclose(oef.get_e_dirichlet(alpha).sum(axis=0), 1.0)
     p = np.array([[0.2, 0.3, 0.5]])
     assert np.isclose(oef.multinoulli_entropy(p)[0], scipy.stats.multinomial.entropy(1, p[0]), atol=1e-12)
+
+
+def test_beta_entropy_against_scipy_stats():
+    """LRVB/test_exponential_families.py:60-64 (the product's `ExponentialFamilies.beta_entropy`, a host closed form)."""
+    import lrvb_amd.ExponentialFamilies as ef
+    tau = np.array([[1, 2], [3, 4], [5, 6]], dtype=np.float64)
+    want = sum(scipy.stats.beta.entropy(tau[i, 0], tau[i, 1]) for i in range(tau.shape[0]))
+    assert abs(ef.beta_entropy(tau) - want) < 1e-12
+    # shape of the multinoulli entropy (:66-72): one value per row
+    rng = np.random.default_rng(3)
+    p = rng.random((100, 4)); p /= p.sum(axis=1, keepdims=True)
+    assert ef.multinoulli_entropy(p).shape == (100,)
