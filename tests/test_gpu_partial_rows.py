@@ -164,3 +164,42 @@ print('ok', copies[0])
 '''.format(root=root, first=first, second=second, torch_first=(order == 'torch first'))
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and 'ok' in out.stdout, out.stderr[-2000:]
+
+
+def test_every_cross_hessian_variant_and_vector_jacobian(vb):
+    """The six cross-Hessian methods of TwoParameterObjective (LRVB/SparseObjectives.py:389-438), `fun_grad1`, `eval_fun`,
+    and `Objective.fun_vector_jacobian`, for the weights in lower-bounded free coordinates (w = exp f) and the tilt."""
+    rng = np.random.default_rng(8)
+    N, P = 400, 10
+    spec = [('box', 'u', 6, -np.inf, np.inf), ('box', 'pos', 4, 0.0, np.inf)]
+    par, lay = make_par(vb, spec)
+    x, y, w = glm_data(rng, N, P, om.LOGISTIC)
+    fun = vb.DeviceObjective(par, x=x, y=y, loss='logistic', quad_A=np.full(P, 0.6))
+    fun.weights_par = wpar = vb.VectorParam('weights', N, lb=0.0, val=np.ones(N))
+    theta = rng.normal(size=P) * 0.2
+    eta = lay.constrain(theta)
+    model = om.DeclaredModel(lay, loss=om.LOGISTIC, x=x, y=y, w=w, quad_A=np.full(P, 0.6))
+    G_free = model.obs_grad(theta).T                       # D x N: d2 f / d theta d w^T
+    G_vec = model.obs_grad_vec(eta).T                      # V x N
+    two = vb.TwoParameterObjective(par, wpar, fun)
+    fw = np.log(w)
+    assert rel_err(two.fun_hessian_free1_vector2(theta, w), G_free) < 1e-11
+    assert rel_err(two.fun_free_hessian12(theta, fw), G_free * w[None, :]) < 1e-11           # d w / d f = w
+    assert rel_err(two.fun_free_hessian21(theta, fw), (G_free * w[None, :]).T) < 1e-11
+    assert rel_err(two.fun_vector_hessian12(eta, w), G_vec) < 1e-11
+    assert rel_err(two.fun_vector_hessian21(eta, w), G_vec.T) < 1e-11
+    assert rel_err(two.fun_hessian_vector1_free2(eta, fw), G_vec * w[None, :]) < 1e-11
+    assert rel_err(two.fun_grad1(theta, w, True, False), model.grad(theta)) < 1e-11
+    assert rel_err(two.fun_grad1(eta, fw, False, True), model.grad_vec(eta)) < 1e-11
+    assert abs(two.eval_fun(theta, w, True, False) - model.value(theta)) < 1e-11 * abs(model.value(theta))
+    assert rel_err(par.get_free(), theta) < 1e-14 and rel_err(wpar.get_vector(), w) < 1e-14   # both left at the point
+    # the tilt: d2 f / d theta d b^T = s J^T, in vector coordinates s I
+    two_t = vb.TwoParameterObjective(par, fun.tilt_par, fun)
+    b = rng.normal(size=P)
+    assert rel_err(two_t.fun_hessian_free1_vector2(theta, b), model.cross_hessian_tilt(theta)) < 1e-13
+    assert rel_err(two_t.fun_vector_hessian12(eta, b), np.eye(P)) < 1e-14
+    # Objective.fun_vector_jacobian of a moment functor: d (B eta) / d eta = B
+    B = rng.normal(size=(3, lay.V))
+    mobj = vb.Objective(par, vb.LinearMoments(par, B=B))
+    assert rel_err(mobj.fun_vector_jacobian(eta), B) < 1e-14
+    assert rel_err(mobj.fun_free_jacobian(theta), B @ lay.jac(theta)) < 1e-13
