@@ -96,3 +96,46 @@ def test_matrix_and_offset_helpers():
     assert len(hs) == 1 and abs(hs[0].toarray()[2, 2] - 2.0 * s * (1 - s) * (1 - 2 * s)) < 1e-14
     sp = pr.offset_sparse_matrix(np.array([[1.0, 0.0], [0.0, 2.0]]), (1, 2), (4, 5)).toarray()
     assert sp.shape == (4, 5) and sp[1, 2] == 1.0 and sp[2, 3] == 2.0 and sp.sum() == 3.0
+
+
+def test_small_family_and_container_methods():
+    """E[exp(x)^2] of the univariate normal families (Monte Carlo), the moment array filled from a constant, the Wishart's LKJ
+    prior term, array ranges of a stack of PSD matrices, dictionary renaming, the logger's message, the converter forwarders."""
+    rng = np.random.default_rng(6)
+    u = vb.UVNParamVector('u', length=3)
+    u['mean'].set(np.array([0.1, -0.3, 0.5])); u['info'].set(np.array([4.0, 9.0, 2.5]))
+    draws = rng.normal(u['mean'].get(), 1 / np.sqrt(u['info'].get()), size=(200000, 3))
+    e2 = np.exp(draws) ** 2
+    assert np.all(np.abs(u.e2_exp() - e2.mean(axis=0)) < 4 * e2.std(axis=0) / np.sqrt(len(e2)))
+    s = vb.UVNParam('s'); s['mean'].set(0.2); s['info'].set(5.0)
+    assert abs(s.e2_exp() - np.exp(2 * 0.2 + 2.0 / 5.0)) < 1e-12
+    arr = vb.UVNParamArray('a', shape=(2, 2)); arr['mean'].set(np.full((2, 2), 0.1)); arr['info'].set(np.full((2, 2), 4.0))
+    np.testing.assert_allclose(arr.e2_exp(), np.exp(0.2 + 0.5))
+    mom = vb.UVNMomentParamArray('m', shape=(2, 3))
+    const = vb.ArrayParam('c', shape=(2, 3), val=np.arange(6.0).reshape(2, 3) + 1)
+    mom.set_from_constant(const)
+    np.testing.assert_allclose(mom.e(), const.get()); np.testing.assert_allclose(mom.var(), 0.0, atol=1e-15)
+    np.testing.assert_allclose(mom.e2_exp(), mom.e_exp() ** 2 + mom.var_exp())
+    wp = vb.WishartParam('w', size=3)
+    a = rng.normal(size=(3, 3)); v = a @ a.T / 3 + np.eye(3)
+    wp['df'].set(8.5); wp['v'].set(v)
+    assert abs(wp.e_log_lkj_inv_prior(2.0) - ef.expected_ljk_prior(2.0, 8.5, v)) < 1e-14
+    stack = vb.PosDefMatrixParamArray('ps', array_shape=(2, 2), matrix_size=2)
+    ranges = stack.get_array_ranges()
+    assert [len(r) for r in ranges] == [2, 2]
+    d = vb.ModelParamsDict('old'); d.set_name('new'); assert d.name == 'new'
+    lg = vb.Logger(print_every=1)
+    seen = []
+    lg.callback = lambda logger: seen.append(logger.iter)
+    lg.log(1.0, np.zeros(1)); lg.log(0.5, np.ones(1))
+    assert seen == [0, 1]
+    lg.callback = None
+    lg.print_message()                                        # the reference's default message: prints, returns nothing
+    # converter forwarders with an opaque closure: values in all four coordinate combinations
+    pin, pout = vb.VectorParam('x', 2, lb=0.0), vb.VectorParam('y', 2, lb=1.0)
+    conv = vb.ParameterConverter(pin, pout, lambda: pout.set_vector(1.0 + pin.get() ** 2))
+    f = np.array([0.2, -0.1]); xv = np.exp(f)
+    np.testing.assert_allclose(conv.converter_free_to_vec(f), 1.0 + xv ** 2)
+    np.testing.assert_allclose(conv.converter_vec_to_vec(xv), 1.0 + xv ** 2)
+    np.testing.assert_allclose(conv.converter_free_to_free(f), np.log(xv ** 2))
+    np.testing.assert_allclose(conv.converter_vec_to_free(xv), np.log(xv ** 2))
