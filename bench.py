@@ -253,7 +253,7 @@ def run_config(args):
     time from the library's profile marks) against the algorithmic bytes / flops of SURVEY.md section 8(d)."""
     import numpy as np
     import lrvb_amd as vb
-    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))          # synthetic problem generators (no oracle, no test module)
     if int(os.environ.get('WORLD_SIZE', '1')) != 1 or args.gpus != 1:
         raise SystemExit('bench: --config {} is a one-GPU line (the multi-GPU curve is the headline, --config h)'.format(args.config))
     rng = np.random.default_rng(20240 + int(args.config[1]))
@@ -278,7 +278,7 @@ def run_config(args):
         bound, alg, unit, peak = 'hbm', 8.0 * N * (k + 2), 'GB/s', PEAK_HBM_GBS
         ctx = fun.ctx
     elif cfg == 'c3':
-        from test_mixture_host_math import clustered_problem
+        from synthetic import clustered_problem
         N, V, K = int(args.n_obs) if args.n_obs != 1e6 else 1_000_000, 31, 32
         x, w, fg, fz, lam = clustered_problem(N, V, K, seed=11)
         theta = np.concatenate([fg, fz.ravel()])
@@ -299,11 +299,11 @@ def run_config(args):
         ctx = fun.ctx
         extra['repo_algorithm_flops'] = 2.0 * 528 * 528 * N
     elif cfg == 'c4':
-        from test_lmm_host_math import make_par as lmm_par
+        from synthetic import lmm_par as _lmm_par
         N, p, G = 1_250_000, 43, 10_000
         x = rng.normal(size=(N, p)); gid = rng.integers(0, G, size=N).astype(np.int32); gid[:G] = np.arange(G)
         y = x @ rng.normal(size=p) + rng.normal(size=G)[gid] * 0.7 + rng.normal(size=N) * 0.5
-        par = lmm_par(p, G)
+        par = _lmm_par(vb, p, G)
         fun = vb.LMMObjective(par, x, y, gid, G, weights=rng.uniform(0.5, 1.5, N))
         theta = par.get_free()
         D = None

@@ -2,7 +2,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (ROOT, os.path.join(ROOT, 'tests')):
+for p in (ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'tools')):
     if p not in sys.path:
         sys.path.insert(0, p)
 

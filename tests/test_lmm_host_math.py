@@ -9,13 +9,8 @@ import torch_ref as tr
 
 
 def make_par(p, G):
-    par = vb.ModelParamsDict('params')
-    par.push_param(vb.MVNParam('beta', dim=p))
-    par.push_param(vb.UVNParam('mu'))
-    par.push_param(vb.GammaParam('tau_y'))
-    par.push_param(vb.GammaParam('tau_mu'))
-    par.push_param(vb.UVNParamVector('u', length=G))
-    return par
+    from synthetic import lmm_par
+    return lmm_par(vb, p, G)
 
 
 def shell(par, p, G, priors):
