@@ -19,22 +19,29 @@ from .packing import (ModelParamsDict, ScalarParam, VectorParam, ArrayParam, Pos
 
 
 class MVNParam(ModelParamsDict):
+    """q(x) = N(mean, info^-1): a mean vector and an information matrix in log-Cholesky coordinates
+    (moments as LRVB/NormalParams.py:6-23 defines them)."""
+
     def __init__(self, name='', dim=2, min_info=0.0):
-        super().__init__(name=name)
-        self._dim = dim
-        self.push_param(VectorParam('mean', dim))
-        self.push_param(PosDefMatrixParam('info', dim, diag_lb=min_info))
+        ModelParamsDict.__init__(self, name=name)
+        self._dim = int(dim)
+        for child in (VectorParam('mean', self._dim), PosDefMatrixParam('info', self._dim, diag_lb=min_info)):
+            self.push_param(child)
 
     def e(self):
         return self['mean'].get()
 
     def cov(self):
-        return np.linalg.inv(self['info'].get())
+        # the information matrix is positive definite by construction: invert through its Cholesky factor
+        info = np.asarray(self['info'].get(), dtype=np.float64)
+        chol = np.linalg.cholesky(info)
+        half = np.linalg.solve(chol, np.eye(info.shape[0]))           # L^-1
+        return half.T @ half
 
     def e_outer(self):
-        mean = self['mean'].get()
-        e_outer = np.outer(mean, mean) + self.cov()
-        return 0.5 * (e_outer + e_outer.transpose())
+        m = np.asarray(self.e())
+        second = self.cov() + m[:, None] * m[None, :]
+        return (second + second.T) / 2.0
 
     def entropy(self):
         return ef.multivariate_normal_entropy(self['info'].get())
