@@ -425,27 +425,23 @@ __global__ __launch_bounds__(256)
 void gemv_t_tall_kernel(i64 M, i64 N, const double* __restrict__ A, i64 lda, const double* __restrict__ x,
                         i64 rows_per_block, double* __restrict__ part /* [gridDim.x][N] */)
 {
-    __shared__ double sh[4][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    // thread t owns column t (+ 256, + 512, ...) for the workgroup's rows: the four waves read one whole 2 KiB piece of a
+    // row together, eight rows in flight per thread, and no cross-thread reduction is needed inside the workgroup
     const i64 r0 = (i64)blockIdx.x * rows_per_block;
     i64 r1 = r0 + rows_per_block; if (r1 > M) r1 = M;
-    for (i64 j0 = 0; j0 < N; j0 += 64) {
-        const i64 col = j0 + tx;
+    for (i64 col = threadIdx.x; col < N; col += 256) {
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        if (col < N) {
-            i64 k = r0 + ty;
-            for (; k + 12 < r1; k += 16) {
-                s0 += __builtin_nontemporal_load(A + k * lda + col) * x[k];
-                s1 += __builtin_nontemporal_load(A + (k + 4) * lda + col) * x[k + 4];
-                s2 += __builtin_nontemporal_load(A + (k + 8) * lda + col) * x[k + 8];
-                s3 += __builtin_nontemporal_load(A + (k + 12) * lda + col) * x[k + 12];
-            }
-            for (; k < r1; k += 4) s0 += __builtin_nontemporal_load(A + k * lda + col) * x[k];
+        i64 k = r0;
+        for (; k + 7 < r1; k += 8) {
+            const double a0 = __builtin_nontemporal_load(A + k * lda + col), a1 = __builtin_nontemporal_load(A + (k + 1) * lda + col);
+            const double a2 = __builtin_nontemporal_load(A + (k + 2) * lda + col), a3 = __builtin_nontemporal_load(A + (k + 3) * lda + col);
+            const double a4 = __builtin_nontemporal_load(A + (k + 4) * lda + col), a5 = __builtin_nontemporal_load(A + (k + 5) * lda + col);
+            const double a6 = __builtin_nontemporal_load(A + (k + 6) * lda + col), a7 = __builtin_nontemporal_load(A + (k + 7) * lda + col);
+            s0 += a0 * x[k];     s1 += a1 * x[k + 1]; s2 += a2 * x[k + 2]; s3 += a3 * x[k + 3];
+            s0 += a4 * x[k + 4]; s1 += a5 * x[k + 5]; s2 += a6 * x[k + 6]; s3 += a7 * x[k + 7];
         }
-        sh[ty][tx] = (s0 + s1) + (s2 + s3);
-        __syncthreads();
-        if (ty == 0 && col < N) part[(i64)blockIdx.x * N + col] = (sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx]);
-        __syncthreads();
+        for (; k < r1; ++k) s0 += __builtin_nontemporal_load(A + k * lda + col) * x[k];
+        part[(i64)blockIdx.x * N + col] = (s0 + s1) + (s2 + s3);
     }
 }
 __global__ __launch_bounds__(512)
