@@ -124,12 +124,36 @@ int         lrvb_device_count(int* out);
 int lrvb_ctx_create (lrvb_ctx** out, int device_id, const lrvb_model_desc* model);
 int lrvb_ctx_destroy(lrvb_ctx* ctx);
 int lrvb_ctx_sync   (lrvb_ctx* ctx);                 /* hipStreamSynchronize on the ctx stream */
-/* use_caller_stream != 0: run the context on the caller-owned HIP stream `hip_stream` (e.g.
- * torch's current stream -- whose handle is NULL for the legacy default stream -- so that
- * kernels, RCCL collectives and the caller's own work are ordered without host
- * synchronisation).  use_caller_stream == 0: back to a private non-blocking stream.  The
- * previous stream is drained first.                                                         */
+/* ---- STREAM ORDERING (the contract of every entry point that takes or returns a DEVICE pointer: the `_dev`
+ * functions, lrvb_set_data_dev / lrvb_set_weights_dev, lrvb_allreduce_hessian, the reduce hook) -------------------
+ * All device work of a context is issued on ONE HIP stream, "the context's stream", and `_dev` entry points return
+ * as soon as that work is queued.  A device operand is read, and a device result written, IN THE ORDER OF THAT
+ * STREAM and in no other order.  The caller is responsible for ordering its own producers and consumers against it:
+ *   (1) By default the context's stream is a private BLOCKING stream (hipStreamDefault): HIP orders it after all
+ *       work already queued on the legacy default stream (handle NULL -- torch's current stream unless the caller
+ *       changed it), and orders later default-stream work after it.  A caller that works on the default stream
+ *       therefore needs nothing else: operands written by default-stream kernels are visible, results are complete
+ *       before a later default-stream kernel or copy reads them.
+ *   (2) A caller that works on ANY OTHER stream (torch side streams, hipStreamNonBlocking streams, per-thread
+ *       default streams) must do one of: lrvb_ctx_set_stream(ctx, its stream, 1) -- the context then runs ON that
+ *       stream; or bracket the calls with lrvb_ctx_wait_stream (before: the context's stream waits for everything
+ *       queued so far on the caller's stream) and lrvb_stream_wait_ctx (after: the caller's stream waits for
+ *       everything the context has queued); or synchronise on the host (its own stream before, lrvb_ctx_sync after).
+ *   (3) Host-pointer entry points (no `_dev` suffix) synchronise the context's stream before they return: their
+ *       outputs are complete on return, and their inputs may be reused at once.
+ * Buffers adopted with lrvb_set_data_dev / lrvb_set_weights_dev are read by every later call: a caller that
+ * overwrites them must order that write after the context's queued work (rule 1 or 2) like any other consumer.
+ *
+ * lrvb_ctx_set_stream: use_caller_stream != 0 runs the context on the caller-owned HIP stream `hip_stream` (e.g.
+ * torch's current stream -- whose handle is NULL for the legacy default stream -- so that kernels, RCCL collectives
+ * and the caller's own work are ordered without host synchronisation).  use_caller_stream == 0: back to a private
+ * blocking stream.  The previous stream is drained first.                                                          */
 int lrvb_ctx_set_stream(lrvb_ctx* ctx, void* hip_stream, int use_caller_stream);
+/* Event hand-offs, no host synchronisation: the context's stream waits for the work queued so far on `hip_stream`
+ * (call before handing the context operands produced there) ...                                                    */
+int lrvb_ctx_wait_stream(lrvb_ctx* ctx, void* hip_stream);
+/* ... and `hip_stream` waits for the work the context has queued so far (call before consuming results there).     */
+int lrvb_stream_wait_ctx(lrvb_ctx* ctx, void* hip_stream);
 int lrvb_ctx_sizes  (lrvb_ctx* ctx, int64_t* D, int64_t* V, int64_t* n_obs);
 
 /* Observations / constants: uploaded once, resident in HBM afterwards.  rows/cols must

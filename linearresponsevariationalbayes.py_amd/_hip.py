@@ -53,6 +53,8 @@ _SIGNATURES = {
     'lrvb_ctx_destroy': [_VP],
     'lrvb_ctx_sync': [_VP],
     'lrvb_ctx_set_stream': [_VP, _VP, ctypes.c_int],
+    'lrvb_ctx_wait_stream': [_VP, _VP],
+    'lrvb_stream_wait_ctx': [_VP, _VP],
     'lrvb_ctx_sizes': [_VP, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)],
     'lrvb_set_data': [_VP, ctypes.c_int, _VP, c_i64, c_i64],
     'lrvb_set_data_dev': [_VP, ctypes.c_int, _VP, c_i64, c_i64],

@@ -132,7 +132,10 @@ extern "C" int lrvb_ctx_create(lrvb_ctx** out, int device_id, const lrvb_model_d
     c->data_only = (c->loss == LRVB_LOSS_DATA_ONLY);
 
     hipError_t e = hipSetDevice(device_id);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    // A BLOCKING stream (hipStreamDefault): it orders itself against the legacy default stream in both directions, so a
+    // caller that produces operands on the default stream (torch's current stream unless told otherwise) and hands their
+    // device pointers to a `_dev` entry point needs no further synchronisation (include/lrvb_hip.h, "stream ordering").
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamDefault);
     if (e != hipSuccess) { lrvb_set_error("context init: %s", hipGetErrorString(e)); delete c; return LRVB_ERR_HIP; }
 
     int st = LRVB_OK;
@@ -185,6 +188,7 @@ extern "C" int lrvb_ctx_destroy(lrvb_ctx* c) {
     for (DevBuf* b : all) buf_free(*b);
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
     for (int k = 0; k < 3; ++k) for (hipEvent_t e : c->ev_pool[k]) (void)hipEventDestroy(e);
+    if (c->ev_order) (void)hipEventDestroy(c->ev_order);
     if (c->stream && c->stream_owned) (void)hipStreamDestroy(c->stream);
     delete c;
     return LRVB_OK;
@@ -201,13 +205,30 @@ extern "C" int lrvb_ctx_set_stream(lrvb_ctx* c, void* hip_stream, int use_caller
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->stream && c->stream_owned) HIP_TRY(hipStreamDestroy(c->stream));
     if (!use_caller_stream) {
-        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamDefault));
         c->stream_owned = true;
     } else {
         c->stream = reinterpret_cast<hipStream_t>(hip_stream);
         c->stream_owned = false;
     }
     return LRVB_OK;
+}
+
+// Event hand-off between the context's stream and another stream of the same device (no host synchronisation).
+static int stream_handoff(lrvb_ctx* c, hipStream_t from, hipStream_t to) {
+    if (from == to) return LRVB_OK;
+    if (!c->ev_order) HIP_TRY(hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(c->ev_order, from));
+    HIP_TRY(hipStreamWaitEvent(to, c->ev_order, 0));
+    return LRVB_OK;
+}
+extern "C" int lrvb_ctx_wait_stream(lrvb_ctx* c, void* hip_stream) {
+    LRVB_TRY(ctx_bind(c));
+    return stream_handoff(c, reinterpret_cast<hipStream_t>(hip_stream), c->stream);
+}
+extern "C" int lrvb_stream_wait_ctx(lrvb_ctx* c, void* hip_stream) {
+    LRVB_TRY(ctx_bind(c));
+    return stream_handoff(c, c->stream, reinterpret_cast<hipStream_t>(hip_stream));
 }
 
 extern "C" int lrvb_ctx_sizes(lrvb_ctx* c, int64_t* D, int64_t* V, int64_t* n_obs) {

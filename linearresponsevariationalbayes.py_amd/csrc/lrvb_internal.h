@@ -33,6 +33,7 @@ struct lrvb_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool stream_owned = true;
+    hipEvent_t ev_order = nullptr;          // hand-off event of lrvb_ctx_wait_stream / lrvb_stream_wait_ctx
 
     // layout
     std::vector<lrvb_block_desc> blocks;

@@ -105,8 +105,8 @@ class DeviceContext(object):
         that triggered it and is re-raised from there."""
         self._hook_error = None
         if fn is None:
-            self._hook_cb = None
             self._check(self._lib.lrvb_set_reduce_hook(self._h, None, None))
+            self._hook_cb = None
             return
 
         def trampoline(_user, buf, n, stream):
@@ -116,8 +116,9 @@ class DeviceContext(object):
             except BaseException as e:            # never let an exception cross the C frame
                 self._hook_error = e
                 return -1
-        self._hook_cb = _hip.REDUCE_FN(trampoline)      # keep the callback object alive as long as it is installed
-        self._check(self._lib.lrvb_set_reduce_hook(self._h, ctypes.cast(self._hook_cb, ctypes.c_void_p), None))
+        cb = _hip.REDUCE_FN(trampoline)
+        self._check(self._lib.lrvb_set_reduce_hook(self._h, ctypes.cast(cb, ctypes.c_void_p), None))
+        self._hook_cb = cb      # keep the callback object alive as long as it is installed (the old one until replaced)
 
     # -- in-library RCCL communicator (one process per GPU) ------------------------------------------------------
     @staticmethod
@@ -132,8 +133,8 @@ class DeviceContext(object):
         if len(comm_id) != 128:
             raise ValueError('a communicator id has 128 bytes')
         buf = ctypes.create_string_buffer(bytes(comm_id), 128)
-        self._hook_cb = None
         self._check(self._lib.lrvb_comm_init(self._h, int(world_size), int(rank), ctypes.cast(buf, ctypes.c_void_p)))
+        self._hook_cb = None          # only now: a failed call leaves the C side pointing at the old trampoline
 
     def comm_destroy(self):
         self._check(self._lib.lrvb_comm_destroy(self._h))
@@ -162,6 +163,16 @@ class DeviceContext(object):
             self._check(self._lib.lrvb_ctx_set_stream(self._h, None, 0))
         else:       # 0 is a valid handle: the legacy default stream
             self._check(self._lib.lrvb_ctx_set_stream(self._h, ctypes.c_void_p(int(hip_stream_handle)), 1))
+
+    def wait_stream(self, hip_stream_handle):
+        """The context's stream waits for everything queued so far on the caller's stream (an integer handle; 0 / None =
+        the legacy default stream): call before passing device pointers produced there (include/lrvb_hip.h, "stream
+        ordering")."""
+        self._check(self._lib.lrvb_ctx_wait_stream(self._h, ctypes.c_void_p(int(hip_stream_handle or 0))))
+
+    def stream_wait(self, hip_stream_handle):
+        """The caller's stream waits for everything this context has queued: call before consuming `_dev` results there."""
+        self._check(self._lib.lrvb_stream_wait_ctx(self._h, ctypes.c_void_p(int(hip_stream_handle or 0))))
 
     # -- packing ------------------------------------------------------------------------
     def constrain(self, free):

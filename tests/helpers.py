@@ -46,3 +46,13 @@ def rel_err(a, b):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     denom = max(np.max(np.abs(b)), 1e-300)
     return float(np.max(np.abs(a - b)) / denom)
+
+
+def on_torch_stream(ctx, torch_device=None):
+    """Run `ctx` on torch's current stream, so that tensors torch produces and the `_dev` entry points that read or
+    write them through raw pointers are ordered on ONE stream (include/lrvb_hip.h, "stream ordering", rule 2).  Every
+    GPU test that hands a torch pointer to the library calls this (or brackets the calls with wait_stream /
+    stream_wait); tests/test_gpu_streams.py covers the default private-stream rule on its own."""
+    import torch
+    ctx.set_stream(torch.cuda.current_stream(torch_device).cuda_stream)
+    return ctx

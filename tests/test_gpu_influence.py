@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from oracle import models as om
-from helpers import make_par, glm_data, rel_err, LOSS_NAME
+from helpers import make_par, glm_data, rel_err, LOSS_NAME, on_torch_stream
 
 pytestmark = pytest.mark.gpu
 
@@ -112,7 +112,7 @@ def test_full_size_rows(vb):
     wv = torch.rand((N,), dtype=torch.float64, device=dev, generator=g) + 0.5
     blocks = [dict(kind=0, free_size=P - 256, vec_size=P - 256, dim0=P - 256, dim1=0, lb=-np.inf, ub=np.inf),
               dict(kind=0, free_size=256, vec_size=256, dim0=256, dim1=0, lb=0.0, ub=np.inf)]
-    ctx = vb.DeviceContext(blocks, loss='gaussian', n_obs=N, n_cols=P, lik_info=2.0, quad_kind=1)
+    ctx = on_torch_stream(vb.DeviceContext(blocks, loss='gaussian', n_obs=N, n_cols=P, lik_info=2.0, quad_kind=1), dev)
     ctx.set_data_dev(0, X.data_ptr(), N, P); ctx.set_data_dev(1, yv.data_ptr(), N, 1); ctx.set_weights_dev(wv.data_ptr(), N)
     ctx.set_data(2, np.ones(P))
     rng = np.random.default_rng(2)

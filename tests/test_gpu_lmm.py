@@ -8,7 +8,7 @@ import torch
 
 import torch_ref as tr
 from oracle import packing as opk
-from helpers import rel_err
+from helpers import rel_err, on_torch_stream
 from test_lmm_host_math import make_par, random_eta, host_stats
 
 pytestmark = pytest.mark.gpu
@@ -153,7 +153,7 @@ def test_config4_shard_scale_statistics(vb):
     w = torch.rand((N,), dtype=torch.float64, device=dev, generator=gen) + 0.5
     par = make_par(p, G)
     assert par.free_size() - 2 * G == 995
-    ctx = vb.DeviceContext(par.layout_blocks(), loss='data_only', n_obs=N, n_cols=p + 1)
+    ctx = on_torch_stream(vb.DeviceContext(par.layout_blocks(), loss='data_only', n_obs=N, n_cols=p + 1), dev)
     ctx.set_data_dev(0, Z.data_ptr(), N, p + 1)
     ctx.set_weights_dev(w.data_ptr(), N)
     ctx.set_groups(gid.cpu().numpy(), G)

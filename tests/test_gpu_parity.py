@@ -9,7 +9,7 @@ import pytest
 
 from oracle import models as om
 from oracle import solvers as osv
-from helpers import make_par, glm_data, rel_err, LOSS_NAME
+from helpers import make_par, glm_data, rel_err, LOSS_NAME, on_torch_stream
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -293,6 +293,7 @@ def test_sharded_engine_single_rank_matches_direct_build(vb):
     Hw = model.hessian(theta)
     assert rel_err(H, Hw) < TOL
     H2 = torch.empty((P, P), dtype=torch.float64, device=dev)
+    on_torch_stream(fun.ctx, dev)
     fun.ctx.hessian_dev(th.data_ptr(), H2.data_ptr(), P); fun.ctx.sync()
     assert np.array_equal(H2.cpu().numpy(), H)          # same kernels, same order: bitwise equal
     eng = DeviceEngine(fun.ctx, dev)
@@ -369,7 +370,7 @@ def test_full_size_properties_headline_shape(vb):
     w1 = torch.rand((N,), dtype=torch.float64, device=dev, generator=g) + 0.5
     w2 = torch.rand((N,), dtype=torch.float64, device=dev, generator=g) + 0.5
     blocks = [dict(kind=0, free_size=P, vec_size=P, dim0=P, dim1=0, lb=-np.inf, ub=np.inf)]
-    ctx = vb.DeviceContext(blocks, loss='gaussian', n_obs=N, n_cols=P, lik_info=1.5, quad_kind=0)
+    ctx = on_torch_stream(vb.DeviceContext(blocks, loss='gaussian', n_obs=N, n_cols=P, lik_info=1.5, quad_kind=0), dev)
     ctx.set_data_dev(0, X.data_ptr(), N, P); ctx.set_data_dev(1, yv.data_ptr(), N, 1)
     theta = torch.zeros((P,), dtype=torch.float64, device=dev)
     def build(wt):
@@ -468,7 +469,7 @@ def test_more_than_2_31_matrix_elements(vb):
     blocks = [dict(kind=0, free_size=P, vec_size=P, dim0=P, dim1=0, lb=-np.inf, ub=np.inf)]
 
     def make(r0, r1, prior):
-        ctx = vb.DeviceContext(blocks, loss='logistic', n_obs=r1 - r0, n_cols=P, quad_kind=vb._hip.QUAD_DIAG)
+        ctx = on_torch_stream(vb.DeviceContext(blocks, loss='logistic', n_obs=r1 - r0, n_cols=P, quad_kind=vb._hip.QUAD_DIAG), dev)
         ctx.set_data_dev(0, X[r0:r1].data_ptr(), r1 - r0, P)
         ctx.set_data_dev(1, yv[r0:r1].data_ptr(), r1 - r0, 1)
         ctx.set_weights_dev(w[r0:r1].data_ptr(), r1 - r0)

@@ -219,8 +219,15 @@ def test_in_library_rccl_communicator_one_rank():
     th = torch.tensor(theta, device=dev)
     stats = torch.empty(ctx.stats_size(), dtype=torch.float64, device=dev)
     Hd = torch.empty((P, P), dtype=torch.float64, device=dev)
+    # th / stats / Hd live on torch's current stream, the context on its own: explicit event hand-offs both ways
+    # (include/lrvb_hip.h "stream ordering", rule 2; round 2's version of this test cloned `stats` with no ordering at
+    # all and read the buffer before the tiles had landed)
+    ts = torch.cuda.current_stream(dev).cuda_stream
+    ctx.wait_stream(ts)
     ctx.hessian_partial_dev(th.data_ptr(), stats.data_ptr())
+    ctx.stream_wait(ts)
     before = stats.clone()
+    ctx.wait_stream(ts)                                       # the clone must have read `stats` before the collective rewrites it
     ctx.allreduce_hessian(stats.data_ptr(), stats.numel())
     ctx.hessian_finish_dev(th.data_ptr(), stats.data_ptr(), Hd.data_ptr(), P)
     ctx.sync()
