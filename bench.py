@@ -291,7 +291,7 @@ def run_config(args):
         D = fun.n_global
 
         def step():
-            return fun.global_hessian(theta)
+            return fun.global_hessian(theta, want_host=False)      # the result stays in HBM (what chol_factor_last factors)
         metric = 'Schur-complement ELBO-Hessian builds/sec, Dirichlet-multinomial mixture K=32, N={:g} obs x D={} global free params'.format(float(N), D)
         workload = ('config 3: Dirichlet-multinomial mixture K=32, V=31, N={}; one step = per-row simplex blocks eliminated on the '
                     'GPU (rows kernel + Kronecker GEMM + statistics) + device Schur assembly of the {} x {} global block').format(N, D, D)
@@ -309,11 +309,9 @@ def run_config(args):
         D = None
 
         def step():
-            fun._stats_cache = None
-            fun.local_stats()
-            return fun.global_hessian(theta)
-        H0 = step()
-        D = H0.shape[0]
+            fun.invalidate_stats()                                # the pass over the observations is part of every step
+            return fun.global_hessian(theta, want_host=False)      # the result stays in HBM (what chol_factor_last factors)
+        D = fun.n_global
         metric = 'arrow-Hessian Schur-complement builds/sec, hierarchical LMM G=1e4 groups, one GPU shard N=1.25e6 of 1e7 obs x D={} global free params'.format(D)
         workload = ('config 4: hierarchical LMM p=43, G=1e4, ONE of the eight 1.25e6-row shards of the N=1e7 problem; one step = '
                     'sufficient statistics of the shard on the GPU (Gram q=44 + per-group sums) + arrow-Hessian assembly and Schur complement')

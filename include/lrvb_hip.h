@@ -215,6 +215,9 @@ int lrvb_hvp_vec    (lrvb_ctx* ctx, const double* vec_in, const double* v, int64
 int lrvb_hvec_begin(lrvb_ctx* ctx);
 int lrvb_hvec_add_block(lrvb_ctx* ctx, const double* block, int64_t rows, int64_t cols, int64_t row_off,
                         int64_t col_off, int mirror);
+/* H[rows[a], cols[b]] += block[a, b] (nr x nc, row-major): a dense block scattered over index lists -- the coupled
+ * rows of an arrow Hessian are not contiguous.  No index may appear twice in one list.                               */
+int lrvb_hvec_add_indexed(lrvb_ctx* ctx, const double* block, int64_t nr, int64_t nc, const int64_t* rows, const int64_t* cols);
 int lrvb_hvec_add_symkron(lrvb_ctx* ctx, const double* A, const double* B, int64_t k, double coef,
                           int64_t row_off, int64_t col_off, int mirror);
 int lrvb_hvec_finish(lrvb_ctx* ctx, const double* point, int64_t n_in, int is_free, const double* g_vec,
@@ -288,6 +291,21 @@ int lrvb_obs_quadform(lrvb_ctx* ctx, const double* M, const double* c, int64_t K
  * n_groups x (1 + n_cols) matrix [ sum_g w | sum_g w z ].  n_cols <= 64.                        */
 int lrvb_set_groups(lrvb_ctx* ctx, const int32_t* gid, int64_t n, int64_t n_groups);
 int lrvb_group_sums(lrvb_ctx* ctx, double* out);
+/* Both statistics of a hierarchical model in one call, [S = Z^T diag(w) Z (q x q) | group sums (G x (1 + q))], in ONE
+ * device buffer that goes to the sum-over-ranks hook once and stays resident for lrvb_lmm_group_terms.  Either host
+ * copy may be NULL.                                                                                                   */
+int lrvb_grouped_stats(lrvb_ctx* ctx, double* S_out, double* gs_out);
+/* The hierarchical linear mixed model of doc/lmm.lyx:77-160 (y_i ~ N(x_i.beta + u_g[i], 1/tau_y), u_g ~ N(mu, 1/tau_mu),
+ * q(u_g) = N(e_g, 1/i_g)): elimination of the 2 G local parameters on the device, from the resident grouped
+ * statistics (Z = [x | y], q = p + 1).  par (8 + p) = [E tau_y, E tau_mu, E mu, d E tau_y / d (a_y, b_y), d E tau_mu / d
+ * (a_mu, b_mu), lower bound of the i_g, mean of q(beta) (p)]; f_local (2 G) = FREE local parameters [e_g | log(i_g - lb)].
+ * out (128 + (p + 5)^2): out[0 .. p) = sum_g e_g sum_g w x; out[64 ..] = sum e_g r_g, sum W_g (e_g^2 + 1/i_g),
+ * sum (e_g - E mu)^2 + 1/i_g, sum (e_g - E mu), sum log i_g, sum W_g, squared norm of the free local gradient
+ * (r_g = sum_g w y - m . sum_g w x); then M = H_gl H_ll^-1 H_lg on the p + 5 coupled rows [mean of q(beta) | E mu | a_y |
+ * b_y | a_mu | b_mu] in vector coordinates of those rows and free coordinates of the local parameters (H_ll is
+ * diagonal for this model) -- what the reference would obtain from the D x D autograd Hessian and a sparse solve
+ * (LRVB/SparseObjectives.py:581-657).                                                                                  */
+int lrvb_lmm_group_terms(lrvb_ctx* ctx, const double* par, int64_t n_par, const double* f_local, int64_t n_local, double* out);
 
 /* Mixture models with a SimplexParam row per observation (LRVB/SimplexParams.py:69-175): for every
  * row, on one wavefront, the simplex map and its closed-form Jacobian / Hessian (:33-63), the local
@@ -311,6 +329,18 @@ int lrvb_mixture_rows(lrvb_ctx* ctx, int32_t K, const double* theta_z, const dou
  * replace the host contraction the reference would do with sparse Jacobian lists.  All host pointers. */
 int lrvb_mixture_schur(lrvb_ctx* ctx, int32_t K, int32_t q, const double* R, const double* Jlam,
                        const double* Hgg, const double* scale, const double* diag_add, double* H_out);
+/* lrvb_mixture_rows without the per-row gradient and WITHOUT copying the Schur operand to the host: it is summed over
+ * the ranks (with the other statistics, in one reduction) and stays resident for the Schur assembly below.          */
+int lrvb_mixture_stats(lrvb_ctx* ctx, int32_t K, const double* theta_z, const double* Lam, int32_t want_schur,
+                       double* val2_out, double* S64_out);
+/* lrvb_mixture_schur with both n x n inputs generated on the device from their O(n) description.  The Dirichlet
+ * blocks make d vec(Lam) / d alpha and the global Hessian block "diagonal plus a constant per Dirichlet"
+ * (LRVB/ExponentialFamilies.py:114-120, DirichletParams.py:19-26): vecs (4 n) = [diagonal of d Lam | diagonal of Hgg |
+ * scale | diag_add], consts (2 (K + 1)) = [constant of d Lam per Dirichlet | constant of Hgg per Dirichlet]
+ * (Dirichlet 0 = the K mixture weights at indices 0 .. K-1, Dirichlet 1 + k = column k of the (V, K) array at
+ * indices K + v K + k).  Uses the operand the last lrvb_mixture_rows / lrvb_mixture_stats call left on the device;
+ * the result stays on the device for lrvb_chol_factor_last, H_out may be NULL.                                      */
+int lrvb_mixture_schur_dirichlet(lrvb_ctx* ctx, int32_t K, int32_t q, const double* vecs, const double* consts, double* H_out);
 
 /* Gram matrix G^T G (D x D, free coordinates) of the per-observation gradients
  * g_n[k] = 1/2 z_n^T M_k z_n + c_k (K = V matrices, one per vector coordinate): the Kronecker rows
@@ -382,8 +412,14 @@ int lrvb_hessian_dev(lrvb_ctx* ctx, const double* free_dev, double* H_dev, int64
  * -- e.g. an RCCL all-reduce launched on that stream -- and return 0.  Every rank then holds the global value,
  * gradient, product, Hessian and iterates, bit-identical, so the device CG / trust-region loops stay in lockstep
  * with one D-vector all-reduce per product; no counterpart in the reference, which is
- * single-process.  lrvb_hessian_partial_dev, the per-observation row outputs (lrvb_obs_*) and the raw statistics
- * calls (lrvb_weighted_gram, lrvb_group_sums, lrvb_mixture_rows, lrvb_quadform_gram) stay rank-local by contract.
+ * single-process.  The statistics calls of the other model families are sums over observations too and go through
+ * the hook the same way, EXACTLY ONCE PER CALL, on the device buffer, before anything is copied to the host:
+ * lrvb_weighted_gram (S), lrvb_group_sums, lrvb_grouped_stats ([S | group sums]), lrvb_mixture_rows /
+ * lrvb_mixture_stats ([S64 | val2 | count of indefinite rows | packed Schur operand]: every rank fails together when
+ * any rank has an indefinite row), lrvb_quadform_gram ([K4 tiles | s | observation count]) and
+ * lrvb_logitnormal_terms ([Hessian blocks | gradient | value], the part that was asked for).  A call must therefore
+ * be made by ALL ranks, with the same arguments apart from the rows they hold.  lrvb_hessian_partial_dev and the
+ * per-observation row outputs (lrvb_obs_*, the gradient rows of lrvb_mixture_rows) stay rank-local by contract.
  * fn == NULL removes the hook.                                                                                */
 typedef int (*lrvb_reduce_fn)(void* user, double* buf_dev, int64_t n, void* hip_stream);
 int lrvb_set_reduce_hook(lrvb_ctx* ctx, lrvb_reduce_fn fn, void* user);

@@ -80,6 +80,7 @@ _SIGNATURES = {
     'lrvb_logitnormal_terms': [_VP, _VP, _VP, c_i64, _VP, _VP, ctypes.c_int32, _VP, _VP, _VP],
     'lrvb_hvec_begin': [_VP],
     'lrvb_hvec_add_block': [_VP, _VP, c_i64, c_i64, c_i64, c_i64, ctypes.c_int],
+    'lrvb_hvec_add_indexed': [_VP, _VP, c_i64, c_i64, _VP, _VP],
     'lrvb_hvec_add_symkron': [_VP, _VP, _VP, c_i64, ctypes.c_double, c_i64, c_i64, ctypes.c_int],
     'lrvb_hvec_finish': [_VP, _VP, c_i64, ctypes.c_int, _VP, _VP],
     'lrvb_obs_influence': [_VP, _VP, c_i64, _VP, c_i64, c_i64, c_i64, _VP],
@@ -93,8 +94,12 @@ _SIGNATURES = {
     'lrvb_minimize_trust_ncg': [_VP, _VP, ctypes.c_int64, _VP, ctypes.c_double, ctypes.c_int64, ctypes.c_double,
                                 ctypes.c_double, ctypes.c_double, _VP, _VP, _VP],
     'lrvb_mixture_schur': [_VP, ctypes.c_int32, ctypes.c_int32, _VP, _VP, _VP, _VP, _VP, _VP],
+    'lrvb_mixture_stats': [_VP, ctypes.c_int32, _VP, _VP, ctypes.c_int32, _VP, _VP],
+    'lrvb_mixture_schur_dirichlet': [_VP, ctypes.c_int32, ctypes.c_int32, _VP, _VP, _VP],
     'lrvb_set_groups': [_VP, _VP, c_i64, c_i64],
     'lrvb_group_sums': [_VP, _VP],
+    'lrvb_grouped_stats': [_VP, _VP, _VP],
+    'lrvb_lmm_group_terms': [_VP, _VP, c_i64, _VP, c_i64, _VP],
     'lrvb_quadform_gram': [_VP, _VP, _VP, c_i64, _VP, _VP, c_i64],
     'lrvb_cg_solve_matrix': [_VP, _VP, _VP, _VP, _VP, ctypes.c_double, c_i64, c_i64, _VP,
                              ctypes.POINTER(ctypes.c_int), ctypes.POINTER(c_i64)],

@@ -184,7 +184,7 @@ extern "C" int lrvb_ctx_destroy(lrvb_ctx* c) {
     DevBuf* all[] = { &c->X, &c->y, &c->w, &c->quadA, &c->quadM, &c->quadB, &c->theta, &c->eta, &c->j1, &c->j2,
                       &c->vtmp, &c->vtmp2, &c->vtmp3, &c->g_eta, &c->g_free, &c->lp, &c->cw, &c->zbuf,
                       &c->part_vec, &c->part_val, &c->stats, &c->tile_part, &c->Heta, &c->Hfree, &c->Jdense,
-                      &c->Tdense, &c->work1, &c->chol, &c->cholW, &c->cgH, &c->groups, &c->mx_theta, &c->mx_lam, &c->mx_A, &c->mx_U, &c->mx_g, &c->mx_Xk, &c->mx_R, &c->cgT, &c->ones, &c->cgm[0], &c->cgm[1], &c->cgm[2], &c->cgm[3], &c->cgm[4], &c->cgm[5], &c->cgm[6], &c->cgm[7], &c->cgm[8], &c->rhs, &c->cgx, &c->cgr, &c->cgp, &c->cgq, &c->cgz, &c->scal, &c->opt, &c->dkw, &c->cyv, &c->rvec, &c->red_scratch };
+                      &c->Tdense, &c->work1, &c->chol, &c->cholW, &c->cgH, &c->groups, &c->mx_theta, &c->mx_lam, &c->mx_A, &c->mx_U, &c->mx_g, &c->mx_Xk, &c->mx_R, &c->cgT, &c->ones, &c->cgm[0], &c->cgm[1], &c->cgm[2], &c->cgm[3], &c->cgm[4], &c->cgm[5], &c->cgm[6], &c->cgm[7], &c->cgm[8], &c->rhs, &c->cgx, &c->cgr, &c->cgp, &c->cgq, &c->cgz, &c->scal, &c->opt, &c->dkw, &c->cyv, &c->rvec, &c->red_scratch, &c->gstats };
     for (DevBuf* b : all) buf_free(*b);
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
     for (int k = 0; k < 3; ++k) for (hipEvent_t e : c->ev_pool[k]) (void)hipEventDestroy(e);
@@ -272,7 +272,7 @@ extern "C" int lrvb_set_data(lrvb_ctx* c, int slot, const double* host, int64_t 
     if (!b->owned) { b->p = nullptr; b->n = 0; b->owned = true; }
     LRVB_TRY(buf_reserve(c, *b, n));
     LRVB_TRY(h2d(c, b->p, host, n));
-    if (slot == LRVB_SLOT_X) { c->have_X = true; c->x2_ready = false; }
+    if (slot == LRVB_SLOT_X) { c->have_X = true; c->x2_ready = false; c->gstats_valid = false; }
     if (slot == LRVB_SLOT_Y) c->have_y = true;
     return LRVB_OK;
 }
@@ -284,7 +284,7 @@ extern "C" int lrvb_set_data_dev(lrvb_ctx* c, int slot, const double* data_dev, 
     LRVB_TRY(slot_shape_check(c, slot, rows, cols, &b, &n));
     if (b->p && b->owned) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(b->p)); }
     b->p = const_cast<double*>(data_dev); b->n = n; b->owned = false;
-    if (slot == LRVB_SLOT_X) { c->have_X = true; c->x2_ready = false; }
+    if (slot == LRVB_SLOT_X) { c->have_X = true; c->x2_ready = false; c->gstats_valid = false; }
     if (slot == LRVB_SLOT_Y) c->have_y = true;
     return LRVB_OK;
 }
@@ -294,6 +294,7 @@ extern "C" int lrvb_set_weights(lrvb_ctx* c, const double* w, int64_t n) {
     if (c->loss == LRVB_LOSS_NONE) LRVB_FAIL(LRVB_ERR_STATE, "model has no data term");
     if (!w || n != c->N) LRVB_FAIL(LRVB_ERR_SIZE, "weights must have %lld entries (got %lld)", (long long)c->N, (long long)n);
     if (!c->w.owned) { c->w.p = nullptr; c->w.n = 0; c->w.owned = true; }
+    c->gstats_valid = false;
     LRVB_TRY(buf_reserve(c, c->w, (size_t)n));
     return h2d(c, c->w.p, w, (size_t)n);
 }
@@ -304,6 +305,7 @@ extern "C" int lrvb_set_weights_dev(lrvb_ctx* c, const double* w_dev, int64_t n)
     if (!w_dev || n != c->N) LRVB_FAIL(LRVB_ERR_SIZE, "weights must have %lld entries (got %lld)", (long long)c->N, (long long)n);
     if (c->w.p && c->w.owned) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->w.p)); }
     c->w.p = const_cast<double*>(w_dev); c->w.n = (size_t)n; c->w.owned = false;
+    c->gstats_valid = false;
     return LRVB_OK;
 }
 
@@ -981,6 +983,37 @@ extern "C" int lrvb_hvec_add_block(lrvb_ctx* c, const double* block, int64_t row
     EW(hvec_add_block_kernel, rows * cols, cols, c->work1.p, c->Heta.p, c->V, row_off, col_off, mirror);
     return LRVB_OK;
 }
+// H[rows[a], cols[b]] += block[a, b]: a dense block scattered over index lists (the coupled rows of an arrow Hessian
+// are not contiguous).  The index lists travel as doubles behind the block (one upload).
+__global__ void hvec_add_indexed_kernel(i64 total, i64 nc, const double* __restrict__ Bk, const double* __restrict__ ridx,
+                                        const double* __restrict__ cidx, double* __restrict__ H, i64 ld)
+{
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const i64 a = e / nc, b = e - a * nc;
+    H[(i64)ridx[a] * ld + (i64)cidx[b]] += Bk[e];
+}
+extern "C" int lrvb_hvec_add_indexed(lrvb_ctx* c, const double* block, int64_t nr, int64_t nc, const int64_t* rows, const int64_t* cols) {
+    LRVB_TRY(ctx_bind(c));
+    if (!c->hvec_open) LRVB_FAIL(LRVB_ERR_STATE, "call lrvb_hvec_begin first");
+    if (!block || !rows || !cols || nr <= 0 || nc <= 0) LRVB_FAIL(LRVB_ERR_INVALID, "bad argument");
+    std::vector<double> pack((size_t)(nr * nc + nr + nc));
+    memcpy(pack.data(), block, (size_t)(nr * nc) * sizeof(double));
+    for (i64 a = 0; a < nr; ++a) {
+        if (rows[a] < 0 || rows[a] >= c->V) LRVB_FAIL(LRVB_ERR_INVALID, "row index %lld outside [0, %lld)", (long long)rows[a], (long long)c->V);
+        pack[(size_t)(nr * nc + a)] = (double)rows[a];
+    }
+    for (i64 b = 0; b < nc; ++b) {
+        if (cols[b] < 0 || cols[b] >= c->V) LRVB_FAIL(LRVB_ERR_INVALID, "column index %lld outside [0, %lld)", (long long)cols[b], (long long)c->V);
+        pack[(size_t)(nr * nc + nr + b)] = (double)cols[b];
+    }
+    // two entries of one index list must not name the same element twice (the += would race): lists of a parameter layout never do
+    LRVB_TRY(buf_reserve(c, c->work1, pack.size()));
+    LRVB_TRY(h2d(c, c->work1.p, pack.data(), pack.size()));
+    EW(hvec_add_indexed_kernel, nr * nc, nc, (const double*)c->work1.p, (const double*)(c->work1.p + nr * nc),
+       (const double*)(c->work1.p + nr * nc + nr), c->Heta.p, c->V);
+    return LRVB_OK;
+}
 extern "C" int lrvb_hvec_add_symkron(lrvb_ctx* c, const double* A, const double* B, int64_t k, double coef,
                                      int64_t row_off, int64_t col_off, int mirror) {
     LRVB_TRY(ctx_bind(c));
@@ -1166,6 +1199,7 @@ extern "C" int lrvb_weighted_gram(lrvb_ctx* c, double* S_out, int64_t ld) {
     LRVB_TRY(launch_wsyrk(c, c->zbuf.p, tiles));
     LRVB_TRY(buf_reserve(c, c->Hfree, (size_t)c->P * (size_t)c->P));
     LRVB_TRY(launch_tiles_to_dense(c, tiles, c->P, c->Hfree.p, c->P, 0, 0, false));
+    LRVB_TRY(obs_reduce(c, c->Hfree.p, c->P * c->P));          // observation shards: summed on the device, before the copy
     HIP_TRY(hipMemcpy2DAsync(S_out, (size_t)ld * 8, c->Hfree.p, (size_t)c->P * 8, (size_t)c->P * 8, (size_t)c->P, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return LRVB_OK;
@@ -1249,6 +1283,7 @@ extern "C" int lrvb_set_groups(lrvb_ctx* c, const int32_t* gid, int64_t n, int64
     HIP_TRY(hipMemcpyAsync(dev + n, offs.data(), ((size_t)n_groups + 1) * sizeof(i64), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->n_groups = n_groups;
+    c->gstats_valid = false;
     return LRVB_OK;
 }
 
@@ -1264,16 +1299,158 @@ extern "C" int lrvb_group_sums(lrvb_ctx* c, double* out) {
     hipLaunchKernelGGL(group_sums_kernel, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, c->stream,
                        c->X.p, c->P, (int)c->P, c->w.p, dev, dev + c->N, G, c->work1.p);
     HIP_TRY(hipGetLastError());
+    LRVB_TRY(obs_reduce(c, c->work1.p, (i64)n_out));
     return d2h(c, out, c->work1.p, n_out);
 }
 
+// ---- hierarchical LMM (config 4): statistics resident on the device, group effects eliminated there ---------------
+// [S (q x q) | group sums (G x (q + 1))] in ONE device buffer, handed to the sum-over-ranks hook once and kept
+// resident for lrvb_lmm_group_terms; both host copies are optional.
+extern "C" int lrvb_grouped_stats(lrvb_ctx* c, double* S_out, double* gs_out) {
+    LRVB_TRY(ctx_bind(c));
+    if (c->n_groups <= 0) LRVB_FAIL(LRVB_ERR_STATE, "no groups: call lrvb_set_groups first");
+    if (c->loss == LRVB_LOSS_NONE || !c->have_X) LRVB_FAIL(LRVB_ERR_STATE, "no data matrix: call lrvb_set_data(LRVB_SLOT_X) first");
+    const i64 G = c->n_groups, q = c->P;
+    const size_t n_s = (size_t)q * q, n_g = (size_t)G * (size_t)(q + 1);
+    LRVB_TRY(buf_reserve(c, c->gstats, n_s + n_g));
+    c->gstats_valid = false;
+    LRVB_TRY(reserve_obs_vec(c, c->zbuf));
+    HIP_TRY(hipMemcpyAsync(c->zbuf.p, c->w.p, (size_t)c->N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    double* tiles = c->stats.p + 1 + c->P;
+    LRVB_TRY(launch_wsyrk(c, c->zbuf.p, tiles));
+    LRVB_TRY(launch_tiles_to_dense(c, tiles, q, c->gstats.p, q, 0, 0, false));
+    const i64* dev = reinterpret_cast<const i64*>(c->groups.p);
+    if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
+    hipLaunchKernelGGL(group_sums_kernel, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, c->stream,
+                       c->X.p, c->P, (int)c->P, c->w.p, dev, dev + c->N, G, c->gstats.p + n_s);
+    HIP_TRY(hipGetLastError());
+    if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
+    LRVB_TRY(obs_reduce(c, c->gstats.p, (i64)(n_s + n_g)));
+    c->gstats_valid = true;
+    if (S_out) LRVB_TRY(d2h(c, S_out, c->gstats.p, n_s));
+    if (gs_out) LRVB_TRY(d2h(c, gs_out, c->gstats.p + n_s, n_g));
+    return LRVB_OK;
+}
+
+// One wavefront per batch of groups, lane = column of the group's row [W_g | sum w x (p) | sum w y] of the resident
+// statistics.  For group g (doc/lmm.lyx:105-160; e_g, i_g the mean and information of q(u_g)):
+//   r_g = sum w y - (sum w x) . m,   a_g = W_g e_g - r_g,   d_g = e_g - e_mu,   D_g = ty W_g + tm,
+// the two columns of the arrow Hessian's cross block that belong to (e_g, i_g), in vector coordinates of the p + 5
+// coupled global rows [mean of q(beta) (p) | e_mu | a_y | b_y | a_mu | b_mu], times d local / d free,
+//   c_e = [ty sum w x | -tm | a_g tay | a_g tby | d_g tam | d_g tbm],
+//   c_i = [0 | 0 | -W_g tay / (2 i_g^2) | -W_g tby / (2 i_g^2) | -tam / (2 i_g^2) | -tbm / (2 i_g^2)] * (i_g - lb),
+// go to rows 2g and 2g + 1 of C (width ldc), the reciprocals of the free local diagonal to the weights; the sums over
+// groups that the global gradient and the scalars of the ELBO need are accumulated per wave (fixed order) in `part`.
+//   sums[0 .. p) = sum_g e_g sum w x;  sums[64 + k]: 0 sum e_g r_g, 1 sum W_g (e_g^2 + 1 / i_g), 2 sum d_g^2 + 1 / i_g,
+//   3 sum d_g, 4 sum log i_g, 5 sum W_g, 6 sum (local free gradient)^2 (a stationarity diagnostic)
+__global__ __launch_bounds__(256)
+void lmm_group_kernel(const double* __restrict__ gs, i64 G, int p, const double* __restrict__ par, const double* __restrict__ floc,
+                      double* __restrict__ C, int ldc, double* __restrict__ wts, double* __restrict__ part)
+{
+    const int lane = threadIdx.x & 63;
+    const i64 gw = (i64)blockIdx.x * 4 + (threadIdx.x >> 6), GW = (i64)gridDim.x * 4;
+    const double ty = par[0], tm = par[1], e_mu = par[2], tay = par[3], tby = par[4], tam = par[5], tbm = par[6], lb = par[7];
+    const double mj = (lane >= 1 && lane <= p) ? par[8 + lane - 1] : 0.0;       // m aligned with the sum w x lanes
+    const int q1 = p + 2;                                                     // entries of a statistics row
+    double v1 = 0.0;                                                          // lane 1 + j: sum_g e_g (sum w x)_j
+    double sc[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (i64 g = gw; g < G; g += GW) {
+        const double val = lane < q1 ? gs[g * q1 + lane] : 0.0;
+        double dotv = val * mj;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dotv += __shfl_xor(dotv, off);
+        const double W = __shfl(val, 0), sy = __shfl(val, p + 1);
+        const double eg = floc[g], ig = lb + exp(floc[G + g]), jl = ig - lb;
+        const double rg = sy - dotv, a = W * eg - rg, d = eg - e_mu, Dg = ty * W + tm;
+        const double i2 = 1.0 / (ig * ig);
+        const double dl_i = Dg * i2 / ig - 0.5 * i2, g_i = -0.5 * Dg * i2 + 0.5 / ig, g_e = ty * a + tm * d;
+        const double dfe = Dg, dfi = dl_i * jl * jl + g_i * jl;
+        const double sx = __shfl(val, lane + 1 < 64 ? lane + 1 : 63);           // lane r < p: (sum w x)_r
+        double ce, ci;
+        if (lane < p) { ce = ty * sx; ci = 0.0; }
+        else if (lane == p) { ce = -tm; ci = 0.0; }
+        else if (lane == p + 1) { ce = a * tay; ci = -0.5 * W * i2 * tay * jl; }
+        else if (lane == p + 2) { ce = a * tby; ci = -0.5 * W * i2 * tby * jl; }
+        else if (lane == p + 3) { ce = d * tam; ci = -0.5 * i2 * tam * jl; }
+        else if (lane == p + 4) { ce = d * tbm; ci = -0.5 * i2 * tbm * jl; }
+        else { ce = 0.0; ci = 0.0; }
+        if (lane < ldc) { C[(2 * g) * (i64)ldc + lane] = ce; C[(2 * g + 1) * (i64)ldc + lane] = ci; }
+        if (lane == 0) { wts[2 * g] = 1.0 / dfe; wts[2 * g + 1] = 1.0 / dfi; }
+        v1 += val * eg;
+        sc[0] += eg * rg; sc[1] += W * (eg * eg + 1.0 / ig); sc[2] += d * d + 1.0 / ig; sc[3] += d;
+        sc[4] += log(ig); sc[5] += W; sc[6] += g_e * g_e + (g_i * jl) * (g_i * jl);
+    }
+    double* dst = part + gw * 128;
+    dst[lane] = (lane >= 1 && lane <= p) ? v1 : 0.0;          // shifted by one: slot 1 + j
+    if (lane < 7) dst[64 + lane] = sc[lane];
+    else dst[64 + lane] = 0.0;
+}
+// sums[k] = sum over the wave partials in wave order; the vector part is moved down by one slot
+__global__ __launch_bounds__(128)
+void lmm_sums_kernel(const double* __restrict__ part, int n_waves, double* __restrict__ sums) {
+    const int k = threadIdx.x;
+    double a = 0.0;
+    for (int wv = 0; wv < n_waves; ++wv) a += part[(i64)wv * 128 + k];
+    if (k < 64) { if (k >= 1) sums[k - 1] = a; if (k == 63) sums[63] = 0.0; }
+    else sums[k] = a;
+}
+
+// par (host, 8 + p): [ty, tm, e_mu, d ty / d a_y, d ty / d b_y, d tm / d a_mu, d tm / d b_mu, lower bound of the local
+// informations, m (p)]; f_local (host, 2 G): the FREE local parameters [e_1..e_G | log(i_g - lb)].  out (host,
+// 128 + (p + 5)^2): the sums of lmm_group_kernel, then M = sum_g c_e c_e^T / dfe + c_i c_i^T / dfi -- the Schur
+// complement of the 2 G local parameters onto the coupled global rows, in vector coordinates of the globals and free
+// coordinates of the locals (H_gl diag(H_ll)^-1 H_lg; the G independent 2 x 2 local blocks of this model are diagonal).
+extern "C" int lrvb_lmm_group_terms(lrvb_ctx* c, const double* par, int64_t n_par, const double* f_local, int64_t n_local, double* out) {
+    LRVB_TRY(ctx_bind(c));
+    if (!par || !f_local || !out) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    if (!c->gstats_valid) LRVB_FAIL(LRVB_ERR_STATE, "no grouped statistics resident: call lrvb_grouped_stats first");
+    const i64 G = c->n_groups, q = c->P, p = q - 1, R = p + 5;
+    if (p < 1 || p + 7 > 64) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "1 <= p <= 57 regressors");
+    LRVB_TRY(check_len(n_par, 8 + p, "par"));
+    LRVB_TRY(check_len(n_local, 2 * G, "local free vector"));
+    const int ldc = (int)((R + 1) & ~(i64)1);                     // even width: 16-byte loads in the narrow Gram kernel
+    i64 grid = (G + 15) / 16; if (grid > 256) grid = 256; if (grid < 1) grid = 1;
+    const i64 n_waves = grid * 4;
+    const size_t nC = (size_t)(2 * G + 16) * (size_t)ldc, nW = (size_t)(2 * G + 64);
+    LRVB_TRY(buf_reserve(c, c->work1, nC + nW + (size_t)(8 + p) + (size_t)(2 * G) + (size_t)n_waves * 128 + 128 + 64 * 64));
+    double* Cm = c->work1.p; double* wts = Cm + nC; double* dpar = wts + nW; double* dloc = dpar + (8 + p);
+    double* part = dloc + 2 * G; double* sums = part + n_waves * 128; double* Md = sums + 128;
+    {   // dpar and dloc are adjacent: one upload
+        std::vector<double> pack((size_t)(8 + p + 2 * G));
+        memcpy(pack.data(), par, (size_t)(8 + p) * sizeof(double));
+        memcpy(pack.data() + 8 + p, f_local, (size_t)(2 * G) * sizeof(double));
+        LRVB_TRY(h2d(c, dpar, pack.data(), pack.size()));
+    }
+    HIP_TRY(hipMemsetAsync(Cm + (size_t)(2 * G) * ldc, 0, (size_t)16 * ldc * sizeof(double), c->stream));
+    HIP_TRY(hipMemsetAsync(wts + 2 * G, 0, 64 * sizeof(double), c->stream));
+    if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
+    hipLaunchKernelGGL(lmm_group_kernel, dim3((unsigned)grid), dim3(256), 0, c->stream,
+                       (const double*)(c->gstats.p + q * q), G, (int)p, (const double*)dpar, (const double*)dloc, Cm, ldc, wts, part);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(lmm_sums_kernel, dim3(1), dim3(128), 0, c->stream, (const double*)part, (int)n_waves, sums);
+    HIP_TRY(hipGetLastError());
+    if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
+    LRVB_TRY(buf_reserve(c, c->Tdense, (size_t)WS_TILE * WS_TILE));
+    LRVB_TRY(launch_gram_small_on(c, Cm, 2 * G, ldc, wts, c->Tdense.p));
+    LRVB_TRY(launch_tiles_to_dense(c, c->Tdense.p, R, Md, R, 0, 0, false));
+    // [sums (128) | M (R x R)] are adjacent: one copy
+    return d2h(c, out, sums, (size_t)(128 + R * R));
+}
+
+// tail[0..1] = val2, tail[2] = number of rows whose local block was not positive definite, tail[3] = 0
+__global__ void mixture_tail_kernel(i64 n, const double* __restrict__ val2, const int* __restrict__ bad, double* __restrict__ tail) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    tail[i] = (i < 2) ? val2[i] : (i == 2 ? (double)(*bad) : 0.0);
+}
 // ---- mixture model: per-row simplex blocks eliminated on the device (config 3) --------------------
 // Inputs: free local parameters theta_z (N x (K-1)), Lam ((V+1) x K) = [E log pi; E log phi].
 // Outputs: val2 = [-sum w z.s, sum w z log z], the free local gradient (N x (K-1)), the weighted
 // sufficient statistics S64 = U^T diag(w) U with U = [x~ (32) | z (32)], and
 // R ((V+1)^2 x K^2) = sum_n w_n^2 (x~_n (x) x~_n) vec(J_n H_nn^-1 J_n^T)^T  (the Schur-complement term).
-extern "C" int lrvb_mixture_rows(lrvb_ctx* c, int32_t K, const double* theta_z, const double* Lam,
-                                 double* val2_out, double* gfree_out, double* S64_out, double* R_out) {
+// mx_flags bit 0: form the Schur operand and leave it on the device (no copy to R_out, which may be NULL)
+static int mixture_rows_impl(lrvb_ctx* c, int32_t K, const double* theta_z, const double* Lam,
+                             double* val2_out, double* gfree_out, double* S64_out, double* R_out, int mx_flags) {
     LRVB_TRY(ctx_bind(c));
     if (!Lam || !val2_out || !S64_out) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
     if (c->loss == LRVB_LOSS_NONE || !c->have_X) LRVB_FAIL(LRVB_ERR_STATE, "no data matrix: call lrvb_set_data(LRVB_SLOT_X) first");
@@ -1298,41 +1475,59 @@ extern "C" int lrvb_mixture_rows(lrvb_ctx* c, int32_t K, const double* theta_z, 
     if (st == LRVB_OK) st = h2d(c, lam.p, Lam, (size_t)((V + 1) * K));
     int* bad = reinterpret_cast<int*>(c->scal.p + 8);
     if (st == LRVB_OK) st = launch_mixture_rows(c, K, thz.p, lam.p, Amat.p, lda, U.p, gfr.p, c->scal.p, bad);
-    int hbad = 0;
-    if (st == LRVB_OK) {
-        if (hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-            hipStreamSynchronize(c->stream) != hipSuccess) { lrvb_set_error("copy failed"); st = LRVB_ERR_HIP; }
-    }
-    if (st == LRVB_OK) st = d2h(c, val2_out, c->scal.p, 2);
-    if (st == LRVB_OK && gfree_out) st = d2h(c, gfree_out, gfr.p, (size_t)(N * KM));
+    if (st == LRVB_OK && gfree_out) st = d2h(c, gfree_out, gfr.p, (size_t)(N * KM));        // rank-local: this rank's rows
+    // Everything that is a SUM OVER OBSERVATIONS goes into one device buffer, [S64 (4096) | val2 (2) | count of
+    // non-positive-definite rows (1) | pad (1) | packed R (ldk x lda)], and is handed to the sum-over-ranks hook ONCE,
+    // before anything is copied out.  Every rank takes the same path up to that reduction whatever its own rows look
+    // like (a rank that stopped early would leave the others waiting in the collective); the indefinite-row count is
+    // judged after it, so all ranks fail together.
+    const i64 TAIL = 4100;
+    const bool want_R = (R_out != nullptr) || (mx_flags & 1);
+    if (st == LRVB_OK) st = buf_reserve(c, Rd, (size_t)(TAIL + (want_R ? ldk * lda : 0)));
+    double* tail = Rd.p;
+    double* Rpk = Rd.p + TAIL;
     // S64 = U^T diag(w) U
     if (st == LRVB_OK) st = reserve_obs_vec(c, c->zbuf);
     if (st == LRVB_OK && hipMemcpyAsync(c->zbuf.p, c->w.p, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, c->stream) != hipSuccess) { lrvb_set_error("copy failed"); st = LRVB_ERR_HIP; }
     if (st == LRVB_OK) st = buf_reserve(c, c->Tdense, (size_t)WS_TILE * WS_TILE);
     if (st == LRVB_OK) st = launch_gram_small_on(c, U.p, N, 64, c->zbuf.p, c->Tdense.p);
-    if (st == LRVB_OK) st = buf_reserve(c, c->Hfree, 64 * 64);
-    if (st == LRVB_OK) st = launch_tiles_to_dense(c, c->Tdense.p, 64, c->Hfree.p, 64, 0, 0, false);
-    if (st == LRVB_OK) st = d2h(c, S64_out, c->Hfree.p, 64 * 64);
-    if (st == LRVB_OK && R_out) {
-        if (hbad) { lrvb_set_error("a local (simplex) Hessian block is not positive definite: the Schur complement is undefined at this point"); st = LRVB_ERR_NOT_POSDEF; }
+    if (st == LRVB_OK) st = launch_tiles_to_dense(c, c->Tdense.p, 64, tail, 64, 0, 0, false);
+    if (st == LRVB_OK) { EW(mixture_tail_kernel, (i64)4, (const double*)c->scal.p, (const int*)bad, tail + 4096); }
+    if (st == LRVB_OK && want_R) {
         const bool onchip = (V == 31 && K == 32);        // 528 x N x 528: the x~ (x) x~ operand is generated inside the GEMM
         if (st == LRVB_OK && !onchip) st = buf_reserve(c, Xk, (size_t)((N + 16) * ldk));
         if (st == LRVB_OK && !onchip) st = launch_kron_rows(c, Xk.p, ldk);
-        if (st == LRVB_OK) st = buf_reserve(c, Rd, (size_t)(ldk * lda));
         if (st == LRVB_OK) { EW(fill_kernel, N, 1.0, c->zbuf.p); }
         if (st == LRVB_OK && ((!onchip && hipMemsetAsync(Xk.p + N * ldk, 0, (size_t)(16 * ldk) * sizeof(double), c->stream) != hipSuccess) ||
                               hipMemsetAsync(Amat.p + N * lda, 0, (size_t)(16 * lda) * sizeof(double), c->stream) != hipSuccess)) {
             lrvb_set_error("memset failed"); st = LRVB_ERR_HIP;
         }
-        if (st == LRVB_OK) st = onchip ? launch_atb_kron32(c, c->X.p, Amat.p, N, c->zbuf.p, Rd.p)
-                                       : launch_atb(c, Xk.p, ldk, Amat.p, lda, N, c->zbuf.p, Rd.p, true);
+        if (st == LRVB_OK) st = onchip ? launch_atb_kron32(c, c->X.p, Amat.p, N, c->zbuf.p, Rpk)
+                                       : launch_atb(c, Xk.p, ldk, Amat.p, lda, N, c->zbuf.p, Rpk, true);
+    }
+    if (st == LRVB_OK) st = obs_reduce(c, Rd.p, TAIL + (want_R ? ldk * lda : 0));
+    double htail[4] = {0.0, 0.0, 0.0, 0.0};
+    if (st == LRVB_OK) st = d2h(c, htail, tail + 4096, 4);
+    if (st == LRVB_OK) { val2_out[0] = htail[0]; val2_out[1] = htail[1]; }
+    if (st == LRVB_OK) st = d2h(c, S64_out, tail, 64 * 64);
+    if (st == LRVB_OK && want_R) {
+        if (htail[2] != 0.0) { lrvb_set_error("a local (simplex) Hessian block is not positive definite: the Schur complement is undefined at this point"); st = LRVB_ERR_NOT_POSDEF; }
         // Amat is dead now: reuse it for the expanded (V+1)^2 x K^2 result
         if (st == LRVB_OK) st = buf_reserve(c, Amat, (size_t)(QQ * KK));
-        if (st == LRVB_OK) st = launch_mixture_expand(c, Rd.p, lda, V + 1, K, Amat.p);
-        if (st == LRVB_OK) st = d2h(c, R_out, Amat.p, (size_t)(QQ * KK));
+        if (st == LRVB_OK) st = launch_mixture_expand(c, Rpk, lda, V + 1, K, Amat.p);
+        if (st == LRVB_OK && !(mx_flags & 1)) st = d2h(c, R_out, Amat.p, (size_t)(QQ * KK));
         if (st == LRVB_OK) { c->mx_res_K = K; c->mx_res_q = V + 1; }
     }
     return st;
+}
+
+extern "C" int lrvb_mixture_rows(lrvb_ctx* c, int32_t K, const double* theta_z, const double* Lam,
+                                 double* val2_out, double* gfree_out, double* S64_out, double* R_out) {
+    return mixture_rows_impl(c, K, theta_z, Lam, val2_out, gfree_out, S64_out, R_out, 0);
+}
+extern "C" int lrvb_mixture_stats(lrvb_ctx* c, int32_t K, const double* theta_z, const double* Lam, int32_t want_schur,
+                                  double* val2_out, double* S64_out) {
+    return mixture_rows_impl(c, K, theta_z, Lam, val2_out, nullptr, S64_out, nullptr, want_schur ? 1 : 0);
 }
 
 // ---- Schur complement of the mixture's global block, assembled on the device -------------------------
@@ -1360,13 +1555,26 @@ __global__ void mixture_schur_finish_kernel(i64 total, i64 n, const double* __re
     H[e] = v - 0.5 * (S[e] + S[cc * n + r]);
 }
 
+// Shared tail of the two Schur entry points: Jd (n x n) and Hd (n x n) are on the device, sc / dg (nullable) too.
+static int mixture_schur_core(lrvb_ctx* c, int32_t K, int32_t q, const double* sc, const double* dg, double* H_out) {
+    const i64 n = (i64)K * q, nn = n * n;
+    DevBuf &Rfull = c->mx_A, &Rm = c->mx_Xk, &Jd = c->mx_U, &T = c->mx_R, &Hd = c->mx_g;
+    LRVB_TRY(buf_reserve(c, Rm, (size_t)nn));
+    EW(mixture_permute_kernel, nn, (int)q, (int)K, Rfull.p, Rm.p);
+    LRVB_TRY(buf_reserve(c, T, (size_t)nn));
+    LRVB_TRY(gemm_tn(c, n, n, n, Rm.p, Jd.p, T.p));              // T = Rm^T J (Rm is symmetric up to rounding)
+    LRVB_TRY(gemm_tn(c, n, n, n, Jd.p, T.p, Rm.p));              // S = J^T T, into the dead Rm
+    EW(mixture_schur_finish_kernel, nn, n, (const double*)Hd.p, sc, dg, (const double*)Rm.p, c->Hfree.p);
+    return H_out ? d2h(c, H_out, c->Hfree.p, (size_t)nn) : LRVB_OK;
+}
+
 extern "C" int lrvb_mixture_schur(lrvb_ctx* c, int32_t K, int32_t q, const double* R, const double* Jlam, const double* Hgg,
                                   const double* scale, const double* diag_add, double* H_out) {
     LRVB_TRY(ctx_bind(c));
     if (!Jlam || !Hgg || !H_out) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
     if (K < 1 || q < 1 || (i64)K * q > 8192) LRVB_FAIL(LRVB_ERR_INVALID, "K, q out of range");
     const i64 n = (i64)K * q, nn = n * n;
-    DevBuf &Rfull = c->mx_A, &Rm = c->mx_Xk, &Jd = c->mx_U, &T = c->mx_R, &Hd = c->mx_g;
+    DevBuf &Rfull = c->mx_A, &Jd = c->mx_U, &Hd = c->mx_g;
     c->x2_ready = false;
     if (R) {
         LRVB_TRY(buf_reserve(c, Rfull, (size_t)nn));
@@ -1375,13 +1583,8 @@ extern "C" int lrvb_mixture_schur(lrvb_ctx* c, int32_t K, int32_t q, const doubl
     } else if (c->mx_res_K != K || c->mx_res_q != q) {
         LRVB_FAIL(LRVB_ERR_STATE, "R is NULL and no lrvb_mixture_rows result of this shape is resident");
     }
-    LRVB_TRY(buf_reserve(c, Rm, (size_t)nn));
-    EW(mixture_permute_kernel, nn, (int)q, (int)K, Rfull.p, Rm.p);
     LRVB_TRY(buf_reserve(c, Jd, (size_t)nn));
     LRVB_TRY(h2d(c, Jd.p, Jlam, (size_t)nn));
-    LRVB_TRY(buf_reserve(c, T, (size_t)nn));
-    LRVB_TRY(gemm_tn(c, n, n, n, Rm.p, Jd.p, T.p));              // T = Rm^T J (Rm is symmetric up to rounding)
-    LRVB_TRY(gemm_tn(c, n, n, n, Jd.p, T.p, Rm.p));              // S = J^T T, into the dead Rm
     // Hgg, scale and diag go through the Hessian scratch
     LRVB_TRY(buf_reserve(c, Hd, (size_t)(nn)));
     LRVB_TRY(buf_reserve(c, c->Hfree, (size_t)(nn + 2 * n)));
@@ -1389,9 +1592,57 @@ extern "C" int lrvb_mixture_schur(lrvb_ctx* c, int32_t K, int32_t q, const doubl
     double* sc = nullptr; double* dg = nullptr;
     if (scale) { sc = c->Hfree.p + nn; LRVB_TRY(h2d(c, sc, scale, (size_t)n)); }
     if (diag_add) { dg = c->Hfree.p + nn + n; LRVB_TRY(h2d(c, dg, diag_add, (size_t)n)); }
-    EW(mixture_schur_finish_kernel, nn, n, (const double*)Hd.p, (const double*)sc, (const double*)dg, (const double*)Rm.p, c->Hfree.p);
-    LRVB_TRY(d2h(c, H_out, c->Hfree.p, (size_t)nn));
-    return LRVB_OK;
+    return mixture_schur_core(c, K, q, sc, dg, H_out);
+}
+
+// A matrix that is diagonal plus a constant on the blocks of a partition, times a column scaling:
+//   out[r, c] = ( [r == c] diag[r] + [group(r) == group(c)] gconst[group(r)] ) * colscale[c],
+// group(r) = 0 for r < K (the Dirichlet over the K mixture weights), 1 + (r mod K) otherwise (the K Dirichlets over the
+// vocabulary, parameter (v, k) at index K + v K + k): the shape of d E log p / d alpha and of the Dirichlet entropy /
+// expectation Hessians (diag(psi1(alpha)) - psi1(alpha_0): LRVB/ExponentialFamilies.py:118-120, DirichletParams.py:19-26).
+__global__ void dirichlet_blocks_kernel(i64 total, i64 n, int K, const double* __restrict__ diag, const double* __restrict__ gconst,
+                                        const double* __restrict__ colscale, double* __restrict__ out)
+{
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const i64 r = e / n, cc = e - r * n;
+    const int gr = r < K ? 0 : 1 + (int)(r % K), gc = cc < K ? 0 : 1 + (int)(cc % K);
+    double v = (gr == gc) ? gconst[gr] : 0.0;
+    if (r == cc) v += diag[r];
+    out[e] = colscale ? v * colscale[cc] : v;
+}
+
+// The same Schur complement with BOTH n x n inputs generated on the device from their O(n) description (six n-vectors
+// and two (K + 1)-vectors instead of two 8 MB matrices at n = 1024), the operand R taken from the lrvb_mixture_rows /
+// lrvb_mixture_stats call before it, and the result left on the device (H_out nullable; lrvb_chol_factor_last factors it).
+// Parameter order: the K weights first, then the (V, K) array row-major.  vecs = [dl_diag | h_diag | scale | diag_add]
+// (4 n), consts = [dl_const | h_const] (2 (K + 1)).
+extern "C" int lrvb_mixture_schur_dirichlet(lrvb_ctx* c, int32_t K, int32_t q, const double* vecs, const double* consts, double* H_out) {
+    LRVB_TRY(ctx_bind(c));
+    if (!vecs || !consts) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    if (K < 1 || q < 1 || (i64)K * q > 8192) LRVB_FAIL(LRVB_ERR_INVALID, "K, q out of range");
+    if (c->mx_res_K != K || c->mx_res_q != q) LRVB_FAIL(LRVB_ERR_STATE, "no lrvb_mixture_rows / lrvb_mixture_stats result of this shape is resident");
+    const i64 n = (i64)K * q, nn = n * n;
+    if (c->D != n) LRVB_FAIL(LRVB_ERR_SIZE, "the context's layout has %lld free parameters, the Dirichlet blocks %lld", (long long)c->D, (long long)n);
+    DevBuf &Jd = c->mx_U, &Hd = c->mx_g;
+    c->x2_ready = false;
+    LRVB_TRY(buf_reserve(c, Jd, (size_t)nn));
+    LRVB_TRY(buf_reserve(c, Hd, (size_t)nn));
+    const i64 nv = 4 * n + 2 * (K + 1);
+    LRVB_TRY(buf_reserve(c, c->Hfree, (size_t)(nn + nv)));
+    double* v = c->Hfree.p + nn;
+    LRVB_TRY(buf_reserve(c, c->work1, (size_t)nv));
+    {   // one upload: through the pinned page when it fits, else pageable
+        std::vector<double> pack((size_t)nv);
+        memcpy(pack.data(), vecs, (size_t)(4 * n) * sizeof(double));
+        memcpy(pack.data() + 4 * n, consts, (size_t)(2 * (K + 1)) * sizeof(double));
+        LRVB_TRY(h2d(c, v, pack.data(), (size_t)nv));
+    }
+    const double* dl_diag = v; const double* h_diag = v + n; const double* sc = v + 2 * n; const double* dg = v + 3 * n;
+    const double* dl_const = v + 4 * n; const double* h_const = dl_const + (K + 1);
+    EW(dirichlet_blocks_kernel, nn, n, (int)K, dl_diag, dl_const, sc, Jd.p);                        // Jlam = DLam diag(scale)
+    EW(dirichlet_blocks_kernel, nn, n, (int)K, h_diag, h_const, (const double*)nullptr, Hd.p);       // Hgg (vector coordinates)
+    return mixture_schur_core(c, K, q, sc, dg, H_out);
 }
 
 // Gram matrix of per-observation gradients g_n[k] = 1/2 z_n^T M_k z_n + c_k, in FREE coordinates:
@@ -1426,11 +1677,12 @@ __global__ void svec_kernel(const double* __restrict__ S1 /* q x q */, int q, do
     const int a = v >> 6, b = v & 63;
     sv[v] = (b < q) ? S1[a * q + b] : 0.0;
 }
-__global__ void rank_terms_kernel(i64 V, double n_obs, const double* __restrict__ t, const double* __restrict__ cvec,
+__global__ void rank_terms_kernel(i64 V, const double* __restrict__ n_obs_dev, const double* __restrict__ t, const double* __restrict__ cvec,
                                   double* __restrict__ A /* V x V, holds M~^T K4 M~ */) {
     const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     const i64 i = blockIdx.y;
     if (j >= V) return;
+    const double n_obs = *n_obs_dev;                 // the number of observations of ALL shards (summed with the statistics)
     A[i * V + j] = 0.25 * A[i * V + j] + 0.5 * (t[i] * cvec[j] + cvec[i] * t[j]) + n_obs * cvec[i] * cvec[j];
 }
 
@@ -1453,16 +1705,21 @@ extern "C" int lrvb_quadform_gram(lrvb_ctx* c, const double* M, const double* cv
     LRVB_TRY(buf_reserve(c, c->stats, 1 + (size_t)c->P + (size_t)WS_TILE * WS_TILE));
     double* tile0 = c->stats.p + 1 + c->P;
     LRVB_TRY(launch_wsyrk(c, c->zbuf.p, tile0));
-    LRVB_TRY(buf_reserve(c, c->vtmp, (size_t)(q * q > V ? q * q : V)));
-    LRVB_TRY(launch_tiles_to_dense(c, tile0, q, c->vtmp.p, q, 0, 0, false));
+    // the three sums over observations -- the K4 tiles, s (q x q) and the observation count -- share one buffer and go
+    // to the sum-over-ranks hook ONCE: [K4 tiles | s | N]
+    const size_t tiles_n = (size_t)nbk * (nbk + 1) / 2 * WS_TILE * WS_TILE;
+    LRVB_TRY(buf_reserve(c, c->Tdense, tiles_n + (size_t)q * q + 2));
+    double* sdense = c->Tdense.p + tiles_n;
+    double* ncount = sdense + (size_t)q * q;
+    LRVB_TRY(launch_tiles_to_dense(c, tile0, q, sdense, q, 0, 0, false));
+    EW(fill_kernel, (i64)1, (double)c->N, ncount);
+    // K4 (dense, Pv_t x Pv_t)
+    LRVB_TRY(launch_wsyrk_kron(c, c->zbuf.p, c->Tdense.p));
+    LRVB_TRY(obs_reduce(c, c->Tdense.p, (i64)(tiles_n + (size_t)q * q + 1)));
     LRVB_TRY(buf_reserve(c, c->vtmp2, (size_t)(Pv_t > V ? Pv_t : V)));
     HIP_TRY(hipMemsetAsync(c->vtmp2.p, 0, (size_t)Pv_t * sizeof(double), c->stream));
-    hipLaunchKernelGGL(svec_kernel, dim3(nb256(Pv)), dim3(256), 0, c->stream, c->vtmp.p, q, c->vtmp2.p);
+    hipLaunchKernelGGL(svec_kernel, dim3(nb256(Pv)), dim3(256), 0, c->stream, sdense, q, c->vtmp2.p);
     HIP_TRY(hipGetLastError());
-    // K4 (dense, Pv_t x Pv_t)
-    const size_t tiles_n = (size_t)nbk * (nbk + 1) / 2 * WS_TILE * WS_TILE;
-    LRVB_TRY(buf_reserve(c, c->Tdense, tiles_n));
-    LRVB_TRY(launch_wsyrk_kron(c, c->zbuf.p, c->Tdense.p));
     LRVB_TRY(buf_reserve(c, c->Heta, (size_t)Pv_t * (size_t)Pv_t));
     LRVB_TRY(launch_tiles_to_dense(c, c->Tdense.p, Pv_t, c->Heta.p, Pv_t, 0, 0, false));
     // M~ (Pv_t x V), uploaded through a staging buffer
@@ -1488,7 +1745,7 @@ extern "C" int lrvb_quadform_gram(lrvb_ctx* c, const double* M, const double* cv
     if (st == LRVB_OK) st = h2d(c, c->g_eta.p, cvec, (size_t)V);
     if (st == LRVB_OK) {
         dim3 grid(nb256(V), (unsigned)V);
-        hipLaunchKernelGGL(rank_terms_kernel, grid, dim3(256), 0, c->stream, V, (double)c->N, c->vtmp3.p, c->g_eta.p, Av.p);
+        hipLaunchKernelGGL(rank_terms_kernel, grid, dim3(256), 0, c->stream, V, (const double*)ncount, c->vtmp3.p, c->g_eta.p, Av.p);
         if (hipGetLastError() != hipSuccess) st = LRVB_ERR_HIP;
     }
     // free coordinates: J^T Av J
@@ -1953,6 +2210,20 @@ void logitnormal_coef_kernel(i64 n, const double* __restrict__ mu, const double*
     __syncthreads();
     if (threadIdx.x == 0) vpart[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
+// out[0] = sum of part[0 .. n) in a fixed order (one workgroup: strided partial sums, then a tree)
+__global__ __launch_bounds__(256)
+void sum_partials_kernel(const double* __restrict__ part, i64 n, double* __restrict__ out) {
+    __shared__ double sh[256];
+    double a = 0.0;
+    for (i64 i = threadIdx.x; i < n; i += 256) a += part[i];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sh[0];
+}
 __global__ void rowscale_kernel(i64 n, i64 P, const double* __restrict__ cvec, const double* __restrict__ B, double* __restrict__ o) {
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) o[i] = cvec[i / P] * B[i];
@@ -1998,23 +2269,30 @@ extern "C" int lrvb_logitnormal_terms(lrvb_ctx* c, const double* mean, const dou
     LRVB_TRY(launch_gemv(c, false, N, P, 1.0, X2.p, P, dv, 0.0, vv));
     EW(logitnormal_coef_kernel, N, (const double*)mu, (const double*)vv, (const double*)c->y.p, (const double*)c->w.p, (const double*)g,
        (const double*)(g + 128), (int)n_nodes, a1, a2, c11, c12, c22, vpart);
-    std::vector<double> hpart((size_t)nblk);
-    LRVB_TRY(d2h(c, hpart.data(), vpart, (size_t)nblk));
-    double val = 0.0;
-    for (i64 b = 0; b < nblk; ++b) val += hpart[(size_t)b];                   // fixed order
-    *value_out = val;
-    if (grad_out) {
-        LRVB_TRY(launch_gemv(c, true, N, P, 1.0, c->X.p, P, a1, 0.0, gout));
-        LRVB_TRY(launch_gemv(c, true, N, P, 1.0, X2.p, P, a2, 0.0, gout + P));
-        LRVB_TRY(d2h(c, grad_out, gout, (size_t)(2 * P)));
+    // every sum over observations of this call in ONE device buffer, [H blocks (3 P^2) | gradient (2 P) | value], summed
+    // over the ranks once -- the suffix that was asked for -- before anything is copied out
+    const bool want_g = grad_out != nullptr, want_H = H_blocks_out != nullptr;
+    LRVB_TRY(buf_reserve(c, c->Hfree, (size_t)(3 * P * P + 2 * P + 1)));
+    double* Hb = c->Hfree.p;
+    double* gred = Hb + 3 * P * P;
+    double* vred = gred + 2 * P;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)vpart, nblk, vred);
+    HIP_TRY(hipGetLastError());
+    if (want_g) {
+        LRVB_TRY(launch_gemv(c, true, N, P, 1.0, c->X.p, P, a1, 0.0, gred));
+        LRVB_TRY(launch_gemv(c, true, N, P, 1.0, X2.p, P, a2, 0.0, gred + P));
     }
-    if (H_blocks_out) {
-        LRVB_TRY(buf_reserve(c, c->Hfree, (size_t)(3 * P * P)));
-        LRVB_TRY(weighted_tn(c, c->X.p, c->X.p, P, N, c11, c->Hfree.p, c->mx_A));
-        LRVB_TRY(weighted_tn(c, c->X.p, X2.p, P, N, c12, c->Hfree.p + P * P, c->mx_A));
-        LRVB_TRY(weighted_tn(c, X2.p, X2.p, P, N, c22, c->Hfree.p + 2 * P * P, c->mx_A));
-        LRVB_TRY(d2h(c, H_blocks_out, c->Hfree.p, (size_t)(3 * P * P)));
+    if (want_H) {
+        LRVB_TRY(weighted_tn(c, c->X.p, c->X.p, P, N, c11, Hb, c->mx_A));
+        LRVB_TRY(weighted_tn(c, c->X.p, X2.p, P, N, c12, Hb + P * P, c->mx_A));
+        LRVB_TRY(weighted_tn(c, X2.p, X2.p, P, N, c22, Hb + 2 * P * P, c->mx_A));
+        if (!want_g) HIP_TRY(hipMemsetAsync(gred, 0, (size_t)(2 * P) * sizeof(double), c->stream));
     }
+    double* first = want_H ? Hb : (want_g ? gred : vred);
+    LRVB_TRY(obs_reduce(c, first, (i64)(vred + 1 - first)));
+    LRVB_TRY(d2h(c, value_out, vred, 1));
+    if (want_g) LRVB_TRY(d2h(c, grad_out, gred, (size_t)(2 * P)));
+    if (want_H) LRVB_TRY(d2h(c, H_blocks_out, Hb, (size_t)(3 * P * P)));
     return LRVB_OK;
 }
 

@@ -68,6 +68,7 @@ struct lrvb_ctx {
     DevBuf tile_part;              // weighted-SYRK split partials
     DevBuf Heta, Hfree, Jdense, Tdense, work1;   // dense V x V / D x D scratch
     DevBuf groups; i64 n_groups = 0;   // [perm (N) | offsets (G+1)] as int64
+    DevBuf gstats; bool gstats_valid = false;   // [S (q x q) | group sums (G x (q+1))] of lrvb_grouped_stats, summed over ranks
     DevBuf mx_theta, mx_lam, mx_A, mx_U, mx_g, mx_Xk, mx_R;   // mixture rows pipeline (kept between calls)
     i64 mx_theta_n = 0;            // simplex logits resident in mx_theta (entries; 0 = none)
     DevBuf cgH; i64 cgH_n = 0;     // dense matrix of lrvb_cg_solve_matrix

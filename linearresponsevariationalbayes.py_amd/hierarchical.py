@@ -90,6 +90,17 @@ class LMMObjective(object):
         if self._is.stop != par.vector_size() or self._is.start != self._es.stop:
             raise ValueError('the group-effect parameter must be pushed last')
         self._dup = duplication_matrix(p)
+        self._tril = np.tril_indices(p)
+        # the device elimination (lrvb_lmm_group_terms) takes the FREE local parameters as [e_1..e_G | log(i_g - lb)]
+        fi = par.free_indices_dict
+        fsub = par[nu].free_indices_dict
+        self._fe = slice(fi[nu].start + fsub['mean'].start, fi[nu].start + fsub['mean'].stop)
+        self._fi = slice(fi[nu].start + fsub['info'].start, fi[nu].start + fsub['info'].stop)
+        info = par[nu]['info']
+        self._info_lb = float(getattr(info, '_lb', 0.0))
+        self._device_path = (self._fe.start == self.n_global and self._fi.start == self._fe.stop
+                             and self._fi.stop == par.free_size() and np.isinf(getattr(info, '_ub', np.inf))
+                             and self._iby == self._iay + 1 and self._ibm == self._iam + 1 and p <= 57)
 
     # ---- sufficient statistics (GPU) ---------------------------------------------------------
     def _push_state(self):
@@ -98,14 +109,29 @@ class LMMObjective(object):
             self.ctx.set_weights(w)
             self._w_cache = w.copy()
             self._stats_cache = None
+            self._S_dev = None
+
+    def invalidate_stats(self):
+        """Forget the cached statistics (the weights on the device were changed behind this object's back, or a
+        benchmark wants the pass over the observations inside every step)."""
+        self._stats_cache = None
+        self._S_dev = None
+
+    def device_stats(self):
+        """S (q x q, host copy) with the group sums left ON THE DEVICE, both summed over the ranks inside the library
+        when the context carries a reduce hook (`ShardedObjective`, `native_comm_init`)."""
+        self._push_state()
+        if getattr(self, '_S_dev', None) is None:
+            self._S_dev = self.ctx.grouped_stats(want_S=True, want_gs=False)[0]
+        return self._S_dev
 
     def local_stats(self):
-        """This process's statistics as one flat vector [S (q*q) | group sums (G*(q+1))] -- the
-        buffer that is all-reduced when observations are sharded over GPUs."""
+        """The statistics as one flat host vector [S (q*q) | group sums (G*(q+1))]: this process's own rows -- the
+        buffer a host-side all-reduce (`allreduce_stats`, the gloo tests) sums over shards -- or, when the context carries
+        a reduce hook, already the sum over all ranks (one reduction of the device buffer inside `lrvb_grouped_stats`)."""
         self._push_state()
         if self._stats_cache is None:
-            S = self.ctx.weighted_gram()
-            gs = self.ctx.group_sums()
+            S, gs = self.ctx.grouped_stats(want_S=True, want_gs=True)
             self._stats_cache = np.concatenate([S.ravel(), gs.ravel()])
         return self._stats_cache
 
@@ -289,7 +315,7 @@ class LMMObjective(object):
         eta = self.ctx.constrain(free_val)
         g, Hgg, (xrows, Hx), dl = self._arrow(eta)
         ng, G, D = self.n_global, self.G, free_val.size
-        self.global_hessian(free_val)                       # builds the global-block packing context
+        self._ensure_gctx()
         Hgg_free = self._gctx.free_hessian_from_vector(free_val[:ng], g[:ng], Hgg)
         ig = eta[self._is]
         jl = np.concatenate([np.ones(G), ig])
@@ -307,26 +333,122 @@ class LMMObjective(object):
         return np.diag(self._gctx.free_to_vector_jac(free_g)).copy()
 
     # ---- arrow structure: Schur complement onto the global block, free coordinates --------------------
+    def _ensure_gctx(self):
+        """Packing of the global block: a layout that covers only the global parameters."""
+        if not hasattr(self, '_gctx'):
+            blocks, size = [], 0
+            for b in self.par.layout_blocks():
+                if size >= self.n_global:
+                    break
+                blocks.append(b)
+                size += b['vec_size']
+            assert size == self.n_global
+            self._gctx = DeviceContext(blocks, quad_kind=_hip.QUAD_DIAG, device=self.ctx.device)
+        return self._gctx
+
+    def _sym_from_vech(self, v):
+        p = self.p
+        L = np.zeros((p, p))
+        L[self._tril] = v
+        return L + L.T - np.diag(np.diag(L))
+
+    def _vech_dupT(self, A):
+        """Dup^T vec(A) for a symmetric A: its lower triangle with the off-diagonal entries doubled."""
+        B = A + A.T
+        B[np.diag_indices(self.p)] = np.diag(A)
+        return B[self._tril]
+
     @_hip.host_blas
-    def global_hessian(self, free_val):
+    def global_hessian(self, free_val, want_host=True):
         """H_S = H_gg - H_gl diag(H_ll)^-1 H_lg in FREE coordinates (n_global x n_global): the
-        matrix whose inverse is the linear-response covariance block of the global parameters."""
+        matrix whose inverse is the linear-response covariance block of the global parameters.
+
+        Device path (this process's own statistics, or statistics reduced inside the library): the group sums never leave
+        the GPU -- `lrvb_lmm_group_terms` eliminates the 2 G local parameters there and returns the p + 5 coupled rows of
+        the Schur term plus a handful of sums over groups; the host evaluates the closed forms in the p x p matrices and
+        the six scalars, the device writes the Kronecker block, converts to free coordinates and keeps the result for
+        `chol_factor_last` (want_host=False skips the copy back)."""
+        if self._device_path and self._external_stats is None:
+            return self._global_hessian_device(_hip.as_f64(free_val).ravel(), want_host)
+        return self._global_hessian_host(free_val)
+
+    def _global_hessian_device(self, fv, want_host):
+        p, G, ng = self.p, self.G, self.n_global
+        if fv.size != ng + 2 * G:
+            raise ValueError('Free value is the wrong length')
+        gc = self._ensure_gctx()
+        S = self.device_stats()
+        eta = gc.constrain(fv[:ng])
+        Sxx, Sxy, Syy = S[:p, :p], S[:p, p], S[p, p]
+        m = eta[self._ms]
+        lam = self._sym_from_vech(eta[self._ls])
+        e_mu, i_mu = eta[self._iem], eta[self._iim]
+        ay, by, am, bm = eta[self._iay], eta[self._iby], eta[self._iam], eta[self._ibm]
+        ty, tm = ay / by, am / bm
+        tay, tby, tam, tbm = 1.0 / by, -ay / by ** 2, 1.0 / bm, -am / bm ** 2
+        par = np.concatenate([[ty, tm, e_mu, tay, tby, tam, tbm, self._info_lb], m])
+        sums, M = self.ctx.lmm_group_terms(par, fv[ng:])
+        v1, s_eg_rg, s_W_e2, s_d2, dsum, W = sums[:p], sums[64], sums[65], sums[66], sums[67], sums[69]
+        self.last_local_grad_norm = float(np.sqrt(sums[70]))
+        P = np.linalg.inv(lam)
+        SxxP = Sxx @ P
+        um = Sxx @ m - Sxy + v1
+        rss = Syy - 2.0 * (m @ Sxy) + m @ Sxx @ m
+        Ay = rss + np.trace(SxxP) - 2.0 * s_eg_rg + s_W_e2
+        Am = s_d2 + G / i_mu
+        C = ty * Sxx + self.lam0
+        Gc = P @ C @ P
+        PSP = P @ SxxP
+        f_ty, f_tm = 0.5 * Ay + self.b0y, 0.5 * Am + self.b0m
+        f_Ly, f_Lm = -0.5 * W - (self.a0y - 1.0), -0.5 * G - (self.a0m - 1.0)
+        ms, ls = self._ms, self._ls
+        iem, iim, iay, iby, iam, ibm = self._iem, self._iim, self._iay, self._iby, self._iam, self._ibm
+        # gradient of the global parameters (vector coordinates): feeds the second-order packing term
+        g = np.zeros(ng)
+        g[ms] = ty * um + self.lam0 @ (m - self.beta0)
+        g[ls] = self._vech_dupT(-0.5 * Gc + 0.5 * P)
+        g[iem] = -tm * dsum + self.kappa0 * (e_mu - self.mu0)
+        g[iim] = -0.5 * (tm * G + self.kappa0) / i_mu ** 2 + 0.5 / i_mu
+        gy, Hy = _gamma_block(ay, by, f_ty, f_Ly)
+        gm_, Hm_ = _gamma_block(am, bm, f_tm, f_Lm)
+        g[iay], g[iby] = gy
+        g[iam], g[ibm] = gm_
+        # the dense part of the global block lives on the p + 6 rows [mean of q(beta) | e_mu, i_mu, a_y, b_y, a_mu, b_mu]
+        # (plus the two columns a_y, b_y of the information rows): one scattered block, the Schur term already subtracted
+        n6 = p + 6
+        B = np.zeros((n6, n6))
+        jem, jim, jay, jby, jam, jbm = p, p + 1, p + 2, p + 3, p + 4, p + 5
+        B[:p, :p] = C
+        B[:p, jay] = B[jay, :p] = um * tay
+        B[:p, jby] = B[jby, :p] = um * tby
+        B[jem, jem] = tm * G + self.kappa0
+        B[jem, jam] = B[jam, jem] = -dsum * tam
+        B[jem, jbm] = B[jbm, jem] = -dsum * tbm
+        B[jim, jim] = (tm * G + self.kappa0) / i_mu ** 3 - 0.5 / i_mu ** 2
+        B[jim, jam] = B[jam, jim] = -0.5 * G / i_mu ** 2 * tam
+        B[jim, jbm] = B[jbm, jim] = -0.5 * G / i_mu ** 2 * tbm
+        B[jay:jby + 1, jay:jby + 1] = Hy
+        B[jam:jbm + 1, jam:jbm + 1] = Hm_
+        xr = np.concatenate([np.arange(p), [jem, jay, jby, jam, jbm]])            # the p + 5 coupled rows inside B
+        B[np.ix_(xr, xr)] -= M
+        rows = np.concatenate([np.arange(ms.start, ms.stop), [iem, iim, iay, iby, iam, ibm]])
+        gl = self._vech_dupT(-0.5 * PSP)
+        gc.hvec_begin()
+        gc.hvec_add_indexed(B, rows, rows)
+        gc.hvec_add_block(np.stack([gl * tay, gl * tby], axis=1), ls.start, iay, mirror=True)
+        gc.hvec_add_symkron(Gc, P, 0.5, ls.start, ls.start)
+        gc.hvec_add_symkron(P, Gc, 0.5, ls.start, ls.start)
+        gc.hvec_add_symkron(P, P, -0.5, ls.start, ls.start)
+        return gc.hvec_finish(fv[:ng], g, True, want_host=want_host)
+
+    @_hip.host_blas
+    def _global_hessian_host(self, free_val):
         free_val = _hip.as_f64(free_val).ravel()
         eta = self.ctx.constrain(free_val)
         g, Hgg, (rows, Hx), dl = self._arrow(eta, kron_block=False)
         Gc, P = self._kron_factors
         ng, G = self.n_global, self.G
-        # packing of the global block through a layout that covers only the global parameters
-        if not hasattr(self, '_gctx'):
-            blocks = []
-            size = 0
-            for b in self.par.layout_blocks():
-                if size >= ng:
-                    break
-                blocks.append(b)
-                size += b['vec_size']
-            assert size == ng
-            self._gctx = DeviceContext(blocks, quad_kind=_hip.QUAD_DIAG, device=self.ctx.device)
+        self._ensure_gctx()
         # global block: the dense part from the host, the Kronecker block of q(beta)'s information matrix written
         # by the device (lrvb_hvec_add_symkron), conversion to free coordinates on the resident matrix
         gc = self._gctx

@@ -224,10 +224,51 @@ class MixtureObjective(object):
                           '(Schur complement onto the Dirichlet block)')
 
     # ---- arrow structure ---------------------------------------------------------------------------------
-    def global_hessian(self, free_val, return_parts=False):
-        """H_S = H_gg - sum_n H_gn H_nn^-1 H_ng in FREE coordinates ((K + V K) square): the matrix whose
-        inverse is the linear-response covariance of the Dirichlet parameters."""
+    def _canonical_order(self):
+        K, V = self.K, self.V
+        return (np.array_equal(self._ipi, np.arange(K)) and np.array_equal(self._iphi.ravel(), K + np.arange(V * K))
+                and np.all(self._lb == self._lb[0]))
+
+    def _global_hessian_device(self, free_val, want_host):
+        """Everything O(n^2) on the device: the statistics call leaves the Schur operand in HBM (summed over the ranks
+        there when the context carries a reduce hook), the Dirichlet blocks of d Lam / d alpha and of the global Hessian
+        are "diagonal plus a constant per Dirichlet" and are generated by a kernel from O(n) numbers
+        (`lrvb_mixture_schur_dirichlet`), and the result stays resident for `chol_factor_last`."""
         V, K = self.V, self.K
+        fg, fz = self._split(free_val)
+        eta_g = self._lb + np.exp(fg)
+        alpha, beta, lam = self._lam(eta_g)
+        self._push_state()
+        val2, S64 = self.ctx.mixture_stats(K, self._fz_arg(fz), lam, want_schur=True)
+        C = S64[:V + 1, 32:32 + K]
+        jg = eta_g - self._lb
+        # pi
+        a0s = np.sum(alpha)
+        e = alpha - 1.0 - (C[0] + self.a0 - 1.0)
+        p1, p2 = special.polygamma(1, alpha), special.polygamma(2, alpha)
+        p10, p20 = special.polygamma(1, a0s), special.polygamma(2, a0s)
+        se = np.sum(e)
+        g_pi, hd_pi, hc_pi, dc_pi = e * p1 - se * p10, p1 + e * p2, -p10 - se * p20, -p10
+        # phi: K independent Dirichlets over the V rows
+        b0s = np.sum(beta, axis=0)
+        eb = beta - 1.0 - (C[1:] + self.b0 - 1.0)
+        q1, q2 = special.polygamma(1, beta), special.polygamma(2, beta)
+        q10, q20 = special.polygamma(1, b0s), special.polygamma(2, b0s)
+        es = np.sum(eb, axis=0)
+        g_phi, hd_phi = eb * q1 - es * q10, q1 + eb * q2
+        g_vec = np.concatenate([g_pi, g_phi.ravel()])
+        return self.ctx.mixture_schur_dirichlet(
+            K, V + 1, dl_diag=np.concatenate([p1, q1.ravel()]), dl_const=np.concatenate([[dc_pi], -q10]),
+            h_diag=np.concatenate([hd_pi, hd_phi.ravel()]), h_const=np.concatenate([[hc_pi], -q10 - es * q20]),
+            scale=jg, diag_add=g_vec * jg, want_host=want_host)
+
+    def global_hessian(self, free_val, return_parts=False, want_host=True):
+        """H_S = H_gg - sum_n H_gn H_nn^-1 H_ng in FREE coordinates ((K + V K) square): the matrix whose
+        inverse is the linear-response covariance of the Dirichlet parameters.  want_host=False leaves the result on
+        the device (for `ctx.chol_factor_last()`) and returns None."""
+        V, K = self.V, self.K
+        if self._external_stats is None and not return_parts and self._canonical_order():
+            return self._global_hessian_device(free_val, want_host)
         fg, eta_g, alpha, beta, val2, gz, C, R = self._rows(free_val, False, True)
         _, g_vec, Hgg = self._global_terms(alpha, beta, C)
         q = V + 1
@@ -246,8 +287,11 @@ class MixtureObjective(object):
     def global_cov(self, free_val, moment_jac=None):
         """Linear-response covariance  M H_S^-1 M^T  of moments of the Dirichlet parameters whose
         free Jacobian is M (default: the free parameters themselves), by the device Cholesky path."""
-        HS = self.global_hessian(free_val)
-        self.ctx.chol_factor(HS)
+        if self._external_stats is None and self._canonical_order():
+            self.global_hessian(free_val, want_host=False)          # stays on the device: factored where it lies
+            self.ctx.chol_factor_last()
+        else:
+            self.ctx.chol_factor(self.global_hessian(free_val))
         M = np.eye(self.n_global) if moment_jac is None else _hip.as_f64(moment_jac)
         return self.ctx.lrvb_cov(M)
 

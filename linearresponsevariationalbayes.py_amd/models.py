@@ -66,6 +66,8 @@ class DeviceContext(object):
         self.n_obs, self.n_cols = int(n_obs), int(n_cols)
         self.device = int(device)
         self.quad_scale = 1.0
+        self.has_reduce_hook = False   # a sum-over-ranks hook is installed: the statistics calls return GLOBAL sums
+        self._hook_cb = None
 
     def close(self):
         if getattr(self, '_h', None) is not None and self._h.value:
@@ -107,6 +109,7 @@ class DeviceContext(object):
         if fn is None:
             self._check(self._lib.lrvb_set_reduce_hook(self._h, None, None))
             self._hook_cb = None
+            self.has_reduce_hook = False
             return
 
         def trampoline(_user, buf, n, stream):
@@ -119,6 +122,7 @@ class DeviceContext(object):
         cb = _hip.REDUCE_FN(trampoline)
         self._check(self._lib.lrvb_set_reduce_hook(self._h, ctypes.cast(cb, ctypes.c_void_p), None))
         self._hook_cb = cb      # keep the callback object alive as long as it is installed (the old one until replaced)
+        self.has_reduce_hook = True
 
     # -- in-library RCCL communicator (one process per GPU) ------------------------------------------------------
     @staticmethod
@@ -135,9 +139,12 @@ class DeviceContext(object):
         buf = ctypes.create_string_buffer(bytes(comm_id), 128)
         self._check(self._lib.lrvb_comm_init(self._h, int(world_size), int(rank), ctypes.cast(buf, ctypes.c_void_p)))
         self._hook_cb = None          # only now: a failed call leaves the C side pointing at the old trampoline
+        self.has_reduce_hook = True
 
     def comm_destroy(self):
         self._check(self._lib.lrvb_comm_destroy(self._h))
+        if self._hook_cb is None:
+            self.has_reduce_hook = False
 
     def allreduce_hessian(self, stats_ptr, n):
         self._check(self._lib.lrvb_allreduce_hessian(self._h, ctypes.c_void_p(stats_ptr), int(n)))
@@ -312,6 +319,16 @@ class DeviceContext(object):
         B = B.reshape(B.shape[0], -1) if B.ndim > 1 else B.reshape(-1, 1)
         self._check(self._lib.lrvb_hvec_add_block(self._h, _hip.ptr(B), B.shape[0], B.shape[1], int(row_off), int(col_off), int(bool(mirror))))
 
+    def hvec_add_indexed(self, block, rows, cols):
+        """H[rows[a], cols[b]] += block[a, b] (lrvb_hvec_add_indexed)."""
+        B = _hip.as_f64(block)
+        r = np.ascontiguousarray(rows, dtype=np.int64).ravel()
+        cidx = np.ascontiguousarray(cols, dtype=np.int64).ravel()
+        if B.shape != (r.size, cidx.size):
+            raise ValueError('block must be len(rows) x len(cols)')
+        self._check(self._lib.lrvb_hvec_add_indexed(self._h, _hip.ptr(B), r.size, cidx.size,
+                                                   r.ctypes.data_as(ctypes.c_void_p), cidx.ctypes.data_as(ctypes.c_void_p)))
+
     def hvec_add_symkron(self, A, B, coef, row_off, col_off, mirror=False):
         A, B = _hip.as_f64(A), _hip.as_f64(B)
         if A.ndim != 2 or A.shape[0] != A.shape[1] or A.shape != B.shape:
@@ -401,6 +418,48 @@ class DeviceContext(object):
     def group_sums(self):
         out = np.empty((self.n_groups, self.n_cols + 1))
         self._check(self._lib.lrvb_group_sums(self._h, _hip.ptr(out)))
+        return out
+
+    def grouped_stats(self, want_S=True, want_gs=False):
+        """[S | group sums] on the device in one buffer (lrvb_grouped_stats): summed over the ranks once, resident for
+        `lmm_group_terms`.  Returns (S or None, group sums or None) -- whichever host copies were asked for."""
+        S = np.empty((self.n_cols, self.n_cols)) if want_S else None
+        gs = np.empty((self.n_groups, self.n_cols + 1)) if want_gs else None
+        self._check(self._lib.lrvb_grouped_stats(self._h, _hip.ptr(S), _hip.ptr(gs)))
+        return S, gs
+
+    def lmm_group_terms(self, par, f_local):
+        """Elimination of the 2 G local parameters of the hierarchical model from the resident grouped statistics
+        (lrvb_lmm_group_terms): returns (sums (128,), M (p + 5, p + 5))."""
+        par, fl = _hip.as_f64(par).ravel(), _hip.as_f64(f_local).ravel()
+        R = self.n_cols - 1 + 5
+        out = np.empty(128 + R * R)
+        self._check(self._lib.lrvb_lmm_group_terms(self._h, _hip.ptr(par), par.size, _hip.ptr(fl), fl.size, _hip.ptr(out)))
+        return out[:128], out[128:].reshape(R, R)
+
+    def mixture_stats(self, K, theta_z, lam, want_schur=True):
+        """`mixture_rows` without the per-row gradient and with the Schur operand left on the device (summed over the
+        ranks there): returns (val2, S64)."""
+        tz, lam = (None if theta_z is None else _hip.as_f64(theta_z).ravel()), _hip.as_f64(lam)
+        V = self.n_cols
+        if (tz is not None and tz.size != self.n_obs * (K - 1)) or lam.shape != (V + 1, K):
+            raise ValueError('expected theta_z with {} entries and Lam of shape {}'.format(self.n_obs * (K - 1), (V + 1, K)))
+        val2, S64 = np.empty(2), np.empty((64, 64))
+        self._check(self._lib.lrvb_mixture_stats(self._h, int(K), _hip.ptr(tz), _hip.ptr(lam), 1 if want_schur else 0,
+                                                _hip.ptr(val2), _hip.ptr(S64)))
+        return val2, S64
+
+    def mixture_schur_dirichlet(self, K, q, dl_diag, dl_const, h_diag, h_const, scale, diag_add, want_host=True):
+        """The Schur complement of `mixture_schur` with d Lam / d alpha and the global Hessian block generated on the
+        device from their diagonals and per-Dirichlet constants (lrvb_mixture_schur_dirichlet); the result stays on the
+        device for `chol_factor_last`, and comes back only when want_host."""
+        n = int(K) * int(q)
+        vecs = np.concatenate([_hip.as_f64(v).ravel() for v in (dl_diag, h_diag, scale, diag_add)])
+        consts = np.concatenate([_hip.as_f64(v).ravel() for v in (dl_const, h_const)])
+        if vecs.size != 4 * n or consts.size != 2 * (K + 1):
+            raise ValueError('expected four vectors of length {} and two of length {}'.format(n, K + 1))
+        out = np.empty((n, n)) if want_host else None
+        self._check(self._lib.lrvb_mixture_schur_dirichlet(self._h, int(K), int(q), _hip.ptr(vecs), _hip.ptr(consts), _hip.ptr(out)))
         return out
 
     def quadform_gram(self, M, c, free):

@@ -197,3 +197,62 @@ def test_config4_full_pipeline_at_shard_scale(vb):
     fa = vb.LMMObjective(make_par(p, G), x[:half], y[:half], gid[:half], G)
     fb = vb.LMMObjective(make_par(p, G), x[half:], y[half:], gid[half:], G)
     assert rel_err(fa.local_stats() + fb.local_stats(), fun.local_stats()) < 1e-12
+
+
+@pytest.mark.parametrize('N,p,G', [(400, 3, 6), (30000, 6, 300), (5000, 2, 1), (20000, 21, 777)])
+def test_device_elimination_matches_host_assembly(vb, N, p, G):
+    """`global_hessian` with the group sums resident on the device (lrvb_grouped_stats -> lrvb_lmm_group_terms ->
+    lrvb_hvec_add_indexed / add_symkron -> finish) against the host assembly from the same statistics copied to numpy
+    (`_global_hessian_host`, which the dense AD checks above pin); then the device-resident continuation -- factor
+    the matrix where it lies, LRVB covariance -- against numpy on the host copy."""
+    rng = np.random.default_rng(N + p + G)
+    x, y, gid, par, fun, ft = _problem(vb, rng, N, p, G)
+    w = rng.uniform(0.5, 1.5, N)
+    fun.weights_par.set_vector(w)
+    theta = _layout(p, G).unconstrain(random_eta(rng, p, G))
+    assert fun._device_path
+    H_dev = fun.global_hessian(theta)
+    H_host = fun._global_hessian_host(theta)
+    assert rel_err(H_dev, H_host) < 1e-11
+    assert np.max(np.abs(H_dev - H_dev.T)) < 1e-12 * np.max(np.abs(H_dev))
+    # the grouped statistics call against the two separate calls, and against numpy
+    S, gs = fun.ctx.grouped_stats(want_S=True, want_gs=True)
+    assert np.array_equal(S, fun.ctx.weighted_gram()) and np.array_equal(gs, fun.ctx.group_sums())
+    assert rel_err(np.concatenate([S.ravel(), gs.ravel()]), host_stats(x, y, gid, G, w)) < 1e-12
+    # new weights invalidate the resident statistics
+    w2 = rng.uniform(0.5, 1.5, N)
+    fun.weights_par.set_vector(w2)
+    H2 = fun.global_hessian(theta)
+    assert rel_err(H2, fun._global_hessian_host(theta)) < 1e-11 and rel_err(H2, H_dev) > 1e-6
+    # device-resident continuation at an optimum (positive definite there)
+    fun.weights_par.set_vector(np.ones(N))
+    eta = _cavi_optimum(x, y, gid, G, np.zeros(p), 0.2 * np.eye(p), 0.1, 0.3, (2.0, 1.0), (1.5, 0.5))
+    theta_opt = _layout(p, G).unconstrain(eta)
+    assert fun.global_hessian(theta_opt, want_host=False) is None
+    assert fun.last_local_grad_norm < 1e-6 * N                 # the kernel's own stationarity diagnostic
+    fun._gctx.chol_factor_last()
+    ng = fun.n_global
+    M = rng.normal(size=(5, ng))
+    HS = fun._global_hessian_host(theta_opt)
+    assert rel_err(fun._gctx.lrvb_cov(M), M @ np.linalg.solve(HS, M.T)) < 1e-8
+
+
+def test_scattered_block_of_the_device_assembly(vb):
+    """lrvb_hvec_add_indexed: a dense block scattered over index lists, accumulated with the other block kinds."""
+    rng = np.random.default_rng(8)
+    par = vb.ModelParamsDict('p'); par.push_param(vb.VectorParam('a', 9)); par.push_param(vb.VectorParam('b', 5, lb=0.0))
+    ctx = vb.DeviceContext(par.layout_blocks(), quad_kind=1)
+    rows, cols = np.array([0, 3, 13, 7]), np.array([2, 12, 5])
+    B = rng.normal(size=(4, 3))
+    base = rng.normal(size=(14, 14))
+    ctx.hvec_begin()
+    ctx.hvec_add_block(base, 0, 0)
+    ctx.hvec_add_indexed(B, rows, cols)
+    got = ctx.hvec_finish(np.zeros(14), np.zeros(14), is_free=False)
+    want = base.copy(); want[np.ix_(rows, cols)] += B
+    assert np.array_equal(got, want)
+    ctx.hvec_begin()
+    with pytest.raises(ValueError):
+        ctx.hvec_add_indexed(B, rows, np.array([2, 12, 14]))        # column outside the matrix
+    with pytest.raises(ValueError):
+        ctx.hvec_add_indexed(B, rows[:3], cols)                      # block shape

@@ -199,3 +199,29 @@ def test_full_size_properties(vb):
     cov = fun.global_cov(theta)
     assert rel_err(cov @ HS, np.eye(fun.n_global)) < 1e-7
     print('\n[mixture N=1e6 K=32 V=31] local_stats {:.1f} ms (host buffers in and out)'.format(1e3 * (t1 - t0)))
+
+
+@pytest.mark.parametrize('N,V,K', [(150, 3, 2), (200, 4, 3), (240, 5, 4), (300, 31, 32), (260, 7, 16)])
+def test_device_generated_dirichlet_blocks_match_the_uploaded_matrices(vb, N, V, K):
+    """`global_hessian` (statistics with the Schur operand left on the device + lrvb_mixture_schur_dirichlet, which writes
+    d Lam / d alpha and the global Hessian block from their diagonals and per-Dirichlet constants) against the route
+    that builds both n x n matrices with numpy and uploads them (`return_parts=True`), and the resident result against
+    its host copy through the device Cholesky."""
+    x, w, theta = near_optimum_problem(N, V, K, seed=7 * K)       # the seeds of test_schur_complement_matches_ad: positive definite there
+    par = make_par(N, V, K)
+    fun = vb.MixtureObjective(par, x, pi_prior=1.5, phi_prior=0.8, weights=w)      # the priors near_optimum_problem fitted with
+    assert fun._canonical_order()
+    HS_dev = fun.global_hessian(theta)
+    HS_up = fun.global_hessian(theta, return_parts=True)[0]
+    assert rel_err(HS_dev, HS_up) < 1e-12
+    assert np.array_equal(HS_dev, HS_dev.T)
+    assert fun.global_hessian(theta, want_host=False) is None
+    # the resident matrix is the one that came back: the device Cholesky agrees with numpy's verdict on it either way
+    if np.linalg.eigvalsh(HS_up).min() > 1e-9 * np.abs(HS_up).max():
+        fun.ctx.chol_factor_last()
+        M = np.random.default_rng(1).normal(size=(4, fun.n_global))
+        assert rel_err(fun.ctx.lrvb_cov(M), M @ np.linalg.solve(HS_up, M.T)) < 1e-7
+    else:
+        assert np.linalg.eigvalsh(HS_up).min() < 0
+        with pytest.raises(np.linalg.LinAlgError):
+            fun.ctx.chol_factor_last()
