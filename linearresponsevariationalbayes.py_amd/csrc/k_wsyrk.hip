@@ -593,22 +593,32 @@ void gram_small_kernel(const double* __restrict__ Z, i64 ldz, i64 N, int P,
     }
 }
 
-// tiles[0] (128 x 128) <- sum_b partial[b] (64 x 64), fixed order
+// tiles[0] (128 x 128) <- sum_b partial[b] (64 x 64), fixed order, two levels: slice s of S sums the blocks
+// s, s + S, ... (grid 16 x S: 1024 block partials were 75 us on one level of 16 workgroups), then the slices in order.
 __global__ __launch_bounds__(256)
-void gram_small_reduce_kernel(const double* __restrict__ partial, int nblk, int P, double* __restrict__ tile0)
+void gram_small_reduce_l1_kernel(const double* __restrict__ partial, int nblk, int S, double* __restrict__ lvl)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int sl = blockIdx.y;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int b = sl;
+    for (; b + 3 * S < nblk; b += 4 * S) {
+        s0 += partial[(i64)b * 4096 + e]; s1 += partial[(i64)(b + S) * 4096 + e];
+        s2 += partial[(i64)(b + 2 * S) * 4096 + e]; s3 += partial[(i64)(b + 3 * S) * 4096 + e];
+    }
+    for (; b < nblk; b += S) s0 += partial[(i64)b * 4096 + e];
+    lvl[(i64)sl * 4096 + e] = (s0 + s1) + (s2 + s3);
+}
+__global__ __launch_bounds__(256)
+void gram_small_reduce_kernel(const double* __restrict__ lvl, int S, int P, double* __restrict__ tile0)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= 64 * 64) return;
     const int row = e >> 6, col = e & 63;
     if (row >= P || col >= P) return;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int b = 0;
-    for (; b + 3 < nblk; b += 4) {
-        s0 += partial[(i64)b * 4096 + e]; s1 += partial[(i64)(b + 1) * 4096 + e];
-        s2 += partial[(i64)(b + 2) * 4096 + e]; s3 += partial[(i64)(b + 3) * 4096 + e];
-    }
-    for (; b < nblk; ++b) s0 += partial[(i64)b * 4096 + e];
-    tile0[row * WS_TILE + col] = (s0 + s1) + (s2 + s3);
+    double a = 0.0;
+    for (int sl = 0; sl < S; ++sl) a += lvl[(i64)sl * 4096 + e];
+    tile0[row * WS_TILE + col] = a;
 }
 
 int launch_gram_small_on(lrvb_ctx* c, const double* Z, i64 N, i64 P, const double* cvec_dev, double* tiles_out_dev) {
@@ -617,7 +627,9 @@ int launch_gram_small_on(lrvb_ctx* c, const double* Z, i64 N, i64 P, const doubl
     i64 grid = (stages + 3) / 4;
     if (grid > 1024) grid = 1024;
     if (grid < 1) grid = 1;
-    LRVB_TRY(buf_reserve(c, c->tile_part, (size_t)grid * 4096));
+    const int S = grid >= 64 ? 32 : 1;
+    LRVB_TRY(buf_reserve(c, c->tile_part, (size_t)(grid + S) * 4096));
+    double* lvl = c->tile_part.p + (size_t)grid * 4096;
     const int aligned16 = ((P % 2) == 0) && ((((uintptr_t)Z) & 15) == 0);
     if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
     if (P <= 32)
@@ -629,8 +641,11 @@ int launch_gram_small_on(lrvb_ctx* c, const double* Z, i64 N, i64 P, const doubl
     HIP_TRY(hipGetLastError());
     if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
     HIP_TRY(hipMemsetAsync(tiles_out_dev, 0, sizeof(double) * WS_TILE * WS_TILE, c->stream));   // unused entries stay finite
+    hipLaunchKernelGGL(gram_small_reduce_l1_kernel, dim3(16, (unsigned)S), dim3(256), 0, c->stream,
+                       (const double*)c->tile_part.p, (int)grid, S, lvl);
+    HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(gram_small_reduce_kernel, dim3(16), dim3(256), 0, c->stream,
-                       c->tile_part.p, (int)grid, (int)P, tiles_out_dev);
+                       (const double*)lvl, S, (int)P, tiles_out_dev);
     HIP_TRY(hipGetLastError());
     if (c->prof_on) {
         c->prof.wsyrk_flops = (double)N * (double)P * (double)(P + 1);

@@ -7,6 +7,7 @@
 #include <string.h>
 #include <math.h>
 #include <new>
+#include <algorithm>
 
 static thread_local char g_err[1024] = "";
 
@@ -184,7 +185,7 @@ extern "C" int lrvb_ctx_destroy(lrvb_ctx* c) {
     DevBuf* all[] = { &c->X, &c->y, &c->w, &c->quadA, &c->quadM, &c->quadB, &c->theta, &c->eta, &c->j1, &c->j2,
                       &c->vtmp, &c->vtmp2, &c->vtmp3, &c->g_eta, &c->g_free, &c->lp, &c->cw, &c->zbuf,
                       &c->part_vec, &c->part_val, &c->stats, &c->tile_part, &c->Heta, &c->Hfree, &c->Jdense,
-                      &c->Tdense, &c->work1, &c->chol, &c->cholW, &c->cgH, &c->groups, &c->mx_theta, &c->mx_lam, &c->mx_A, &c->mx_U, &c->mx_g, &c->mx_Xk, &c->mx_R, &c->cgT, &c->ones, &c->cgm[0], &c->cgm[1], &c->cgm[2], &c->cgm[3], &c->cgm[4], &c->cgm[5], &c->cgm[6], &c->cgm[7], &c->cgm[8], &c->rhs, &c->cgx, &c->cgr, &c->cgp, &c->cgq, &c->cgz, &c->scal, &c->opt, &c->dkw, &c->cyv, &c->rvec, &c->red_scratch, &c->gstats };
+                      &c->Tdense, &c->work1, &c->chol, &c->cholW, &c->cgH, &c->groups, &c->mx_theta, &c->mx_lam, &c->mx_A, &c->mx_U, &c->mx_g, &c->mx_Xk, &c->mx_R, &c->cgT, &c->ones, &c->cgm[0], &c->cgm[1], &c->cgm[2], &c->cgm[3], &c->cgm[4], &c->cgm[5], &c->cgm[6], &c->cgm[7], &c->cgm[8], &c->rhs, &c->cgx, &c->cgr, &c->cgp, &c->cgq, &c->cgz, &c->scal, &c->opt, &c->dkw, &c->cyv, &c->rvec, &c->red_scratch, &c->gstats, &c->Zs, &c->ws, &c->bpart, &c->gpad };
     for (DevBuf* b : all) buf_free(*b);
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
     for (int k = 0; k < 3; ++k) for (hipEvent_t e : c->ev_pool[k]) (void)hipEventDestroy(e);
@@ -272,7 +273,7 @@ extern "C" int lrvb_set_data(lrvb_ctx* c, int slot, const double* host, int64_t 
     if (!b->owned) { b->p = nullptr; b->n = 0; b->owned = true; }
     LRVB_TRY(buf_reserve(c, *b, n));
     LRVB_TRY(h2d(c, b->p, host, n));
-    if (slot == LRVB_SLOT_X) { c->have_X = true; c->x2_ready = false; c->gstats_valid = false; }
+    if (slot == LRVB_SLOT_X) { c->have_X = true; c->x2_ready = false; c->gstats_valid = false; c->zs_valid = false; }
     if (slot == LRVB_SLOT_Y) c->have_y = true;
     return LRVB_OK;
 }
@@ -284,7 +285,7 @@ extern "C" int lrvb_set_data_dev(lrvb_ctx* c, int slot, const double* data_dev, 
     LRVB_TRY(slot_shape_check(c, slot, rows, cols, &b, &n));
     if (b->p && b->owned) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(b->p)); }
     b->p = const_cast<double*>(data_dev); b->n = n; b->owned = false;
-    if (slot == LRVB_SLOT_X) { c->have_X = true; c->x2_ready = false; c->gstats_valid = false; }
+    if (slot == LRVB_SLOT_X) { c->have_X = true; c->x2_ready = false; c->gstats_valid = false; c->zs_valid = false; }
     if (slot == LRVB_SLOT_Y) c->have_y = true;
     return LRVB_OK;
 }
@@ -294,7 +295,7 @@ extern "C" int lrvb_set_weights(lrvb_ctx* c, const double* w, int64_t n) {
     if (c->loss == LRVB_LOSS_NONE) LRVB_FAIL(LRVB_ERR_STATE, "model has no data term");
     if (!w || n != c->N) LRVB_FAIL(LRVB_ERR_SIZE, "weights must have %lld entries (got %lld)", (long long)c->N, (long long)n);
     if (!c->w.owned) { c->w.p = nullptr; c->w.n = 0; c->w.owned = true; }
-    c->gstats_valid = false;
+    c->gstats_valid = false; c->ws_valid = false;
     LRVB_TRY(buf_reserve(c, c->w, (size_t)n));
     return h2d(c, c->w.p, w, (size_t)n);
 }
@@ -305,7 +306,7 @@ extern "C" int lrvb_set_weights_dev(lrvb_ctx* c, const double* w_dev, int64_t n)
     if (!w_dev || n != c->N) LRVB_FAIL(LRVB_ERR_SIZE, "weights must have %lld entries (got %lld)", (long long)c->N, (long long)n);
     if (c->w.p && c->w.owned) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->w.p)); }
     c->w.p = const_cast<double*>(w_dev); c->w.n = (size_t)n; c->w.owned = false;
-    c->gstats_valid = false;
+    c->gstats_valid = false; c->ws_valid = false;
     return LRVB_OK;
 }
 
@@ -1276,14 +1277,22 @@ extern "C" int lrvb_set_groups(lrvb_ctx* c, const int32_t* gid, int64_t n, int64
     for (i64 g = 0; g < n_groups; ++g) offs[(size_t)g + 1] += offs[(size_t)g];
     std::vector<i64> cur(offs.begin(), offs.end() - 1);
     for (i64 i = 0; i < n; ++i) perm[(size_t)cur[(size_t)gid[i]]++] = i;      // stable: rows of a group keep their order
-    const size_t words = (size_t)n + (size_t)n_groups + 1;
+    // the fused one-pass statistics kernel (k_lmm.hip) gives wave w the rows [w R, (w + 1) R) of the sorted order:
+    // the group that holds each wave's first row
+    const i64 R = grouped_rows_per_wave(n), NW = (n + R - 1) / R;
+    std::vector<i64> wg0((size_t)NW);
+    for (i64 wv = 0; wv < NW; ++wv)
+        wg0[(size_t)wv] = (i64)(std::upper_bound(offs.begin(), offs.end(), wv * R) - offs.begin()) - 1;
+    const size_t words = (size_t)n + (size_t)n_groups + 1 + (size_t)NW;
     LRVB_TRY(buf_reserve(c, c->groups, words));          // i64 and double are both 8 bytes
     i64* dev = reinterpret_cast<i64*>(c->groups.p);
     HIP_TRY(hipMemcpyAsync(dev, perm.data(), (size_t)n * sizeof(i64), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(dev + n, offs.data(), ((size_t)n_groups + 1) * sizeof(i64), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(dev + n + n_groups + 1, wg0.data(), (size_t)NW * sizeof(i64), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->n_groups = n_groups;
     c->gstats_valid = false;
+    c->zs_valid = false; c->ws_valid = false;
     return LRVB_OK;
 }
 
@@ -1314,17 +1323,23 @@ extern "C" int lrvb_grouped_stats(lrvb_ctx* c, double* S_out, double* gs_out) {
     const size_t n_s = (size_t)q * q, n_g = (size_t)G * (size_t)(q + 1);
     LRVB_TRY(buf_reserve(c, c->gstats, n_s + n_g));
     c->gstats_valid = false;
-    LRVB_TRY(reserve_obs_vec(c, c->zbuf));
-    HIP_TRY(hipMemcpyAsync(c->zbuf.p, c->w.p, (size_t)c->N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-    double* tiles = c->stats.p + 1 + c->P;
-    LRVB_TRY(launch_wsyrk(c, c->zbuf.p, tiles));
-    LRVB_TRY(launch_tiles_to_dense(c, tiles, q, c->gstats.p, q, 0, 0, false));
-    const i64* dev = reinterpret_cast<const i64*>(c->groups.p);
-    if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
-    hipLaunchKernelGGL(group_sums_kernel, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, c->stream,
-                       c->X.p, c->P, (int)c->P, c->w.p, dev, dev + c->N, G, c->gstats.p + n_s);
-    HIP_TRY(hipGetLastError());
-    if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
+    if (grouped_fused_supported(c) && !c->force_generic_wsyrk) {
+        // one pass over the group-sorted rows: Gram on the matrix cores and the per-group sums from the same registers
+        LRVB_TRY(launch_grouped_stats_fused(c, c->gstats.p, c->gstats.p + n_s));
+    } else {
+        // odd row length (8-byte rows cannot take 16-byte loads): the narrow Gram kernel, then one wavefront per group
+        LRVB_TRY(reserve_obs_vec(c, c->zbuf));
+        HIP_TRY(hipMemcpyAsync(c->zbuf.p, c->w.p, (size_t)c->N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        double* tiles = c->stats.p + 1 + c->P;
+        LRVB_TRY(launch_wsyrk(c, c->zbuf.p, tiles));
+        LRVB_TRY(launch_tiles_to_dense(c, tiles, q, c->gstats.p, q, 0, 0, false));
+        const i64* dev = reinterpret_cast<const i64*>(c->groups.p);
+        if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
+        hipLaunchKernelGGL(group_sums_kernel, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, c->stream,
+                           c->X.p, c->P, (int)c->P, c->w.p, dev, dev + c->N, G, c->gstats.p + n_s);
+        HIP_TRY(hipGetLastError());
+        if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
+    }
     LRVB_TRY(obs_reduce(c, c->gstats.p, (i64)(n_s + n_g)));
     c->gstats_valid = true;
     if (S_out) LRVB_TRY(d2h(c, S_out, c->gstats.p, n_s));
@@ -1385,14 +1400,25 @@ void lmm_group_kernel(const double* __restrict__ gs, i64 G, int p, const double*
     if (lane < 7) dst[64 + lane] = sc[lane];
     else dst[64 + lane] = 0.0;
 }
-// sums[k] = sum over the wave partials in wave order; the vector part is moved down by one slot
-__global__ __launch_bounds__(128)
+// sums[k] = sum over the wave partials in a fixed order (eight interleaved slices, then the slices in order); the vector
+// part is moved down by one slot
+__global__ __launch_bounds__(1024)
 void lmm_sums_kernel(const double* __restrict__ part, int n_waves, double* __restrict__ sums) {
-    const int k = threadIdx.x;
-    double a = 0.0;
-    for (int wv = 0; wv < n_waves; ++wv) a += part[(i64)wv * 128 + k];
-    if (k < 64) { if (k >= 1) sums[k - 1] = a; if (k == 63) sums[63] = 0.0; }
-    else sums[k] = a;
+    __shared__ double sh[8][128];
+    const int k = threadIdx.x & 127, sl = threadIdx.x >> 7;
+    double a0 = 0.0, a1 = 0.0;
+    int wv = sl;
+    for (; wv + 8 < n_waves; wv += 16) { a0 += part[(i64)wv * 128 + k]; a1 += part[(i64)(wv + 8) * 128 + k]; }
+    if (wv < n_waves) a0 += part[(i64)wv * 128 + k];
+    sh[sl][k] = a0 + a1;
+    __syncthreads();
+    if (sl == 0) {
+        double a = 0.0;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) a += sh[s][k];
+        if (k < 64) { if (k >= 1) sums[k - 1] = a; if (k == 63) sums[63] = 0.0; }
+        else sums[k] = a;
+    }
 }
 
 // par (host, 8 + p): [ty, tm, e_mu, d ty / d a_y, d ty / d b_y, d tm / d a_mu, d tm / d b_mu, lower bound of the local
@@ -1409,7 +1435,7 @@ extern "C" int lrvb_lmm_group_terms(lrvb_ctx* c, const double* par, int64_t n_pa
     LRVB_TRY(check_len(n_par, 8 + p, "par"));
     LRVB_TRY(check_len(n_local, 2 * G, "local free vector"));
     const int ldc = (int)((R + 1) & ~(i64)1);                     // even width: 16-byte loads in the narrow Gram kernel
-    i64 grid = (G + 15) / 16; if (grid > 256) grid = 256; if (grid < 1) grid = 1;
+    i64 grid = (G + 31) / 32; if (grid > 128) grid = 128; if (grid < 1) grid = 1;       // <= 512 wave partials
     const i64 n_waves = grid * 4;
     const size_t nC = (size_t)(2 * G + 16) * (size_t)ldc, nW = (size_t)(2 * G + 64);
     LRVB_TRY(buf_reserve(c, c->work1, nC + nW + (size_t)(8 + p) + (size_t)(2 * G) + (size_t)n_waves * 128 + 128 + 64 * 64));
@@ -1427,7 +1453,7 @@ extern "C" int lrvb_lmm_group_terms(lrvb_ctx* c, const double* par, int64_t n_pa
     hipLaunchKernelGGL(lmm_group_kernel, dim3((unsigned)grid), dim3(256), 0, c->stream,
                        (const double*)(c->gstats.p + q * q), G, (int)p, (const double*)dpar, (const double*)dloc, Cm, ldc, wts, part);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(lmm_sums_kernel, dim3(1), dim3(128), 0, c->stream, (const double*)part, (int)n_waves, sums);
+    hipLaunchKernelGGL(lmm_sums_kernel, dim3(1), dim3(1024), 0, c->stream, (const double*)part, (int)n_waves, sums);
     HIP_TRY(hipGetLastError());
     if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
     LRVB_TRY(buf_reserve(c, c->Tdense, (size_t)WS_TILE * WS_TILE));
@@ -1652,7 +1678,22 @@ extern "C" int lrvb_mixture_schur_dirichlet(lrvb_ctx* c, int32_t K, int32_t q, c
 // contraction weights (~66 TFLOP/s at 4096^3) when the operands are even-width and 16-byte aligned,
 // the generic 64 x 64 tile GEMM otherwise.
 static int gemm_tn(lrvb_ctx* c, i64 K, i64 PA, i64 PB, const double* A, const double* B, double* C) {
-    const bool fast = !(PA % 2) && !(PB % 2) && !(((uintptr_t)A) & 15) && !(((uintptr_t)B) & 15) && K >= 512 && PA >= 128 && PB >= 128;
+    const bool big = K >= 512 && PA >= 128 && PB >= 128;
+    if (big && ((PA % 2) || (PB % 2) || (((uintptr_t)A) & 15) || (((uintptr_t)B) & 15))) {
+        // odd widths (the 995 global parameters of config 4): the MFMA kernel wants even, 16-byte aligned rows.  Copy the
+        // operands into zero-padded even-width scratch (three 8 MB copies at n = 995: ~15 us) instead of running the
+        // generic 64 x 64 tile GEMM (82 us per product there).
+        const i64 PAe = PA + (PA & 1), PBe = PB + (PB & 1);
+        LRVB_TRY(buf_reserve(c, c->gpad, (size_t)(K * PAe + K * PBe + PAe * PBe)));
+        double* Ap = c->gpad.p; double* Bp = Ap + K * PAe; double* Cp = Bp + K * PBe;
+        HIP_TRY(hipMemsetAsync(Ap, 0, (size_t)(K * PAe + K * PBe) * sizeof(double), c->stream));
+        HIP_TRY(hipMemcpy2DAsync(Ap, (size_t)PAe * 8, A, (size_t)PA * 8, (size_t)PA * 8, (size_t)K, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpy2DAsync(Bp, (size_t)PBe * 8, B, (size_t)PB * 8, (size_t)PB * 8, (size_t)K, hipMemcpyDeviceToDevice, c->stream));
+        LRVB_TRY(gemm_tn(c, K, PAe, PBe, Ap, Bp, Cp));
+        HIP_TRY(hipMemcpy2DAsync(C, (size_t)PB * 8, Cp, (size_t)PBe * 8, (size_t)PB * 8, (size_t)PA, hipMemcpyDeviceToDevice, c->stream));
+        return LRVB_OK;
+    }
+    const bool fast = big && !(PA % 2) && !(PB % 2) && !(((uintptr_t)A) & 15) && !(((uintptr_t)B) & 15);
     if (!fast) return launch_gemm(c, true, false, PA, PB, K, 1.0, A, PA, B, PB, 0.0, C, PB);
     if (c->ones_n != K) {                      // the kernel reads up to 32 weights past K: they must be zero
         LRVB_TRY(buf_reserve(c, c->ones, (size_t)(K + 64)));

@@ -68,6 +68,7 @@ struct lrvb_ctx {
     DevBuf tile_part;              // weighted-SYRK split partials
     DevBuf Heta, Hfree, Jdense, Tdense, work1;   // dense V x V / D x D scratch
     DevBuf groups; i64 n_groups = 0;   // [perm (N) | offsets (G+1)] as int64
+    DevBuf Zs, ws, bpart; bool zs_valid = false, ws_valid = false;   // fused grouped statistics (k_lmm.hip): group-sorted rows (+4 zero rows), weights in that order, pieces of groups cut by wave boundaries
     DevBuf gstats; bool gstats_valid = false;   // [S (q x q) | group sums (G x (q+1))] of lrvb_grouped_stats, summed over ranks
     DevBuf mx_theta, mx_lam, mx_A, mx_U, mx_g, mx_Xk, mx_R;   // mixture rows pipeline (kept between calls)
     i64 mx_theta_n = 0;            // simplex logits resident in mx_theta (entries; 0 = none)
@@ -86,6 +87,7 @@ struct lrvb_ctx {
     DevBuf opt;                    // trust-region Newton-CG: 12 D-vectors (+ the D x D preconditioner)
     DevBuf cgm[9];                 // blocked CG: B, X, R, P, Q, Z (Q x D), U, W (Q x V), R^T (P x Q)
     DevBuf cgT;                    // N x Q products X U^T of the blocked HVP
+    DevBuf gpad;                   // even-width zero-padded copies of odd-width TN GEMM operands
     DevBuf ones; i64 ones_n = 0;   // [1 x n | 0 x 64] contraction weights of the plain TN GEMM
     double* host_pinned = nullptr; size_t host_pinned_n = 0;
 
@@ -146,6 +148,11 @@ int  launch_atb_kron32(lrvb_ctx* c, const double* X31, const double* B, i64 N, c
 int  launch_wsyrk_kron(lrvb_ctx* c, const double* cvec_dev, double* tiles_out_dev /* nb = ceil(q/2) tile rows */);
 int  launch_tiles_to_dense(lrvb_ctx* c, const double* tiles_dev, i64 P, double* dense_dev, i64 ld,
                            i64 row_off, i64 col_off, bool accumulate);
+
+// k_lmm.hip
+i64  grouped_rows_per_wave(i64 N);
+bool grouped_fused_supported(const lrvb_ctx* c);
+int  launch_grouped_stats_fused(lrvb_ctx* c, double* S_dense_dev /* q x q */, double* gs_dev /* G x (q + 1) */);
 
 // k_linalg.hip
 int launch_gemm(lrvb_ctx* c, bool transA, bool transB, i64 M, i64 Nn, i64 K, double alpha,

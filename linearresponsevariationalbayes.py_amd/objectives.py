@@ -11,10 +11,12 @@ effects --
   ParametricSensitivity     :487-573  (deprecated there too)
   Timer / Logger / safe_matmul / make_index_param / get_sparse_sub_matrix / CSR packing
 -- but every derivative is one call into liblrvb_hip.so instead of D+1 autograd tape walks.
-`fun` must therefore be a declared objective (models.DeviceObjective or another object exposing
-the same functor protocol); an opaque Python closure is still accepted for the value-only
-methods (`fun_free`, `fun_vector`, `fun_free_cond`), exactly as the reference calls it, and
-raises NotImplementedError when a derivative is requested.
+`fun` is a declared objective (models.DeviceObjective or another object exposing the same functor
+protocol).  An opaque Python closure is still accepted, exactly as the reference calls it: the
+value-only methods run it as is, and for up to NUMERIC_FALLBACK_MAX_D parameters its derivatives come
+from Richardson-extrapolated differences on the host (`_NumericFunctor`: plumbing for the reference's
+small closed-form models, not a compute path); above that a derivative request raises
+NotImplementedError.
 
 Side-effect contract kept from the reference (comment at :131-140): after every call `par` holds
 the numeric value of the evaluation point.
@@ -32,9 +34,70 @@ _NO_DERIV = ('derivatives of an opaque Python closure need a tracing AD engine o
              'models.DeviceObjective / GLMObjective / QuadraticObjective / LinearMoments')
 
 
-def _functor(fun):
+NUMERIC_FALLBACK_MAX_D = 64
+
+
+class _NumericFunctor(object):
+    """Small-D stand-in for autograd on an OPAQUE zero-argument closure (`Objective(par, lambda: ...)`, as
+    LRVB/SparseObjectives.py:96-116 accepts and BASELINE.json's "plumbing" config words it): gradient, Jacobian, Hessian
+    and Hessian-vector product by Richardson-extrapolated central differences of the closure itself (steps h, h/2, h/4:
+    error O(h^6) in the first, O(h^6) in the mixed second differences; exact up to rounding for the reference's quadratic
+    test models).  Host plumbing for a handful of parameters -- refused above NUMERIC_FALLBACK_MAX_D, where the declared
+    objectives on the device are the path."""
+
+    def __init__(self, par, fun):
+        self.par, self.fun = par, fun
+
+    def _f(self, is_free, argv, argk):
+        def f(x):
+            set_par(self.par, x, is_free)
+            return np.asarray(self.fun(*argv, **argk), dtype=np.float64)
+        return f
+
+    def _check(self, x):
+        if np.size(x) > NUMERIC_FALLBACK_MAX_D:
+            raise NotImplementedError('{} parameters: '.format(np.size(x)) + _NO_DERIV)
+        return np.asarray(x, dtype=np.float64).ravel()
+
+    def value(self, x, is_free, *argv, **argk):
+        return self._f(is_free, argv, argk)(x)
+
+    def jacobian(self, x, is_free, *argv, **argk):
+        f, x = self._f(is_free, argv, argk), self._check(x)
+        J = numeric_jacobian(f, x)
+        return J.reshape(np.shape(f(x)) + (x.size,))            # autograd.jacobian: ans.shape + x.shape
+
+    def grad(self, x, is_free, *argv, **argk):
+        return self.jacobian(x, is_free, *argv, **argk).reshape(np.size(x))
+
+    def hessian(self, x, is_free, *argv, **argk):
+        x, f = self._check(x), self._f(is_free, argv, argk)
+        n = x.size
+        h0 = 1e-2 * np.maximum(1.0, np.abs(x))
+        est = []
+        for h in (h0, h0 / 2, h0 / 4):
+            H = np.empty((n, n))
+            for i in range(n):
+                for j in range(i + 1):
+                    ei, ej = np.zeros(n), np.zeros(n)
+                    ei[i], ej[j] = h[i], h[j]
+                    H[i, j] = H[j, i] = (f(x + ei + ej) - f(x + ei - ej) - f(x - ei + ej) + f(x - ei - ej)) / (4 * h[i] * h[j])
+            est.append(H)
+        r1 = [(4 * est[1] - est[0]) / 3, (4 * est[2] - est[1]) / 3]
+        return (16 * r1[1] - r1[0]) / 15
+
+    def hvp(self, x, v, is_free, *argv, **argk):
+        x, v = self._check(x), np.asarray(v, dtype=np.float64).ravel()
+        scale = max(np.max(np.abs(v)), 1e-300)
+        g = lambda t: self.grad(x + t[0] * v / scale, is_free, *argv, **argk)
+        return numeric_jacobian(g, np.zeros(1), rel_step=1e-2)[:, 0] * scale
+
+
+def _functor(fun, par=None):
     if getattr(fun, '_lrvb_device_functor', False):
         return fun
+    if par is not None and callable(fun):
+        return _NumericFunctor(par, fun)
     raise NotImplementedError(_NO_DERIV)
 
 
@@ -87,18 +150,15 @@ class Logger(object):
         self.initialize()
 
     def initialize(self):
+        # plain attributes, assigned here and in log(), as in the reference (LRVB/SparseObjectives.py:53-60): subclasses
+        # that override initialize() the reference's way, and callbacks that reset last_x, keep working
         self.iter = 0
+        self.last_x = None
+        self.x = None
+        self.value = None
+        self.last_value = None
         self.x_array = []
         self.val_array = []
-
-    def _tail(self, seq, back):
-        return seq[-back] if len(seq) >= back else None
-
-    x = property(lambda self: self._tail(self.x_array, 1))
-    value = property(lambda self: self._tail(self.val_array, 1))
-    # after log() returns, the reference's last_x / last_value equal the point just logged
-    last_x = property(lambda self: self._tail(self.x_array, 1))
-    last_value = property(lambda self: self._tail(self.val_array, 1))
 
     @property
     def x_diff(self):
@@ -111,9 +171,12 @@ class Logger(object):
         print('Iter ', self.iter, ' value: ', self.value)
 
     def log(self, value, x):
+        self.value, self.x = value, x
         self.x_array.append(x)
         self.val_array.append(value)
-        if self.print_every and self.iter % self.print_every == 0:
+        self.last_x, self.last_value = x, value          # before the callback runs, as in the reference (:77-78)
+        # (the reference's `iter % print_every` raises ZeroDivisionError for print_every = 0; so does this)
+        if self.iter % self.print_every == 0:
             (self.callback or type(self).print_message)(self)
         self.iter += 1
 
@@ -150,7 +213,7 @@ class Objective(object):
 
     # ---- derivatives: one device call each, then restore `par` (reference :142-150) -------
     def _eval(self, method, val, is_free, *argv, **argk):
-        result = getattr(_functor(self.fun), method)(np.asarray(val, dtype=np.float64), is_free, *argv, **argk)
+        result = getattr(_functor(self.fun, self.par), method)(np.asarray(val, dtype=np.float64), is_free, *argv, **argk)
         if is_free:
             self.par.set_free(val)
         else:
@@ -192,13 +255,13 @@ class Objective(object):
     # the reference (comment at LRVB/SparseObjectives.py:176-182).
     def fun_free_hvp(self, *argv, **argk):
         args, vec = argv[:-1], argv[-1]
-        result = _functor(self.fun).hvp(np.asarray(args[0], dtype=np.float64), vec, True, *args[1:], **argk)
+        result = _functor(self.fun, self.par).hvp(np.asarray(args[0], dtype=np.float64), vec, True, *args[1:], **argk)
         self.par.set_free(args[0])
         return result
 
     def fun_vector_hvp(self, *argv, **argk):
         args, vec = argv[:-1], argv[-1]
-        result = _functor(self.fun).hvp(np.asarray(args[0], dtype=np.float64), vec, False, *args[1:], **argk)
+        result = _functor(self.fun, self.par).hvp(np.asarray(args[0], dtype=np.float64), vec, False, *args[1:], **argk)
         self.par.set_vector(args[0])
         return result
 
@@ -360,7 +423,7 @@ def numeric_jacobian(f, x, rel_step=1e-3):
         d = []
         for step in (h, h / 2, h / 4):
             e = np.zeros_like(x); e[k] = step
-            d.append((np.asarray(f(x + e), dtype=np.float64) - np.asarray(f(x - e), dtype=np.float64)) / (2 * step))
+            d.append(np.atleast_1d(np.asarray(f(x + e), dtype=np.float64) - np.asarray(f(x - e), dtype=np.float64)) / (2 * step))
         r1 = [(4 * d[1] - d[0]) / 3, (4 * d[2] - d[1]) / 3]
         cols.append((16 * r1[1] - r1[0]) / 15)
     return np.stack(cols, axis=1)

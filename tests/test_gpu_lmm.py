@@ -217,7 +217,7 @@ def test_device_elimination_matches_host_assembly(vb, N, p, G):
     assert np.max(np.abs(H_dev - H_dev.T)) < 1e-12 * np.max(np.abs(H_dev))
     # the grouped statistics call against the two separate calls, and against numpy
     S, gs = fun.ctx.grouped_stats(want_S=True, want_gs=True)
-    assert np.array_equal(S, fun.ctx.weighted_gram()) and np.array_equal(gs, fun.ctx.group_sums())
+    assert rel_err(S, fun.ctx.weighted_gram()) < 1e-13 and rel_err(gs, fun.ctx.group_sums()) < 1e-13   # other kernels, other summation order
     assert rel_err(np.concatenate([S.ravel(), gs.ravel()]), host_stats(x, y, gid, G, w)) < 1e-12
     # new weights invalidate the resident statistics
     w2 = rng.uniform(0.5, 1.5, N)
@@ -256,3 +256,43 @@ def test_scattered_block_of_the_device_assembly(vb):
         ctx.hvec_add_indexed(B, rows, np.array([2, 12, 14]))        # column outside the matrix
     with pytest.raises(ValueError):
         ctx.hvec_add_indexed(B, rows[:3], cols)                      # block shape
+
+
+@pytest.mark.parametrize('q', [2, 8, 16, 18, 30, 32, 34, 44, 48, 50, 64, 45, 7])
+def test_fused_grouped_statistics_layouts_and_ragged_groups(vb, q):
+    """lrvb_grouped_stats, the one-pass kernel over group-sorted rows (even q; odd q takes the two-kernel route): every
+    column layout (pair groups of 32 columns + a trailing block of <= 16), groups that are empty, of 1..5 rows, cut by
+    one wave boundary, and one group that spans many waves; unsorted group ids; bitwise reproducible."""
+    rng = np.random.default_rng(q)
+    sizes = np.concatenate([[0, 1, 2, 3, 4, 5, 0, 0, 7, 63, 64, 65, 1000, 129], rng.integers(0, 40, size=200), [0]])
+    G = sizes.size
+    gid = np.repeat(np.arange(G), sizes).astype(np.int32)
+    rng.shuffle(gid)
+    N = gid.size
+    assert N > 20 * 64                                  # several waves of 64 rows; the 1000-row group spans >= 15 of them
+    Z = rng.normal(size=(N, q))
+    w = rng.uniform(0.5, 1.5, N)
+    blocks = [dict(kind=0, free_size=1, vec_size=1, dim0=1, dim1=0, lb=-np.inf, ub=np.inf)]
+    ctx = vb.DeviceContext(blocks, loss='data_only', n_obs=N, n_cols=q)
+    ctx.set_groups(gid, G)                               # groups before data: the sorted copy is built lazily
+    ctx.set_data(vb._hip.SLOT_X, Z)
+    ctx.set_weights(w)
+    S, gs = ctx.grouped_stats(want_S=True, want_gs=True)
+    want_gs = np.zeros((G, q + 1))
+    np.add.at(want_gs[:, 0], gid, w)
+    np.add.at(want_gs[:, 1:], gid, w[:, None] * Z)
+    assert rel_err(S, Z.T @ (w[:, None] * Z)) < 1e-13
+    assert np.max(np.abs(gs - want_gs)) < 1e-12 * np.max(np.abs(want_gs))
+    assert np.all(gs[sizes == 0] == 0.0)
+    S2, gs2 = ctx.grouped_stats(want_S=True, want_gs=True)
+    assert np.array_equal(S, S2) and np.array_equal(gs, gs2)
+    # new data in the same context: the sorted copy is rebuilt
+    Z2 = rng.normal(size=(N, q))
+    ctx.set_data(vb._hip.SLOT_X, Z2)
+    S3, gs3 = ctx.grouped_stats(want_S=True, want_gs=True)
+    assert rel_err(S3, Z2.T @ (w[:, None] * Z2)) < 1e-13
+    # the two-kernel route on the same rows (tuning bit 0)
+    ctx.set_tuning(0, 1)
+    S4, gs4 = ctx.grouped_stats(want_S=True, want_gs=True)
+    ctx.set_tuning(0, 0)
+    assert rel_err(S4, S3) < 1e-13 and rel_err(gs4, gs3) < 1e-13

@@ -268,10 +268,14 @@ def test_errors_and_loud_failures(vb):
         fun.ctx.set_weights(np.ones(9))
     with pytest.raises(AssertionError):
         obj.fun_free_hessian_cond(np.zeros(4))
+    # an opaque closure: small D goes through the host's difference fallback (tests/test_host_logic.py pins it with the
+    # reference's known answers), a large one is refused -- there is no silent O(D^2)-evaluations route
     closure_obj = vb.Objective(par, lambda: float(np.sum(par.get_vector() ** 2)))
     assert closure_obj.fun_free(np.ones(4)) == 4.0
+    np.testing.assert_allclose(closure_obj.fun_free_hessian(np.ones(4)), 2.0 * np.eye(4), atol=1e-8)
+    big = vb.VectorParam('big', size=200)
     with pytest.raises(NotImplementedError):
-        closure_obj.fun_free_hessian(np.ones(4))
+        vb.Objective(big, lambda: float(np.sum(big.get() ** 2))).fun_free_hessian(np.ones(200))
 
 
 def test_sharded_engine_single_rank_matches_direct_build(vb):

@@ -139,15 +139,95 @@ def test_keyword_passthrough_and_logger():
     np.testing.assert_array_almost_equal(2 * np.eye(2) * 2 * 3 * 16, objective.fun_free_hessian_cond(x_val, 2, z=3))
 
 
-def test_opaque_closure_values_work_derivatives_raise():
+def test_opaque_closure_known_answers_of_the_reference():
+    """LRVB/test_objectives.py:161-217 with the reference's OWN kind of `fun` -- a plain Python closure, no declared
+    model: sum(x^2) z y has gradient 2 z y x, Hessian 2 z y I, products 2 z y v, and x16 under the preconditioner 4 I.
+    `Objective` differentiates such a closure on the host by Richardson-extrapolated differences (small D only)."""
     x = vb.VectorParam('x', size=2)
     objective = vb.Objective(x, lambda y, z=1.: np.sum(x.get() ** 2) * z * y)
-    assert objective.fun_free(np.array([0., 1.]), 2, z=3) == 6.0
+    x_val, hv = np.array([0., 1.]), np.array([2., 3.])
+    assert objective.fun_free(x_val, 2, z=3) == 6.0
+    assert objective.fun_free(x_val, 2, z=3, verbose=True) == 6.0 and objective.logger.iter == 1
     assert objective.fun_vector(np.array([0., 2.]), 1) == 4.0
+    for g in (objective.fun_free_grad, objective.fun_vector_grad, objective.fun_free_jacobian, objective.fun_vector_jacobian):
+        np.testing.assert_allclose(g(x_val, 2, z=3), 2 * x_val * 2 * 3, atol=1e-7)
+        np.testing.assert_array_equal(x.get(), x_val)                       # par is left at the evaluation point
+    for h in (objective.fun_free_hessian, objective.fun_vector_hessian):
+        np.testing.assert_allclose(h(x_val, 2, z=3), 2 * np.eye(2) * 2 * 3, atol=1e-7)
+    for p in (objective.fun_free_hvp, objective.fun_vector_hvp):
+        np.testing.assert_allclose(p(x_val, 2, hv, z=3), 2 * hv * 2 * 3, atol=1e-7)
+    objective.preconditioner = 4 * np.eye(2)
+    assert objective.fun_free_cond(x_val, 2, z=3) == 1 * 2 * 3 * 16
+    np.testing.assert_allclose(objective.fun_free_grad_cond(x_val, 2, z=3), 2 * x_val * 2 * 3 * 16, atol=1e-6)
+    np.testing.assert_allclose(objective.fun_free_hessian_cond(x_val, 2, z=3), 2 * np.eye(2) * 2 * 3 * 16, atol=1e-6)
+    np.testing.assert_allclose(objective.fun_free_hvp_cond(x_val, 2, hv, z=3), 2 * hv * 2 * 3 * 16, atol=1e-6)
+
+
+def test_opaque_closure_on_a_constrained_layout_and_the_size_limit():
+    """A smooth non-quadratic closure over box + PSD parameters against its analytic derivatives (free coordinates), a
+    vector-valued closure's Jacobian, and the refusal above NUMERIC_FALLBACK_MAX_D parameters."""
+    par = vb.ModelParamsDict('p')
+    par.push_param(vb.VectorParam('a', 3, lb=0.0))
+    par.push_param(vb.PosDefMatrixParam('m', 2))
+    rng = np.random.default_rng(2)
+    c = rng.normal(size=3)
+
+    def f():
+        a, m = par['a'].get(), par['m'].get()
+        return np.sum(c * np.log(a)) + 0.5 * np.sum(a ** 2) + np.trace(m @ m) + np.linalg.slogdet(m)[1]
+    objective = vb.Objective(par, f)
+    theta = rng.normal(size=par.free_size()) * 0.3
+    # analytic: a = exp(t) -> c t + exp(2 t) / 2; the PSD part through torch AD of the same expression
+    import torch
+    def ft(th):
+        t, fm = th[:3], th[3:]
+        L = torch.zeros((2, 2), dtype=torch.float64)
+        L[0, 0] = torch.exp(fm[0]); L[1, 0] = fm[1]; L[1, 1] = torch.exp(fm[2])
+        m = L @ L.T
+        return torch.sum(torch.tensor(c) * t) + 0.5 * torch.sum(torch.exp(2 * t)) + torch.trace(m @ m) + torch.logdet(m)
+    tt = torch.tensor(theta)
+    assert abs(objective.fun_free(theta) - ft(tt).item()) < 1e-12
+    g_ad = torch.func.grad(ft)(tt).numpy(); H_ad = torch.func.hessian(ft)(tt).numpy()
+    np.testing.assert_allclose(objective.fun_free_grad(theta), g_ad, rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(objective.fun_free_hessian(theta), H_ad, rtol=1e-6, atol=1e-7)
+    v = rng.normal(size=theta.size)
+    np.testing.assert_allclose(objective.fun_free_hvp(theta, v), H_ad @ v, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(par.get_free(), theta, atol=1e-12)
+    moments = vb.Objective(par, lambda: np.concatenate([par['a'].get(), [np.trace(par['m'].get())]]))
+    J = moments.fun_free_jacobian(theta)
+    assert J.shape == (4, theta.size)
+    np.testing.assert_allclose(J[:3, :3], np.diag(np.exp(theta[:3])), rtol=1e-8, atol=1e-9)
+    big = vb.VectorParam('big', size=vb.SparseObjectives.NUMERIC_FALLBACK_MAX_D + 1)
     with pytest.raises(NotImplementedError):
-        objective.fun_free_grad(np.array([0., 1.]), 2)
-    with pytest.raises(NotImplementedError):
-        objective.fun_free_hvp(np.array([0., 1.]), 2, np.ones(2))
+        vb.Objective(big, lambda: np.sum(big.get() ** 2)).fun_free_grad(np.zeros(big.free_size()))
+
+
+def test_logger_subclass_written_the_reference_way():
+    """LRVB/SparseObjectives.py:53-60: x, value, last_x, last_value are plain attributes that initialize() assigns -- a
+    subclass overriding initialize() with the reference's body, and a callback that resets last_x, must keep working; and
+    print_every = 0 fails the way the reference's modulo does."""
+    class MyLogger(vb.SparseObjectives.Logger):
+        def initialize(self):
+            self.iter = 0
+            self.last_x = None
+            self.x = None
+            self.value = None
+            self.last_value = None
+            self.x_array = []
+            self.val_array = []
+            self.extra = 'mine'
+    lg = MyLogger(print_every=1)
+    seen = []
+
+    def cb(logger):
+        seen.append((logger.iter, logger.value, None if logger.last_x is None else float(logger.last_x[0])))
+        logger.last_x = None                                    # a callback may assign it
+    lg.callback = cb
+    lg.log(3.0, np.array([1.0])); lg.log(2.0, np.array([4.0]))
+    assert seen == [(0, 3.0, 1.0), (1, 2.0, 4.0)] and lg.last_x is None and lg.x[0] == 4.0 and lg.extra == 'mine'
+    assert lg.x_diff == 3.0
+    with pytest.raises(ZeroDivisionError):
+        vb.SparseObjectives.Logger(print_every=0).log(1.0, np.zeros(1))
 
 
 def test_two_parameter_objective_and_converter():
