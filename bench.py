@@ -42,9 +42,12 @@ def parse(argv=None):
     ap.add_argument('--cpu-budget-s', type=float, default=30.0,
                     help='rough bound on the CPU work of the cpu_baseline leg (seconds)')
     ap.add_argument('--n-splits', type=int, default=0)
+    ap.add_argument('--no-configs', action='store_true',
+                    help='headline run only: skip the short embedded runs of configurations c2..c5 (the `configs` object)')
     ap.add_argument('--config', default='h', choices=['h', 'c2', 'c3', 'c4', 'c5'],
-                    help='h = the headline metric (default, what the driver runs); c2..c5 = the other BASELINE.json '
-                         'configurations on one GPU, one line each with its own roofline')
+                    help='h = the headline metric (default, what the driver runs; at N = 1 its line also carries short runs of '
+                         'c2..c5 under `configs`); c2..c5 = the other BASELINE.json configurations, one line each with its own '
+                         'roofline, observations sharded over --gpus ranks')
     return ap.parse_args(argv)
 
 
@@ -230,41 +233,79 @@ def cpu_baseline(fetch_rows, n_total, D, n_pos, loss, lik_info, prior_info, thet
     }
 
 
-# ---- the other BASELINE.json configurations: one GPU, one line each -------------------------
-def _timed_steps(step, warmup, steps, ctx):
+# ---- the other BASELINE.json configurations -------------------------------------------------------
+# `python bench.py --config cN [--gpus G]`: one JSON line for configuration N, observations sharded over the G ranks (strong
+# scaling on the configuration's N; every sum over observations is reduced ON THE DEVICE inside the library's statistics
+# call, once per call).  The headline run (`--config h`, what the driver runs) also embeds a short run of c2..c5 at N = 1 in
+# its line (`configs`), so that all five rooflines are in the driver's record.
+def _timed_steps(step, warmup, steps, ctx, fence):
     for _ in range(warmup):
         step()
-    ctx.sync()
+    fence()
     ctx.profile_enable(True)
     ctx.profile_reset()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
-    ctx.sync()
+    fence()
     elapsed = time.perf_counter() - t0
     prof = ctx.profile_get()
     ctx.profile_enable(False)
     return elapsed, prof
 
 
-def run_config(args):
+def _fingerprint(np, H):
+    H = np.asarray(H)
+    n = min(64, H.shape[0])
+    return {'trace': float(np.trace(H)), 'sum_abs_64x64': float(np.abs(H[:n, :n]).sum()), 'last_row_sum': float(H[-1].sum())}
+
+
+def run_config(args, cfg=None, steps=None, warmup=None, env=None):
     """Configurations 2-5: `value` = builds per second of the configuration's per-step product with the observations,
-    the weights and the evaluation point resident in HBM; `roofline` = the statistics kernel(s) of the step (HIP-event
-    time from the library's profile marks) against the algorithmic bytes / flops of SURVEY.md section 8(d)."""
+    the weights and the evaluation point resident in HBM; `roofline` = ALL statistics-kernel launches of the step (HIP-event
+    time from the library's profile marks) against the algorithmic bytes / flops of SURVEY.md section 8(d), plus the same
+    algorithmic work against the whole step (`step_frac`).  env = (world, rank, dev, backend, use_dist) when called from a
+    process that has already set up its rank; None = set it up here."""
     import numpy as np
+    import torch
+    import torch.distributed as dist
     import lrvb_amd as vb
+    from lrvb_amd.distributed import shard_rows, torch_reduce_hook, native_comm_init
     sys.path.insert(0, os.path.join(ROOT, 'tools'))          # synthetic problem generators (no oracle, no test module)
-    if int(os.environ.get('WORLD_SIZE', '1')) != 1 or args.gpus != 1:
-        raise SystemExit('bench: --config {} is a one-GPU line (the multi-GPU curve is the headline, --config h)'.format(args.config))
-    rng = np.random.default_rng(20240 + int(args.config[1]))
-    cfg = args.config
+    cfg = cfg or args.config
+    steps = steps or args.steps
+    warmup = args.warmup if warmup is None else warmup
+    own_group = env is None
+    if own_group:
+        world, rank, local_rank, dev, backend, use_dist, rehearse = dist_setup(args, torch, dist)
+    else:
+        world, rank, dev, backend, use_dist = env
+    native = use_dist and backend == 'nccl' and os.environ.get('LRVB_BENCH_NATIVE_RCCL', '0') == '1'
+    device_index = dev.index or 0
+    rng = np.random.default_rng(20240 + int(cfg[1]))          # the same full problem on every rank; each keeps its rows
+    n_override = int(args.n_obs) if args.n_obs != 1e6 else None
     extra = {}
+
+    def shard(ctx):
+        """Observations are sharded: the context's statistics calls return sums over ALL ranks (one in-place device
+        all-reduce per call, RCCL with the nccl backend)."""
+        if not use_dist:
+            return
+        ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        if native:
+            native_comm_init(ctx)
+        else:
+            ctx.set_reduce_hook(torch_reduce_hook(dev))
+
     if cfg == 'c2':
-        N, k = 100_000, 21
+        N, k = n_override or 100_000, 21
         x = rng.normal(size=(N, k)); y = x @ rng.normal(size=k) + rng.normal(size=N) / np.sqrt(2.0)
+        wts = rng.uniform(0.5, 1.5, N)
+        r0, r1 = shard_rows(N, rank, world)
         par = vb.ModelParamsDict('p'); par.push_param(vb.MVNParam('beta', dim=k)); par.push_param(vb.GammaParam('tau'))
-        fun = vb.MVNRegressionObjective(par, x, y, prior_mean=np.zeros(k), prior_info=np.eye(k), prior_shape=2.0, prior_rate=2.0,
-                                        weights=rng.uniform(0.5, 1.5, N))
+        fun = vb.MVNRegressionObjective(par, x[r0:r1], y[r0:r1], prior_mean=np.zeros(k), prior_info=np.eye(k), prior_shape=2.0,
+                                        prior_rate=2.0, weights=wts[r0:r1], device=device_index)
+        shard(fun.ctx)
         obj = vb.Objective(par, fun)
         theta = par.get_free()
         D = theta.size
@@ -273,82 +314,120 @@ def run_config(args):
             fun._S = None                                     # statistics recomputed from the resident rows and weights
             fun._h_key = None
             return obj.fun_free_hessian(theta)
-        metric = 'ELBO-Hessian builds/sec, MVNParam regression N=1e5 obs x D={} free params'.format(D)
-        workload = 'config 2: MVNParam regression (k=21 -> D={}), N=1e5; one step = weighted Gram of [x|y] on the GPU + closed-form assembly + device free-Hessian conversion'.format(D)
-        bound, alg, unit, peak = 'hbm', 8.0 * N * (k + 2), 'GB/s', PEAK_HBM_GBS
+        final = step
+        metric = 'ELBO-Hessian builds/sec, MVNParam regression N={:g} obs x D={} free params'.format(float(N), D)
+        workload = ('config 2: MVNParam regression (k=21 -> D={}), N={}; one step = weighted Gram of [x|y] + sum of the weights on the GPU '
+                    '+ closed-form assembly + device free-Hessian conversion, Hessian returned to the host').format(D, N)
+        bound, alg, unit, peak = 'hbm', 8.0 * (r1 - r0) * (k + 2), 'GB/s', PEAK_HBM_GBS
         ctx = fun.ctx
     elif cfg == 'c3':
         from synthetic import clustered_problem
-        N, V, K = int(args.n_obs) if args.n_obs != 1e6 else 1_000_000, 31, 32
+        N, V, K = n_override or 1_000_000, 31, 32
         x, w, fg, fz, lam = clustered_problem(N, V, K, seed=11)
-        theta = np.concatenate([fg, fz.ravel()])
+        r0, r1 = shard_rows(N, rank, world)
+        theta = np.concatenate([fg, fz[r0:r1].ravel()])        # the globals, then THIS rank's simplex rows
         par = vb.ModelParamsDict('params')
         par.push_param(vb.DirichletParamArray('pi', shape=(K,)))
         par.push_param(vb.DirichletParamArray('phi', shape=(V, K)))
-        par.push_param(vb.SimplexParam('z', shape=(N, K)))
-        fun = vb.MixtureObjective(par, x, pi_prior=1.2, phi_prior=0.9, weights=w)
+        par.push_param(vb.SimplexParam('z', shape=(r1 - r0, K)))
+        fun = vb.MixtureObjective(par, x[r0:r1], pi_prior=1.2, phi_prior=0.9, weights=w[r0:r1], device=device_index)
+        shard(fun.ctx)
         fun.keep_logits_resident = True                       # the local part of the point (N x 31 logits) stays in HBM
         D = fun.n_global
 
         def step():
             return fun.global_hessian(theta, want_host=False)      # the result stays in HBM (what chol_factor_last factors)
+
+        def final():
+            return fun.global_hessian(theta)
         metric = 'Schur-complement ELBO-Hessian builds/sec, Dirichlet-multinomial mixture K=32, N={:g} obs x D={} global free params'.format(float(N), D)
         workload = ('config 3: Dirichlet-multinomial mixture K=32, V=31, N={}; one step = per-row simplex blocks eliminated on the '
-                    'GPU (rows kernel + Kronecker GEMM + statistics) + device Schur assembly of the {} x {} global block').format(N, D, D)
-        bound, alg, unit, peak = 'hbm', 8.0 * N * (K - 1 + V) + 8.0 * D * D, 'GB/s', PEAK_HBM_GBS
+                    'GPU (rows kernel + Kronecker GEMM + statistics) + device Schur assembly of the {} x {} global block, left in HBM').format(N, D, D)
+        # the repo's algorithm is a 528 x N x 528 fp64 GEMM (packed lower triangles of both Kronecker factors): matrix-core bound;
+        # SURVEY 8(d)'s byte count ("if the blocks stay on chip") is carried beside it
+        bound, alg, unit, peak = 'mfma', 2.0 * 528 * 528 * (r1 - r0), 'TFLOP/s', PEAK_FP64_MFMA_TFLOPS
+        extra['survey_8d_bytes'] = 8.0 * (r1 - r0) * (K - 1 + V) + 8.0 * D * D
         ctx = fun.ctx
-        extra['repo_algorithm_flops'] = 2.0 * 528 * 528 * N
     elif cfg == 'c4':
         from synthetic import lmm_par as _lmm_par
-        N, p, G = 1_250_000, 43, 10_000
+        N, p, G = n_override or 1_250_000, 43, 10_000
         x = rng.normal(size=(N, p)); gid = rng.integers(0, G, size=N).astype(np.int32); gid[:G] = np.arange(G)
         y = x @ rng.normal(size=p) + rng.normal(size=G)[gid] * 0.7 + rng.normal(size=N) * 0.5
+        wts = rng.uniform(0.5, 1.5, N)
+        r0, r1 = shard_rows(N, rank, world)                    # whole groups per rank are NOT required: group sums are summed too
         par = _lmm_par(vb, p, G)
-        fun = vb.LMMObjective(par, x, y, gid, G, weights=rng.uniform(0.5, 1.5, N))
+        fun = vb.LMMObjective(par, x[r0:r1], y[r0:r1], gid[r0:r1], G, weights=wts[r0:r1], device=device_index)
+        shard(fun.ctx)
         theta = par.get_free()
-        D = None
+        D = fun.n_global
 
         def step():
             fun.invalidate_stats()                                # the pass over the observations is part of every step
             return fun.global_hessian(theta, want_host=False)      # the result stays in HBM (what chol_factor_last factors)
-        D = fun.n_global
-        metric = 'arrow-Hessian Schur-complement builds/sec, hierarchical LMM G=1e4 groups, one GPU shard N=1.25e6 of 1e7 obs x D={} global free params'.format(D)
-        workload = ('config 4: hierarchical LMM p=43, G=1e4, ONE of the eight 1.25e6-row shards of the N=1e7 problem; one step = '
-                    'sufficient statistics of the shard on the GPU (Gram q=44 + per-group sums) + arrow-Hessian assembly and Schur complement')
-        bound, alg, unit, peak = 'hbm', float(N) * (8.0 * (p + 2) + 4.0), 'GB/s', PEAK_HBM_GBS
+
+        def final():
+            return fun.global_hessian(theta)
+        metric = 'arrow-Hessian Schur-complement builds/sec, hierarchical LMM G=1e4 groups, N={:g} obs x D={} global free params'.format(float(N), D)
+        workload = ('config 4: hierarchical LMM p=43, G=1e4, N={} (one of the eight 1.25e6-row shards of the N=1e7 problem unless --n-obs says otherwise); '
+                    'one step = sufficient statistics in one pass (Gram q=44 + per-group sums, weights resident in group order) + elimination of the 2G '
+                    'local parameters on the GPU + arrow-Hessian assembly, left in HBM').format(N)
+        bound, alg, unit, peak = 'hbm', float(r1 - r0) * (8.0 * (p + 2) + 4.0), 'GB/s', PEAK_HBM_GBS
         ctx = fun.ctx
     else:
-        N, d = int(args.n_obs) if args.n_obs != 1e6 else 1_000_000, 63
+        N, d = n_override or 1_000_000, 63
         yy = rng.normal(size=(N, d))
+        r0, r1 = shard_rows(N, rank, world)
         par = vb.ModelParamsDict('p'); par.push_param(vb.MVNParam('mu', dim=d)); par.push_param(vb.WishartParam('lambda', size=d))
-        fun = vb.WishartMVNObjective(par, yy)
+        fun = vb.WishartMVNObjective(par, yy[r0:r1], device=device_index)
+        shard(fun.ctx)
         par['lambda']['df'].set(d + 5.0)
         theta = par.get_free()
         D = theta.size
 
         def step():
             return fun.gram(theta)
+        final = step
         metric = 'G^T G (per-observation ELBO-gradient Gram matrix) builds/sec, Wishart+MVN N={:g} obs x D={} free params'.format(float(N), D)
         workload = ('config 5: Wishart + MVN full-covariance model d=63 -> D=4096, N={}; one step = G^T G with the Kronecker rows of G '
                     'generated on chip (fp64-MFMA Kronecker SYRK + four 4096^3 TN products), result copied to the host').format(N)
-        bound, alg, unit, peak = 'mfma', float(N) * D * (D + 1), 'TFLOP/s', PEAK_FP64_MFMA_TFLOPS
+        bound, alg, unit, peak = 'mfma', float(r1 - r0) * D * (D + 1), 'TFLOP/s', PEAK_FP64_MFMA_TFLOPS
         ctx = fun.ctx
-    elapsed, prof = _timed_steps(step, args.warmup, args.steps, ctx)
-    kernel_ms = prof['wsyrk_ms'] / args.steps                 # all statistics-kernel launches of one step
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+            torch.cuda.synchronize()
+    elapsed, prof = _timed_steps(step, warmup, steps, ctx, fence)
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        if backend == 'gloo':
+            th = t.cpu(); dist.all_reduce(th, op=dist.ReduceOp.MAX); t = th
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = prof['wsyrk_ms'] / steps                      # all statistics-kernel launches of one step
+    ms_per_step = elapsed / steps * 1e3
     scale = 1e9 if unit == 'GB/s' else 1e12
     achieved = alg / (kernel_ms * 1e-3) / scale if kernel_ms > 0 else 0.0
     out = {
-        'metric': metric, 'value': args.steps / elapsed, 'unit': 'builds/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+        'metric': metric, 'value': steps / elapsed, 'unit': 'builds/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
+        'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
         'dtype': 'f64', 'data': 'synthetic',
-        'config': {'workload': workload, 'n_obs_total': N, 'n_free': D, 'ranks_seen': 1, 'backend': 'none (single process)'},
+        'config': {'workload': workload, 'n_obs_total': N, 'n_obs_per_gpu': r1 - r0, 'n_free': D,
+                   'ranks_seen': dist.get_world_size() if use_dist else 1,
+                   'backend': (backend + (' (in-library communicator)' if native else '')) if use_dist else 'none (single process)',
+                   'parallelism': 'observation shards x{} + 1 device all-reduce per statistics call'.format(world),
+                   'result_fingerprint': _fingerprint(np, final())},
         'roofline': {'bound': bound, 'achieved': achieved, 'peak': peak, 'unit': unit, 'frac': achieved / peak, 'traffic': None,
-                     'kernel': 'statistics kernels of one step (library profile marks: {} launches per step)'.format(
-                         prof['wsyrk_calls'] // max(args.steps, 1)),
-                     'kernel_ms': kernel_ms, 'algorithmic_per_step': alg},
+                     'kernel': 'ALL statistics kernels of one step on this rank (library profile marks: {} launch groups per step)'.format(
+                         prof['wsyrk_calls'] // max(steps, 1)),
+                     'kernel_ms': kernel_ms, 'algorithmic_per_step': alg,
+                     'step_frac': alg / (ms_per_step * 1e-3) / scale / peak},
     }
     out['roofline'].update(extra)
-    if cfg == 'c5':
+    if cfg == 'c5' and world == 1 and own_group:
         # the LRVB solve of the configuration: exact Hessian (sufficient statistics), Cholesky, CG on the resident matrix
         obj = vb.Objective(par, fun)
         t0 = time.perf_counter(); H = obj.fun_free_hessian(theta); t1 = time.perf_counter()
@@ -359,18 +438,35 @@ def run_config(args):
         _, info, iters = fun.ctx.cg_solve_matrix(None, b, tol=1e-8); t5 = time.perf_counter()
         out['lrvb_solve_ms'] = {'exact_hessian_build': (t1 - t0) * 1e3, 'cho_factor_host_matrix_in': (t3 - t2) * 1e3,
                                 'cg_resident_matrix_tol1e-8': (t5 - t4) * 1e3, 'cg_iterations': int(iters), 'cg_info': int(info)}
+    if use_dist and own_group:
+        if native:
+            ctx.comm_destroy()
+        dist.destroy_process_group()
+    return out if rank == 0 else None
+
+
+def embedded_configs(args, env, budget_s=90.0):
+    """Short runs of c2..c5 inside the headline's process (N = 1): {cfg: {ms_per_step, kernel_ms, roofline...}} for the
+    `configs` object of the one JSON line.  Bounded: a configuration is skipped once the budget is spent."""
+    out, t0 = {}, time.perf_counter()
+    for cfg, steps, warmup in (('c2', 20, 3), ('c4', 20, 3), ('c3', 8, 2), ('c5', 2, 1)):
+        if time.perf_counter() - t0 > budget_s:
+            out[cfg] = {'skipped': 'time budget of the embedded runs spent'}
+            continue
+        try:
+            r = run_config(args, cfg=cfg, steps=steps, warmup=warmup, env=env)
+            out[cfg] = {'metric': r['metric'], 'value': r['value'], 'ms_per_step': r['ms_per_step'], 'steps': steps,
+                        'kernel_ms': r['roofline']['kernel_ms'], 'roofline': r['roofline'],
+                        'result_fingerprint': r['config']['result_fingerprint']}
+        except Exception as e:                                # the headline line must not be lost to a secondary configuration
+            out[cfg] = {'error': '{}: {}'.format(type(e).__name__, e)}
+    out['seconds'] = time.perf_counter() - t0
     return out
 
 
-def main(args):
-    import numpy as np
-    if getattr(args, 'config', 'h') != 'h':
-        return run_config(args)
-    import torch
-    import torch.distributed as dist
-    import lrvb_amd as vb
-    from lrvb_amd.distributed import ShardedHessian, DeviceEngine, shard_rows
-
+def dist_setup(args, torch, dist):
+    """Rank environment, device and process group of this process: (world, rank, local_rank, device, backend, use_dist,
+    rehearse).  One process per GPU (RANK / LOCAL_RANK / WORLD_SIZE from torchrun); RCCL ("nccl") unless rehearsing."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -404,6 +500,19 @@ def main(args):
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group('gloo', rank=rank, world_size=world)
+    return world, rank, local_rank, dev, backend, use_dist, rehearse
+
+
+def main(args):
+    import numpy as np
+    if getattr(args, 'config', 'h') != 'h':
+        return run_config(args)
+    import torch
+    import torch.distributed as dist
+    import lrvb_amd as vb
+    from lrvb_amd.distributed import ShardedHessian, DeviceEngine, shard_rows
+
+    world, rank, local_rank, dev, backend, use_dist, rehearse = dist_setup(args, torch, dist)
 
     N_total, D = int(args.n_obs), int(args.n_free)
     n_pos = D // 4                       # box constraint (lb = 0) on the last quarter
@@ -526,7 +635,9 @@ def main(args):
         'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': 'headline dense-design {} GLM-type ELBO term: N={} observations x D={} free '
                                'parameters (last {} box-constrained lb=0), Gaussian prior; one step = one dense '
-                               'Hessian build'.format(args.loss, N_total, D, n_pos),
+                               'Hessian build with theta, the weights w (re-read by the kernels in every build, uploaded once: '
+                               'the 8 MB host-to-device copy of w is outside the timed region) and X, y resident in HBM, H left '
+                               'in HBM'.format(args.loss, N_total, D, n_pos),
                    'n_obs_total': N_total, 'n_obs_per_gpu': n_local, 'n_free': D,
                    'ranks_seen': dist.get_world_size() if use_dist else 1,
                    'backend': (backend + (' (in-library communicator)' if native else '')) if use_dist else 'none (single process)',
@@ -608,6 +719,11 @@ def main(args):
                 return X[a:b].cpu().numpy(), y[a:b].cpu().numpy()
             out['cpu_baseline'] = cpu_baseline(fetch_rows, N_total, D, n_pos, args.loss, lik_info, prior_info,
                                                theta.cpu().numpy(), budget_s=args.cpu_budget_s)
+    if world == 1 and rank == 0 and not args.no_configs:
+        # the other four BASELINE.json configurations, short runs in this process (SURVEY.md section 8(d) lists all five)
+        del X, y, w, H
+        torch.cuda.empty_cache()
+        out['configs'] = embedded_configs(args, (world, rank, dev, backend, use_dist))
     if use_dist:
         dist.destroy_process_group()
     return out if rank == 0 else None

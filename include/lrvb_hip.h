@@ -279,6 +279,9 @@ int lrvb_logitnormal_terms(lrvb_ctx* ctx, const double* mean, const double* var,
  * weighted sufficient statistics sum_n w_n z_n z_n^T that `np.einsum('ni,ij,nj,n', ...)` at
  * Example.ipynb:262 and LRVB/regression_utils.py:59-88 contract on the host.                  */
 int lrvb_weighted_gram(lrvb_ctx* ctx, double* S_out, int64_t ld);
+/* The same with the sum of the weights, W = sum_n w_n (the -1/2 W log|Lambda| term of Example.ipynb:247-274), formed on the
+ * device and summed over the ranks in the SAME reduction as S.                                                       */
+int lrvb_weighted_gram_sum(lrvb_ctx* ctx, double* S_out, int64_t ld, double* wsum_out);
 /* out[n - n0, k] = 1/2 z_n^T M_k z_n + c_k for K symmetric matrices M_k (K x n_cols x n_cols)
  * and offsets c (K): rows of the cross Hessian d2 f / d w_n d eta_k of such an objective
  * (TwoParameterObjective.fun_vector_hessian21 with par2 = weights,

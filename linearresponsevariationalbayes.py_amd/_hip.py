@@ -88,6 +88,7 @@ _SIGNATURES = {
     'lrvb_cross_hessian_tilt': [_VP, _VP, c_i64, _VP],
     'lrvb_gram': [_VP, _VP, c_i64, _VP, c_i64],
     'lrvb_weighted_gram': [_VP, _VP, c_i64],
+    'lrvb_weighted_gram_sum': [_VP, _VP, c_i64, _VP],
     'lrvb_obs_quadform': [_VP, _VP, _VP, c_i64, c_i64, c_i64, _VP],
     'lrvb_mixture_rows': [_VP, ctypes.c_int32, _VP, _VP, _VP, _VP, _VP, _VP],
     'lrvb_dk_grad_vec': [_VP, _VP, ctypes.c_int64, ctypes.c_int32, _VP, _VP, ctypes.c_int32, _VP],

@@ -1188,7 +1188,31 @@ void obs_quadform_kernel(const double* __restrict__ Z, i64 ldz, int q, const dou
     out[(n - n0) * K + k] = 0.5 * s + (cvec ? cvec[k] : 0.0);
 }
 
-extern "C" int lrvb_weighted_gram(lrvb_ctx* c, double* S_out, int64_t ld) {
+// part[b] = sum of v over block b's contiguous slice (fixed tree); the partials are summed by sum_partials_kernel
+__global__ __launch_bounds__(256)
+void vec_block_sums_kernel(i64 n, const double* __restrict__ v, double* __restrict__ part) {
+    __shared__ double sh[256];
+    const i64 per = (n + gridDim.x - 1) / gridDim.x;
+    const i64 a = (i64)blockIdx.x * per, b = a + per < n ? a + per : n;
+    double s = 0.0;
+    for (i64 i = a + threadIdx.x; i < b; i += 256) s += v[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+__global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ part, i64 n, double* __restrict__ out);
+
+static int weighted_gram_impl(lrvb_ctx* c, double* S_out, int64_t ld, double* wsum_out);
+extern "C" int lrvb_weighted_gram(lrvb_ctx* c, double* S_out, int64_t ld) { return weighted_gram_impl(c, S_out, ld, nullptr); }
+extern "C" int lrvb_weighted_gram_sum(lrvb_ctx* c, double* S_out, int64_t ld, double* wsum_out) {
+    if (!wsum_out) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    return weighted_gram_impl(c, S_out, ld, wsum_out);
+}
+static int weighted_gram_impl(lrvb_ctx* c, double* S_out, int64_t ld, double* wsum_out) {
     LRVB_TRY(ctx_bind(c));
     if (!S_out) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
     if (c->loss == LRVB_LOSS_NONE || !c->have_X) LRVB_FAIL(LRVB_ERR_STATE, "no data matrix: call lrvb_set_data(LRVB_SLOT_X) first");
@@ -1198,11 +1222,19 @@ extern "C" int lrvb_weighted_gram(lrvb_ctx* c, double* S_out, int64_t ld) {
     HIP_TRY(hipMemcpyAsync(c->zbuf.p, c->w.p, (size_t)c->N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     double* tiles = c->stats.p + 1 + c->P;
     LRVB_TRY(launch_wsyrk(c, c->zbuf.p, tiles));
-    LRVB_TRY(buf_reserve(c, c->Hfree, (size_t)c->P * (size_t)c->P));
+    const i64 PP = c->P * c->P;
+    LRVB_TRY(buf_reserve(c, c->Hfree, (size_t)PP + 1 + 256));
     LRVB_TRY(launch_tiles_to_dense(c, tiles, c->P, c->Hfree.p, c->P, 0, 0, false));
-    LRVB_TRY(obs_reduce(c, c->Hfree.p, c->P * c->P));          // observation shards: summed on the device, before the copy
+    if (wsum_out) {                                              // sum of the weights rides in the same buffer: [S | sum w]
+        hipLaunchKernelGGL(vec_block_sums_kernel, dim3(256), dim3(256), 0, c->stream, c->N, (const double*)c->w.p, c->Hfree.p + PP + 1);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)(c->Hfree.p + PP + 1), (i64)256, c->Hfree.p + PP);
+        HIP_TRY(hipGetLastError());
+    }
+    LRVB_TRY(obs_reduce(c, c->Hfree.p, PP + (wsum_out ? 1 : 0)));          // observation shards: summed on the device, ONCE, before the copy
     HIP_TRY(hipMemcpy2DAsync(S_out, (size_t)ld * 8, c->Hfree.p, (size_t)c->P * 8, (size_t)c->P * 8, (size_t)c->P, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (wsum_out) LRVB_TRY(d2h(c, wsum_out, c->Hfree.p + PP, 1));
     return LRVB_OK;
 }
 
@@ -1500,7 +1532,9 @@ static int mixture_rows_impl(lrvb_ctx* c, int32_t K, const double* theta_z, cons
     if (st == LRVB_OK && theta_z) { c->mx_theta_n = 0; st = h2d(c, thz.p, theta_z, (size_t)(N * KM)); if (st == LRVB_OK) c->mx_theta_n = N * KM; }
     if (st == LRVB_OK) st = h2d(c, lam.p, Lam, (size_t)((V + 1) * K));
     int* bad = reinterpret_cast<int*>(c->scal.p + 8);
+    if (st == LRVB_OK && c->prof_on) st = prof_mark(c, PROF_WSYRK);                     // the per-row kernel counts among the statistics kernels
     if (st == LRVB_OK) st = launch_mixture_rows(c, K, thz.p, lam.p, Amat.p, lda, U.p, gfr.p, c->scal.p, bad);
+    if (st == LRVB_OK && c->prof_on) st = prof_mark(c, PROF_WSYRK);
     if (st == LRVB_OK && gfree_out) st = d2h(c, gfree_out, gfr.p, (size_t)(N * KM));        // rank-local: this rank's rows
     // Everything that is a SUM OVER OBSERVATIONS goes into one device buffer, [S64 (4096) | val2 (2) | count of
     // non-positive-definite rows (1) | pad (1) | packed R (ldk x lda)], and is handed to the sum-over-ranks hook ONCE,

@@ -203,6 +203,7 @@ class MixtureObjective(object):
     def __call__(self):
         return self.value(np.asarray(self.par.get_free(), dtype=np.float64), True)
 
+    @_hip.host_blas
     def value(self, x, is_free=True):
         if not is_free:
             raise NotImplementedError('the mixture objective is evaluated in free coordinates')
@@ -210,6 +211,7 @@ class MixtureObjective(object):
         # val2[0] = -tr(Lam^T C) is already inside the Dirichlet terms (d = C + prior - 1)
         return float(val2[1] + self._global_terms(alpha, beta, C)[0])
 
+    @_hip.host_blas
     def grad(self, x, is_free=True):
         if not is_free:
             raise NotImplementedError('the mixture objective is evaluated in free coordinates')
@@ -262,6 +264,7 @@ class MixtureObjective(object):
             h_diag=np.concatenate([hd_pi, hd_phi.ravel()]), h_const=np.concatenate([[hc_pi], -q10 - es * q20]),
             scale=jg, diag_add=g_vec * jg, want_host=want_host)
 
+    @_hip.host_blas
     def global_hessian(self, free_val, return_parts=False, want_host=True):
         """H_S = H_gg - sum_n H_gn H_nn^-1 H_ng in FREE coordinates ((K + V K) square): the matrix whose
         inverse is the linear-response covariance of the Dirichlet parameters.  want_host=False leaves the result on

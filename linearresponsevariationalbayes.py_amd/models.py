@@ -359,10 +359,16 @@ class DeviceContext(object):
         return G
 
     # -- objectives quadratic in the data -------------------------------------------------
-    def weighted_gram(self):
+    def weighted_gram(self, with_sum=False):
+        """S = Z^T diag(w) Z; with_sum also returns W = sum w, formed on the device and (under a reduce hook) summed over
+        the ranks in the same reduction as S."""
         S = np.empty((self.n_cols, self.n_cols))
-        self._check(self._lib.lrvb_weighted_gram(self._h, _hip.ptr(S), self.n_cols))
-        return S
+        if not with_sum:
+            self._check(self._lib.lrvb_weighted_gram(self._h, _hip.ptr(S), self.n_cols))
+            return S
+        W = np.empty(1)
+        self._check(self._lib.lrvb_weighted_gram_sum(self._h, _hip.ptr(S), self.n_cols, _hip.ptr(W)))
+        return S, float(W[0])
 
     def obs_quadform(self, M, c=None, n0=0, n1=None):
         M = _hip.as_f64(M)

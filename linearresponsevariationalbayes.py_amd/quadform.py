@@ -71,8 +71,9 @@ class QuadraticDataObjective(object):
             return ext[:-1].reshape(self.q, self.q), float(ext[-1])
         self._push_state()
         if self._S is None:
-            self._S = self.ctx.weighted_gram()           # GPU: sum_n w_n z_n z_n^T
-            self._W = float(np.sum(self._w_cache))
+            # GPU: sum_n w_n z_n z_n^T and sum_n w_n in one buffer -- with a reduce hook on the context (observations sharded
+            # over ranks) both arrive summed over all ranks, one reduction
+            self._S, self._W = self.ctx.weighted_gram(with_sum=True)
         return self._S, self._W
 
     # ---- observations sharded over GPUs: the statistics are sums over rows ---------------------------
@@ -107,10 +108,12 @@ class QuadraticDataObjective(object):
         """(value, gradient) only; subclasses whose Hessian blocks are expensive override this."""
         return self._terms(eta, S, W)[:2]
 
+    @_hip.host_blas
     def value(self, x, is_free):
         S, W = self._stats()
         return float(self._terms_vg(self._eta(x, is_free), S, W)[0])
 
+    @_hip.host_blas
     def grad(self, x, is_free):
         S, W = self._stats()
         g = self._terms_vg(self._eta(x, is_free), S, W)[1]
@@ -120,6 +123,7 @@ class QuadraticDataObjective(object):
 
     jacobian = grad
 
+    @_hip.host_blas
     def hessian(self, x, is_free):
         S, W = self._stats()
         _, g, H = self._terms(self._eta(x, is_free), S, W)
@@ -138,6 +142,7 @@ class QuadraticDataObjective(object):
     def hvp(self, x, v, is_free):
         return self._hessian_cached(x, is_free) @ _hip.as_f64(v).ravel()
 
+    @_hip.host_blas
     def gram(self, free_val):
         """G^T G of the per-observation gradient matrix in free coordinates (Kronecker rows generated
         on chip, contracted on the fp64 matrix cores)."""
@@ -287,7 +292,24 @@ class MVNRegressionObjective(QuadraticDataObjective):
         lam = (self._dup @ eta[self._ls.start:self._ls.stop]).reshape(k, k)
         return m, lam, eta[self._ia], eta[self._ib]
 
-    def _terms(self, eta, S, W):
+    @_hip.host_blas
+    def hessian(self, x, is_free):
+        """The (k(k+1)/2)^2 block of q(beta)'s information matrix is three Kronecker products of k x k matrices: the device
+        writes it from the factors (lrvb_hvec_add_symkron) and converts the assembled matrix to free coordinates; the host
+        sends the rest of the vector-coordinate Hessian (its other blocks are O(V k) numbers)."""
+        S, W = self._stats()
+        eta = self._eta(x, is_free)
+        _, g, H = self._terms(eta, S, W, kron=False)
+        G, P = self._kron_factors
+        c, l0 = self.ctx, self._ls.start
+        c.hvec_begin()
+        c.hvec_add_block(H, 0, 0)
+        c.hvec_add_symkron(G, P, 0.5, l0, l0)
+        c.hvec_add_symkron(P, G, 0.5, l0, l0)
+        c.hvec_add_symkron(P, P, -0.5, l0, l0)
+        return c.hvec_finish(x if is_free else eta, g, is_free)
+
+    def _terms(self, eta, S, W, kron=True):
         sp = self._special
         k = self.k
         m, lam, a, b = self._unpack(eta)
@@ -320,7 +342,10 @@ class MVNRegressionObjective(QuadraticDataObjective):
         g[ia] = f_e / b + f_L * psi1 - (1.0 + (1.0 - a) * psi1)
         g[ib] = -f_e * a / b ** 2 - f_L / b + 1.0 / b
         H[ms, ms] = C
-        H[ls, ls] = self._dup.T @ (0.5 * (np.kron(G, P) + np.kron(P, G)) - 0.5 * np.kron(P, P)) @ self._dup
+        if kron:                          # dense duplication-matrix algebra: 2 k^6 flops, the reference's shape of the computation
+            H[ls, ls] = self._dup.T @ (0.5 * (np.kron(G, P) + np.kron(P, G)) - 0.5 * np.kron(P, P)) @ self._dup
+        else:
+            self._kron_factors = (G, P)
         H[ia, ia] = f_L * psi2 + psi1 - (1.0 - a) * psi2
         H[ia, ib] = H[ib, ia] = -f_e / b ** 2
         H[ib, ib] = 2.0 * f_e * a / b ** 3 + f_L / b ** 2 - 1.0 / b ** 2

@@ -274,3 +274,160 @@ def test_bench_gpus_2_without_a_second_gpu_fails_loudly():
                          text=True, timeout=600)
     assert out.returncode != 0 and out.stdout.strip() == ''
     assert 'needs GPU 1' in out.stderr
+
+
+# ---- the statistics entry points of the other model families (configs 2-5): reduced ON THE DEVICE, once per call ----------
+def _stat_problems():
+    """Small seeded instances of every model family whose O(N) work is a statistics call."""
+    from test_mixture_host_math import near_optimum_problem
+    rng = np.random.default_rng(77)
+    N, p, G = 3001, 5, 40                                    # q = 6: the fused one-pass kernel; uneven shards
+    x = rng.normal(size=(N, p)); gid = rng.integers(0, G, size=N).astype(np.int32); gid[gid == 7] = 8      # group 7 is empty
+    y = x @ rng.normal(size=p) + rng.normal(size=G)[gid] * 0.7 + rng.normal(size=N) * 0.5
+    w = rng.uniform(0.5, 1.5, N)
+    d = 3
+    yy = rng.normal(size=(N, d))
+    xm, wm, theta_m = near_optimum_problem(240, 5, 4, seed=28)
+    P = 6
+    xl = rng.normal(size=(N, P)) / np.sqrt(P)
+    yl = (rng.uniform(size=N) < 0.5).astype(np.float64)
+    return dict(N=N, p=p, G=G, x=x, y=y, gid=gid, w=w, d=d, yy=yy, xm=xm, wm=wm, theta_m=theta_m, P=P, xl=xl, yl=yl)
+
+
+def _stat_objects(vb, pr, r0, r1, m0, m1):
+    """The five objects over the row range [r0, r1) (mixture: [m0, m1)) and the points they are evaluated at."""
+    from test_lmm_host_math import make_par as lmm_par, random_eta
+    from test_gpu_lmm import _layout as lmm_layout
+    rng = np.random.default_rng(5)
+    p, G, d, P = pr['p'], pr['G'], pr['d'], pr['P']
+    lmm = vb.LMMObjective(lmm_par(p, G), pr['x'][r0:r1], pr['y'][r0:r1], pr['gid'][r0:r1], G, weights=pr['w'][r0:r1])
+    th_lmm = lmm_layout(p, G).unconstrain(random_eta(rng, p, G))
+    par2 = vb.ModelParamsDict('p'); par2.push_param(vb.MVNParam('beta', dim=p)); par2.push_param(vb.GammaParam('tau'))
+    reg = vb.MVNRegressionObjective(par2, pr['x'][r0:r1], pr['y'][r0:r1], prior_mean=np.zeros(p), prior_info=np.eye(p), prior_shape=2.0,
+                                    prior_rate=2.0, weights=pr['w'][r0:r1])
+    th_reg = par2.get_free() + 0.1 * rng.normal(size=par2.free_size())
+    par5 = vb.ModelParamsDict('p'); par5.push_param(vb.MVNParam('mu', dim=d)); par5.push_param(vb.WishartParam('lambda', size=d))
+    wish = vb.WishartMVNObjective(par5, pr['yy'][r0:r1])
+    par5['lambda']['df'].set(d + 4.0)
+    th_w = par5.get_free() + 0.05 * rng.normal(size=par5.free_size())
+    K, V = 4, 5
+    par3 = vb.ModelParamsDict('params')
+    par3.push_param(vb.DirichletParamArray('pi', shape=(K,))); par3.push_param(vb.DirichletParamArray('phi', shape=(V, K)))
+    par3.push_param(vb.SimplexParam('z', shape=(m1 - m0, K)))
+    mix = vb.MixtureObjective(par3, pr['xm'][m0:m1], pi_prior=1.5, phi_prior=0.8, weights=pr['wm'][m0:m1])
+    ng = mix.n_global
+    th_mix = np.concatenate([pr['theta_m'][:ng], pr['theta_m'][ng:].reshape(240, K - 1)[m0:m1].ravel()])
+    parl = vb.ModelParamsDict('p'); parl.push_param(vb.UVNParamVector('beta', length=P))
+    lgt = vb.LogitNormalRegressionObjective(parl, pr['xl'][r0:r1], pr['yl'][r0:r1], weights=pr['w'][r0:r1])
+    eta_l = np.concatenate([rng.normal(size=P) * 0.3, rng.uniform(0.5, 2.0, P)])
+    return (lmm, th_lmm), (reg, th_reg), (wish, th_w), (mix, th_mix), (lgt, eta_l)
+
+
+def _stat_results(objs):
+    (lmm, th_lmm), (reg, th_reg), (wish, th_w), (mix, th_mix), (lgt, eta_l) = objs
+    S, gs = lmm.ctx.grouped_stats(want_S=True, want_gs=True)
+    out = [S.ravel(), gs.ravel(), lmm.ctx.group_sums().ravel(), lmm.global_hessian(th_lmm).ravel()]
+    Sw, W = reg.ctx.weighted_gram(with_sum=True)
+    out += [Sw.ravel(), [W], reg.hessian(th_reg, True).ravel(), [reg.value(th_reg, True)]]
+    out += [wish.gram(th_w).ravel(), wish.hessian(th_w, True).ravel()]
+    out += [mix.global_hessian(th_mix).ravel(), [mix.value(th_mix)]]
+    val, g, Hb = lgt.ctx.logitnormal_terms(eta_l[:lgt.P], 1.0 / eta_l[lgt.P:], lgt.gh_x, lgt.gh_w)
+    out += [[val], g, Hb[0].ravel(), Hb[1].ravel(), Hb[2].ravel(), lgt.hessian(eta_l, False).ravel()]
+    return [np.asarray(o, dtype=np.float64).ravel() for o in out]
+
+
+_STAT_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, 'tests')); sys.path.insert(0, os.path.join({root!r}, 'tools'))
+import torch
+import torch.distributed as dist
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = sys.argv[3]
+dist.init_process_group('gloo', rank=rank, world_size=world)
+import lrvb_amd as vb
+from lrvb_amd.distributed import shard_rows, torch_reduce_hook
+from test_gpu_sharded import _stat_problems, _stat_objects, _stat_results
+pr = _stat_problems()
+r0, r1 = shard_rows(pr['N'], rank, world)
+m0, m1 = shard_rows(240, rank, world)
+dev = torch.device('cuda', 0)
+torch.cuda.set_device(0)
+objs = _stat_objects(vb, pr, r0, r1, m0, m1)
+counts = []
+for f, _ in objs:                 # observations are sharded: every statistics call of these contexts returns the sum over ranks
+    f.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    inner = torch_reduce_hook(dev)
+    f.ctx.set_reduce_hook(lambda ptr, n, stream, inner=inner: (counts.append(n), inner(ptr, n, stream)))
+res = _stat_results(objs)
+flat = np.concatenate(res)
+t = torch.from_numpy(flat.copy())
+gathered = [torch.empty_like(t) for _ in range(world)]
+dist.all_gather(gathered, t)
+if rank == 0:
+    assert all(torch.equal(gathered[0], q) for q in gathered), 'ranks disagree'
+    np.savez(sys.argv[4], flat=flat, sizes=np.array([r.size for r in res]), counts=np.array(counts))
+dist.destroy_process_group()
+'''
+
+
+def test_two_ranks_statistics_calls_of_every_model_family(tmp_path):
+    """lrvb_grouped_stats / lrvb_group_sums / lrvb_lmm_group_terms (config 4), lrvb_weighted_gram_sum (config 2),
+    lrvb_quadform_gram (config 5), lrvb_mixture_stats + the device Schur assembly (config 3) and lrvb_logitnormal_terms with
+    the observations sharded over two processes on GPU 0: every call reduces its device buffer through the hook ONCE, the
+    ranks agree bitwise, and the results equal those of one unsharded context over all rows (which the other GPU tests pin
+    to the oracles)."""
+    import lrvb_amd as vb
+    world = 2
+    port = _free_port()
+    out_path = str(tmp_path / 'stats.npz')
+    script = tmp_path / 'stat_worker.py'
+    script.write_text(_STAT_WORKER.format(root=ROOT))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), str(port), out_path], env=env) for r in range(world)]
+    codes = [p.wait(timeout=600) for p in procs]
+    assert codes == [0] * world
+    rec = np.load(out_path)
+    pr = _stat_problems()
+    want = _stat_results(_stat_objects(vb, pr, 0, pr['N'], 0, 240))
+    assert [w.size for w in want] == list(rec['sizes'])
+    o = 0
+    for i, w in enumerate(want):
+        got = rec['flat'][o:o + w.size]; o += w.size
+        scale = max(np.max(np.abs(w)), 1e-300)
+        assert np.max(np.abs(got - w)) < 1e-10 * scale, (i, np.max(np.abs(got - w)) / scale)
+    # ONE reduction per statistics call, of exactly the buffer the header documents
+    q, G, p = pr['p'] + 1, pr['G'], pr['p']
+    d = pr['d']; qw = d + 1
+    P = pr['P']
+    nbk = (qw + 1) // 2
+    kron = nbk * (nbk + 1) // 2 * 128 * 128 + qw * qw + 1
+    mixn = 4100 + (21 + 21 % 2) * (10 + 10 % 2)             # [S64 | val2 | bad | pad | packed R]: q = 6 -> 21, K = 4 -> 10 packed columns
+    assert list(rec['counts']) == [q * q + G * (q + 1), G * (q + 1), q * q + G * (q + 1),      # grouped_stats, group_sums, global_hessian
+                                   q * q + 1, q * q + 1, kron, qw * qw + 1,                     # weighted_gram_sum, the class's own (cached after), gram, Wishart stats
+                                   mixn, 4100, 3 * P * P + 2 * P + 1, 3 * P * P + 2 * P + 1]
+
+
+def test_statistics_calls_reduce_once_and_fail_together():
+    """In process, a counting hook over a one-rank group: each statistics entry point hands exactly one buffer to the hook;
+    an indefinite simplex block is reported after the reduction, by the reduced count."""
+    import lrvb_amd as vb
+    pr = _stat_problems()
+    objs = _stat_objects(vb, pr, 0, pr['N'], 0, 240)
+    (lmm, th_lmm), (reg, th_reg), (wish, th_w), (mix, th_mix), (lgt, eta_l) = objs
+    calls = []
+    for f, _ in objs:
+        f.ctx.set_reduce_hook(lambda ptr, n, stream: calls.append(n))
+        assert f.ctx.has_reduce_hook
+    q, G = pr['p'] + 1, pr['G']
+    lmm.ctx.grouped_stats(); assert calls == [q * q + G * (q + 1)]; calls.clear()
+    lmm.ctx.weighted_gram(); lmm.ctx.weighted_gram(with_sum=True); assert calls == [q * q, q * q + 1]; calls.clear()
+    mix.ctx.mixture_stats(4, th_mix[mix.n_global:], mix._lam(np.exp(th_mix[:mix.n_global]))[2], want_schur=False)
+    assert calls == [4100]; calls.clear()
+    bad = th_mix.copy(); bad[mix.n_global:] = -bad[mix.n_global:] * 3.0 + 4.0
+    with pytest.raises(np.linalg.LinAlgError):
+        mix.global_hessian(bad)
+    assert len(calls) == 1                                   # the reduction ran before the verdict: no rank stops early
+    for f, _ in objs:
+        f.ctx.set_reduce_hook(None)
+        assert not f.ctx.has_reduce_hook
