@@ -30,7 +30,10 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 
 // (stride mod 32 doubles) == 16: the two 16-lane halves of a ds_read_b64 lane group read
 // consecutive observations and land on disjoint banks.
-constexpr int WS_LDS_STRIDE = WS_TILE + 16;
+#ifndef LRVB_WS_STRIDE
+#define LRVB_WS_STRIDE (WS_TILE + 16)
+#endif
+constexpr int WS_LDS_STRIDE = LRVB_WS_STRIDE;
 
 int wsyrk_num_tiles(i64 P) {
     i64 nb = (P + WS_TILE - 1) / WS_TILE;
