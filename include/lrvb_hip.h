@@ -194,7 +194,9 @@ int lrvb_hessian(lrvb_ctx* ctx, const double* free_in, int64_t D, double* H_out,
 /* Objective.fun_free_hvp (LRVB/SparseObjectives.py:183-187): out = H(theta) v.  Host-callback optimisers
  * (scipy's cg and trust-ncg, as the reference drives them) call this many times at one point: the point state
  * (eta, packing Jacobian, per-observation curvature) of the last lrvb_hvp / lrvb_hvp_vec call is kept and reused
- * when the next call names the same point and no other entry point of this context ran in between.  Data
+ * when the next call names the same point and no other entry point of this context ran in between (lrvb_cg_solve and
+ * lrvb_cg_solve_multi keep and reuse the state the same way: the reference's ConjugateGradientSolver is built for ONE
+ * point and solves for many right-hand sides there, LRVB/ConjugateGradient.py:63-105).  Data
  * installed zero-copy with lrvb_set_data_dev must be installed again after its contents change.               */
 int lrvb_hvp    (lrvb_ctx* ctx, const double* free_in, const double* v, int64_t D, double* out);
 

@@ -29,6 +29,9 @@ typedef double d2 __attribute__((ext_vector_type(2)));
     :: "v"(voff), "s"(sbase), "s"(ldsaddr) : "memory")
 
 constexpr int HM_ROWS = 8;               // observations per chunk
+#ifndef HM_REGIONS
+#define HM_REGIONS 1
+#endif
 
 // TONLY = true stops after step A and writes the scaled rows of T instead (out[n][q] = c_n (X U)[n][q]):
 // the streamed weight-sensitivity product of lrvb_obs_influence.
@@ -38,8 +41,13 @@ template <int NB, bool TONLY, int NW>    // NB = P / 128
 __global__ __launch_bounds__(64 * NW, 1)
 void hvp_multi_kernel(const double* __restrict__ X, int Preal, i64 N, const double* __restrict__ cw,
                       const double* __restrict__ U, i64 ldu, int Q, double* __restrict__ Rpart,
-                      double* __restrict__ Tout, i64 ldt)
+                      double* __restrict__ Tout, i64 ldt, const double* __restrict__ live /* nullable: Q flags */)
 {
+    if (live) {                            // the blocked CG queues one iteration ahead of its convergence test: when every
+        bool any = false;                  // system of this block has stopped, the product is skipped on the device
+        for (int q = 0; q < Q; ++q) any = any || (live[q] != 0.0);
+        if (!any) return;
+    }
     constexpr int P = NB * 128;           // columns rounded up to whole 128-column DMA instructions (Preal is even)
     constexpr int PW = P / NW;            // columns per wave (a multiple of 32)
     constexpr int NBW = PW / 32;          // 32-column blocks per wave
@@ -94,10 +102,18 @@ void hvp_multi_kernel(const double* __restrict__ X, int Preal, i64 N, const doub
     };
 
     const unsigned cvoff = (unsigned)l4 * 8u;
-    i64 ch = blockIdx.x;
+    // Chunk order: the workgroups form HM_REGIONS groups, each streaming its own contiguous part of the rows, the workgroups
+    // of a group taking its chunks round-robin (HM_REGIONS = 1: one chip-wide window).
+    const int nreg = HM_REGIONS <= (int)gridDim.x ? HM_REGIONS : 1;
+    const int region = (int)(blockIdx.x % nreg), gstride = (int)(gridDim.x / nreg);
+    const i64 per = (nchunks + nreg - 1) / nreg;
+    const i64 cbeg = region * per, cend = (cbeg + per < nchunks) ? cbeg + per : nchunks;
+    i64 ch = cbeg + (blockIdx.x / nreg);
+    if ((int)(blockIdx.x / nreg) >= gstride) ch = cend;          // leftover workgroups of an uneven split: nothing to do
+    const i64 step = gstride;
     int buf = 0;
-    if (ch < nchunks) issue(ch, 0);
-    for (; ch < nchunks; ch += gridDim.x) {
+    if (ch < cend) issue(ch, 0);
+    for (; ch < cend; ch += step) {
         // weights of this chunk's rows in the D-register layout of T: reg s <-> row l4 + 4 s
         double c0, c1;
         {
@@ -107,8 +123,8 @@ void hvp_multi_kernel(const double* __restrict__ X, int Preal, i64 N, const doub
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): this wave's part of the stage has landed
         __syncthreads();                                      // ... and everybody's; the other buffer is free again
-        const i64 nxt = ch + gridDim.x;
-        if (nxt < nchunks) issue(nxt, buf ^ 1);
+        const i64 nxt = ch + step;
+        if (nxt < cend) issue(nxt, buf ^ 1);
         const double* Xs = lds + buf * (HM_ROWS * STRIDE);
 
         // ---- step A: partial T over this wave's columns ------------------------------------------------
@@ -213,8 +229,13 @@ void hvp_multi_kernel(const double* __restrict__ X, int Preal, i64 N, const doub
 // (the one-thread-per-element form took 64 us per call, 4 % of a blocked-CG iteration)
 __global__ __launch_bounds__(256)
 void hvp_multi_reduce_kernel(const double* __restrict__ Rpart, int G, int P, int Ppad, int Q, i64 ldo, i64 off,
-                             double* __restrict__ Out)
+                             double* __restrict__ Out, const double* __restrict__ live /* nullable: Q flags */)
 {
+    if (live) {
+        bool any = false;
+        for (int q = 0; q < Q; ++q) any = any || (live[q] != 0.0);
+        if (!any) return;
+    }
     __shared__ double sh[8][32];
     const int col = threadIdx.x & 31, row = threadIdx.x >> 5;
     const int e = blockIdx.x * 32 + col;                         // e = p * 16 + q
@@ -248,12 +269,13 @@ int launch_hvp_multi(lrvb_ctx* c, i64 Q, const double* U_dev, i64 ldu, double* O
     if (grid > nchunks) grid = (int)nchunks;
     LRVB_TRY(buf_reserve(c, c->part_vec, (size_t)grid * (size_t)P * 16));
     const double* Uoff = U_dev + c->glm_off;
+    const double* live = c->hm_live;           // set by the blocked CG around its products, null otherwise
     const bool eight = ((P / 128) % 2 == 0) && !c->hm_four_waves;      // two waves per SIMD where the columns split evenly
     const size_t lds_bytes = (size_t)(2 * HM_ROWS * (P + 2) + (eight ? 8 : 4) * 2 * 64) * sizeof(double);
 #define HM_LAUNCH_W(NB, NW) do { \
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&hvp_multi_kernel<NB, false, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
         hipLaunchKernelGGL((hvp_multi_kernel<NB, false, NW>), dim3((unsigned)grid), dim3(64 * NW), lds_bytes, c->stream, \
-                           c->X.p, Preal, c->N, c->cw.p, Uoff, ldu, (int)Q, c->part_vec.p, (double*)nullptr, (i64)0); } while (0)
+                           c->X.p, Preal, c->N, c->cw.p, Uoff, ldu, (int)Q, c->part_vec.p, (double*)nullptr, (i64)0, live); } while (0)
 #define HM_LAUNCH(NB) HM_LAUNCH_W(NB, 4)
 #define HM_LAUNCH_E(NB) do { if (eight) HM_LAUNCH_W(NB, 8); else HM_LAUNCH_W(NB, 4); } while (0)
     switch (P / 128) {
@@ -265,7 +287,7 @@ int launch_hvp_multi(lrvb_ctx* c, i64 Q, const double* U_dev, i64 ldu, double* O
 #undef HM_LAUNCH
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(hvp_multi_reduce_kernel, dim3((unsigned)((Preal * 16 + 31) / 32)), dim3(256), 0, c->stream,
-                       c->part_vec.p, grid, Preal, P, (int)Q, ldo, c->glm_off, Out_dev);
+                       c->part_vec.p, grid, Preal, P, (int)Q, ldo, c->glm_off, Out_dev, live);
     HIP_TRY(hipGetLastError());
     return LRVB_OK;
 }
@@ -288,7 +310,7 @@ int launch_rows_times_matrix(lrvb_ctx* c, i64 n0, i64 n1, i64 Q, const double* Z
 #define HM_LAUNCH_TW(NB, NW) do { \
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&hvp_multi_kernel<NB, true, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
         hipLaunchKernelGGL((hvp_multi_kernel<NB, true, NW>), dim3((unsigned)grid), dim3(64 * NW), lds_bytes, c->stream, \
-                           c->X.p + n0 * (i64)Preal, Preal, rows, rowscale_dev + n0, Zt_dev, ldz, (int)Q, (double*)nullptr, Tout_dev, ldt); } while (0)
+                           c->X.p + n0 * (i64)Preal, Preal, rows, rowscale_dev + n0, Zt_dev, ldz, (int)Q, (double*)nullptr, Tout_dev, ldt, (const double*)nullptr); } while (0)
 #define HM_LAUNCH_T(NB) HM_LAUNCH_TW(NB, 4)
 #define HM_LAUNCH_TE(NB) do { if (eight) HM_LAUNCH_TW(NB, 8); else HM_LAUNCH_TW(NB, 4); } while (0)
     switch (P / 128) {

@@ -190,6 +190,8 @@ extern "C" int lrvb_ctx_destroy(lrvb_ctx* c) {
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
     for (int k = 0; k < 3; ++k) for (hipEvent_t e : c->ev_pool[k]) (void)hipEventDestroy(e);
     if (c->ev_order) (void)hipEventDestroy(c->ev_order);
+    for (int k = 0; k < 2; ++k) if (c->aux_ev[k]) (void)hipEventDestroy(c->aux_ev[k]);
+    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->stream && c->stream_owned) (void)hipStreamDestroy(c->stream);
     delete c;
     return LRVB_OK;
@@ -2064,6 +2066,8 @@ extern "C" int lrvb_obs_influence_vec(lrvb_ctx* c, const double* vec_in, int64_t
 extern "C" int lrvb_cg_solve(lrvb_ctx* c, const double* free_in, const double* b, const double* x0,
                              const double* Minv, double tol, int64_t maxiter, int64_t D,
                              double* x_out, int* info_out, int64_t* iters_out) {
+    const bool reuse = same_point(c, free_in, D, true);          // many right-hand sides at one point: the state stays
+    const bool prepared = reuse && c->hvp_pt_prepared;
     LRVB_TRY(ctx_bind(c));
     if (!free_in || !b || !x_out) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
     LRVB_TRY(check_len(D, c->D, "free vector"));
@@ -2072,12 +2076,14 @@ extern "C" int lrvb_cg_solve(lrvb_ctx* c, const double* free_in, const double* b
     DevBuf* vecs[] = { &c->rhs, &c->cgx, &c->cgr, &c->cgp, &c->cgq, &c->cgz };
     for (DevBuf* v : vecs) LRVB_TRY(buf_reserve(c, *v, (size_t)D));
     if (Minv) { LRVB_TRY(buf_reserve(c, c->Hfree, (size_t)D * (size_t)D)); LRVB_TRY(h2d(c, c->Hfree.p, Minv, (size_t)D * (size_t)D)); }
-    LRVB_TRY(h2d(c, c->theta.p, free_in, (size_t)D));
     LRVB_TRY(h2d(c, c->rhs.p, b, (size_t)D));
     // point state once: eta, J, g_eta, cached curvature
-    LRVB_TRY(set_point(c, c->theta.p, true));
-    LRVB_TRY(eval_grad_eta(c, c->stats.p, true));
-    LRVB_TRY(prepare_general_hvp(c, c->theta.p));
+    if (!reuse) {
+        LRVB_TRY(h2d(c, c->theta.p, free_in, (size_t)D));
+        LRVB_TRY(set_point(c, c->theta.p, true));
+        LRVB_TRY(eval_grad_eta(c, c->stats.p, true));
+    }
+    if (!prepared) LRVB_TRY(prepare_general_hvp(c, c->theta.p));
 
     double* s = c->scal.p;                     // s[0] = ||b||^2, s[1] = ||r||^2, s[2] = r.z, s[3] = p.q
     double hs[4];
@@ -2122,6 +2128,7 @@ extern "C" int lrvb_cg_solve(lrvb_ctx* c, const double* free_in, const double* b
     LRVB_TRY(d2h(c, x_out, c->cgx.p, (size_t)D));
     if (info_out) *info_out = info;
     if (iters_out) *iters_out = it;
+    remember_point(c, free_in, D, true, true);
     return LRVB_OK;
 }
 
@@ -2693,9 +2700,144 @@ __global__ void cg_multi_alpha_kernel(int Q, double* __restrict__ s) {
     s[4 * Q + q] = alpha; s[5 * Q + q] = 1.0; s[6 * Q + q] = -alpha; s[7 * Q + q] = 1.0;
 }
 
+// ---- blocked CG, fused form (box layouts, no preconditioner): an iteration is FIVE launches and no host round trip ------
+// s: [ |b|^2 (Q) | rho_prev (Q) | r.r (Q) | live (Q) | iterations (Q) ].  head: r.r, the convergence test, beta, p = r + beta p
+// and the product's operand u = eta' o p in one kernel (one workgroup per system); tail: q = eta' (W + s A u) + g eta'' p
+// formed on the fly, p.q, alpha, x += alpha p, r -= alpha q.  The host runs ONE ITERATION AHEAD of its convergence test
+// (the status of iteration k is read on a side stream while iteration k + 1 is already queued); when every system has
+// stopped, the queued product is skipped on the device by the `live` flags.  Round 2's loop had twelve launches, a
+// device-to-host and a host-to-device copy per iteration: ~135 us beside the 1.52 ms product.
+__global__ __launch_bounds__(256)
+void cg_multi_head_kernel(i64 D, i64 it, double tol, const double* __restrict__ j1, const double* __restrict__ R,
+                          double* __restrict__ Pm, double* __restrict__ U, double* __restrict__ s, i64 Q)
+{
+    __shared__ double sh[256];
+    __shared__ double bc[2];
+    const i64 q = blockIdx.x;
+    const double* r = R + q * D;
+    double a = 0.0;
+    for (i64 d = threadIdx.x; d < D; d += 256) a += r[d] * r[d];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) { if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off]; __syncthreads(); }
+    if (threadIdx.x == 0) {
+        const double rr = sh[0];
+        double live = s[3 * Q + q], beta = 0.0;
+        if (live != 0.0) {
+            if (sqrt(rr) < tol * sqrt(s[q])) { live = 0.0; s[4 * Q + q] = (double)it; }
+            else { const double rp = s[Q + q]; beta = (it > 0 && rp != 0.0) ? rr / rp : 0.0; s[Q + q] = rr; s[4 * Q + q] = (double)(it + 1); }
+        }
+        s[2 * Q + q] = rr; s[3 * Q + q] = live;
+        bc[0] = live; bc[1] = beta;
+    }
+    __syncthreads();
+    const bool live = bc[0] != 0.0;
+    const double beta = bc[1];
+    double* p = Pm + q * D; double* u = U + q * D;
+    for (i64 d = threadIdx.x; d < D; d += 256) {
+        const double pv = live ? r[d] + beta * p[d] : p[d];           // a stopped system keeps its direction
+        p[d] = pv; u[d] = j1[d] * pv;
+    }
+}
+__global__ __launch_bounds__(256)
+void cg_multi_tail_kernel(i64 D, double sq, const double* __restrict__ quadA /* nullable */, const double* __restrict__ j1,
+                          const double* __restrict__ j2, const double* __restrict__ g, const double* __restrict__ W,
+                          const double* __restrict__ U, const double* __restrict__ Pm, double* __restrict__ X,
+                          double* __restrict__ R, const double* __restrict__ s, i64 Q)
+{
+    __shared__ double sh[256];
+    const i64 q = blockIdx.x;
+    if (s[3 * Q + q] == 0.0) return;                                  // stopped: nothing moves
+    const double* p = Pm + q * D; const double* w = W + q * D; const double* u = U + q * D;
+    auto qv = [&](i64 d) { return j1[d] * (w[d] + (quadA ? sq * quadA[d] * u[d] : 0.0)) + g[d] * j2[d] * p[d]; };
+    double a = 0.0;
+    for (i64 d = threadIdx.x; d < D; d += 256) a += p[d] * qv(d);
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) { if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off]; __syncthreads(); }
+    const double alpha = s[2 * Q + q] / sh[0];
+    double* x = X + q * D; double* r = R + q * D;
+    for (i64 d = threadIdx.x; d < D; d += 256) { x[d] += alpha * p[d]; r[d] -= alpha * qv(d); }
+}
+
+static bool cg_multi_fused_ok(const lrvb_ctx* c, const double* Minv, i64 Q) {
+    return Q <= 400 && c->all_box && !Minv && c->loss != LRVB_LOSS_NONE && c->quad_kind != LRVB_QUAD_DENSE && c->V == c->D &&
+           hvp_multi_supported(c, 1) && !c->force_generic_wsyrk;
+}
+
+// the loop of lrvb_cg_solve_multi after the common set-up (Bd, Xd, Rd, Pd = 0 in place; s[0..Q) = |b|^2 on the device)
+static int cg_multi_fused_loop(lrvb_ctx* c, i64 Q, i64 D, double tol, i64 maxiter, double* Xd, double* Rd, double* Pd,
+                               std::vector<int>& info, std::vector<int64_t>& iters) {
+    double* s = c->scal.p;
+    double* U = c->cgm[6].p; double* W = c->cgm[7].p;
+    if (!c->aux_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) HIP_TRY(hipEventCreateWithFlags(&c->aux_ev[k], hipEventDisableTiming));
+    }
+    LRVB_TRY(pinned_reserve(c, 4096));
+    // live = (|b| > 0), rho_prev = 0, iterations = 0
+    std::vector<double> init((size_t)(5 * Q), 0.0), hb((size_t)Q);
+    LRVB_TRY(d2h(c, hb.data(), s, (size_t)Q));
+    for (i64 q = 0; q < Q; ++q) { init[q] = hb[q]; init[3 * Q + q] = hb[q] > 0.0 ? 1.0 : 0.0; if (hb[q] == 0.0) HIP_TRY(hipMemsetAsync(Xd + q * D, 0, (size_t)D * sizeof(double), c->stream)); }
+    LRVB_TRY(h2d(c, s, init.data(), (size_t)(5 * Q)));
+    const double* quadA = c->quad_kind == LRVB_QUAD_DIAG ? c->quadA.p : nullptr;
+    double* status = c->host_pinned + 2048;                        // [live (Q)] of the iteration whose head kernel ran last
+    auto queue_iteration = [&](i64 it) -> int {
+        hipLaunchKernelGGL(cg_multi_head_kernel, dim3((unsigned)Q), dim3(256), 0, c->stream, D, it, tol, (const double*)c->j1.p,
+                           (const double*)Rd, Pd, U, s, Q);
+        HIP_TRY(hipGetLastError());
+        // status of THIS iteration's test, copied on the side stream as soon as the head kernel is done
+        HIP_TRY(hipEventRecord(c->aux_ev[0], c->stream));
+        HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->aux_ev[0], 0));
+        HIP_TRY(hipMemcpyAsync(status + (it & 1) * 1024, s + 3 * Q, (size_t)Q * sizeof(double), hipMemcpyDeviceToHost, c->aux_stream));
+        HIP_TRY(hipMemsetAsync(W, 0, (size_t)(Q * D) * sizeof(double), c->stream));
+        for (i64 q0 = 0; q0 < Q; q0 += 16) {
+            const i64 qn = (Q - q0 < 16) ? Q - q0 : 16;
+            c->hm_live = s + 3 * Q + q0;
+            const int st = launch_hvp_multi(c, qn, U + q0 * D, D, W + q0 * D, D);
+            c->hm_live = nullptr;
+            LRVB_TRY(st);
+        }
+        LRVB_TRY(obs_reduce(c, W, Q * D));                            // every rank queues the same iterations (identical scalars)
+        hipLaunchKernelGGL(cg_multi_tail_kernel, dim3((unsigned)Q), dim3(256), 0, c->stream, D, c->quad_scale, quadA, (const double*)c->j1.p,
+                           (const double*)c->j2.p, (const double*)c->g_eta.p, (const double*)W, (const double*)U, (const double*)Pd, Xd, Rd,
+                           (const double*)s, Q);
+        HIP_TRY(hipGetLastError());
+        return LRVB_OK;
+    };
+    i64 queued = 0;
+    bool stop = false;
+    if (maxiter > 0) { LRVB_TRY(queue_iteration(0)); queued = 1; }
+    for (i64 it = 0; it < maxiter && !stop; ++it) {
+        if (it + 1 < maxiter) { LRVB_TRY(queue_iteration(it + 1)); queued = it + 2; }      // one ahead of the test below
+        // wait for the status copy of iteration `it` only (the side stream), not for the main stream
+        HIP_TRY(hipStreamSynchronize(c->aux_stream));
+        // the copy of iteration it + 1 may be queued behind it on the side stream: wait covers both, which is fine (it only
+        // means the head kernel of it + 1 ran, i.e. iteration `it` is complete)
+        const double* st = status + (it & 1) * 1024;
+        bool any = false;
+        for (i64 q = 0; q < Q; ++q) any = any || (st[q] != 0.0);
+        if (!any) stop = true;
+    }
+    (void)queued;
+    std::vector<double> fin((size_t)(5 * Q));
+    LRVB_TRY(d2h(c, fin.data(), s, (size_t)(5 * Q)));
+    for (i64 q = 0; q < Q; ++q) {
+        info[(size_t)q] = fin[3 * Q + q] != 0.0 ? (int)maxiter : 0;
+        iters[(size_t)q] = (int64_t)fin[4 * Q + q];
+    }
+    return LRVB_OK;
+}
+
 extern "C" int lrvb_cg_solve_multi(lrvb_ctx* c, const double* free_in, const double* B, const double* X0,
                                    const double* Minv, double tol, int64_t maxiter, int64_t D, int64_t Q,
                                    double* X_out, int* info_out, int64_t* iters_out) {
+    // Same point as the previous product / solve on this context, nothing else in between: eta, the packing Jacobian,
+    // d f / d eta and the per-observation curvature are still in place (the reference's ConjugateGradientSolver is built
+    // for ONE point x0 and solves for many right-hand sides there, LRVB/ConjugateGradient.py:63-105) -- no second
+    // gradient pass over X.
+    const bool reuse = same_point(c, free_in, D, true);
+    const bool prepared = reuse && c->hvp_pt_prepared;
     LRVB_TRY(ctx_bind(c));
     if (!free_in || !B || !X_out || Q <= 0) LRVB_FAIL(LRVB_ERR_INVALID, "bad argument");
     LRVB_TRY(check_len(D, c->D, "free vector"));
@@ -2713,11 +2855,13 @@ extern "C" int lrvb_cg_solve_multi(lrvb_ctx* c, const double* free_in, const dou
     }
     double *Bd = c->cgm[0].p, *Xd = c->cgm[1].p, *Rd = c->cgm[2].p, *Pd = c->cgm[3].p, *Qd = c->cgm[4].p, *Zd = c->cgm[5].p;
     if (Minv) { LRVB_TRY(buf_reserve(c, c->Hfree, (size_t)D * (size_t)D)); LRVB_TRY(h2d(c, c->Hfree.p, Minv, (size_t)D * (size_t)D)); }
-    LRVB_TRY(h2d(c, c->theta.p, free_in, (size_t)D));
     LRVB_TRY(h2d(c, Bd, B, qd));
-    LRVB_TRY(set_point(c, c->theta.p, true));
-    LRVB_TRY(eval_grad_eta(c, c->stats.p, true));
-    LRVB_TRY(prepare_general_hvp(c, c->theta.p));
+    if (!reuse) {
+        LRVB_TRY(h2d(c, c->theta.p, free_in, (size_t)D));
+        LRVB_TRY(set_point(c, c->theta.p, true));
+        LRVB_TRY(eval_grad_eta(c, c->stats.p, true));
+    }
+    if (!prepared) LRVB_TRY(prepare_general_hvp(c, c->theta.p));
     // scalars: s[0..Q) = ||b||^2 | rr | rz | pq | alpha | beta | minus_alpha | one
     LRVB_TRY(buf_reserve(c, c->scal, (size_t)(8 * Q + 16)));
     double* s = c->scal.p;
@@ -2742,6 +2886,13 @@ extern "C" int lrvb_cg_solve_multi(lrvb_ctx* c, const double* free_in, const dou
         bnorm[q] = sqrt(hs[q]);
         if (bnorm[q] == 0.0) { active[q] = 0; HIP_TRY(hipMemsetAsync(Xd + q * D, 0, (size_t)D * sizeof(double), c->stream)); }
         else { info[q] = (int)maxiter; ++n_active; }
+    }
+    if (cg_multi_fused_ok(c, Minv, Q)) {
+        LRVB_TRY(cg_multi_fused_loop(c, Q, D, tol, maxiter, Xd, Rd, Pd, info, iters));
+        LRVB_TRY(d2h(c, X_out, Xd, qd));
+        for (i64 q = 0; q < Q; ++q) { if (info_out) info_out[q] = info[q]; if (iters_out) iters_out[q] = iters[q]; }
+        remember_point(c, free_in, D, true, true);
+        return LRVB_OK;
     }
     for (i64 it = 0; it < maxiter && n_active > 0; ++it) {
         if (Minv) LRVB_TRY(launch_gemm(c, false, true, Q, D, D, 1.0, Rd, D, c->Hfree.p, D, 0.0, Zd, D));   // Z = R Minv^T
@@ -2772,6 +2923,7 @@ extern "C" int lrvb_cg_solve_multi(lrvb_ctx* c, const double* free_in, const dou
     }
     LRVB_TRY(d2h(c, X_out, Xd, qd));
     for (i64 q = 0; q < Q; ++q) { if (info_out) info_out[q] = info[q]; if (iters_out) iters_out[q] = iters[q]; }
+    remember_point(c, free_in, D, true, true);
     return LRVB_OK;
 }
 

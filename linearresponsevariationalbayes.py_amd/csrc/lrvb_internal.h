@@ -87,6 +87,8 @@ struct lrvb_ctx {
     DevBuf opt;                    // trust-region Newton-CG: 12 D-vectors (+ the D x D preconditioner)
     DevBuf cgm[9];                 // blocked CG: B, X, R, P, Q, Z (Q x D), U, W (Q x V), R^T (P x Q)
     DevBuf cgT;                    // N x Q products X U^T of the blocked HVP
+    const double* hm_live = nullptr;   // blocked CG: device flags of the systems still running (launch_hvp_multi passes them on)
+    hipStream_t aux_stream = nullptr; hipEvent_t aux_ev[2] = {nullptr, nullptr};   // side stream for the CG status read-back
     DevBuf gpad;                   // even-width zero-padded copies of odd-width TN GEMM operands
     DevBuf ones; i64 ones_n = 0;   // [1 x n | 0 x 64] contraction weights of the plain TN GEMM
     double* host_pinned = nullptr; size_t host_pinned_n = 0;

@@ -153,3 +153,42 @@ def test_errors(vb):
         fun.ctx.cg_solve_multi(np.zeros(4), np.zeros((3, 5)))
     with pytest.raises(ValueError):
         fun.ctx.cg_solve_multi(np.zeros(3), np.zeros((3, 4)))
+
+
+def test_point_state_is_reused_only_when_nothing_changed(vb):
+    """lrvb_cg_solve / lrvb_cg_solve_multi keep the point state (eta, J, d f / d eta, curvature) of the last solve or product
+    and skip the gradient pass when the next solve names the same point with nothing in between -- the reference's
+    ConjugateGradientSolver solves many right-hand sides at ONE point (LRVB/ConjugateGradient.py:63-105).  The reuse must
+    not survive a new point, new weights or a new quadratic scale; every solve is checked against a direct solve with the
+    oracle's Hessian for the state it ran at, and the profile counts the gradient passes."""
+    rng = np.random.default_rng(12)
+    N, P, Q = 3000, 256, 6
+    par, lay = make_par(vb, [('box', 'a', P // 2, -np.inf, np.inf), ('box', 'b', P - P // 2, 0.0, np.inf)])
+    x, y, w = glm_data(rng, N, P, om.LOGISTIC)
+    fun = vb.DeviceObjective(par, x=x, y=y, loss='logistic', quad_A=np.full(P, 1.0), weights=w)
+    fun._push_state()
+    ctx = fun.ctx
+    B = rng.normal(size=(Q, P))
+    th1, th2 = rng.normal(size=P) * 0.1, rng.normal(size=P) * 0.1
+
+    def check(theta, weights, scale=1.0):
+        model = om.DeclaredModel(lay, loss=om.LOGISTIC, x=x, y=y, w=weights, quad_A=np.full(P, scale))
+        H = model.hessian(theta)
+        X, info, _ = ctx.cg_solve_multi(theta, B, tol=1e-10)
+        assert np.all(info == 0) and np.max(np.abs(X - np.linalg.solve(H, B.T).T)) < 1e-7
+        x1, i1, _ = ctx.cg_solve(theta, B[0], tol=1e-10)
+        assert i1 == 0 and np.max(np.abs(x1 - np.linalg.solve(H, B[0]))) < 1e-7
+    ctx.profile_enable(True); ctx.profile_reset()
+    check(th1, w)                                     # pass 1 (multi), reused by the single solve
+    check(th1, w)                                     # same point again: no pass at all
+    assert ctx.profile_get()['pass_calls'] == 1
+    check(th2, w)                                     # new point: one more
+    check(th1, w)                                     # and back
+    assert ctx.profile_get()['pass_calls'] == 3
+    w2 = rng.uniform(0.5, 1.5, N)
+    ctx.set_weights(w2)
+    check(th1, w2)                                    # same point, new weights: the state is rebuilt
+    ctx.set_quad_scale(2.5)
+    check(th1, w2, scale=2.5)
+    assert ctx.profile_get()['pass_calls'] == 5
+    ctx.profile_enable(False)
