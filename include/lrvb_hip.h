@@ -298,7 +298,10 @@ int lrvb_set_groups(lrvb_ctx* ctx, const int32_t* gid, int64_t n, int64_t n_grou
 int lrvb_group_sums(lrvb_ctx* ctx, double* out);
 /* Both statistics of a hierarchical model in one call, [S = Z^T diag(w) Z (q x q) | group sums (G x (1 + q))], in ONE
  * device buffer that goes to the sum-over-ranks hook once and stays resident for lrvb_lmm_group_terms.  Either host
- * copy may be NULL.                                                                                                   */
+ * copy may be NULL.  For an even n_cols the rows are read from a group-sorted copy that is built when the group ids and
+ * the data are set (one pass instead of two): data adopted with lrvb_set_data_dev must be installed again after its
+ * contents change (as for the point state of lrvb_hvp); weights adopted with lrvb_set_weights_dev are re-read by
+ * every call.                                                                                                         */
 int lrvb_grouped_stats(lrvb_ctx* ctx, double* S_out, double* gs_out);
 /* The hierarchical linear mixed model of doc/lmm.lyx:77-160 (y_i ~ N(x_i.beta + u_g[i], 1/tau_y), u_g ~ N(mu, 1/tau_mu),
  * q(u_g) = N(e_g, 1/i_g)): elimination of the 2 G local parameters on the device, from the resident grouped

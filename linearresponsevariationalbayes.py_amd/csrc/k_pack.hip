@@ -260,10 +260,78 @@ __global__ void box_third_dense_kernel(const double* __restrict__ theta, const d
 
 static inline unsigned nblk(i64 n, int t = 256) { return (unsigned)((n + t - 1) / t); }
 
+// ---- all box blocks of a layout in ONE launch ---------------------------------------------------------------------------
+// A layout with many small box blocks (the hierarchical model's global block: mean, five scalars, ...) paid one 4-5 us
+// launch per block and map (constrain, Jacobian, second-order term: ~21 launches in the config-4 step).  The per-element
+// description of every box entry -- free index, vector index, bounds -- is uploaded once with the context (boxmap), and each
+// map is one kernel over all box entries.  MODE 0: eta, eta', eta''; 1: dense Jacobian entries; 2: second-order term
+// T[f, f] += g[v] eta''; 3: unconstrain.
+template <int MODE>
+__global__ void box_all_kernel(i64 nbe, const i64* __restrict__ foff, const i64* __restrict__ voff, const double* __restrict__ lbs,
+                               const double* __restrict__ ubs, const double* __restrict__ in, const double* __restrict__ g,
+                               double* __restrict__ o0, double* __restrict__ o1, double* __restrict__ o2, i64 ld, int* __restrict__ bad)
+{
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nbe) return;
+    const i64 f = foff[i], v = voff[i];
+    const double lb = lbs[i], ub = ubs[i];
+    if (MODE == 3) {
+        const double x = in[v];
+        if (!(x <= ub) || !(x >= lb)) { atomicOr(bad, 1); }
+        const bool has_lb = lb > -INFINITY, has_ub = ub < INFINITY;
+        double t;
+        if (!has_lb && !has_ub) t = x;
+        else if (has_lb && !has_ub) t = log(x - lb);
+        else if (!has_lb && has_ub) t = -log(ub - x);
+        else t = log(x - lb) - log(ub - x);
+        o0[f] = t;
+        return;
+    }
+    double e, d1, d2;
+    box_eval(in[f], lb, ub, e, d1, d2);
+    if (MODE == 0) { o0[v] = e; if (o1) o1[f] = d1; if (o2) o2[f] = d2; }
+    if (MODE == 1) o0[v * ld + f] = d1;
+    if (MODE == 2) o0[f * ld + f] += g[v] * d2;
+}
+static bool box_fused(const lrvb_ctx* c) { return c->n_box_blocks >= 2 && c->boxmap.p != nullptr; }
+template <int MODE>
+static int launch_box_all(lrvb_ctx* c, const double* in, const double* g, double* o0, double* o1, double* o2, i64 ld, int* bad) {
+    const i64 nbe = c->n_box_entries;
+    if (nbe <= 0) return LRVB_OK;
+    const i64* foff = reinterpret_cast<const i64*>(c->boxmap.p);
+    const i64* voff = foff + nbe;
+    const double* lbs = c->boxmap.p + 2 * nbe;
+    const double* ubs = lbs + nbe;
+    hipLaunchKernelGGL(box_all_kernel<MODE>, dim3(nblk(nbe)), dim3(256), 0, c->stream, nbe, foff, voff, lbs, ubs, in, g, o0, o1, o2, ld, bad);
+    HIP_TRY(hipGetLastError());
+    return LRVB_OK;
+}
+// called once by lrvb_ctx_create (after the blocks are known): the per-entry description of the box blocks
+int upload_boxmap(lrvb_ctx* c) {
+    i64 nbe = 0; int nb = 0;
+    for (const auto& b : c->blocks) if (b.kind == LRVB_BLOCK_BOX && b.free_size > 0) { nbe += b.free_size; ++nb; }
+    c->n_box_blocks = nb; c->n_box_entries = nbe;
+    if (nb < 2) return LRVB_OK;
+    std::vector<double> host((size_t)(4 * nbe));
+    i64* foff = reinterpret_cast<i64*>(host.data());
+    i64* voff = foff + nbe;
+    double* lbs = host.data() + 2 * nbe; double* ubs = lbs + nbe;
+    i64 e = 0;
+    for (const auto& b : c->blocks)
+        if (b.kind == LRVB_BLOCK_BOX)
+            for (i64 i = 0; i < b.free_size; ++i, ++e) { foff[e] = b.free_off + i; voff[e] = b.vec_off + i; lbs[e] = b.lb; ubs[e] = b.ub; }
+    LRVB_TRY(buf_reserve(c, c->boxmap, (size_t)(4 * nbe)));
+    HIP_TRY(hipMemcpyAsync(c->boxmap.p, host.data(), (size_t)(4 * nbe) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LRVB_OK;
+}
+
 int launch_constrain(lrvb_ctx* c, const double* theta_dev, double* eta_dev, double* j1_dev, double* j2_dev) {
+    const bool fused = box_fused(c);
+    if (fused) LRVB_TRY(launch_box_all<0>(c, theta_dev, nullptr, eta_dev, j1_dev, j2_dev, 0, nullptr));
     for (const auto& b : c->blocks) {
         if (b.kind == LRVB_BLOCK_BOX) {
-            if (b.free_size > 0)
+            if (b.free_size > 0 && !fused)
                 hipLaunchKernelGGL(box_constrain_kernel, dim3(nblk(b.free_size)), dim3(256), 0, c->stream,
                                    theta_dev, b.free_off, b.vec_off, b.free_size, b.lb, b.ub, eta_dev, j1_dev, j2_dev);
         } else if (b.kind == LRVB_BLOCK_PSD) {
@@ -279,9 +347,11 @@ int launch_constrain(lrvb_ctx* c, const double* theta_dev, double* eta_dev, doub
 }
 
 int launch_unconstrain(lrvb_ctx* c, const double* eta_dev, double* theta_dev, int* bad_flag_dev) {
+    const bool fused = box_fused(c);
+    if (fused) LRVB_TRY(launch_box_all<3>(c, eta_dev, nullptr, theta_dev, nullptr, nullptr, 0, bad_flag_dev));
     for (const auto& b : c->blocks) {
         if (b.kind == LRVB_BLOCK_BOX) {
-            if (b.free_size > 0)
+            if (b.free_size > 0 && !fused)
                 hipLaunchKernelGGL(box_unconstrain_kernel, dim3(nblk(b.free_size)), dim3(256), 0, c->stream,
                                    eta_dev, b.free_off, b.vec_off, b.free_size, b.lb, b.ub, theta_dev, bad_flag_dev);
         } else if (b.kind == LRVB_BLOCK_PSD) {
@@ -299,9 +369,11 @@ int launch_unconstrain(lrvb_ctx* c, const double* eta_dev, double* theta_dev, in
 int launch_dense_jac(lrvb_ctx* c, const double* theta_dev, double* J_dev) {
     HIP_TRY(hipMemsetAsync(J_dev, 0, sizeof(double) * (size_t)c->V * (size_t)c->D, c->stream));
     const i64 ldj = c->D;
+    const bool fused = box_fused(c);
+    if (fused) LRVB_TRY(launch_box_all<1>(c, theta_dev, nullptr, J_dev, nullptr, nullptr, ldj, nullptr));
     for (const auto& b : c->blocks) {
         if (b.kind == LRVB_BLOCK_BOX) {
-            if (b.free_size > 0)
+            if (b.free_size > 0 && !fused)
                 hipLaunchKernelGGL(box_jac_dense_kernel, dim3(nblk(b.free_size)), dim3(256), 0, c->stream,
                                    theta_dev, b.free_off, b.vec_off, b.free_size, b.lb, b.ub, J_dev, ldj);
         } else if (b.kind == LRVB_BLOCK_PSD) {
@@ -320,9 +392,11 @@ int launch_dense_jac(lrvb_ctx* c, const double* theta_dev, double* J_dev) {
 // T (D x D) must be zero-initialised or hold a matrix to accumulate into.
 int launch_third_order(lrvb_ctx* c, const double* theta_dev, const double* g_eta_dev, double* T_dev) {
     const i64 ldt = c->D;
+    const bool fused = box_fused(c);
+    if (fused) LRVB_TRY(launch_box_all<2>(c, theta_dev, g_eta_dev, T_dev, nullptr, nullptr, ldt, nullptr));
     for (const auto& b : c->blocks) {
         if (b.kind == LRVB_BLOCK_BOX) {
-            if (b.free_size > 0)
+            if (b.free_size > 0 && !fused)
                 hipLaunchKernelGGL(box_third_dense_kernel, dim3(nblk(b.free_size)), dim3(256), 0, c->stream,
                                    theta_dev, g_eta_dev, b.free_off, b.vec_off, b.free_size, b.lb, b.ub, T_dev, ldt);
         } else if (b.kind == LRVB_BLOCK_PSD) {

@@ -139,7 +139,7 @@ extern "C" int lrvb_ctx_create(lrvb_ctx** out, int device_id, const lrvb_model_d
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamDefault);
     if (e != hipSuccess) { lrvb_set_error("context init: %s", hipGetErrorString(e)); delete c; return LRVB_ERR_HIP; }
 
-    int st = LRVB_OK;
+    int st = upload_boxmap(c);
     auto need = [&](DevBuf& b, size_t n) { if (st == LRVB_OK) st = buf_reserve(c, b, n); };
     need(c->theta, (size_t)(V > D ? V : D)); need(c->eta, (size_t)V); need(c->j1, (size_t)D); need(c->j2, (size_t)D);
     need(c->g_eta, (size_t)V); need(c->g_free, (size_t)D);
@@ -185,7 +185,7 @@ extern "C" int lrvb_ctx_destroy(lrvb_ctx* c) {
     DevBuf* all[] = { &c->X, &c->y, &c->w, &c->quadA, &c->quadM, &c->quadB, &c->theta, &c->eta, &c->j1, &c->j2,
                       &c->vtmp, &c->vtmp2, &c->vtmp3, &c->g_eta, &c->g_free, &c->lp, &c->cw, &c->zbuf,
                       &c->part_vec, &c->part_val, &c->stats, &c->tile_part, &c->Heta, &c->Hfree, &c->Jdense,
-                      &c->Tdense, &c->work1, &c->chol, &c->cholW, &c->cgH, &c->groups, &c->mx_theta, &c->mx_lam, &c->mx_A, &c->mx_U, &c->mx_g, &c->mx_Xk, &c->mx_R, &c->cgT, &c->ones, &c->cgm[0], &c->cgm[1], &c->cgm[2], &c->cgm[3], &c->cgm[4], &c->cgm[5], &c->cgm[6], &c->cgm[7], &c->cgm[8], &c->rhs, &c->cgx, &c->cgr, &c->cgp, &c->cgq, &c->cgz, &c->scal, &c->opt, &c->dkw, &c->cyv, &c->rvec, &c->red_scratch, &c->gstats, &c->Zs, &c->ws, &c->bpart, &c->gpad };
+                      &c->Tdense, &c->work1, &c->chol, &c->cholW, &c->cgH, &c->groups, &c->mx_theta, &c->mx_lam, &c->mx_A, &c->mx_U, &c->mx_g, &c->mx_Xk, &c->mx_R, &c->cgT, &c->ones, &c->cgm[0], &c->cgm[1], &c->cgm[2], &c->cgm[3], &c->cgm[4], &c->cgm[5], &c->cgm[6], &c->cgm[7], &c->cgm[8], &c->rhs, &c->cgx, &c->cgr, &c->cgp, &c->cgq, &c->cgz, &c->scal, &c->opt, &c->dkw, &c->cyv, &c->rvec, &c->red_scratch, &c->gstats, &c->Zs, &c->ws, &c->bpart, &c->gpad, &c->boxmap };
     for (DevBuf* b : all) buf_free(*b);
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
     for (int k = 0; k < 3; ++k) for (hipEvent_t e : c->ev_pool[k]) (void)hipEventDestroy(e);

@@ -296,3 +296,19 @@ def test_fused_grouped_statistics_layouts_and_ragged_groups(vb, q):
     S4, gs4 = ctx.grouped_stats(want_S=True, want_gs=True)
     ctx.set_tuning(0, 0)
     assert rel_err(S4, S3) < 1e-13 and rel_err(gs4, gs3) < 1e-13
+
+
+@pytest.mark.parametrize('N,G', [(1, 1), (2, 3), (5, 2), (63, 70), (64, 1), (65, 4), (129, 129)])
+def test_fused_grouped_statistics_tiny_inputs(vb, N, G):
+    """Fewer rows than one k-step, fewer rows than groups, one group, one row per group."""
+    rng = np.random.default_rng(N * 131 + G)
+    q = 6
+    gid = rng.integers(0, G, size=N).astype(np.int32)
+    Z = rng.normal(size=(N, q)); w = rng.uniform(0.5, 1.5, N)
+    ctx = vb.DeviceContext([dict(kind=0, free_size=1, vec_size=1, dim0=1, dim1=0, lb=-np.inf, ub=np.inf)], loss='data_only', n_obs=N, n_cols=q)
+    ctx.set_data(vb._hip.SLOT_X, Z); ctx.set_groups(gid, G); ctx.set_weights(w)
+    S, gs = ctx.grouped_stats(want_S=True, want_gs=True)
+    want = np.zeros((G, q + 1))
+    np.add.at(want[:, 0], gid, w); np.add.at(want[:, 1:], gid, w[:, None] * Z)
+    assert np.max(np.abs(S - Z.T @ (w[:, None] * Z))) < 1e-12 * max(1.0, np.max(np.abs(S)))
+    assert np.max(np.abs(gs - want)) < 1e-12 * max(1.0, np.max(np.abs(want)))
