@@ -28,6 +28,9 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define HM_GLDS16_S(sbase, voff, ldsaddr) asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1 nt" \
     :: "v"(voff), "s"(sbase), "s"(ldsaddr) : "memory")
 
+#define HM_GLDS4_S(sbase, voff, ldsaddr) asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dword %0, %1" \
+    :: "v"(voff), "s"(sbase), "s"(ldsaddr) : "memory")
+
 constexpr int HM_ROWS = 8;               // observations per chunk
 #ifndef HM_REGIONS
 #define HM_REGIONS 1
@@ -54,8 +57,9 @@ void hvp_multi_kernel(const double* __restrict__ X, int Preal, i64 N, const doub
     constexpr int RPW = HM_ROWS / NW;     // rows of a chunk staged by one wave (2 or 1)
     constexpr int STRIDE = P + 2;         // doubles; (STRIDE / 2) odd -> rows land on distinct 16-byte bank groups
     constexpr int NT = PW / 16;           // 16-column tiles of R per wave
-    extern __shared__ double lds[];       // [2][HM_ROWS][STRIDE] chunk buffers | [NW][2][64] partial T tiles
+    extern __shared__ double lds[];       // [2][HM_ROWS][STRIDE] chunk buffers | [2][NW][2][64] partial T tiles (two slots)
     double* Tpart = lds + 2 * HM_ROWS * STRIDE;
+    double* Cst = Tpart + 2 * NW * 2 * 64;           // [2][HM_ROWS] weights of the staged chunks (they ride with the stage's DMA)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -99,9 +103,13 @@ void hvp_multi_kernel(const double* __restrict__ X, int Preal, i64 N, const doub
             for (int j = 0; j < NB; ++j)
                 HM_GLDS16_S(rowp, voff[j], base + (unsigned)(row * STRIDE + 128 * j) * 8u);
         }
+        // the chunk's 8 weights (64 bytes) travel with it: loading them at the top of the iteration that uses them put a
+        // fresh global load in front of the vmcnt(0) wait -- its whole latency, every chunk
+        if (wave == 0 && lane < 16)
+            HM_GLDS4_S(reinterpret_cast<const char*>(cw + ch * HM_ROWS), (unsigned)lane * 4u,
+                       lds0 + (unsigned)(2 * HM_ROWS * STRIDE + 2 * NW * 2 * 64 + buf * HM_ROWS) * 8u);
     };
 
-    const unsigned cvoff = (unsigned)l4 * 8u;
     // Chunk order: the workgroups form HM_REGIONS groups, each streaming its own contiguous part of the rows, the workgroups
     // of a group taking its chunks round-robin (HM_REGIONS = 1: one chip-wide window).
     const int nreg = HM_REGIONS <= (int)gridDim.x ? HM_REGIONS : 1;
@@ -112,27 +120,13 @@ void hvp_multi_kernel(const double* __restrict__ X, int Preal, i64 N, const doub
     if ((int)(blockIdx.x / nreg) >= gstride) ch = cend;          // leftover workgroups of an uneven split: nothing to do
     const i64 step = gstride;
     int buf = 0;
-    if (ch < cend) issue(ch, 0);
-    for (; ch < cend; ch += step) {
-        // weights of this chunk's rows in the D-register layout of T: reg s <-> row l4 + 4 s
-        double c0, c1;
-        {
-            const double* cb = cw + ch * HM_ROWS;              // wave-uniform
-            asm volatile("global_load_dwordx2 %0, %2, %3\n\tglobal_load_dwordx2 %1, %2, %3 offset:32"
-                         : "=&v"(c0), "=&v"(c1) : "v"(cvoff), "s"(cb) : "memory");
-        }
-        __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): this wave's part of the stage has landed
-        __syncthreads();                                      // ... and everybody's; the other buffer is free again
-        const i64 nxt = ch + step;
-        if (nxt < cend) issue(nxt, buf ^ 1);
-        const double* Xs = lds + buf * (HM_ROWS * STRIDE);
-
-        // ---- step A: partial T over this wave's columns ------------------------------------------------
-        // v_mfma_f64_4x4x4_4b: four independent 4 x 4 x 4 blocks per instruction, A lane = i + 4 blk + 16 k,
-        // B lane = j + 4 blk + 16 k, D lane = j + 4 blk + 16 i (tools/mfma_f64_4x4_probe.hip).  Block blk takes the
-        // vectors q = 4 blk + j, all four blocks the same four observations: one instruction per row group of four,
-        // two per k-step -- a 16 x 16 x 4 tile would spend half of its rows on padding (8-row chunks).
-        // The result lands as T[row = 4 rg + l4][q = l15], the layout step B wants.
+    // step A of one staged chunk: partial T over this wave's columns.
+    // v_mfma_f64_4x4x4_4b: four independent 4 x 4 x 4 blocks per instruction, A lane = i + 4 blk + 16 k,
+    // B lane = j + 4 blk + 16 k, D lane = j + 4 blk + 16 i (tools/mfma_f64_4x4_probe.hip).  Block blk takes the
+    // vectors q = 4 blk + j, all four blocks the same four observations: one instruction per row group of four,
+    // two per k-step -- a 16 x 16 x 4 tile would spend half of its rows on padding (8-row chunks).
+    // The result lands as T[row = 4 rg + l4][q = l15], the layout step B wants.
+    auto step_a = [&](const double* Xs, double (&tp)[2]) {
         const double* arow = Xs + (lane & 3) * STRIDE + pc0 + 8 * l4;
         double tpa[2] = {0.0, 0.0}, tpb[2] = {0.0, 0.0};       // [row group]; even / odd k-steps on separate chains
         // fragments of block b + 1 are read while the 16 MFMAs of block b run (explicit register double buffer)
@@ -162,54 +156,114 @@ void hvp_multi_kernel(const double* __restrict__ X, int Preal, i64 N, const doub
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        const double tp[2] = {tpa[0] + tpb[0], tpa[1] + tpb[1]};
-        // ---- the four partial tiles meet in LDS; every wave leaves with the full T, scaled by c ----------
-        Tpart[(wave * 2 + 0) * 64 + lane] = tp[0];             // rows l4       (register 0)
-        Tpart[(wave * 2 + 1) * 64 + lane] = tp[1];             // rows l4 + 4   (register 1)
-        // LDS traffic only: a __syncthreads() here makes hipcc drain vmcnt(0) as well, i.e. wait for the NEXT
-        // chunk's LDS-DMA in the middle of this one -- the prefetch would overlap step A and nothing else
-        __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0)
-        __builtin_amdgcn_s_barrier();
+        tp[0] = tpa[0] + tpb[0]; tp[1] = tpa[1] + tpb[1];
+    };
+    auto load_weights = [&](int b, double& c0, double& c1) {
+        // weights of the staged chunk's rows in the D-register layout of T: reg s <-> row l4 + 4 s (after the barrier)
+        c0 = Cst[b * HM_ROWS + l4]; c1 = Cst[b * HM_ROWS + 4 + l4];
+    };
+    // the full T of a chunk from the eight partial tiles in LDS slot `sl`, scaled by the chunk's weights
+    auto gather_t = [&](const double* Tp, double c0, double c1, double& t0, double& t1) {
         double pa[NW], pb[NW];
 #pragma unroll
-        for (int w = 0; w < NW; ++w) { pa[w] = Tpart[(w * 2 + 0) * 64 + lane]; pb[w] = Tpart[(w * 2 + 1) * 64 + lane]; }
+        for (int w = 0; w < NW; ++w) { pa[w] = Tp[(w * 2 + 0) * 64 + lane]; pb[w] = Tp[(w * 2 + 1) * 64 + lane]; }
         __builtin_amdgcn_sched_barrier(0);                    // all reads in flight before the first add
-        double t0 = pa[0], t1 = pb[0];
+        t0 = pa[0]; t1 = pb[0];
 #pragma unroll
         for (int w = 1; w < NW; ++w) { t0 += pa[w]; t1 += pb[w]; }
         t0 *= c0; t1 *= c1;
-        if (TONLY) {
+    };
+
+    if (TONLY) {
+        if (ch < cend) issue(ch, 0);
+        for (; ch < cend; ch += step) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): this wave's part of the stage has landed
+            __syncthreads();                                      // ... and everybody's; the other buffer is free again
+            double c0, c1;
+            load_weights(buf, c0, c1);
+            const i64 nxt = ch + step;
+            if (nxt < cend) issue(nxt, buf ^ 1);
+            double tp[2];
+            step_a(lds + buf * (HM_ROWS * STRIDE), tp);
+            Tpart[(wave * 2 + 0) * 64 + lane] = tp[0];             // rows l4       (register 0)
+            Tpart[(wave * 2 + 1) * 64 + lane] = tp[1];             // rows l4 + 4   (register 1)
+            // LDS traffic only: a __syncthreads() here makes hipcc drain vmcnt(0) as well, i.e. wait for the NEXT
+            // chunk's LDS-DMA in the middle of this one
+            __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0)
+            __builtin_amdgcn_s_barrier();
+            double t0, t1;
+            gather_t(Tpart, c0, c1, t0, t1);
             if (wave == 0 && l15 < Q) {
                 const i64 n = ch * HM_ROWS + l4;
                 if (n < N) Tout[n * ldt + l15] = t0;
                 if (n + 4 < N) Tout[(n + 4) * ldt + l15] = t1;
             }
             buf ^= 1;
-            continue;
         }
+        return;
+    }
 
-        // ---- step B: R tiles of this wave's columns += X_chunk^T (c o T) ---------------------------------
-        // one 16-byte read feeds two tiles: tile m takes the columns pc0 + 32 (m >> 1) + 2 i + (m & 1)
-        const double* brow0 = Xs + l4 * STRIDE + pc0 + 2 * l15;
-        const double* brow1 = brow0 + 4 * STRIDE;
-        d2 xr[2][2];
-        xr[0][0] = *reinterpret_cast<const d2*>(brow0);
-        xr[0][1] = *reinterpret_cast<const d2*>(brow1);
+    // ---- both contractions, ONE barrier per chunk ------------------------------------------------------------------
+    // Round 2's loop had two: "the stage has landed" and "the partial T tiles have met".  Alone (its loads switched off)
+    // that loop took 1.30 ms for the 8.2 GB headline matrix against 0.83 ms of matrix-pipe time, the loads alone 1.13 ms
+    // (tools/stream_probe.hip: LDS-DMA of this very staging streams at 7.3 TB/s), together 1.52 ms: the kernel is bound by
+    // what sits between its MFMAs, and all eight waves -- both waves of every SIMD -- stop at each barrier together.
+    // Now step B runs one chunk BEHIND step A: iteration k does  barrier | issue DMA(k+1) | gather T(k-1), step B(k-1) from
+    // REGISTERS | step A(k), write partial T(k) | copy this wave's step-B fragments of chunk k to registers.  The partial
+    // tiles are written before the barrier and read after it (two slots, alternating), the stage buffer of chunk k-1 is
+    // free at barrier k because its fragments were copied out, and the MFMAs of B(k-1) and A(k) run back to back.
+    const double* brow0_0 = lds + l4 * STRIDE + pc0 + 2 * l15;               // step-B fragment rows inside buffer 0
+    d2 xb[NT / 2][2];                                                        // fragments of the previous chunk
+    double c0p = 0.0, c1p = 0.0;
+    bool have_prev = false;
+    int slot = 0;
+    auto step_b = [&](double t0, double t1) {
+        // one 16-byte fragment feeds two tiles: tile m takes the columns pc0 + 32 (m >> 1) + 2 i + (m & 1)
 #pragma unroll
         for (int h = 0; h < NT / 2; ++h) {
-            const int cur = h & 1;
-            if (h + 1 < NT / 2) {
-                xr[cur ^ 1][0] = *reinterpret_cast<const d2*>(brow0 + 32 * (h + 1));
-                xr[cur ^ 1][1] = *reinterpret_cast<const d2*>(brow1 + 32 * (h + 1));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            acc[2 * h]     = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[cur][0][0], t0, acc[2 * h], 0, 0, 0);
-            acc[2 * h + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[cur][0][1], t0, acc[2 * h + 1], 0, 0, 0);
-            acc[2 * h]     = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[cur][1][0], t1, acc[2 * h], 0, 0, 0);
-            acc[2 * h + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[cur][1][1], t1, acc[2 * h + 1], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            acc[2 * h]     = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[h][0][0], t0, acc[2 * h], 0, 0, 0);
+            acc[2 * h + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[h][0][1], t0, acc[2 * h + 1], 0, 0, 0);
+            acc[2 * h]     = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[h][1][0], t1, acc[2 * h], 0, 0, 0);
+            acc[2 * h + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[h][1][1], t1, acc[2 * h + 1], 0, 0, 0);
         }
-        buf ^= 1;
+    };
+    if (ch < cend) issue(ch, 0);
+    for (; ch < cend; ch += step) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): this wave's part of the stage has landed
+        __syncthreads();                                      // everybody's has; T(k-1) is complete; the other buffer is free
+        double c0, c1;
+        load_weights(buf, c0, c1);
+        const i64 nxt = ch + step;
+#ifdef HM_LAB_NO_DMA
+        if (nxt < cend && nxt < cbeg + 4 * step) issue(nxt, buf ^ 1);      // lab: only the first stages are loaded (compute-only time)
+#else
+        if (nxt < cend) issue(nxt, buf ^ 1);
+#endif
+        if (have_prev) {
+            double t0, t1;
+            gather_t(Tpart + (slot ^ 1) * (NW * 2 * 64), c0p, c1p, t0, t1);
+            step_b(t0, t1);
+        }
+        const double* Xs = lds + buf * (HM_ROWS * STRIDE);
+        double tp[2];
+        step_a(Xs, tp);
+        double* Tp = Tpart + slot * (NW * 2 * 64);
+        Tp[(wave * 2 + 0) * 64 + lane] = tp[0];                // rows l4       (register 0)
+        Tp[(wave * 2 + 1) * 64 + lane] = tp[1];                // rows l4 + 4   (register 1)
+        const double* b0 = brow0_0 + buf * (HM_ROWS * STRIDE);
+#pragma unroll
+        for (int h = 0; h < NT / 2; ++h) {
+            xb[h][0] = *reinterpret_cast<const d2*>(b0 + 32 * h);
+            xb[h][1] = *reinterpret_cast<const d2*>(b0 + 4 * STRIDE + 32 * h);
+        }
+        c0p = c0; c1p = c1; have_prev = true;
+        slot ^= 1; buf ^= 1;
+    }
+    if (have_prev) {                                          // the last chunk's step B
+        __syncthreads();
+        double t0, t1;
+        gather_t(Tpart + (slot ^ 1) * (NW * 2 * 64), c0p, c1p, t0, t1);
+        step_b(t0, t1);
     }
     if (TONLY) return;
     // partial R of this workgroup: [P][16]
@@ -271,7 +325,7 @@ int launch_hvp_multi(lrvb_ctx* c, i64 Q, const double* U_dev, i64 ldu, double* O
     const double* Uoff = U_dev + c->glm_off;
     const double* live = c->hm_live;           // set by the blocked CG around its products, null otherwise
     const bool eight = ((P / 128) % 2 == 0) && !c->hm_four_waves;      // two waves per SIMD where the columns split evenly
-    const size_t lds_bytes = (size_t)(2 * HM_ROWS * (P + 2) + (eight ? 8 : 4) * 2 * 64) * sizeof(double);
+    const size_t lds_bytes = (size_t)(2 * HM_ROWS * (P + 2) + 2 * (eight ? 8 : 4) * 2 * 64 + 2 * HM_ROWS) * sizeof(double);
 #define HM_LAUNCH_W(NB, NW) do { \
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&hvp_multi_kernel<NB, false, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
         hipLaunchKernelGGL((hvp_multi_kernel<NB, false, NW>), dim3((unsigned)grid), dim3(64 * NW), lds_bytes, c->stream, \
@@ -306,7 +360,7 @@ int launch_rows_times_matrix(lrvb_ctx* c, i64 n0, i64 n1, i64 Q, const double* Z
     int grid = 256;
     if (grid > nchunks) grid = (int)nchunks;
     const bool eight = ((P / 128) % 2 == 0) && !c->hm_four_waves;
-    const size_t lds_bytes = (size_t)(2 * HM_ROWS * (P + 2) + (eight ? 8 : 4) * 2 * 64) * sizeof(double);
+    const size_t lds_bytes = (size_t)(2 * HM_ROWS * (P + 2) + 2 * (eight ? 8 : 4) * 2 * 64 + 2 * HM_ROWS) * sizeof(double);
 #define HM_LAUNCH_TW(NB, NW) do { \
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&hvp_multi_kernel<NB, true, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
         hipLaunchKernelGGL((hvp_multi_kernel<NB, true, NW>), dim3((unsigned)grid), dim3(64 * NW), lds_bytes, c->stream, \
