@@ -149,6 +149,9 @@ void hvp_multi_kernel(const double* __restrict__ X, int Preal, i64 N, const doub
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < 8; t += 2) {
+#ifdef HM_LAB_NO_A
+                tpa[0] += fr[cur][t >> 1][0] + fr[cur][4 + (t >> 1)][0]; tpb[0] += fr[cur][t >> 1][1] + fr[cur][4 + (t >> 1)][1]; continue;
+#endif
                 tpa[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(fr[cur][t >> 1][0], uf[b][t], tpa[0], 0, 0, 0);
                 tpa[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(fr[cur][4 + (t >> 1)][0], uf[b][t], tpa[1], 0, 0, 0);
                 tpb[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(fr[cur][t >> 1][1], uf[b][t + 1], tpb[0], 0, 0, 0);
@@ -221,6 +224,9 @@ void hvp_multi_kernel(const double* __restrict__ X, int Preal, i64 N, const doub
         // one 16-byte fragment feeds two tiles: tile m takes the columns pc0 + 32 (m >> 1) + 2 i + (m & 1)
 #pragma unroll
         for (int h = 0; h < NT / 2; ++h) {
+#ifdef HM_LAB_NO_B
+            acc[2 * h][0] += xb[h][0][0] * t0 + xb[h][1][0] * t1; acc[2 * h + 1][0] += xb[h][0][1] * t0 + xb[h][1][1] * t1; continue;
+#endif
             acc[2 * h]     = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[h][0][0], t0, acc[2 * h], 0, 0, 0);
             acc[2 * h + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[h][0][1], t0, acc[2 * h + 1], 0, 0, 0);
             acc[2 * h]     = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[h][1][0], t1, acc[2 * h], 0, 0, 0);

@@ -99,6 +99,61 @@ void k_reg(const double* __restrict__ X, long N, double* __restrict__ out)
     if (acc == 12345.678) out[tid] = acc;
 }
 
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+// mode 3: the LDS-DMA staging with NM fp64 MFMAs (16x16x4) per wave and chunk between the issue of the next stage and the
+// wait for it (how well do loads and matrix work overlap with ONE stage in flight?); NBUF stages of RB rows, vmcnt-counted
+template <int NM, int NBUF, int RB>
+__global__ __launch_bounds__(512, 1)
+void k_dma_mfma(const double* __restrict__ X, long N, double* __restrict__ out)
+{
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) double*)lds;
+    const long nch = N / RB;
+    constexpr int PER = RB * 8 / NW;              // DMA instructions per wave and stage (RB rows x 8 pieces / 8 waves)
+    unsigned voff[8];
+    for (int j = 0; j < 8; ++j) voff[j] = (unsigned)((128 * j + 2 * lane) * 8);
+    auto issue = [&](long ch, int buf) {
+        const unsigned base = lds0 + (unsigned)(buf * RB * P) * 8u;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int piece = wave * PER + i;      // piece = row * 8 + j
+            const int row = piece >> 3, j = piece & 7;
+            const char* rowp = reinterpret_cast<const char*>(X + (ch * RB + row) * (long)P);
+            GLDS16_S(rowp, voff[j], base + (unsigned)(row * P + 128 * j) * 8u);
+        }
+    };
+    d4 acc[4];
+    for (int i = 0; i < 4; ++i) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
+    double a = 1.0 + lane, b = 0.5;
+    long ch = blockIdx.x;
+    // prologue: NBUF - 1 stages in flight
+    for (int k = 0; k < NBUF - 1; ++k) if (ch + (long)k * gridDim.x < nch) issue(ch + (long)k * gridDim.x, k);
+    int buf = 0;
+    for (; ch < nch; ch += gridDim.x) {
+        // wait until only the NBUF - 2 younger stages may still be in flight
+        if (NBUF == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (NBUF == 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory");
+        if (NBUF == 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PER) : "memory");
+        __builtin_amdgcn_s_barrier();
+        const long nxt = ch + (long)(NBUF - 1) * gridDim.x;
+        int nb = buf + NBUF - 1; if (nb >= NBUF) nb -= NBUF;
+        if (nxt < nch) issue(nxt, nb);
+        else {                                     // keep the instruction count per iteration constant for the vmcnt arithmetic
+#pragma unroll
+            for (int i = 0; i < PER; ++i) GLDS16_S(reinterpret_cast<const char*>(X), voff[0], lds0 + (unsigned)(NBUF * RB * P) * 8u);
+        }
+        b += lds[buf * RB * P + tid];
+#pragma unroll
+        for (int i = 0; i < NM; ++i) acc[i & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i & 3], 0, 0, 0);
+        buf = buf + 1 == NBUF ? 0 : buf + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 12345.678) out[tid] = acc[0][0];
+}
+
 __global__ void fill_kernel(double* X, long n) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     for (; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -132,5 +187,17 @@ int main(int argc, char** argv)
             }
             printf("mode %d grid %d: %.3f ms  %.2f TB/s\n", mode, grid, best, (double)N * P * 8 / (best * 1e-3) / 1e12);
         }
+
+#define RUN3(NM, NBUF, RB) do { \
+        const size_t l = (size_t)(NBUF * RB * P + 1024) * 8; \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dma_mfma<NM, NBUF, RB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l); \
+        float best = 1e9f; \
+        for (int rep = 0; rep < 5; ++rep) { hipEventRecord(e0); hipLaunchKernelGGL((k_dma_mfma<NM, NBUF, RB>), dim3(256), dim3(512), l, 0, X, N, out); \
+            hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); if (rep && ms < best) best = ms; } \
+        printf("dma+mfma: %2d MFMAs per wave and %d-row stage, %d stages: %.3f ms  %.2f TB/s  (MFMA-only time %.3f ms)\n", NM, RB, NBUF, best, \
+               (double)N * P * 8 / (best * 1e-3) / 1e12, (double)(N / RB) / 256.0 * NM * 2 * 64 / 2.4e9 * 1e3); } while (0)
+    RUN3(0, 2, 8); RUN3(16, 2, 8); RUN3(24, 2, 8); RUN3(32, 2, 8);
+    RUN3(8, 4, 4); RUN3(12, 4, 4); RUN3(16, 4, 4);
+    RUN3(12, 3, 4); RUN3(16, 3, 4);
     return 0;
 }
