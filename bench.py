@@ -449,7 +449,10 @@ def embedded_configs(args, env, budget_s=90.0):
     """Short runs of c2..c5 inside the headline's process (N = 1): {cfg: {ms_per_step, kernel_ms, roofline...}} for the
     `configs` object of the one JSON line.  Bounded: a configuration is skipped once the budget is spent."""
     out, t0 = {}, time.perf_counter()
-    for cfg, steps, warmup in (('c2', 20, 3), ('c4', 20, 3), ('c3', 8, 2), ('c5', 2, 1)):
+    order = (('c2', 20, 3), ('c4', 20, 3), ('c3', 8, 2), ('c5', 2, 1))
+    if os.environ.get('LRVB_EMBED_ORDER'):
+        order = tuple(o for name in os.environ['LRVB_EMBED_ORDER'].split(',') for o in order if o[0] == name)
+    for cfg, steps, warmup in order:
         if time.perf_counter() - t0 > budget_s:
             out[cfg] = {'skipped': 'time budget of the embedded runs spent'}
             continue
@@ -513,6 +516,16 @@ def main(args):
     from lrvb_amd.distributed import ShardedHessian, DeviceEngine, shard_rows
 
     world, rank, local_rank, dev, backend, use_dist, rehearse = dist_setup(args, torch, dist)
+
+    # The other four BASELINE.json configurations, short runs in this process (SURVEY.md section 8(d) lists all five), FIRST:
+    # their steps are a few dozen small kernels and host round trips each, and measured after the headline phase (8 GB of
+    # tensors freed, a 30 s numpy leg on 64 BLAS threads) the same steps came out 2-7 x slower than in a process of their own.
+    configs_out = None
+    if world == 1 and rank == 0 and not args.no_configs:
+        import gc
+        configs_out = embedded_configs(args, (world, rank, dev, backend, use_dist))
+        gc.collect()
+        torch.cuda.empty_cache()
 
     N_total, D = int(args.n_obs), int(args.n_free)
     n_pos = D // 4                       # box constraint (lb = 0) on the last quarter
@@ -724,11 +737,8 @@ def main(args):
                 return X[a:b].cpu().numpy(), y[a:b].cpu().numpy()
             out['cpu_baseline'] = cpu_baseline(fetch_rows, N_total, D, n_pos, args.loss, lik_info, prior_info,
                                                theta.cpu().numpy(), budget_s=args.cpu_budget_s)
-    if world == 1 and rank == 0 and not args.no_configs:
-        # the other four BASELINE.json configurations, short runs in this process (SURVEY.md section 8(d) lists all five)
-        del X, y, w, H
-        torch.cuda.empty_cache()
-        out['configs'] = embedded_configs(args, (world, rank, dev, backend, use_dist))
+    if configs_out is not None:
+        out['configs'] = configs_out
     if use_dist:
         dist.destroy_process_group()
     return out if rank == 0 else None
