@@ -548,10 +548,10 @@ class WishartMVNObjective(QuadraticDataObjective):
         M = np.zeros((Vn, q, q))
         c = np.zeros(Vn)
         vm = v @ m
-        for i in range(d):
-            Mi = M[self._ms.start + i]
-            Mi[:d, d] = Mi[d, :d] = -nu * v[:, i]
-            Mi[d, d] = 2.0 * nu * vm[i]
+        Mm = M[self._ms.start:self._ms.start + d]
+        Mm[:, :d, d] = -nu * v.T
+        Mm[:, d, :d] = -nu * v.T
+        Mm[:, d, d] = 2.0 * nu * vm
         PVP = P @ v @ P
         r, cidx = np.tril_indices(d)
         fac = np.where(r == cidx, 1.0, 2.0)
@@ -564,15 +564,17 @@ class WishartMVNObjective(QuadraticDataObjective):
         c[self._inu] = 0.5 * np.sum(v * P) - 0.5 * kap1
         cmat = 0.5 * nu * P - 0.5 * Vi
         c[self._vs.start:self._vs.stop] = cmat[r, cidx] * fac
-        for k, (i, j) in enumerate(zip(r, cidx)):
-            Mk = M[self._vs.start + k]
-            Mk[i, j] += nu
-            if i != j:
-                Mk[j, i] += nu
-            Em = np.zeros(d)
-            Em[i] += m[j]
-            if i != j:
-                Em[j] += m[i]
-            Mk[:d, d] = Mk[d, :d] = -nu * Em
-            Mk[d, d] = nu * (m @ Em)
+        # the d (d + 1) / 2 matrices of the scale parameters, all at once (a Python loop over 2016 of them was ~10 ms at d = 63):
+        # M_k = nu [[E_ij + E_ji, -Em], [-Em^T, m . Em]],  Em = e_i m_j + e_j m_i  (once for i = j)
+        kk = np.arange(r.size)
+        Mv = M[self._vs.start:self._vs.stop]
+        off = r != cidx
+        Mv[kk, r, cidx] += nu
+        Mv[kk[off], cidx[off], r[off]] += nu
+        Em = np.zeros((r.size, d))
+        Em[kk, r] += m[cidx]
+        Em[kk[off], cidx[off]] += m[r[off]]
+        Mv[:, :d, d] = -nu * Em
+        Mv[:, d, :d] = -nu * Em
+        Mv[:, d, d] = nu * (Em @ m)
         return M, c
