@@ -75,7 +75,8 @@ int launch_mixture_rows(lrvb_ctx* c, int K, const double* theta_z_dev, const dou
     const int V = (int)c->P;
     if (V + 1 > 32 || K > 32 || K < 2) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "mixture kernel supports V + 1 <= 32 and 2 <= K <= 32");
     if (c->N > 2147483647LL) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "mixture kernel indexes rows with 32 bits");
-    i64 grid = (c->N + 3) / 4;
+    if (lda != (i64)mixture_rows_lda(K)) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "mixture kernel writes rows of K (K + 1) / 2 doubles padded to an even length (got lda = %lld)", (long long)lda);
+    i64 grid = ((c->N + 1) / 2 + 3) / 4;                  // two rows per wavefront, four wavefronts per workgroup
     if (grid > 4096) grid = 4096;
     LRVB_TRY(buf_reserve(c, c->part_val, (size_t)(2 * grid)));
     // todo list of rows for the dense pass: N ints + the counter, in the observation scratch buffer

@@ -8,7 +8,7 @@ int mixture_rows_launch_3(lrvb_ctx* c, int K, unsigned grid, unsigned dgrid, con
 {
 #define MX_LAUNCH(KK) do { \
         hipLaunchKernelGGL(mixture_rows_kernel<KK>, dim3(grid), dim3(256), 0, c->stream, \
-            theta_z_dev, c->X.p, V, c->w.p, lam_dev, c->N, Amat_dev, lda, U_dev, gfree_dev, c->part_val.p, bad_dev, \
+            theta_z_dev, c->X.p, V, c->w.p, lam_dev, c->N, Amat_dev, U_dev, gfree_dev, c->part_val.p, bad_dev, \
             c->force_dense_rows, todo, todo_count); \
         hipLaunchKernelGGL(mixture_rows_dense_kernel<((KK) <= 8 ? 8 : ((KK) <= 16 ? 16 : 32))>, dim3(dgrid), dim3(256), 0, c->stream, \
             KK, theta_z_dev, c->X.p, V, c->w.p, lam_dev, Amat_dev, lda, bad_dev, todo, todo_count); } while (0)

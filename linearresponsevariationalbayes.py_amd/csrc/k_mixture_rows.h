@@ -20,6 +20,8 @@
 #include "lrvb_internal.h"
 #include <math.h>
 
+typedef double d4 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ double mx_bcast(double v, int src_lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
@@ -91,50 +93,191 @@ __device__ __forceinline__ MixRow mixture_row_prelude(int K, const MixIn& in, in
     return r;
 }
 
+// All-reduce over the 32 lanes of a HALF wavefront without the LDS crossbar: four DPP steps inside the 16-lane rows
+// (xor 1, xor 2, half-row mirror, row mirror) and one v_permlane16_swap (gfx950) across the two rows of the half --
+// 17 VALU instructions for a double, against 6 x (2 ds_bpermute + wait) for the full-wave butterfly above.
+template <int CTRL> __device__ __forceinline__ double mx_dpp(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// v of rows (0, 1, 2, 3) -> a = (0, 0, 2, 2) and b = (1, 1, 3, 3) (or the other way round: both uses are symmetric)
+#define MX_ROW_PAIR(v, a, b) \
+    const unsigned v##_lo = (unsigned)__double2loint(v), v##_hi = (unsigned)__double2hiint(v); \
+    const auto v##_l = __builtin_amdgcn_permlane16_swap(v##_lo, v##_lo, false, false); \
+    const auto v##_h = __builtin_amdgcn_permlane16_swap(v##_hi, v##_hi, false, false); \
+    const double a = __hiloint2double((int)v##_h[0], (int)v##_l[0]), b = __hiloint2double((int)v##_h[1], (int)v##_l[1])
+__device__ __forceinline__ double mx_half_sum(double v) {
+    v += mx_dpp<0xB1>(v);           // quad_perm [1, 0, 3, 2]
+    v += mx_dpp<0x4E>(v);           // quad_perm [2, 3, 0, 1]
+    v += mx_dpp<0x141>(v);          // row_half_mirror
+    v += mx_dpp<0x140>(v);          // row_mirror
+    MX_ROW_PAIR(v, a, b);
+    return a + b;
+}
+__device__ __forceinline__ double mx_half_max(double v) {
+    v = fmax(v, mx_dpp<0xB1>(v));
+    v = fmax(v, mx_dpp<0x4E>(v));
+    v = fmax(v, mx_dpp<0x141>(v));
+    v = fmax(v, mx_dpp<0x140>(v));
+    MX_ROW_PAIR(v, a, b);
+    return fmax(a, b);
+}
+
 // Pass 1: values, local gradient, statistics row, and A_n by the O(K) diagonal-plus-rank-two formula.
 // Rows that need the dense factorisation (a small or negative d_k, or force_dense) are appended to `todo`.
+//
+// Round 2 ran one row per wavefront with full-wave ds_bpermute butterflies and K broadcast reads + 4 K fused multiply-adds
+// per lane for A_n: 2.55 ms at N = 1e6, K = 32 (2.1 TB/s of writes).  What changed (measurements: DESIGN.md section 12):
+//  * TWO rows per wavefront: lanes 0..31 <-> the categories of row 2q, lanes 32..63 <-> those of row 2q + 1 (K <= 32): no
+//    lane idles at K = 32 and every reduction stays inside a half (mx_half_sum, no LDS crossbar).
+//  * A_n = diag(c3) + sum_kk R[kk] C[kk]^T is a rank-FOUR update of a diagonal: exactly one v_mfma_f64_16x16x4 per 16 x 16
+//    block (three blocks of the lower triangle at K = 32).
+//  * The packed row of A_n is assembled in LDS and written out LINEARLY, 16 bytes per lane.  The kernel is bound by the
+//    write requests the vector L1 (TCP) can have in flight towards L2 (TA_DATA_STALLED_BY_TC and TCP_PENDING_STALL ~ 100 % of
+//    the kernel's cycles, ~565 cycles per request): written straight from the MFMA layout, a row was 12 instructions of
+//    four unaligned 128-byte segments = ~90 requests of 47 bytes on average; linearly it is 66 full 64-byte requests.
+//  * Every memory operation of the loop is written by hand so that no wait drains the stores: the inputs of the NEXT pair
+//    arrive by LDS-DMA, every store is ALWAYS issued (rows or lanes that must not be written are masked through EXEC,
+//    never branched around), exactly MX_STORES stores follow the DMAs of a pair and the wait for them is vmcnt(MX_STORES).
+//    (hipcc cannot count stores behind branches and waits vmcnt(0) for any load -- draining the stores in every iteration.)
+#ifndef MX_WAVES_ATTR
+#define MX_WAVES_ATTR
+#endif
+// stores and LDS-DMA loads under an explicit EXEC mask (call sites are wave-uniform control flow: EXEC is all ones there)
+#define MX_ST(sbase, voff, val, mask) asm volatile("s_mov_b64 exec, %3\n\tglobal_store_dwordx2 %0, %1, %2\n\ts_mov_b64 exec, -1" \
+    :: "v"(voff), "v"(val), "s"(sbase), "s"(mask) : "memory")
+#ifndef MX_ST16_MODE                  // lab knob: cache-policy bits of the 16-byte stores of A_n
+#define MX_ST16_MODE 0
+#endif
+#if MX_ST16_MODE == 1
+#define MX_ST16_MOD "nt"
+#elif MX_ST16_MODE == 2
+#define MX_ST16_MOD "sc0"
+#elif MX_ST16_MODE == 3
+#define MX_ST16_MOD "sc1"
+#elif MX_ST16_MODE == 4
+#define MX_ST16_MOD "sc0 sc1"
+#elif MX_ST16_MODE == 5
+#define MX_ST16_MOD "nt sc1"
+#else
+#define MX_ST16_MOD ""
+#endif
+#define MX_ST16(sbase, voff, val, mask) asm volatile("s_mov_b64 exec, %3\n\tglobal_store_dwordx4 %0, %1, %2 " MX_ST16_MOD "\n\ts_mov_b64 exec, -1" \
+    :: "v"(voff), "v"(val), "s"(sbase), "s"(mask) : "memory")
+#define MX_DMA4(sbase, voff, ldsaddr, mask) asm volatile("s_mov_b32 m0, %2\n\ts_mov_b64 exec, %3\n\tglobal_load_lds_dword %0, %1\n\ts_mov_b64 exec, -1" \
+    :: "v"(voff), "s"(sbase), "s"(ldsaddr), "s"(mask) : "memory")
+template <int N_> struct MxWait { static __device__ __forceinline__ void vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N_) : "memory"); } };
+typedef double mx_d2 __attribute__((ext_vector_type(2)));
+
+// row length of the operand matrix the kernel writes: the packed lower triangle, padded to an even number of doubles
+__host__ __device__ constexpr int mixture_rows_lda(int K) { return K * (K + 1) / 2 + ((K * (K + 1) / 2) & 1); }
+
 template <int K>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256) MX_WAVES_ATTR
 void mixture_rows_kernel(const double* __restrict__ theta_z, const double* __restrict__ X, int V,
                          const double* __restrict__ w, const double* __restrict__ Lam, i64 N,
-                         double* __restrict__ Amat, i64 lda, double* __restrict__ U,
+                         double* __restrict__ Amat, double* __restrict__ U,
                          double* __restrict__ gfree, double* __restrict__ part_val, int* __restrict__ bad,
                          int force_dense, int* __restrict__ todo, int* __restrict__ todo_count)
 {
     constexpr int KM = K - 1;
+    constexpr int NB = (K > 16) ? 2 : 1;      // 16 x 16 blocks per side of A_n
+    constexpr int TRI = K * (K + 1) / 2, LDA = mixture_rows_lda(K);
+    constexpr int NSEG = (LDA * 8 + 1023) / 1024;             // 1 KiB store instructions per row
+    constexpr int MX_STORES = 3 + 2 * NSEG;                   // per iteration: U (2), gradient, the two rows of A
+    // factors of a row staged for the MFMA by OUTPUT category c (the swap of categories 0 and m undone):
+    //   R[kk][c] at (c >> 4) * 64 + kk * 16 + (c & 15),  C[kk][c] at 128 + the same,  c3[c] at 256 + c
+    // so that the operand of block b (lane <-> (kk = lane >> 4, c & 15 = lane & 15)) is 64 consecutive doubles: conflict-free
+    constexpr int FROW = 288;
+    constexpr int INB = 2 * 64 + 2;           // inputs of a pair: [logits of rows 2q, 2q + 1 (2 KM) | x rows (2 V) | w (2)], doubles
+    constexpr int RB = (LDA > 128 ? LDA : 128) + 2;           // packed row of A_n; before that, x~ and the (p, g) exchange of both halves
     __shared__ double lam_s[32 * 32];
     __shared__ double vsum[4][2];
-    __shared__ double fstage[4][32 * 4];
-    const int tid = threadIdx.x, lane = tid & 63;
+    __shared__ double fstage[4][2][FROW];
+    __shared__ __attribute__((aligned(16))) double rowbuf[4][RB];
+    __shared__ double inbuf[4][2][INB];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, hl = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int e = tid; e < (V + 1) * K; e += 256) lam_s[e] = Lam[e];
     __syncthreads();
 
-    double v_lin = 0.0, v_ent = 0.0;        // -w sum z s  and  w sum z log z of this wave's rows
+    const bool cat = hl < K, loc = cat && hl >= 1;
+    const i64 npair = (N + 1) / 2, nstep = (i64)gridDim.x * 4;
+    const unsigned lds_in = (unsigned)(uintptr_t)(__attribute__((address_space(3))) double*)inbuf[wave][0];
+    const unsigned voff4 = (unsigned)lane * 4u;
+    // five LDS-DMA instructions, always: the dwords of the pair's two logit rows (contiguous: 4 KM), of its two x rows (4 V),
+    // of its two weights; dwords past the last row of the problem are masked
+    auto issue_inputs = [&](i64 q, int buf) {
+        i64 rows = N - 2 * q;
+        if (rows > 2) rows = 2;
+        if (rows < 0) rows = 0;
+        const i64 q0 = rows > 0 ? q : 0;                                 // keep the (unused) addresses in range
+        const int nz = (int)rows * 2 * KM, nx = (int)rows * 2 * V, nw = (int)rows * 2;
+        const char* zb = reinterpret_cast<const char*>(theta_z + 2 * q0 * KM);
+        const char* xb = reinterpret_cast<const char*>(X + 2 * q0 * V);
+        const char* wb = reinterpret_cast<const char*>(w + 2 * q0);
+        const unsigned dst = lds_in + (unsigned)(buf * INB) * 8u;
+        MX_DMA4(zb, voff4, dst, __ballot(lane < nz));
+        MX_DMA4(zb + 256, voff4, dst + 256u, __ballot(lane + 64 < nz));
+        MX_DMA4(xb, voff4, dst + 512u, __ballot(lane < nx));
+        MX_DMA4(xb + 256, voff4, dst + 768u, __ballot(lane + 64 < nx));
+        MX_DMA4(wb, voff4, dst + 1024u, __ballot(lane < nw));
+    };
+
+    double v_lin = 0.0, v_ent = 0.0;        // -w sum z s  and  w sum z log z, per LANE until the end of the kernel
     int flag = 0;
-    const i64 nstep = (i64)gridDim.x * 4;
-    i64 n = (i64)blockIdx.x * 4 + wave;
-    MixIn nxt_in = mixture_row_load(K, theta_z, X, V, w, n < N ? n : N - 1, lane);
-    for (; n < N; n += nstep) {
-        const MixIn in = nxt_in;
-        nxt_in = mixture_row_load(K, theta_z, X, V, w, (n + nstep < N) ? n + nstep : N - 1, lane);   // next row in flight
-        const MixRow r = mixture_row_prelude(K, in, V, lam_s, lane);
-        const double wn = r.wn, ps = r.ps;
-        const bool cat = r.cat;
-        const int m = r.m;
-        v_lin += mx_wave_sum(cat ? -wn * r.p * r.s : 0.0);
-        v_ent += mx_wave_sum(cat ? wn * r.p * r.logp : 0.0);
-        // free local gradient: J^T g, lane j <-> free index j:  p_{j+1} (g_{j+1} - g.p)
-        {
-            const double pn = __shfl_down(r.p, 1, 64), gn = __shfl_down(r.g, 1, 64);
-            if (lane < KM) gfree[n * KM + lane] = pn * (gn - r.gdotp);
+    double* fs = fstage[wave][h];
+    double* rbw = rowbuf[wave];
+    double* es = rbw + 64 * h;              // x~ of the half, then its (p, g) exchange: both dead before the row is assembled
+    const double* lam_col = lam_s + (cat ? hl : 0);
+    const int pg = lane >> 4, pj = lane & 15;
+
+    i64 q = (i64)blockIdx.x * 4 + wave;
+    int buf = 0;
+    issue_inputs(q, 0);
+    MxWait<0>::vm();
+    for (; q < npair; q += nstep, buf ^= 1) {
+        const i64 n = 2 * q + h;
+        const bool valid = n < N;
+        const double* ib = inbuf[wave][buf];
+        const double logit = loc ? ib[h * KM + hl - 1] : 0.0;            // lane (h, hl) <-> row 2 q + h, category hl; logit 0 for category 0
+        const double xt = (hl >= 1 && hl <= V) ? ib[64 + h * V + hl - 1] : ((hl == 0) ? 1.0 : 0.0);
+        const double wn = ib[128 + h];
+        es[hl] = xt;                                                      // x~ of the row, broadcast source of the s loop
+        issue_inputs(q + nstep, buf ^ 1);                                 // 5 DMAs, then exactly MX_STORES stores until the wait below
+        const unsigned long long vm_ = __ballot(valid);
+        const char* ub = reinterpret_cast<const char*>(U + 2 * q * 64);
+        const char* gb = reinterpret_cast<const char*>(gfree + 2 * q * KM);
+        MX_ST(ub, (unsigned)(h * 64 + hl) * 8u, xt, vm_);                 // sufficient-statistics row [x~ (32) | z (32)]
+        const double mxl = mx_half_max(cat ? logit : -INFINITY);
+        const double ex = cat ? exp(logit - mxl) : 0.0;
+        const double den = mx_half_sum(ex);
+        const double p = ex / den;
+        const double logp = cat ? (logit - mxl - log(den)) : 0.0;
+        MX_ST(ub, (unsigned)(h * 64 + 32 + hl) * 8u, cat ? p : 0.0, vm_);
+        double s = 0.0;
+        for (int j = 0; j <= V; ++j) s += es[j] * lam_col[j * K];
+        if (!cat) s = 0.0;
+        const double g = cat ? -wn * (s - logp - 1.0) : 0.0;
+        const double gdotp = mx_half_sum(g * p);
+        if (valid) {
+            v_lin += cat ? -wn * p * s : 0.0;
+            v_ent += cat ? wn * p * logp : 0.0;
         }
-        // sufficient-statistics row [x~ (32) | z (32)]
-        {
-            const double zsh = __shfl(r.p, lane - 32, 64);
-            U[n * 64 + lane] = (lane < 32) ? r.xt : ((lane - 32 < K) ? zsh : 0.0);
-        }
-        if (lda > (i64)K * (K + 1) / 2 && lane == 0) Amat[n * lda + (i64)K * (K + 1) / 2] = 0.0;     // even-width padding column
+        MX_ST(gb, (unsigned)(h * KM + hl - 1) * 8u, p * (g - gdotp), __ballot(valid && loc));     // J^T g:  p_{j+1} (g_{j+1} - g.p)
+        // reference category of the row = its arg-max category m (see mixture_row_prelude): categories 0 and m change places
+        const unsigned long long bal = __ballot(cat && logit == mxl);
+        int m = __ffs((unsigned)(h ? (bal >> 32) : bal)) - 1;
+        if (m < 0) m = 0;                                                 // a row of NaN logits: keep the addresses in range
+        __builtin_amdgcn_wave_barrier();
+        es[2 * hl] = p; es[2 * hl + 1] = g;
+        __builtin_amdgcn_wave_barrier();
+        const double p_m = es[2 * m], g_m = es[2 * m + 1], p_0 = es[0], g_0 = es[1];
+        __builtin_amdgcn_wave_barrier();
+        const double ps = (hl == 0) ? p_m : ((hl == m) ? p_0 : p);
+        const double gs = (hl == 0) ? g_m : ((hl == m) ? g_0 : g);
         // M = Dg - r s^T - s r^T with Dg = diag(d), d_k = w + g_k - g.p, s = r o (d - w/2): a DIAGONAL plus a
         // rank-two term, so M^-1 follows from the Woodbury identity in O(K) and
         //   A = diag(t) - t p^T - p t^T + alpha p p^T - [a1 a2] T^-1 [a1 a2]^T,   t_k = p_k / d_k (k >= 1),
@@ -142,47 +285,75 @@ void mixture_rows_kernel(const double* __restrict__ theta_z, const double* __res
         //   a1 = t - alpha p,  a2 = (p - w t / 2)[k >= 1] - beta p.
         // With Dg > 0, M is positive definite iff det T < 0 (inertia additivity); det T = -p_ref at the
         // optimum of the row.
-        const bool loc = cat && lane >= 1;
-        const double dk = wn + r.gs - r.gdotp;
-        const double dmin = -mx_wave_max(loc ? -dk : -INFINITY);
-        const bool fastp = __builtin_amdgcn_readfirstlane((int)(!force_dense && wn > 0.0 && dmin > 0.05 * wn)) != 0;
-        if (!fastp) {
-            if (lane == 0) todo[atomicAdd(todo_count, 1)] = (int)n;
-            continue;
-        }
+        const double dk = wn + gs - gdotp;
+        const double dmin = -mx_half_max(loc ? -dk : -INFINITY);
+        const bool fastp = !force_dense && wn > 0.0 && dmin > 0.05 * wn;         // uniform over the half
+        if (valid && !fastp && hl == 0) todo[atomicAdd(todo_count, 1)] = (int)n;
+        const bool emit = valid && fastp;
         const double t = loc ? ps / dk : 0.0;
-        const double alpha = mx_wave_sum(t);
-        const double sumq = mx_wave_sum(loc ? ps : 0.0);
+        const double alpha = mx_half_sum(t);
+        const double sumq = mx_half_sum(loc ? ps : 0.0);
         const double beta = sumq - 0.5 * wn * alpha;
-        const double gamma = mx_wave_sum(loc ? ps * dk : 0.0) - wn * sumq + 0.25 * wn * wn * alpha;
+        const double gamma = mx_half_sum(loc ? ps * dk : 0.0) - wn * sumq + 0.25 * wn * wn * alpha;
         const double det = alpha * gamma - (beta - 1.0) * (beta - 1.0);
-        if (!(det < 0.0)) flag = 1;
+        if (emit && !(det < 0.0)) flag = 1;
         const double idet = 1.0 / det;
         const double t11 = gamma * idet, t12 = (1.0 - beta) * idet, t22 = alpha * idet;
         const double a1 = cat ? t - alpha * ps : 0.0;
         const double a2 = cat ? (loc ? ps - 0.5 * wn * t : 0.0) - beta * ps : 0.0;
         const double w2 = wn * wn;
-        const double b1 = w2 * (a1 * t11 + a2 * t12), b2 = w2 * (a1 * t12 + a2 * t22);
-        const double c1 = w2 * (alpha * ps - t), c2 = w2 * ps, c3 = w2 * t;
-        double* fs = fstage[wave];
-        if (lane < 32) { fs[4 * lane] = ps; fs[4 * lane + 1] = t; fs[4 * lane + 2] = a1; fs[4 * lane + 3] = a2; }
+        const int colp = (hl == 0) ? m : ((hl == m) ? 0 : hl);            // lane <-> OUTPUT column (the swap undone)
+        double* fc = fs + (colp >> 4) * 64 + (colp & 15);
+        fc[0] = ps;                          fc[16] = t;              fc[32] = a1;            fc[48] = a2;
+        fc[128] = w2 * (alpha * ps - t);     fc[144] = -w2 * ps;
+        fc[160] = -w2 * (a1 * t11 + a2 * t12);                        fc[176] = -w2 * (a1 * t12 + a2 * t22);
+        fs[256 + colp] = w2 * t;
         __builtin_amdgcn_wave_barrier();
-        // A is symmetric: only its lower triangle is stored, packed (row r, column c <= r at r(r+1)/2 + c);
-        // lane <-> column, so a row is one contiguous store
-        const int colp = (lane == 0) ? m : ((lane == m) ? 0 : lane);
-        double* arow = Amat + n * lda + colp;
-#pragma unroll 8
-        for (int kp = 0; kp < K; ++kp) {
-            const double pk = fs[4 * kp], tk = fs[4 * kp + 1], a1k = fs[4 * kp + 2], a2k = fs[4 * kp + 3];
-            double v = c1 * pk - c2 * tk - b1 * a1k - b2 * a2k;
-            if (kp == lane) v += c3;
-            const int rowp = (kp == 0) ? m : ((kp == m) ? 0 : kp);
-            if (cat && rowp >= colp) arow[rowp * (rowp + 1) / 2] = v;
+        const unsigned long long em = __ballot(emit);
+#pragma unroll
+        for (int row = 0; row < 2; ++row) {
+            const bool on = (em >> (32 * row)) & 1ull;                    // wave-uniform; a row that is off still issues its stores
+            const double* rb = fstage[wave][row];
+#pragma unroll
+            for (int bi = 0; bi < NB; ++bi) {
+                const double aop = rb[64 * bi + lane];
+#pragma unroll
+                for (int bj = 0; bj <= bi; ++bj) {
+                    const double bop = rb[128 + 64 * bj + lane];
+                    d4 acc = {0.0, 0.0, 0.0, 0.0};
+                    if (bi == bj) {
+                        const double dg = rb[256 + 16 * bj + pj];
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) acc[v] = (pg + 4 * v == pj) ? dg : 0.0;
+                    }
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {                          // D: reg v <-> row g + 4 v, column j of the block
+                        const int r = 16 * bi + pg + 4 * v, c = 16 * bj + pj;
+                        if (r < K && c <= r) rbw[r * (r + 1) / 2 + c] = acc[v];       // packed lower triangle
+                    }
+                }
+            }
+            if (LDA > TRI && lane == 0) rbw[TRI] = 0.0;                   // even-width padding column
+            __builtin_amdgcn_wave_barrier();
+            const char* arow = reinterpret_cast<const char*>(Amat + (2 * q + row) * (i64)LDA);
+#pragma unroll
+            for (int sg = 0; sg < NSEG; ++sg) {
+                const int e2 = sg * 64 + lane;                            // pair of doubles
+                const mx_d2 val = *reinterpret_cast<const mx_d2*>(rbw + 2 * (e2 < LDA / 2 ? e2 : 0));
+#ifdef MX_LAB_NO_ASTORE                                                    // ablation: the compute without the 4.2 KB row of A_n
+                MX_ST16(arow, (unsigned)e2 * 16u, val, __ballot(on && e2 < LDA / 2 && val[0] == 1.2345e300));
+#else
+                MX_ST16(arow, (unsigned)e2 * 16u, val, __ballot(on && e2 < LDA / 2));
+#endif
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
+        MxWait<MX_STORES>::vm();                                          // the DMAs of the next pair have landed; the stores fly on
     }
+    v_lin = mx_wave_sum(v_lin); v_ent = mx_wave_sum(v_ent);
     if (lane == 0) { vsum[wave][0] = v_lin; vsum[wave][1] = v_ent; }
-    if (flag && lane == 0) atomicOr(bad, 1);
+    if (flag && hl == 0) atomicOr(bad, 1);
     __syncthreads();
     if (tid == 0) {
         part_val[2 * blockIdx.x] = ((vsum[0][0] + vsum[1][0]) + vsum[2][0]) + vsum[3][0];

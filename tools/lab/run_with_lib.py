@@ -4,6 +4,7 @@ The product library is never replaced; the variant is loaded in its place for th
 import sys, os, runpy
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root)
+sys.path.insert(0, os.path.join(root, 'tools'))
 import lrvb_amd._hip as h
 h.LIB_PATH = os.path.join(root, 'tools', 'lab', sys.argv[1])
 sys.argv = [sys.argv[2]] + sys.argv[3:]
