@@ -16,7 +16,7 @@ Reference module names are importable as attributes for drop-in code
 from .version import __version__
 from . import version
 
-from .packing import (ScalarParam, VectorParam, ArrayParam, PosDefMatrixParam, PosDefMatrixParamVector,
+from .packing import (ScalarParam, VectorParam, HyperVectorParam, ArrayParam, PosDefMatrixParam, PosDefMatrixParamVector,
                       PosDefMatrixParamArray, SimplexParam, SubspaceVectorParam,
                       ModelParamsDict, ModelParamsDictValues, convert_vector_to_free_hessian)
 from .families import (UVNParam, UVNParamVector, UVNParamArray, UVNMomentParamArray, MVNParam,

@@ -21,7 +21,7 @@ from scipy import sparse as sp_sparse
 
 from . import _hip
 from .models import DeviceContext
-from .packing import VectorParam
+from .packing import VectorParam, HyperVectorParam, ResidentVector
 from .quadform import duplication_matrix
 
 
@@ -61,9 +61,9 @@ class LMMObjective(object):
         self.ctx.set_data(_hip.SLOT_X, np.hstack([x, y]))
         self.ctx.set_groups(groups, G)
         w0 = np.ones(self.n_obs) if weights is None else _hip.as_f64(weights).ravel().copy()
-        self.weights_par = VectorParam('weights', self.n_obs, val=w0)
+        self.weights_par = HyperVectorParam('weights', self.n_obs, val=w0)
         self.tilt_par = None
-        self._w_cache = None
+        self._w_res = ResidentVector()
         self._stats_cache = None
         self._external_stats = None
 
@@ -104,10 +104,9 @@ class LMMObjective(object):
 
     # ---- sufficient statistics (GPU) ---------------------------------------------------------
     def _push_state(self):
-        w = np.asarray(self.weights_par.get_vector(), dtype=np.float64)
-        if self._w_cache is None or not np.array_equal(w, self._w_cache):
+        w = self._w_res.changed(self.weights_par)              # O(1) for the objective's own HyperVectorParam
+        if w is not None:
             self.ctx.set_weights(w)
-            self._w_cache = w.copy()
             self._stats_cache = None
             self._S_dev = None
 

@@ -17,7 +17,7 @@ import numpy as np
 
 from . import _hip
 from .models import DeviceContext
-from .packing import VectorParam
+from .packing import VectorParam, HyperVectorParam, ResidentVector
 
 
 class LogitNormalRegressionObjective(object):
@@ -41,16 +41,15 @@ class LogitNormalRegressionObjective(object):
         self._y = _hip.as_f64(y).ravel().copy()
         self.ctx.set_data(_hip.SLOT_Y, self._y)
         w0 = np.ones(self.n_obs) if weights is None else _hip.as_f64(weights).ravel().copy()
-        self.weights_par = VectorParam('weights', self.n_obs, val=w0)
+        self.weights_par = HyperVectorParam('weights', self.n_obs, val=w0)
         self.tilt_par = None
-        self._w_cache = None
+        self._w_res = ResidentVector()
         self._x = x
 
     def _push_state(self):
-        w = np.asarray(self.weights_par.get_vector(), dtype=np.float64)
-        if self._w_cache is None or not np.array_equal(w, self._w_cache):
+        w = self._w_res.changed(self.weights_par)              # O(1) for the objective's own HyperVectorParam
+        if w is not None:
             self.ctx.set_weights(w)
-            self._w_cache = w.copy()
             self._h_key = None
 
     def _eta(self, x, is_free):
@@ -132,7 +131,7 @@ class LogitNormalRegressionObjective(object):
 
     def _hessian_cached(self, x, is_free):
         self._push_state()
-        key = (bool(is_free), np.asarray(x, dtype=np.float64).tobytes(), self._w_cache.tobytes())
+        key = (bool(is_free), np.asarray(x, dtype=np.float64).tobytes(), self._w_res.key)
         if getattr(self, '_h_key', None) != key:
             self._h_val = self.hessian(x, is_free)
             self._h_key = key

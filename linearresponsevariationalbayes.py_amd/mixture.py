@@ -24,7 +24,7 @@ from scipy import special, sparse
 
 from . import _hip
 from .models import DeviceContext
-from .packing import VectorParam
+from .packing import VectorParam, HyperVectorParam, ResidentVector
 
 
 def _dirichlet_terms(alpha, d):
@@ -85,9 +85,9 @@ class MixtureObjective(object):
         self.ctx = DeviceContext(blocks, loss='data_only', n_obs=N, n_cols=V, device=device)
         self.ctx.set_data(_hip.SLOT_X, x)
         w0 = np.ones(N) if weights is None else _hip.as_f64(weights).ravel().copy()
-        self.weights_par = VectorParam('weights', N, val=w0)
+        self.weights_par = HyperVectorParam('weights', N, val=w0)
         self.tilt_par = None
-        self._w_cache = None
+        self._w_res = ResidentVector()
         self._external_stats = None
         # Opt-in for repeated evaluations at ONE local point (benchmarks, several moment sets at an optimum): the
         # N (K - 1) simplex logits are uploaded by the first call and reused from HBM afterwards.  The caller promises
@@ -106,10 +106,9 @@ class MixtureObjective(object):
         return fz
 
     def _push_state(self):
-        w = np.asarray(self.weights_par.get_vector(), dtype=np.float64)
-        if self._w_cache is None or not np.array_equal(w, self._w_cache):
+        w = self._w_res.changed(self.weights_par)              # O(1) for the objective's own HyperVectorParam
+        if w is not None:
             self.ctx.set_weights(w)
-            self._w_cache = w.copy()
 
     # ---- pieces ------------------------------------------------------------------------------------
     def _split(self, free_val):

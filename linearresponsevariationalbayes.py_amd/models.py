@@ -17,7 +17,7 @@ import ctypes
 import numpy as np
 
 from . import _hip
-from .packing import VectorParam
+from .packing import VectorParam, HyperVectorParam, ResidentVector
 
 _LOSSES = {None: _hip.LOSS_NONE, 'none': _hip.LOSS_NONE, 'gaussian': _hip.LOSS_GAUSSIAN,
            'logistic': _hip.LOSS_LOGISTIC, 'poisson': _hip.LOSS_POISSON, 'data_only': _hip.LOSS_DATA_ONLY}
@@ -640,7 +640,8 @@ class DeviceObjective(object):
     declared counterpart of the keyword pass-through at LRVB/test_objectives.py:161-217.
 
     Hyper-parameters (for TwoParameterObjective / ParametricSensitivityLinearApproximation):
-      `weights_par`  VectorParam('weights', N) holding the per-observation weights
+      `weights_par`  HyperVectorParam('weights', N) holding the per-observation weights (a VectorParam whose value is a
+                     private read-only copy with a version stamp: the resident copy is checked in O(1))
                      (Example.ipynb:254, 425-441);
       `tilt_par`     VectorParam('tilt', V) holding the linear tilt b
                      (the `hyper_param @ theta` term of LRVB/test_model_sensitivity.py:56-66).
@@ -682,33 +683,31 @@ class DeviceObjective(object):
         self.scale_fun = scale_fun
         self.weights_par = None
         self.tilt_par = None
-        self._w_cache = None
-        self._b_cache = None
+        self._w_res = ResidentVector()
+        self._b_res = ResidentVector()
         if loss is not None:
             self.ctx.set_data(_hip.SLOT_X, x)
             self.ctx.set_data(_hip.SLOT_Y, _hip.as_f64(y).ravel())
             w0 = np.ones(n_obs) if weights is None else _hip.as_f64(weights).ravel().copy()
-            self.weights_par = VectorParam('weights', n_obs, val=w0)
+            self.weights_par = HyperVectorParam('weights', n_obs, val=w0)
         if quad_kind != _hip.QUAD_NONE:
             self.ctx.set_data(_hip.SLOT_QUAD_A, quad_A)
             if quad_m is not None:
                 self.ctx.set_data(_hip.SLOT_QUAD_M, _hip.as_f64(quad_m).ravel())
             b0 = np.zeros(V) if quad_b is None else _hip.as_f64(quad_b).ravel().copy()
-            self.tilt_par = VectorParam('tilt', V, val=b0)
+            self.tilt_par = HyperVectorParam('tilt', V, val=b0)
         self._push_state()
 
     # ---- state pushed before every evaluation ------------------------------------------
     def _push_state(self):
         if self.weights_par is not None:
-            w = np.asarray(self.weights_par.get_vector(), dtype=np.float64)
-            if self._w_cache is None or not np.array_equal(w, self._w_cache):
+            w = self._w_res.changed(self.weights_par)          # O(1) for the objective's own HyperVectorParam
+            if w is not None:
                 self.ctx.set_weights(w)
-                self._w_cache = w.copy()
         if self.tilt_par is not None:
-            b = np.asarray(self.tilt_par.get_vector(), dtype=np.float64)
-            if self._b_cache is None or not np.array_equal(b, self._b_cache):
+            b = self._b_res.changed(self.tilt_par)
+            if b is not None:
                 self.ctx.set_data(_hip.SLOT_QUAD_B, b)
-                self._b_cache = b.copy()
 
     def _push(self, argv=(), argk=None):
         self._push_state()

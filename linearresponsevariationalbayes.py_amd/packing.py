@@ -233,6 +233,52 @@ class VectorParam(_BoxParam):
         return self._size
 
 
+class HyperVectorParam(VectorParam):
+    """The VectorParam a device objective creates for its per-observation weights (and its tilt): same interface, but the
+    value is a PRIVATE, READ-ONLY copy and every `set` / `set_vector` / `set_free` stamps a new `version`.  The objective
+    keeps the vector resident in HBM and has to know before every evaluation whether that copy is current: comparing
+    N = 1e6 weights on the host cost 0.3-0.9 ms per call -- as much as a whole step of configurations 2 and 4 -- where
+    comparing two version numbers costs nothing.  Writing into the array `get()` returns raises (numpy: "assignment
+    destination is read-only") instead of silently leaving the device copy stale; a plain VectorParam assigned to
+    `weights_par` by the caller is still honoured, by the full comparison."""
+    _stamp = [0]
+
+    def set(self, val):
+        val = np.array(val, dtype=np.float64)                 # private copy
+        if val.size != self.size():
+            raise ValueError('Wrong size for vector ' + self.name + '.  Expected: ' + str(self.size()) +
+                             ', got ' + str(val.size))
+        val = val.reshape(self._size)
+        val.flags.writeable = False
+        self._val = val
+        HyperVectorParam._stamp[0] += 1
+        self.version = HyperVectorParam._stamp[0]
+
+
+class ResidentVector(object):
+    """Whether the device copy of a hyper-parameter vector is current: `changed(par)` returns the vector when it has to
+    be uploaded (first use, a new `version`, or -- for parameters without versions -- different contents), else None;
+    `key` identifies the current contents cheaply (for result memos)."""
+
+    def __init__(self):
+        self.key = None
+        self._val = None
+
+    def changed(self, par):
+        w = np.asarray(par.get_vector(), dtype=np.float64)
+        version = getattr(par, 'version', None)
+        if version is not None:
+            if self.key == ('v', version):
+                return None
+            self.key, self._val = ('v', version), None
+            return w
+        if self._val is not None and np.array_equal(w, self._val):
+            return None
+        self._val = w.copy()
+        self.key = ('b', self._val.tobytes())
+        return w
+
+
 class ArrayParam(_BoxParam):
     """LRVB/Parameters.py:234-322 (C-order flattening)."""
 

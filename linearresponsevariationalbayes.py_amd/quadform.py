@@ -19,7 +19,7 @@ import numpy as np
 
 from . import _hip
 from .models import DeviceContext
-from .packing import VectorParam
+from .packing import VectorParam, HyperVectorParam, ResidentVector
 
 
 def duplication_matrix(k):
@@ -51,18 +51,17 @@ class QuadraticDataObjective(object):
             raise ValueError('layout_blocks() of the parameter disagrees with its free/vector sizes')
         self.ctx.set_data(_hip.SLOT_X, z)
         w0 = np.ones(self.n_obs) if weights is None else _hip.as_f64(weights).ravel().copy()
-        self.weights_par = VectorParam('weights', self.n_obs, val=w0)
+        self.weights_par = HyperVectorParam('weights', self.n_obs, val=w0)
         self.tilt_par = None
-        self._w_cache = None
+        self._w_res = ResidentVector()
         self._S = None
         self._W = None
 
     # ---- device state ----------------------------------------------------------------------
     def _push_state(self):
-        w = np.asarray(self.weights_par.get_vector(), dtype=np.float64)
-        if self._w_cache is None or not np.array_equal(w, self._w_cache):
+        w = self._w_res.changed(self.weights_par)              # O(1) for the objective's own HyperVectorParam
+        if w is not None:
             self.ctx.set_weights(w)
-            self._w_cache = w.copy()
             self._S = None
 
     def _stats(self):
@@ -133,7 +132,7 @@ class QuadraticDataObjective(object):
 
     def _hessian_cached(self, x, is_free):
         self._push_state()
-        key = (bool(is_free), np.asarray(x, dtype=np.float64).tobytes(), self._w_cache.tobytes())
+        key = (bool(is_free), np.asarray(x, dtype=np.float64).tobytes(), self._w_res.key)
         if getattr(self, '_h_key', None) != key:
             self._h_val = self.hessian(x, is_free)
             self._h_key = key

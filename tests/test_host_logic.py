@@ -556,3 +556,35 @@ def test_evaluate_terms_with_callable_terms():
     # the module-level differentiate_terms(hess0, dterms) of the reference: same orders as the order-only recursion
     base = ms.get_taylor_base_terms()
     assert sorted(t.key() for t in ms.differentiate_terms(None, base)) == sorted(t.key() for t in taylor_orders(base))
+
+
+def test_hyper_vector_param_versions_and_resident_vector():
+    """The weights vector of a device objective: a private read-only copy with a version stamp, so that "is the copy in
+    HBM current?" costs O(1) (packing.HyperVectorParam / ResidentVector); plain VectorParams are compared in full."""
+    import lrvb_amd as vb
+    from lrvb_amd.packing import HyperVectorParam, ResidentVector
+    w0 = np.arange(5.0)
+    par = HyperVectorParam('weights', 5, val=w0)
+    w0[0] = 99.0                                               # the caller's array is not adopted
+    assert par.get()[0] == 0.0
+    with pytest.raises(ValueError):
+        par.get()[1] = 3.0                                     # loud, instead of a stale device copy
+    with pytest.raises(ValueError):
+        par.set(np.ones(4))
+    res = ResidentVector()
+    assert np.array_equal(res.changed(par), np.arange(5.0))    # first use: upload
+    assert res.changed(par) is None
+    v = par.version
+    par.set_vector(np.arange(5.0))                             # same contents, new stamp: uploaded again (cheap to decide, never wrong)
+    assert par.version > v and res.changed(par) is not None and res.changed(par) is None
+    par.set_free(np.zeros(5))
+    assert res.changed(par) is not None
+    assert np.array_equal(par.get_free(), np.zeros(5)) and par.free_size() == 5 and par.vector_size() == 5
+    k1 = res.key
+    # a caller's own VectorParam: contents decide
+    plain = vb.VectorParam('weights', 5, val=np.ones(5))
+    res2 = ResidentVector()
+    assert res2.changed(plain) is not None and res2.changed(plain) is None
+    plain.get()[2] = 7.0                                       # in-place edit of a plain parameter is seen
+    assert res2.changed(plain)[2] == 7.0 and res2.changed(plain) is None
+    assert res2.key != k1

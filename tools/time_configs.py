@@ -25,7 +25,7 @@ theta = par.get_free()
 w = rng.uniform(0.5, 1.5, N)
 def build2():
     fun.weights_par.set_vector(w + 0.0 * rng.normal())     # new weights object every call: statistics recomputed
-    fun._w_cache = None
+    fun._w_res.key = None
     return obj.fun_free_hessian(theta)
 ms, H = timeit(build2)
 print('C2  N=1e5 D=%d: Hessian build (statistics on GPU + host closed forms) %.2f ms' % (H.shape[0], ms))
@@ -41,7 +41,7 @@ obj5 = vb.Objective(par5, fun5)
 par5['lambda']['df'].set(d + 5.0)
 th5 = par5.get_free()
 def build5():
-    fun5._w_cache = None
+    fun5._w_res.key = None
     return obj5.fun_free_hessian(th5)
 ms, H5 = timeit(build5, reps=2)
 print('C5  N=1e6 D=%d: exact Hessian build (S on GPU + host closed forms + device free-Hessian conversion) %.1f ms' % (H5.shape[0], ms))
@@ -64,7 +64,7 @@ par4 = lmm_par(p4, G4)
 fun4 = vb.LMMObjective(par4, x4, y4, gid4, G4)
 th4 = par4.get_free()
 def stats4():
-    fun4._w_cache = None; fun4._stats_cache = None
+    fun4._w_res.key = None; fun4._stats_cache = None
     return fun4.local_stats()
 ms, _ = timeit(stats4); print('C4  shard N=1.25e6 p=43 G=1e4: sufficient statistics (host weights in) %.2f ms' % ms)
 ms, HS4 = timeit(lambda: fun4.global_hessian(th4), reps=2); print('C4  Schur complement onto the %d global parameters %.1f ms' % (HS4.shape[0], ms))
