@@ -25,6 +25,7 @@ from scipy import special, sparse
 from . import _hip
 from .models import DeviceContext
 from .packing import VectorParam, HyperVectorParam, ResidentVector
+from .specfun import polygamma12
 
 
 def _dirichlet_terms(alpha, d):
@@ -245,16 +246,17 @@ class MixtureObjective(object):
         jg = eta_g - self._lb
         # pi
         a0s = np.sum(alpha)
+        b0s = np.sum(beta, axis=0)
+        # every trigamma / tetragamma of the step in ONE vectorised pass (specfun.polygamma12; scipy's took 0.3-0.7 ms here)
+        t1, t2 = polygamma12(np.concatenate([alpha, [a0s], beta.ravel(), b0s]))
+        p1, p2, p10, p20 = t1[:K], t2[:K], t1[K], t2[K]
+        q1, q2 = t1[K + 1:K + 1 + V * K].reshape(V, K), t2[K + 1:K + 1 + V * K].reshape(V, K)
+        q10, q20 = t1[K + 1 + V * K:], t2[K + 1 + V * K:]
         e = alpha - 1.0 - (C[0] + self.a0 - 1.0)
-        p1, p2 = special.polygamma(1, alpha), special.polygamma(2, alpha)
-        p10, p20 = special.polygamma(1, a0s), special.polygamma(2, a0s)
         se = np.sum(e)
         g_pi, hd_pi, hc_pi, dc_pi = e * p1 - se * p10, p1 + e * p2, -p10 - se * p20, -p10
         # phi: K independent Dirichlets over the V rows
-        b0s = np.sum(beta, axis=0)
         eb = beta - 1.0 - (C[1:] + self.b0 - 1.0)
-        q1, q2 = special.polygamma(1, beta), special.polygamma(2, beta)
-        q10, q20 = special.polygamma(1, b0s), special.polygamma(2, b0s)
         es = np.sum(eb, axis=0)
         g_phi, hd_phi = eb * q1 - es * q10, q1 + eb * q2
         g_vec = np.concatenate([g_pi, g_phi.ravel()])

@@ -588,3 +588,22 @@ def test_hyper_vector_param_versions_and_resident_vector():
     plain.get()[2] = 7.0                                       # in-place edit of a plain parameter is seen
     assert res2.changed(plain)[2] == 7.0 and res2.changed(plain) is None
     assert res2.key != k1
+
+
+def test_polygamma12_matches_scipy():
+    """specfun.polygamma12: trigamma and tetragamma in one vectorised pass (recurrence + asymptotic series), used by the
+    mixture model's Schur assembly instead of two scipy.special.polygamma calls per Dirichlet array."""
+    from scipy import special
+    from lrvb_amd.specfun import polygamma12
+    rng = np.random.default_rng(3)
+    for lo, hi in ((1e-3, 1e-1), (0.1, 2.0), (1.0, 30.0), (10.0, 1e3), (1e3, 1e6)):
+        x = np.exp(rng.uniform(np.log(lo), np.log(hi), (7, 40)))
+        p1, p2 = polygamma12(x)
+        assert p1.shape == x.shape and p2.shape == x.shape
+        assert np.max(np.abs(p1 / special.polygamma(1, x) - 1.0)) < 4e-15
+        assert np.max(np.abs(p2 / special.polygamma(2, x) - 1.0)) < 4e-15
+    p1, p2 = polygamma12(np.array(2.5))                        # scalars pass through
+    assert abs(p1 - special.polygamma(1, 2.5)) < 1e-15 and abs(p2 - special.polygamma(2, 2.5)) < 1e-15
+    x = np.array([-0.5, 1.5])                                  # outside the series' domain: scipy
+    p1, p2 = polygamma12(x)
+    assert np.allclose(p1, special.polygamma(1, x), rtol=0, atol=0) and np.allclose(p2, special.polygamma(2, x), rtol=0, atol=0)
