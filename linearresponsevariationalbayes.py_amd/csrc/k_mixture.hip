@@ -1,6 +1,7 @@
 // k_mixture.hip -- launchers of the mixture-model pipeline (BASELINE.json config 3); the per-row kernels live in
 // k_mixture_rows.h and are instantiated for K = 2 .. 32 in k_mixture_inst0..3.hip.
 #include "k_mixture_rows.h"
+#include <stdlib.h>
 
 int mixture_rows_launch_0(lrvb_ctx* c, int K, unsigned grid, unsigned dgrid, const double* theta_z_dev, int V,
                            const double* lam_dev, double* Amat_dev, i64 lda, double* U_dev, double* gfree_dev,
@@ -77,7 +78,9 @@ int launch_mixture_rows(lrvb_ctx* c, int K, const double* theta_z_dev, const dou
     if (c->N > 2147483647LL) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "mixture kernel indexes rows with 32 bits");
     if (lda != (i64)mixture_rows_lda(K)) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "mixture kernel writes rows of K (K + 1) / 2 doubles padded to an even length (got lda = %lld)", (long long)lda);
     i64 grid = ((c->N + 1) / 2 + 3) / 4;                  // two rows per wavefront, four wavefronts per workgroup
-    if (grid > 4096) grid = 4096;
+    i64 grid_cap = 4096;
+    if (const char* e = getenv("LRVB_MX_GRID")) { const i64 v = atoll(e); if (v >= 1 && v <= 65536) grid_cap = v; }   // lab knob
+    if (grid > grid_cap) grid = grid_cap;
     LRVB_TRY(buf_reserve(c, c->part_val, (size_t)(2 * grid)));
     // todo list of rows for the dense pass: N ints + the counter, in the observation scratch buffer
     LRVB_TRY(buf_reserve(c, c->lp, (size_t)(c->N / 2 + 2)));

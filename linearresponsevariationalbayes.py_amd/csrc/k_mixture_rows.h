@@ -165,7 +165,10 @@ __device__ __forceinline__ double mx_half_max(double v) {
 #endif
 #define MX_ST16(sbase, voff, val, mask) asm volatile("s_mov_b64 exec, %3\n\tglobal_store_dwordx4 %0, %1, %2 " MX_ST16_MOD "\n\ts_mov_b64 exec, -1" \
     :: "v"(voff), "v"(val), "s"(sbase), "s"(mask) : "memory")
-#define MX_DMA4(sbase, voff, ldsaddr, mask) asm volatile("s_mov_b32 m0, %2\n\ts_mov_b64 exec, %3\n\tglobal_load_lds_dword %0, %1\n\ts_mov_b64 exec, -1" \
+#ifndef MX_DMA_MOD                    // lab knob: cache-policy bits of the input DMAs
+#define MX_DMA_MOD ""
+#endif
+#define MX_DMA4(sbase, voff, ldsaddr, mask) asm volatile("s_mov_b32 m0, %2\n\ts_mov_b64 exec, %3\n\tglobal_load_lds_dword %0, %1 " MX_DMA_MOD "\n\ts_mov_b64 exec, -1" \
     :: "v"(voff), "s"(sbase), "s"(ldsaddr), "s"(mask) : "memory")
 template <int N_> struct MxWait { static __device__ __forceinline__ void vm() {
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N_) : "memory"); } };
