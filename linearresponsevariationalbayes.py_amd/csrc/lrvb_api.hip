@@ -70,6 +70,23 @@ static int pinned_reserve(lrvb_ctx* c, size_t n) {
     return LRVB_OK;
 }
 
+// the context's side stream (non-blocking: ordered against nothing but its own events)
+static int ensure_aux(lrvb_ctx* c) {
+    if (!c->aux_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) HIP_TRY(hipEventCreateWithFlags(&c->aux_ev[k], hipEventDisableTiming));
+    }
+    return LRVB_OK;
+}
+// host -> device on the side stream, complete on return: the copy runs BESIDE whatever is queued on the context's stream
+// (the caller guarantees that nothing queued there touches dst)
+static int h2d_beside(lrvb_ctx* c, double* dst, const double* src, size_t n) {
+    if (n == 0) return LRVB_OK;
+    LRVB_TRY(ensure_aux(c));
+    HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyHostToDevice, c->aux_stream));
+    HIP_TRY(hipStreamSynchronize(c->aux_stream));
+    return LRVB_OK;
+}
 static int h2d(lrvb_ctx* c, double* dst, const double* src, size_t n) {
     if (n == 0) return LRVB_OK;
     HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -1790,19 +1807,25 @@ extern "C" int lrvb_quadform_gram(lrvb_ctx* c, const double* M, const double* cv
     double* ncount = sdense + (size_t)q * q;
     LRVB_TRY(launch_tiles_to_dense(c, tile0, q, sdense, q, 0, 0, false));
     EW(fill_kernel, (i64)1, (double)c->N, ncount);
-    // K4 (dense, Pv_t x Pv_t)
-    LRVB_TRY(launch_wsyrk_kron(c, c->zbuf.p, c->Tdense.p));
-    LRVB_TRY(obs_reduce(c, c->Tdense.p, (i64)(tiles_n + (size_t)q * q + 1)));
+    // K4 (dense, Pv_t x Pv_t).  Every buffer of the call is reserved BEFORE the launch (an allocation may synchronise), and
+    // the three host operands -- M is V q^2 doubles: 134 MB in configuration 5 -- are uploaded on the side stream WHILE
+    // the Kronecker kernel runs (they used to wait for it on the context's stream and then cost 12 ms of a 287 ms step).
     LRVB_TRY(buf_reserve(c, c->vtmp2, (size_t)(Pv_t > V ? Pv_t : V)));
+    LRVB_TRY(buf_reserve(c, c->Heta, (size_t)Pv_t * (size_t)Pv_t));
+    LRVB_TRY(buf_reserve(c, c->work1, (size_t)V * (size_t)q * (size_t)q));
+    LRVB_TRY(buf_reserve(c, c->Jdense, (size_t)Pv_t * (size_t)V > (size_t)V * (size_t)D ? (size_t)Pv_t * (size_t)V : (size_t)V * (size_t)D));
+    LRVB_TRY(buf_reserve(c, c->vtmp3, (size_t)(V > D ? V : D)));
+    LRVB_TRY(buf_reserve(c, c->Hfree, (size_t)D * (size_t)D));
+    LRVB_TRY(launch_wsyrk_kron(c, c->zbuf.p, c->Tdense.p));
+    LRVB_TRY(h2d_beside(c, c->work1.p, M, (size_t)V * (size_t)q * (size_t)q));
+    LRVB_TRY(h2d_beside(c, c->g_eta.p, cvec, (size_t)V));
+    LRVB_TRY(h2d_beside(c, c->theta.p, free_in, (size_t)D));
+    LRVB_TRY(obs_reduce(c, c->Tdense.p, (i64)(tiles_n + (size_t)q * q + 1)));
     HIP_TRY(hipMemsetAsync(c->vtmp2.p, 0, (size_t)Pv_t * sizeof(double), c->stream));
     hipLaunchKernelGGL(svec_kernel, dim3(nb256(Pv)), dim3(256), 0, c->stream, sdense, q, c->vtmp2.p);
     HIP_TRY(hipGetLastError());
-    LRVB_TRY(buf_reserve(c, c->Heta, (size_t)Pv_t * (size_t)Pv_t));
     LRVB_TRY(launch_tiles_to_dense(c, c->Tdense.p, Pv_t, c->Heta.p, Pv_t, 0, 0, false));
-    // M~ (Pv_t x V), uploaded through a staging buffer
-    LRVB_TRY(buf_reserve(c, c->work1, (size_t)V * (size_t)q * (size_t)q));
-    LRVB_TRY(h2d(c, c->work1.p, M, (size_t)V * (size_t)q * (size_t)q));
-    LRVB_TRY(buf_reserve(c, c->Jdense, (size_t)Pv_t * (size_t)V > (size_t)V * (size_t)D ? (size_t)Pv_t * (size_t)V : (size_t)V * (size_t)D));
+    // M~ (Pv_t x V) from the uploaded M (work1)
     DevBuf Mt;                                            // scoped device buffers for this call
     LRVB_TRY(buf_reserve(c, Mt, (size_t)Pv_t * (size_t)V));
     HIP_TRY(hipMemsetAsync(Mt.p, 0, (size_t)Pv_t * (size_t)V * sizeof(double), c->stream));
@@ -1817,19 +1840,15 @@ extern "C" int lrvb_quadform_gram(lrvb_ctx* c, const double* M, const double* cv
     // T1 = K4 M~ ;  Av = M~^T T1 ;  t = M~^T s
     if (st == LRVB_OK) st = gemm_tn(c, Pv_t, Pv_t, V, c->Heta.p, Mt.p, T1.p);        // K4 is symmetric: K4 M~ = K4^T M~
     if (st == LRVB_OK) st = gemm_tn(c, Pv_t, V, V, Mt.p, T1.p, Av.p);
-    if (st == LRVB_OK) st = buf_reserve(c, c->vtmp3, (size_t)(V > D ? V : D));
     if (st == LRVB_OK) st = launch_gemv(c, true, Pv_t, V, 1.0, Mt.p, V, c->vtmp2.p, 0.0, c->vtmp3.p);
-    if (st == LRVB_OK) st = h2d(c, c->g_eta.p, cvec, (size_t)V);
     if (st == LRVB_OK) {
         dim3 grid(nb256(V), (unsigned)V);
         hipLaunchKernelGGL(rank_terms_kernel, grid, dim3(256), 0, c->stream, V, (const double*)ncount, c->vtmp3.p, c->g_eta.p, Av.p);
         if (hipGetLastError() != hipSuccess) st = LRVB_ERR_HIP;
     }
     // free coordinates: J^T Av J
-    if (st == LRVB_OK) st = h2d(c, c->theta.p, free_in, (size_t)D);
     if (st == LRVB_OK) st = launch_dense_jac(c, c->theta.p, c->Jdense.p);
     if (st == LRVB_OK) st = gemm_tn(c, V, V, D, Av.p, c->Jdense.p, T1.p);             // Av is symmetric
-    if (st == LRVB_OK) st = buf_reserve(c, c->Hfree, (size_t)D * (size_t)D);
     if (st == LRVB_OK) st = gemm_tn(c, V, D, D, c->Jdense.p, T1.p, c->Hfree.p);
     if (st == LRVB_OK) {
         if (hipMemcpy2DAsync(GtG_out, (size_t)ld * 8, c->Hfree.p, (size_t)D * 8, (size_t)D * 8, (size_t)D, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
@@ -2770,10 +2789,7 @@ static int cg_multi_fused_loop(lrvb_ctx* c, i64 Q, i64 D, double tol, i64 maxite
                                std::vector<int>& info, std::vector<int64_t>& iters) {
     double* s = c->scal.p;
     double* U = c->cgm[6].p; double* W = c->cgm[7].p;
-    if (!c->aux_stream) {
-        HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
-        for (int k = 0; k < 2; ++k) HIP_TRY(hipEventCreateWithFlags(&c->aux_ev[k], hipEventDisableTiming));
-    }
+    LRVB_TRY(ensure_aux(c));
     LRVB_TRY(pinned_reserve(c, 4096));
     // live = (|b| > 0), rho_prev = 0, iterations = 0
     std::vector<double> init((size_t)(5 * Q), 0.0), hb((size_t)Q);
