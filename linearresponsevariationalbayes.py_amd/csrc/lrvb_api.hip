@@ -87,8 +87,34 @@ static int h2d_beside(lrvb_ctx* c, double* dst, const double* src, size_t n) {
     HIP_TRY(hipStreamSynchronize(c->aux_stream));
     return LRVB_OK;
 }
+// small upload: the device reads the pinned slot itself (a kernel in stream order; a copy-engine transfer would put a
+// cross-queue dependency in front of the next kernel -- measured: configuration 2's step 0.66 -> 1.36 ms)
+__global__ void upload_kernel(double* __restrict__ dst, const double* __restrict__ slot, i64 n) {
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) dst[e] = slot[e];
+}
 static int h2d(lrvb_ctx* c, double* dst, const double* src, size_t n) {
     if (n == 0) return LRVB_OK;
+    if (n <= lrvb_ctx::UP_SLOT_DOUBLES) {
+        // through a pinned slot: the caller's (pageable) buffer is consumed by the memcpy, the device copy is stream-ordered and
+        // nobody waits for it -- a synchronising upload cost 10-20 us of host time per call, a dozen times per step in the
+        // small configurations.  A slot is reused only after the event behind its last copy has completed.
+        if (!c->up_ring) {
+            HIP_TRY(hipHostMalloc((void**)&c->up_ring, lrvb_ctx::UP_SLOTS * lrvb_ctx::UP_SLOT_DOUBLES * sizeof(double), hipHostMallocDefault));
+            for (int k = 0; k < lrvb_ctx::UP_SLOTS; ++k) HIP_TRY(hipEventCreateWithFlags(&c->up_ev[k], hipEventDisableTiming));
+            HIP_TRY(hipHostGetDevicePointer((void**)&c->up_ring_dev, c->up_ring, 0));
+        }
+        const int k = c->up_next;
+        c->up_next = (k + 1) % lrvb_ctx::UP_SLOTS;
+        HIP_TRY(hipEventSynchronize(c->up_ev[k]));            // returns at once for an event that was never recorded
+        double* slot = c->up_ring + (size_t)k * lrvb_ctx::UP_SLOT_DOUBLES;
+        memcpy(slot, src, n * sizeof(double));
+        hipLaunchKernelGGL(upload_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, dst,
+                           (const double*)(c->up_ring_dev + (size_t)k * lrvb_ctx::UP_SLOT_DOUBLES), (i64)n);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->up_ev[k], c->stream));
+        return LRVB_OK;
+    }
     HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));      // src is pageable caller memory
     return LRVB_OK;
@@ -205,6 +231,7 @@ extern "C" int lrvb_ctx_destroy(lrvb_ctx* c) {
                       &c->Tdense, &c->work1, &c->chol, &c->cholW, &c->cgH, &c->groups, &c->mx_theta, &c->mx_lam, &c->mx_A, &c->mx_U, &c->mx_g, &c->mx_Xk, &c->mx_R, &c->cgT, &c->ones, &c->cgm[0], &c->cgm[1], &c->cgm[2], &c->cgm[3], &c->cgm[4], &c->cgm[5], &c->cgm[6], &c->cgm[7], &c->cgm[8], &c->rhs, &c->cgx, &c->cgr, &c->cgp, &c->cgq, &c->cgz, &c->scal, &c->opt, &c->dkw, &c->cyv, &c->rvec, &c->red_scratch, &c->gstats, &c->Zs, &c->ws, &c->bpart, &c->gpad, &c->boxmap };
     for (DevBuf* b : all) buf_free(*b);
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
+    if (c->up_ring) { for (int k = 0; k < lrvb_ctx::UP_SLOTS; ++k) if (c->up_ev[k]) (void)hipEventDestroy(c->up_ev[k]); (void)hipHostFree(c->up_ring); }
     for (int k = 0; k < 3; ++k) for (hipEvent_t e : c->ev_pool[k]) (void)hipEventDestroy(e);
     if (c->ev_order) (void)hipEventDestroy(c->ev_order);
     for (int k = 0; k < 2; ++k) if (c->aux_ev[k]) (void)hipEventDestroy(c->aux_ev[k]);

@@ -93,6 +93,10 @@ struct lrvb_ctx {
     DevBuf gpad;                   // even-width zero-padded copies of odd-width TN GEMM operands
     DevBuf ones; i64 ones_n = 0;   // [1 x n | 0 x 64] contraction weights of the plain TN GEMM
     double* host_pinned = nullptr; size_t host_pinned_n = 0;
+    // small host -> device uploads: a ring of pinned slots, so that the copy is a real asynchronous copy in stream order
+    // and the call does not have to synchronise the stream (a pageable source has to be consumed before the call returns)
+    static constexpr int UP_SLOTS = 16; static constexpr size_t UP_SLOT_DOUBLES = 8192;
+    double* up_ring = nullptr; double* up_ring_dev = nullptr; hipEvent_t up_ev[UP_SLOTS] = {}; int up_next = 0;
 
     int n_splits_user = 0;
     bool force_generic_wsyrk = false;   // tuning/testing: use the register-staged kernel
