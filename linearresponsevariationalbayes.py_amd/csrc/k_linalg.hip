@@ -158,15 +158,15 @@ __global__ __launch_bounds__(256)
 void potrf_inv_diag_kernel(double* __restrict__ A, i64 lda, int nb, double* __restrict__ W /* 64 x 64 */,
                            int* __restrict__ info, int col0)
 {
-    // Wave 0 factors the block, lane i <-> row i.  The cross-lane traffic of the factorisation (step j
-    // needs L[k][j] of every later row k in every lane) goes through LDS: the lanes deposit column j once
-    // and read it back with wave-uniform 16-byte reads -- (63 - j) / 2 broadcast reads per step instead of
-    // 2 (63 - j) v_readlane.  LDS operations of one wave execute in order, so the loop needs no barrier.
+    // Wave 0 factors the block, lane i <-> row i.  The cross-lane traffic of the factorisation (a step
+    // needs the eliminated columns of every later row k in every lane) goes through LDS: the lanes deposit
+    // their entries once per step and read the others' back with wave-uniform 16-byte reads instead of
+    // v_readlane broadcasts.  LDS operations of one wave execute in order, so the loop needs no barrier.
     // W = L^-1 is then formed by all four waves, blocked 16 -> 32 -> 64 with MFMA products:
     //   inv [[P, 0], [Q, R]] = [[P^-1, 0], [-R^-1 Q P^-1, R^-1]].
     __shared__ double Ls[CH_NB * CH_LS];
     __shared__ double Ws[CH_NB * CH_WS];
-    __shared__ double colbuf[CH_NB];
+    __shared__ __attribute__((aligned(16))) double colbuf4[CH_NB * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // coalesced load of the block (row r, column lane), identity padding past nb
     for (int r = wave; r < CH_NB; r += 4) {
@@ -179,18 +179,55 @@ void potrf_inv_diag_kernel(double* __restrict__ A, i64 lda, int nb, double* __re
 #pragma unroll
         for (int k = 0; k < CH_NB; ++k) a[k] = Ls[lane * CH_LS + k];
         int bad = 0;
+        // FOUR columns per step (round 3; one column per step: 19 of the kernel's 29 us were this chain, ~700 cycles per
+        // column of which the LDS round trip and its fences were the larger part).  The lanes deposit their entries of
+        // columns j..j+3 once; every lane factors the 4 x 4 pivot block P = Lp Lp^T redundantly (uniform reads), takes its own
+        // row of L by forward substitution, y_i Lp^T = x_i, and updates its trailing row with
+        //   A[i][k] -= y_i . y_k = (Lp^-T y_i) . x_k = u_i . x_k
+        // where x_k is the RAW deposit of row k: no second exchange.  Same arithmetic as the column-by-column
+        // right-looking factorisation up to the order of the four subtractions.
 #pragma unroll
-        for (int j = 0; j < CH_NB; ++j) {
+        for (int j = 0; j < CH_NB; j += 4) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            colbuf[lane] = a[j];                     // column j of the current trailing matrix
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            const double d = colbuf[j];
-            if (!(d > 0.0) && bad == 0) bad = j + 1;
-            const double rs = rsqrt(d);              // one reciprocal square root instead of a division and a square root
-            a[j] = a[j] * rs;                        // L[i][j]  (lane j: sqrt(d))
-            const double t = a[j] * rs;              // L[i][j] / sqrt(d)
 #pragma unroll
-            for (int k = j + 1; k < CH_NB; ++k) a[k] -= t * colbuf[k];      // A[i][k] -= L[i][j] L[k][j]
+            for (int cq = 0; cq < 4; ++cq) colbuf4[lane * 4 + cq] = a[j + cq];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            const double p00 = colbuf4[j * 4];
+            const double p10 = colbuf4[(j + 1) * 4], p11 = colbuf4[(j + 1) * 4 + 1];
+            const double p20 = colbuf4[(j + 2) * 4], p21 = colbuf4[(j + 2) * 4 + 1], p22 = colbuf4[(j + 2) * 4 + 2];
+            const double p30 = colbuf4[(j + 3) * 4], p31 = colbuf4[(j + 3) * 4 + 1], p32 = colbuf4[(j + 3) * 4 + 2],
+                         p33 = colbuf4[(j + 3) * 4 + 3];
+            const double d0 = p00;
+            const double rs0 = rsqrt(d0);            // reciprocal square roots instead of a division and a square root each
+            const double l10 = p10 * rs0, l20 = p20 * rs0, l30 = p30 * rs0;
+            const double d1 = fma(-l10, l10, p11);
+            const double rs1 = rsqrt(d1);
+            const double l21 = fma(-l20, l10, p21) * rs1, l31 = fma(-l30, l10, p31) * rs1;
+            const double d2 = fma(-l21, l21, fma(-l20, l20, p22));
+            const double rs2 = rsqrt(d2);
+            const double l32 = fma(-l31, l21, fma(-l30, l20, p32)) * rs2;
+            const double d3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, p33)));
+            const double rs3 = rsqrt(d3);
+            if (bad == 0) {
+                if (!(d0 > 0.0)) bad = j + 1;
+                else if (!(d1 > 0.0)) bad = j + 2;
+                else if (!(d2 > 0.0)) bad = j + 3;
+                else if (!(d3 > 0.0)) bad = j + 4;
+            }
+            // this lane's row of L in columns j..j+3
+            const double y0 = a[j] * rs0;
+            const double y1 = fma(-y0, l10, a[j + 1]) * rs1;
+            const double y2 = fma(-y1, l21, fma(-y0, l20, a[j + 2])) * rs2;
+            const double y3 = fma(-y2, l32, fma(-y1, l31, fma(-y0, l30, a[j + 3]))) * rs3;
+            a[j] = y0; a[j + 1] = y1; a[j + 2] = y2; a[j + 3] = y3;
+            // u = Lp^-T y
+            const double u3 = y3 * rs3;
+            const double u2 = fma(-l32, u3, y2) * rs2;
+            const double u1 = fma(-l31, u3, fma(-l21, u2, y1)) * rs1;
+            const double u0 = fma(-l30, u3, fma(-l20, u2, fma(-l10, u1, y0))) * rs0;
+#pragma unroll
+            for (int k = j + 4; k < CH_NB; ++k)
+                a[k] = fma(-u3, colbuf4[k * 4 + 3], fma(-u2, colbuf4[k * 4 + 2], fma(-u1, colbuf4[k * 4 + 1], fma(-u0, colbuf4[k * 4], a[k]))));
         }
         if (lane == 0 && bad != 0 && *info == 0) *info = col0 + bad;
 #pragma unroll
