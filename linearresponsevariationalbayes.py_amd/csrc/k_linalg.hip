@@ -154,9 +154,11 @@ __device__ __forceinline__ d4 tile16_mm_reg(const double* xs, int ldx, d4 t, d4 
     return acc;
 }
 
-__global__ __launch_bounds__(256)
-void potrf_inv_diag_kernel(double* __restrict__ A, i64 lda, int nb, double* __restrict__ W /* 64 x 64 */,
-                           int* __restrict__ info, int col0)
+// The body of the diagonal-block step, for a block that is already in Ls (lower triangle, identity padding past nb; Ws zeroed;
+// a workgroup barrier behind both): factor, write L back to A, form W = L^-1.
+__device__ __forceinline__ void potrf_inv_diag_body(double* __restrict__ Ls, double* __restrict__ Ws, double* __restrict__ colbuf4,
+                                                    double* __restrict__ A, i64 lda, int nb, double* __restrict__ W /* 64 x 64 */,
+                                                    int* __restrict__ info, int col0)
 {
     // Wave 0 factors the block, lane i <-> row i.  The cross-lane traffic of the factorisation (a step
     // needs the eliminated columns of every later row k in every lane) goes through LDS: the lanes deposit
@@ -164,16 +166,7 @@ void potrf_inv_diag_kernel(double* __restrict__ A, i64 lda, int nb, double* __re
     // v_readlane broadcasts.  LDS operations of one wave execute in order, so the loop needs no barrier.
     // W = L^-1 is then formed by all four waves, blocked 16 -> 32 -> 64 with MFMA products:
     //   inv [[P, 0], [Q, R]] = [[P^-1, 0], [-R^-1 Q P^-1, R^-1]].
-    __shared__ double Ls[CH_NB * CH_LS];
-    __shared__ double Ws[CH_NB * CH_WS];
-    __shared__ __attribute__((aligned(16))) double colbuf4[CH_NB * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // coalesced load of the block (row r, column lane), identity padding past nb
-    for (int r = wave; r < CH_NB; r += 4) {
-        Ls[r * CH_LS + lane] = (r < nb && lane < nb) ? ((lane <= r) ? A[(i64)r * lda + lane] : 0.0) : ((r == lane) ? 1.0 : 0.0);
-        Ws[r * CH_WS + lane] = 0.0;
-    }
-    __syncthreads();
     if (wave == 0) {
         double a[CH_NB];
 #pragma unroll
@@ -291,6 +284,148 @@ void potrf_inv_diag_kernel(double* __restrict__ A, i64 lda, int nb, double* __re
     for (int r = wave; r < CH_NB; r += 4) W[r * CH_NB + lane] = Ws[r * CH_WS + lane];
 }
 
+__global__ __launch_bounds__(256)
+void potrf_inv_diag_kernel(double* __restrict__ A, i64 lda, int nb, double* __restrict__ W /* 64 x 64 */,
+                           int* __restrict__ info, int col0)
+{
+    __shared__ double Ls[CH_NB * CH_LS];
+    __shared__ double Ws[CH_NB * CH_WS];
+    __shared__ __attribute__((aligned(16))) double colbuf4[CH_NB * 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // coalesced load of the block (row r, column lane), identity padding past nb
+    for (int r = wave; r < CH_NB; r += 4) {
+        Ls[r * CH_LS + lane] = (r < nb && lane < nb) ? ((lane <= r) ? A[(i64)r * lda + lane] : 0.0) : ((r == lane) ? 1.0 : 0.0);
+        Ws[r * CH_WS + lane] = 0.0;
+    }
+    __syncthreads();
+    potrf_inv_diag_body(Ls, Ws, colbuf4, A, lda, nb, W, info, col0);
+}
+
+// Trailing update of a Cholesky step, A22 -= P P^T on the lower 64 x 64 tiles, with the NEXT step's diagonal block fused in:
+// the workgroup of tile (0, 0) keeps its updated tile in LDS and goes straight on to factor it and form its inverse while
+// the other workgroups are still updating theirs -- one dependent-kernel boundary and the 16 us of the trailing update leave
+// the critical path of every step (a step was diag 27 us -> panel 11 us -> trailing 16 us, each waiting for the last).
+// Both operands of a Cholesky step's products are 64 columns wide: they are staged WHOLE (one barrier, sixteen k-steps
+// without another) instead of in 16-column chunks with two barriers each -- at this size the generic kernel's time was its
+// barriers and dependent loads (10.6 us for a 64-deep product).
+constexpr int CH_KS = CH_NB + 17;          // [k][m] stage rows; an ODD stride: the staging writes run along k (64 lanes, one per row of the stage) and would all fall on one bank with an even one
+__device__ __forceinline__ void chol_tile_product(const double (*As)[CH_KS], const double (*Bs)[CH_KS], d4 (&acc)[2][2],
+                                                  int wr, int wc, int lane)
+{
+#pragma unroll
+    for (int ks = 0; ks < CH_NB / 4; ++ks) {
+        const int krow = ks * 4 + (lane >> 4);
+        double af[2], bf[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) af[a] = As[krow][wr * 32 + a * 16 + (lane & 15)];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) bf[b] = Bs[krow][wc * 32 + b * 16 + (lane & 15)];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+    }
+}
+
+// Panel of a Cholesky step, in place: P (M x 64, row-major) <- P W^T with W the inverse of the diagonal block's factor.
+// One workgroup per 64 rows reads and writes only its own rows.
+__global__ __launch_bounds__(256)
+void chol_panel_kernel(i64 M, double* __restrict__ P, i64 ldp, const double* __restrict__ W /* 64 x 64 */)
+{
+    __shared__ double As[CH_NB][CH_KS];   // [k][m] = P[m][k]
+    __shared__ double Bs[CH_NB][CH_KS];   // [k][n] = W[n][k]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wr = wave >> 1, wc = wave & 1;
+    const i64 m0 = (i64)blockIdx.x * CH_NB;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int idx = it * 256 + tid;
+        const int kk = idx & 63, mm = idx >> 6;
+        As[kk][mm] = (m0 + mm < M) ? P[(m0 + mm) * ldp + kk] : 0.0;
+        Bs[kk][mm] = W[mm * CH_NB + kk];
+    }
+    __syncthreads();
+    d4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+    chol_tile_product(As, Bs, acc, wr, wc, lane);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const i64 gm = m0 + wr * 32 + a * 16 + (lane >> 4) + 4 * r;
+                if (gm < M) P[gm * ldp + wc * 32 + b * 16 + (lane & 15)] = acc[a][b][r];
+            }
+}
+
+// Trailing update of a Cholesky step, A22 -= P P^T on the lower 64 x 64 tiles, with the NEXT step's diagonal block fused in:
+// the workgroup of tile (0, 0) keeps its updated tile in LDS and goes straight on to factor it and form its inverse while
+// the other workgroups are still updating theirs -- one dependent-kernel boundary and the 16 us of the trailing update leave
+// the critical path of every step (a step was diag 27 us -> panel 11 us -> trailing 16 us, each waiting for the last).
+__global__ __launch_bounds__(256)
+void chol_trailing_diag_kernel(i64 M, const double* __restrict__ P, i64 ldp, double* __restrict__ C, i64 ldc,
+                               int nb_next, double* __restrict__ W_next, int* __restrict__ info, int col0_next)
+{
+    // the two 64 x 64 operand stages are dead when the head workgroup starts on the diagonal block: same LDS
+    __shared__ __attribute__((aligned(16))) double lds[2 * CH_NB * CH_KS > CH_NB * CH_LS + CH_NB * CH_WS + CH_NB * 4
+                                                       ? 2 * CH_NB * CH_KS : CH_NB * CH_LS + CH_NB * CH_WS + CH_NB * 4];
+    double (*As)[CH_KS] = reinterpret_cast<double (*)[CH_KS]>(lds);
+    double (*Bs)[CH_KS] = reinterpret_cast<double (*)[CH_KS]>(lds + CH_NB * CH_KS);
+    if (blockIdx.x > blockIdx.y) return;                      // lower tiles only
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wr = wave >> 1, wc = wave & 1;
+    const i64 m0 = (i64)blockIdx.y * CH_NB, n0 = (i64)blockIdx.x * CH_NB;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {                         // both operands are row pieces of the panel: [row][k], k fastest
+        const int idx = it * 256 + tid;
+        const int kk = idx & 63, mm = idx >> 6;
+        As[kk][mm] = (m0 + mm < M) ? P[(m0 + mm) * ldp + kk] : 0.0;
+        Bs[kk][mm] = (n0 + mm < M) ? P[(n0 + mm) * ldp + kk] : 0.0;
+    }
+    __syncthreads();
+    d4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+    chol_tile_product(As, Bs, acc, wr, wc, lane);
+    const bool head = (blockIdx.x == 0 && blockIdx.y == 0);   // the next diagonal block
+    double* Ls = lds;
+    double* Ws = lds + CH_NB * CH_LS;
+    double* colbuf4 = Ws + CH_NB * CH_WS;
+    if (head) {
+        __syncthreads();                                      // every wave is done with the operand stages
+        for (int r = wave; r < CH_NB; r += 4) {
+            Ls[r * CH_LS + lane] = (r == lane) ? 1.0 : 0.0;   // identity padding; the tile's entries are written below
+            Ws[r * CH_WS + lane] = 0.0;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int lm = wr * 32 + a * 16 + (lane >> 4) + 4 * r, ln = wc * 32 + b * 16 + (lane & 15);
+                const i64 gm = m0 + lm, gn = n0 + ln;
+                if (gm < M && gn < M) {
+                    double* dst = C + gm * ldc + gn;
+                    const double v = *dst - acc[a][b][r];
+                    if (!head) *dst = v;                       // the head tile is written by the factorisation (its lower part)
+                    else if (lm < nb_next && ln < nb_next) Ls[lm * CH_LS + ln] = (ln <= lm) ? v : 0.0;
+                }
+            }
+    if (!head) return;
+    __syncthreads();
+    potrf_inv_diag_body(Ls, Ws, colbuf4, C, ldc, nb_next, W_next, info, col0_next);
+}
+
 int launch_potrf_lower(lrvb_ctx* c, double* A, i64 n, i64 lda, int* info_dev) {
     HIP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int), c->stream));
     const i64 nblk = (n + CH_NB - 1) / CH_NB;
@@ -299,16 +434,23 @@ int launch_potrf_lower(lrvb_ctx* c, double* A, i64 n, i64 lda, int* info_dev) {
         const int nb = (int)((n - j0 < CH_NB) ? (n - j0) : CH_NB);
         double* Ajj = A + j0 * lda + j0;
         double* Wj = c->cholW.p + jb * CH_NB * CH_NB;
-        hipLaunchKernelGGL(potrf_inv_diag_kernel, dim3(1), dim3(256), 0, c->stream, Ajj, lda, nb, Wj, info_dev, (int)j0);
-        HIP_TRY(hipGetLastError());
+        if (j0 == 0) {                                       // every later diagonal block is factored by the step before it
+            hipLaunchKernelGGL(potrf_inv_diag_kernel, dim3(1), dim3(256), 0, c->stream, Ajj, lda, nb, Wj, info_dev, (int)j0);
+            HIP_TRY(hipGetLastError());
+        }
         const i64 rows = n - j0 - nb;
         if (rows > 0) {
             double* Pn = A + (j0 + nb) * lda + j0;
             // P <- P W^T (in place: each workgroup reads and writes only its own 64 rows)
-            LRVB_TRY(launch_gemm(c, false, true, rows, nb, nb, 1.0, Pn, lda, Wj, CH_NB, 0.0, Pn, lda));
-            // trailing update A22 -= P P^T, lower tiles only
+            hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)((rows + CH_NB - 1) / CH_NB)), dim3(256), 0, c->stream, rows, Pn, lda, (const double*)Wj);
+            HIP_TRY(hipGetLastError());
+            // trailing update A22 -= P P^T on the lower tiles + the next diagonal block's factorisation and inverse
             double* A22 = A + (j0 + nb) * lda + (j0 + nb);
-            LRVB_TRY(launch_gemm_lower(c, rows, nb, -1.0, Pn, lda, 1.0, A22, lda));
+            const int nb_next = (int)(rows < CH_NB ? rows : CH_NB);
+            const unsigned t = (unsigned)((rows + GM_TILE - 1) / GM_TILE);
+            hipLaunchKernelGGL(chol_trailing_diag_kernel, dim3(t, t), dim3(256), 0, c->stream, rows, (const double*)Pn, lda,
+                               A22, lda, nb_next, Wj + CH_NB * CH_NB, info_dev, (int)(j0 + nb));
+            HIP_TRY(hipGetLastError());
         }
     }
     return LRVB_OK;
