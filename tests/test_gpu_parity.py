@@ -198,6 +198,21 @@ def test_cholesky_lrvb_cov_and_cg(vb):
     assert rel_err(fun.ctx.lrvb_cov(M), osv.lrvb_covariance(Hw, M)) < 1e-9
     with pytest.raises(np.linalg.LinAlgError):
         fun.ctx.chol_factor(-np.eye(P))
+    # a pivot that fails in a LATER 64-column block (those blocks are factored by the head workgroup of the previous
+    # step's trailing update) is reported with its position, and sizes that are not multiples of 64 keep their tail block
+    for n, bad_at in ((200, 150), (130, 129), (64, 10), (193, 64)):
+        A = rng.normal(size=(n, n))
+        S = A @ A.T / n + np.eye(n)
+        Lref = np.linalg.cholesky(S)
+        fun.ctx.chol_factor(S)
+        Bn = rng.normal(size=(n, 5))
+        assert rel_err(fun.ctx.chol_solve(Bn), np.linalg.solve(S, Bn)) < 1e-10
+        # make the leading minor of order bad_at + 1 singular-negative: subtract more than the pivot from that diagonal entry
+        S2 = S.copy()
+        S2[bad_at, bad_at] -= 1.5 * Lref[bad_at, bad_at] ** 2
+        with pytest.raises(np.linalg.LinAlgError) as err:
+            fun.ctx.chol_factor(S2)
+        assert str(bad_at + 1) in str(err.value)
     # CG: device loop vs Cholesky, the reference's own criterion (< 1e-8, test_objectives.py:552-554)
     solver = vb.ConjugateGradientSolver(obj.fun_free_hvp, theta)
     masks = vb.ConjugateGradient.get_masks(P, 40)
