@@ -308,7 +308,7 @@ void potrf_inv_diag_kernel(double* __restrict__ A, i64 lda, int nb, double* __re
 // Both operands of a Cholesky step's products are 64 columns wide: they are staged WHOLE (one barrier, sixteen k-steps
 // without another) instead of in 16-column chunks with two barriers each -- at this size the generic kernel's time was its
 // barriers and dependent loads (10.6 us for a 64-deep product).
-constexpr int CH_KS = CH_NB + 17;          // [k][m] stage rows; an ODD stride: the staging writes run along k (64 lanes, one per row of the stage) and would all fall on one bank with an even one
+constexpr int CH_KS = CH_NB + 1;           // [k][m] stage rows; an ODD stride: the staging writes run along k (64 lanes, one per row of the stage) and would all fall on one bank with an even one
 __device__ __forceinline__ void chol_tile_product(const double (*As)[CH_KS], const double (*Bs)[CH_KS], d4 (&acc)[2][2],
                                                   int wr, int wc, int lane)
 {
@@ -387,6 +387,16 @@ void chol_trailing_diag_kernel(i64 M, const double* __restrict__ P, i64 ldp, dou
         As[kk][mm] = (m0 + mm < M) ? P[(m0 + mm) * ldp + kk] : 0.0;
         Bs[kk][mm] = (n0 + mm < M) ? P[(n0 + mm) * ldp + kk] : 0.0;
     }
+    double cpre[2][2][4];                                     // the tile itself, requested before the product
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const i64 gm = m0 + wr * 32 + a * 16 + (lane >> 4) + 4 * r, gn = n0 + wc * 32 + b * 16 + (lane & 15);
+                cpre[a][b][r] = (gm < M && gn < M) ? C[gm * ldc + gn] : 0.0;
+            }
     __syncthreads();
     d4 acc[2][2];
 #pragma unroll
@@ -416,7 +426,7 @@ void chol_trailing_diag_kernel(i64 M, const double* __restrict__ P, i64 ldp, dou
                 const i64 gm = m0 + lm, gn = n0 + ln;
                 if (gm < M && gn < M) {
                     double* dst = C + gm * ldc + gn;
-                    const double v = *dst - acc[a][b][r];
+                    const double v = cpre[a][b][r] - acc[a][b][r];
                     if (!head) *dst = v;                       // the head tile is written by the factorisation (its lower part)
                     else if (lm < nb_next && ln < nb_next) Ls[lm * CH_LS + ln] = (ln <= lm) ? v : 0.0;
                 }
@@ -456,42 +466,149 @@ int launch_potrf_lower(lrvb_ctx* c, double* A, i64 n, i64 lda, int* info_dev) {
     return LRVB_OK;
 }
 
-// forward substitution only: B <- L^-1 B
-int launch_trsm_lower_forward(lrvb_ctx* c, const double* L, i64 n, i64 ldl, double* B, i64 nrhs, i64 ldb) {
-    for (i64 j0 = 0, jb = 0; j0 < n; j0 += CH_NB, ++jb) {
-        const int nb = (int)((n - j0 < CH_NB) ? (n - j0) : CH_NB);
-        const double* Wj = c->cholW.p + jb * CH_NB * CH_NB;
-        LRVB_TRY(launch_gemm(c, false, false, nb, nrhs, nb, 1.0, Wj, CH_NB, B + j0 * ldb, ldb, 0.0, B + j0 * ldb, ldb));
-        const i64 rows = n - j0 - nb;
-        if (rows > 0)
-            LRVB_TRY(launch_gemm(c, false, false, rows, nrhs, nb, -1.0, L + (j0 + nb) * ldl + j0, ldl,
-                                 B + j0 * ldb, ldb, 1.0, B + (j0 + nb) * ldb, ldb));
+// One step of a blocked triangular solve with the 64 x 64 inverse blocks W of the factor's diagonal (round 3: a step was
+// two dependent launches of the generic GEMM, ~11 us each for 64-deep products; 32 launches for a forward solve at D = 1024):
+//   forward  (BACK = false), step jb:  B_r -= L[r, jb] Y_jb for the row blocks r > jb, and the workgroups of row block jb + 1
+//                                      go straight on to Y_{jb+1} = W_{jb+1} B_{jb+1} -- their tile is complete at that point;
+//   backward (BACK = true),  step jb:  B_r -= L[jb, r]^T X_jb for r < jb, and row block jb - 1 goes on to
+//                                      X_{jb-1} = W_{jb-1}^T B_{jb-1}.
+// head_only: just the multiplication of block jb by W (the first step of a chain).  Same products in the same order as the
+// two-launch form; the operands are staged whole (chol_tile_product).
+template <bool BACK>
+__global__ __launch_bounds__(256)
+void trsm_step_kernel(const double* __restrict__ L, i64 ldl, const double* __restrict__ Wall, i64 n, int jb, int head_only,
+                      double* __restrict__ B, i64 nrhs, i64 ldb)
+{
+    __shared__ double As[CH_NB][CH_KS];   // [k][m]
+    __shared__ double Bs[CH_NB][CH_KS];   // [k][c]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wr = wave >> 1, wc = wave & 1;
+    const bool head = head_only || blockIdx.y == 0;
+    const int rblk = head_only ? jb : (BACK ? jb - 1 - (int)blockIdx.y : jb + 1 + (int)blockIdx.y);
+    const i64 r0 = (i64)rblk * CH_NB, j0 = (i64)jb * CH_NB, c0 = (i64)blockIdx.x * CH_NB;
+    d4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+    // everything the workgroup will need from global memory is requested up front: its own tile of B and (head) the inverse
+    // block ride under the first product instead of costing a round trip each on the critical path of the chain
+    double cpre[2][2][4], wpre[16];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int lm = wr * 32 + a * 16 + (lane >> 4) + 4 * r, lc = wc * 32 + b * 16 + (lane & 15);
+                cpre[a][b][r] = ((r0 + lm < n) && (c0 + lc < nrhs)) ? B[(r0 + lm) * ldb + c0 + lc] : 0.0;
+            }
+    if (head) {
+        const double* Wp = Wall + (i64)rblk * CH_NB * CH_NB;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) wpre[it] = Wp[it * 256 + tid];
     }
+    if (!head_only) {
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int idx = it * 256 + tid;
+            const int lo = idx & 63, hi = idx >> 6;
+            if (BACK) {                   // As[k][m] = L[jb block row k][r block column m]: m runs along the row of L
+                As[hi][lo] = (j0 + hi < n && r0 + lo < n) ? L[(j0 + hi) * ldl + r0 + lo] : 0.0;
+            } else {                      // As[k][m] = L[r block row m][jb block column k]: k runs along the row of L
+                As[lo][hi] = (r0 + hi < n && j0 + lo < n) ? L[(r0 + hi) * ldl + j0 + lo] : 0.0;
+            }
+            Bs[hi][lo] = (j0 + hi < n && c0 + lo < nrhs) ? B[(j0 + hi) * ldb + c0 + lo] : 0.0;
+        }
+        __syncthreads();
+        chol_tile_product(As, Bs, acc, wr, wc, lane);
+    }
+    if (head) __syncthreads();                                // every wave is done with the stages before they are refilled
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int lm = wr * 32 + a * 16 + (lane >> 4) + 4 * r, lc = wc * 32 + b * 16 + (lane & 15);
+                const bool in = (r0 + lm < n) && (c0 + lc < nrhs);
+                const double v = cpre[a][b][r] - acc[a][b][r];   // (0 outside the matrix: masked loads, zero stage rows)
+                if (!head) { if (in) B[(r0 + lm) * ldb + c0 + lc] = v; }
+                else Bs[lm][lc] = v;                           // operand of the product with W: [k = row of the block][c]
+            }
+    if (!head) return;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int idx = it * 256 + tid;
+        const int lo = idx & 63, hi = idx >> 6;
+        if (BACK) As[hi][lo] = wpre[it];                      // As[k][m] = W^T[m][k] = W[k][m]
+        else      As[lo][hi] = wpre[it];                      // As[k][m] = W[m][k]
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+    chol_tile_product(As, Bs, acc, wr, wc, lane);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int lm = wr * 32 + a * 16 + (lane >> 4) + 4 * r, lc = wc * 32 + b * 16 + (lane & 15);
+                if (r0 + lm < n && c0 + lc < nrhs) B[(r0 + lm) * ldb + c0 + lc] = acc[a][b][r];
+            }
+}
+
+// The fused step is for the latency-bound regime (a step of a few hundred tiles: one launch instead of two dependent ones).
+// A step with more tiles than the chip holds at once is throughput-bound: there the pipelined generic GEMM does the update
+// (several workgroups per CU, loads under the MFMAs) and a head-only launch the multiplication by W.
+constexpr i64 TRSM_FUSED_MAX_TILES = 512;
+static int trsm_chain(lrvb_ctx* c, const double* L, i64 n, i64 ldl, double* B, i64 nrhs, i64 ldb, bool backward) {
+    const int nblk = (int)((n + CH_NB - 1) / CH_NB);
+    const unsigned ct = (unsigned)((nrhs + CH_NB - 1) / CH_NB);
+    const double* W = c->cholW.p;
+    if (!backward) {
+        hipLaunchKernelGGL(trsm_step_kernel<false>, dim3(ct, 1), dim3(256), 0, c->stream, L, ldl, W, n, 0, 1, B, nrhs, ldb);
+        for (int jb = 0; jb + 1 < nblk; ++jb) {
+            const i64 rblocks = nblk - 1 - jb;
+            if ((i64)ct * rblocks <= TRSM_FUSED_MAX_TILES) {
+                hipLaunchKernelGGL(trsm_step_kernel<false>, dim3(ct, (unsigned)rblocks), dim3(256), 0, c->stream, L, ldl, W, n, jb, 0, B, nrhs, ldb);
+            } else {
+                const i64 j0 = (i64)jb * CH_NB, rows = n - j0 - CH_NB;
+                LRVB_TRY(launch_gemm(c, false, false, rows, nrhs, CH_NB, -1.0, L + (j0 + CH_NB) * ldl + j0, ldl,
+                                     B + j0 * ldb, ldb, 1.0, B + (j0 + CH_NB) * ldb, ldb));
+                hipLaunchKernelGGL(trsm_step_kernel<false>, dim3(ct, 1), dim3(256), 0, c->stream, L, ldl, W, n, jb + 1, 1, B, nrhs, ldb);
+            }
+        }
+    } else {
+        hipLaunchKernelGGL(trsm_step_kernel<true>, dim3(ct, 1), dim3(256), 0, c->stream, L, ldl, W, n, nblk - 1, 1, B, nrhs, ldb);
+        for (int jb = nblk - 1; jb >= 1; --jb) {
+            if ((i64)ct * jb <= TRSM_FUSED_MAX_TILES) {
+                hipLaunchKernelGGL(trsm_step_kernel<true>, dim3(ct, (unsigned)jb), dim3(256), 0, c->stream, L, ldl, W, n, jb, 0, B, nrhs, ldb);
+            } else {
+                const i64 j0 = (i64)jb * CH_NB;
+                const i64 nb = (n - j0 < CH_NB) ? (n - j0) : CH_NB;
+                LRVB_TRY(launch_gemm(c, true, false, j0, nrhs, nb, -1.0, L + j0 * ldl, ldl, B + j0 * ldb, ldb, 1.0, B, ldb));
+                hipLaunchKernelGGL(trsm_step_kernel<true>, dim3(ct, 1), dim3(256), 0, c->stream, L, ldl, W, n, jb - 1, 1, B, nrhs, ldb);
+            }
+        }
+    }
+    HIP_TRY(hipGetLastError());
     return LRVB_OK;
 }
 
+// forward substitution only: B <- L^-1 B
+int launch_trsm_lower_forward(lrvb_ctx* c, const double* L, i64 n, i64 ldl, double* B, i64 nrhs, i64 ldb) {
+    if (n <= 0 || nrhs <= 0) return LRVB_OK;
+    return trsm_chain(c, L, n, ldl, B, nrhs, ldb, false);
+}
+
 int launch_potrs_lower(lrvb_ctx* c, const double* L, i64 n, i64 ldl, double* B, i64 nrhs, i64 ldb) {
-    // forward: L Y = B
-    for (i64 j0 = 0, jb = 0; j0 < n; j0 += CH_NB, ++jb) {
-        const int nb = (int)((n - j0 < CH_NB) ? (n - j0) : CH_NB);
-        const double* Wj = c->cholW.p + jb * CH_NB * CH_NB;
-        LRVB_TRY(launch_gemm(c, false, false, nb, nrhs, nb, 1.0, Wj, CH_NB, B + j0 * ldb, ldb, 0.0, B + j0 * ldb, ldb));
-        const i64 rows = n - j0 - nb;
-        if (rows > 0)
-            LRVB_TRY(launch_gemm(c, false, false, rows, nrhs, nb, -1.0, L + (j0 + nb) * ldl + j0, ldl,
-                                 B + j0 * ldb, ldb, 1.0, B + (j0 + nb) * ldb, ldb));
-    }
-    // backward: L^T X = Y
-    const i64 last = ((n - 1) / CH_NB) * CH_NB;
-    for (i64 j0 = last, jb = last / CH_NB; j0 >= 0; j0 -= CH_NB, --jb) {
-        const int nb = (int)((n - j0 < CH_NB) ? (n - j0) : CH_NB);
-        const double* Wj = c->cholW.p + jb * CH_NB * CH_NB;
-        LRVB_TRY(launch_gemm(c, true, false, nb, nrhs, nb, 1.0, Wj, CH_NB, B + j0 * ldb, ldb, 0.0, B + j0 * ldb, ldb));
-        if (j0 > 0)
-            LRVB_TRY(launch_gemm(c, true, false, j0, nrhs, nb, -1.0, L + j0 * ldl, ldl,
-                                 B + j0 * ldb, ldb, 1.0, B, ldb));
-    }
-    return LRVB_OK;
+    if (n <= 0 || nrhs <= 0) return LRVB_OK;
+    LRVB_TRY(trsm_chain(c, L, n, ldl, B, nrhs, ldb, false));      // forward: L Y = B
+    return trsm_chain(c, L, n, ldl, B, nrhs, ldb, true);         // backward: L^T X = Y
 }
 
 // ---- vector kernels --------------------------------------------------------------------
