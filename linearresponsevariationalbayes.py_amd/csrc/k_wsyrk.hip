@@ -469,11 +469,10 @@ void wsyrk_glds_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
 // instruction reads 4 x 256 contiguous bytes.  The same registers serve as the A operand (after the
 // c_n scaling) and as the B operand.  MFMA tile t = 2 m + p therefore holds columns 32 m + 2 i + p:
 // a fixed column permutation that is undone when the block partial is written.
-template <int NPAIR>      // NPAIR = ceil(P / 32): 1 -> 2 tiles (3 MFMAs per k-step), 2 -> 4 tiles (10)
+template <int NPAIR, bool ALIGNED16>      // NPAIR = ceil(P / 32): 1 -> 2 tiles (3 MFMAs per k-step), 2 -> 4 tiles (10)
 __global__ __launch_bounds__(256)
 void gram_small_kernel(const double* __restrict__ Z, i64 ldz, i64 N, int P,
-                       const double* __restrict__ cpad, double* __restrict__ partial /* [grid][64*64] */,
-                       int aligned16)
+                       const double* __restrict__ cpad, double* __restrict__ partial /* [grid][64*64] */)
 {
     constexpr int NT = 2 * NPAIR;
     constexpr int NACC = NT * (NT + 1) / 2;
@@ -496,16 +495,22 @@ void gram_small_kernel(const double* __restrict__ Z, i64 ldz, i64 N, int P,
         colp[m] = in1[m] ? c0 : (P >= 2 ? P - 2 : 0);
     }
 
-    auto load_stage = [&](double (&x)[KS][NPAIR][2], double (&cv)[KS], i64 row0) {
+    // Every stage's loads are issued unconditionally (a stage past the end re-reads the last one with zero weights): with
+    // the prefetch behind `if (next < nstages)` hipcc's wait-count bookkeeping assumed the path that issued nothing and
+    // every consume waited for ALL outstanding loads -- the next stage never overlapped the MFMAs of the current one
+    // (round 3, the same finding as in k_lmm.hip).  Here it bought little (0.175 -> 0.167 ms for 1e6 x 64 = 3.1 TB/s): at 260
+    // registers the kernel runs ONE wave per SIMD with one 16-row stage in flight, ~1 us of MFMA work against a longer load
+    // latency; the LDS-DMA ring of k_lmm.hip (three waves per SIMD, six slots) is the design that streams at 4.5 TB/s.
+    auto load_stage = [&](double (&x)[KS][NPAIR][2], double (&cv)[KS], i64 row0, double live) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             i64 n = row0 + ks * 4 + lk;
-            cv[ks] = cpad[n];                                   // zero padding past N
+            cv[ks] = cpad[n] * live;                            // zero padding past N
             if (n > N - 1) n = N - 1;
             const double* rowp = Z + n * ldz;
 #pragma unroll
             for (int m = 0; m < NPAIR; ++m) {
-                if (aligned16) {
+                if (ALIGNED16) {
                     typedef double v2d __attribute__((ext_vector_type(2)));       // streamed once: non-temporal
                     const v2d t = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(rowp + colp[m]));
                     x[ks][m][0] = t[0]; x[ks][m][1] = t[1];
@@ -522,7 +527,10 @@ void gram_small_kernel(const double* __restrict__ Z, i64 ldz, i64 N, int P,
 #pragma unroll
             for (int m = 0; m < NPAIR; ++m) {
                 // a clamped pair (P odd or lane past the last column) is re-mapped to zeros
-                const double v0 = in1[m] ? x[ks][m][0] : (in0[m] ? x[ks][m][(P >= 2) ? 1 : 0] : 0.0);
+                // (a select of two registers: written as x[ks][m][P >= 2 ? 1 : 0] it became a dynamic register index, i.e. a
+                // readfirstlane loop in every k-step)
+                const double xl = (P >= 2) ? x[ks][m][1] : x[ks][m][0];
+                const double v0 = in1[m] ? x[ks][m][0] : (in0[m] ? xl : 0.0);
                 const double v1 = in1[m] ? x[ks][m][1] : 0.0;
                 b[2 * m] = v0; b[2 * m + 1] = v1;
                 a[2 * m] = v0 * cv[ks]; a[2 * m + 1] = v1 * cv[ks];
@@ -542,20 +550,16 @@ void gram_small_kernel(const double* __restrict__ Z, i64 ldz, i64 N, int P,
     const i64 stage_rows = KS * 4;
     const i64 nstages = (N + stage_rows - 1) / stage_rows;
     const i64 gw = (i64)blockIdx.x * 4 + wave, GW = (i64)gridDim.x * 4;
-    i64 st = gw;
-    if (st < nstages) {
+    if (gw < nstages) {
         double xa[KS][NPAIR][2], xb[KS][NPAIR][2], ca[KS], cb[KS];
-        load_stage(xa, ca, st * stage_rows);
-        for (;;) {
-            i64 nx = st + GW;
-            if (nx < nstages) load_stage(xb, cb, nx * stage_rows);
+        const i64 mine = (nstages - gw + GW - 1) / GW;          // stages of this wave
+        auto row0_of = [&](i64 k) { const i64 st = gw + k * GW; return (st < nstages ? st : nstages - 1) * stage_rows; };
+        load_stage(xa, ca, row0_of(0), 1.0);
+        for (i64 k = 0; k < mine; k += 2) {
+            load_stage(xb, cb, row0_of(k + 1), (k + 1 < mine) ? 1.0 : 0.0);
             consume(xa, ca);
-            if (nx >= nstages) break;
-            st = nx; nx = st + GW;
-            if (nx < nstages) load_stage(xa, ca, nx * stage_rows);
-            consume(xb, cb);
-            if (nx >= nstages) break;
-            st = nx;
+            load_stage(xa, ca, row0_of(k + 2), (k + 2 < mine) ? 1.0 : 0.0);
+            consume(xb, cb);                                    // a dead stage contributes zeros
         }
     }
 
@@ -633,14 +637,13 @@ int launch_gram_small_on(lrvb_ctx* c, const double* Z, i64 N, i64 P, const doubl
     const int S = grid >= 64 ? 32 : 1;
     LRVB_TRY(buf_reserve(c, c->tile_part, (size_t)(grid + S) * 4096));
     double* lvl = c->tile_part.p + (size_t)grid * 4096;
-    const int aligned16 = ((P % 2) == 0) && ((((uintptr_t)Z) & 15) == 0);
+    const bool aligned16 = ((P % 2) == 0) && ((((uintptr_t)Z) & 15) == 0);
     if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
-    if (P <= 32)
-        hipLaunchKernelGGL(gram_small_kernel<1>, dim3((unsigned)grid), dim3(256), 0, c->stream,
-                           Z, P, N, (int)P, cvec_dev, c->tile_part.p, aligned16);
-    else
-        hipLaunchKernelGGL(gram_small_kernel<2>, dim3((unsigned)grid), dim3(256), 0, c->stream,
-                           Z, P, N, (int)P, cvec_dev, c->tile_part.p, aligned16);
+#define GS_LAUNCH(NP, AL) hipLaunchKernelGGL((gram_small_kernel<NP, AL>), dim3((unsigned)grid), dim3(256), 0, c->stream, \
+                                             Z, P, N, (int)P, cvec_dev, c->tile_part.p)
+    if (P <= 32) { if (aligned16) GS_LAUNCH(1, true); else GS_LAUNCH(1, false); }
+    else         { if (aligned16) GS_LAUNCH(2, true); else GS_LAUNCH(2, false); }
+#undef GS_LAUNCH
     HIP_TRY(hipGetLastError());
     if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
     HIP_TRY(hipMemsetAsync(tiles_out_dev, 0, sizeof(double) * WS_TILE * WS_TILE, c->stream));   // unused entries stay finite
