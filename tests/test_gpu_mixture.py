@@ -25,7 +25,8 @@ def vb():
 
 
 @pytest.mark.parametrize('N,V,K', [(1, 2, 2), (37, 3, 2), (50, 4, 3), (61, 5, 4), (40, 7, 5), (33, 6, 6), (45, 9, 8),
-                                   (38, 8, 11), (130, 12, 16), (64, 20, 23), (150, 31, 32)])
+                                   (38, 8, 11), (130, 12, 16), (64, 20, 23), (150, 31, 32),
+                                   (9, 31, 2), (21, 1, 32), (2, 1, 2), (131, 17, 17)])      # wide x with two categories, one column, two rows, K just past one MFMA block
 def test_rows_match_oracle(vb, N, V, K):
     x, w, theta = problem(N, V, K, seed=100 + K)
     par = make_par(N, V, K)
