@@ -213,6 +213,16 @@ def test_cholesky_lrvb_cov_and_cg(vb):
         with pytest.raises(np.linalg.LinAlgError) as err:
             fun.ctx.chol_factor(S2)
         assert str(bad_at + 1) in str(err.value)
+    # many right-hand sides: the first block steps have more tiles than the fused solve step takes (they go to the generic
+    # GEMM + a head-only step), the last ones are fused -- both routes in one chain, forward and backward
+    n, q = 1100, 2100
+    A = rng.normal(size=(n, n))
+    S = A @ A.T / n + np.eye(n)
+    fun.ctx.chol_factor(S)
+    Bn = rng.normal(size=(n, q))
+    assert rel_err(fun.ctx.chol_solve(Bn), np.linalg.solve(S, Bn)) < 1e-10
+    Mq = rng.normal(size=(q, n))
+    assert rel_err(fun.ctx.lrvb_cov(Mq), Mq @ np.linalg.solve(S, Mq.T)) < 1e-10
     # CG: device loop vs Cholesky, the reference's own criterion (< 1e-8, test_objectives.py:552-554)
     solver = vb.ConjugateGradientSolver(obj.fun_free_hvp, theta)
     masks = vb.ConjugateGradient.get_masks(P, 40)
