@@ -63,11 +63,15 @@ int launch_mixture_expand(lrvb_ctx* c, const double* Rs, i64 lda, int q, int K, 
     return LRVB_OK;
 }
 
-__global__ void mixture_val_reduce_kernel(const double* __restrict__ part, int nblk, double* __restrict__ out2) {
-    double a = 0.0, b = 0.0;                               // one wavefront, fixed order: deterministic
-    for (int i = threadIdx.x; i < nblk; i += 64) { a += part[2 * i]; b += part[2 * i + 1]; }
+__global__ __launch_bounds__(256)
+void mixture_val_reduce_kernel(const double* __restrict__ part, int nblk, double* __restrict__ out2) {
+    __shared__ double sh[4][2];                            // one workgroup, fixed order: deterministic (one wavefront walking
+    double a = 0.0, b = 0.0;                               // 4096 pairs took 26 us)
+    for (int i = threadIdx.x; i < nblk; i += 256) { a += part[2 * i]; b += part[2 * i + 1]; }
     a = mx_wave_sum(a); b = mx_wave_sum(b);
-    if (threadIdx.x == 0) { out2[0] = a; out2[1] = b; }
+    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6][0] = a; sh[threadIdx.x >> 6][1] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) { out2[0] = (sh[0][0] + sh[1][0]) + (sh[2][0] + sh[3][0]); out2[1] = (sh[0][1] + sh[1][1]) + (sh[2][1] + sh[3][1]); }
 }
 
 int launch_mixture_rows(lrvb_ctx* c, int K, const double* theta_z_dev, const double* lam_dev,
@@ -99,7 +103,7 @@ int launch_mixture_rows(lrvb_ctx* c, int K, const double* theta_z_dev, const dou
         if (!done) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "mixture kernel supports 2 <= K <= 32 (got %d)", K);
     }
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(mixture_val_reduce_kernel, dim3(1), dim3(64), 0, c->stream, c->part_val.p, (int)grid, val2_dev);
+    hipLaunchKernelGGL(mixture_val_reduce_kernel, dim3(1), dim3(256), 0, c->stream, c->part_val.p, (int)grid, val2_dev);
     HIP_TRY(hipGetLastError());
     return LRVB_OK;
 }
