@@ -224,6 +224,16 @@ int lrvb_hvec_add_symkron(lrvb_ctx* ctx, const double* A, const double* B, int64
                           int64_t row_off, int64_t col_off, int mirror);
 int lrvb_hvec_finish(lrvb_ctx* ctx, const double* point, int64_t n_in, int is_free, const double* g_vec,
                      double* H_out);
+/* The same assembly as ONE call (round 3: a begin / add / add / ... / finish sequence cost a binding call, an upload and a
+ * launch per block -- more than the kernels of the small configurations).  `ops` holds n_ops records of 8 int64:
+ *   [kind, off, a, b, c, d, e, f]   with `off` the position of the record's operands in `data` (n_data doubles, uploaded once),
+ *   kind 0  add_block:    block at off (a x b, row-major), row_off c, col_off d, mirror e;
+ *   kind 1  add_indexed:  block at off (a x b), then a row indices and b column indices stored as doubles;
+ *   kind 2  add_symkron:  A at off, B at f (both a x a; two records may share an operand), row_off c, col_off d, mirror e,
+ *                         the coefficient at data[b].
+ * Then exactly lrvb_hvec_finish(point, n_in, is_free, g_vec, H_out).                                                       */
+int lrvb_hvec_program(lrvb_ctx* ctx, const int64_t* ops, int64_t n_ops, const double* data, int64_t n_data,
+                      const double* point, int64_t n_in, int is_free, const double* g_vec, double* H_out);
 
 /* ---- cross Hessians: TwoParameterObjective.fun_hessian_free1_vector2
  * (LRVB/SparseObjectives.py:429-438) for the two hyper-parameters a declared model has ---- */

@@ -83,6 +83,7 @@ _SIGNATURES = {
     'lrvb_hvec_add_indexed': [_VP, _VP, c_i64, c_i64, _VP, _VP],
     'lrvb_hvec_add_symkron': [_VP, _VP, _VP, c_i64, ctypes.c_double, c_i64, c_i64, ctypes.c_int],
     'lrvb_hvec_finish': [_VP, _VP, c_i64, ctypes.c_int, _VP, _VP],
+    'lrvb_hvec_program': [_VP, _VP, c_i64, _VP, c_i64, _VP, c_i64, ctypes.c_int, _VP, _VP],
     'lrvb_obs_influence': [_VP, _VP, c_i64, _VP, c_i64, c_i64, c_i64, _VP],
     'lrvb_obs_influence_vec': [_VP, _VP, c_i64, _VP, c_i64, c_i64, c_i64, _VP],
     'lrvb_cross_hessian_tilt': [_VP, _VP, c_i64, _VP],

@@ -228,7 +228,7 @@ extern "C" int lrvb_ctx_destroy(lrvb_ctx* c) {
     DevBuf* all[] = { &c->X, &c->y, &c->w, &c->quadA, &c->quadM, &c->quadB, &c->theta, &c->eta, &c->j1, &c->j2,
                       &c->vtmp, &c->vtmp2, &c->vtmp3, &c->g_eta, &c->g_free, &c->lp, &c->cw, &c->zbuf,
                       &c->part_vec, &c->part_val, &c->stats, &c->tile_part, &c->Heta, &c->Hfree, &c->Jdense,
-                      &c->Tdense, &c->work1, &c->chol, &c->cholW, &c->cgH, &c->groups, &c->mx_theta, &c->mx_lam, &c->mx_A, &c->mx_U, &c->mx_g, &c->mx_Xk, &c->mx_R, &c->cgT, &c->ones, &c->cgm[0], &c->cgm[1], &c->cgm[2], &c->cgm[3], &c->cgm[4], &c->cgm[5], &c->cgm[6], &c->cgm[7], &c->cgm[8], &c->rhs, &c->cgx, &c->cgr, &c->cgp, &c->cgq, &c->cgz, &c->scal, &c->opt, &c->dkw, &c->cyv, &c->rvec, &c->red_scratch, &c->gstats, &c->Zs, &c->ws, &c->bpart, &c->gpad, &c->boxmap };
+                      &c->Tdense, &c->work1, &c->chol, &c->cholW, &c->hprog, &c->cgH, &c->groups, &c->mx_theta, &c->mx_lam, &c->mx_A, &c->mx_U, &c->mx_g, &c->mx_Xk, &c->mx_R, &c->cgT, &c->ones, &c->cgm[0], &c->cgm[1], &c->cgm[2], &c->cgm[3], &c->cgm[4], &c->cgm[5], &c->cgm[6], &c->cgm[7], &c->cgm[8], &c->rhs, &c->cgx, &c->cgr, &c->cgp, &c->cgq, &c->cgz, &c->scal, &c->opt, &c->dkw, &c->cyv, &c->rvec, &c->red_scratch, &c->gstats, &c->Zs, &c->ws, &c->bpart, &c->gpad, &c->boxmap };
     for (DevBuf* b : all) buf_free(*b);
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
     if (c->up_ring) { for (int k = 0; k < lrvb_ctx::UP_SLOTS; ++k) if (c->up_ev[k]) (void)hipEventDestroy(c->up_ev[k]); (void)hipHostFree(c->up_ring); }
@@ -1078,9 +1078,64 @@ extern "C" int lrvb_hvec_add_symkron(lrvb_ctx* c, const double* A, const double*
 }
 // H_free = J^T H_vec J + sum_k g_k d2 eta_k with H_vec the matrix assembled by the lrvb_hvec_* calls.  The result
 // stays on the device (lrvb_chol_factor_last factors it); H_free_out may be NULL.  is_free = 0 returns H_vec itself.
+static int hvec_finish_impl(lrvb_ctx* c, const double* point, int64_t n_in, int is_free, const double* g_vec, double* H_out);
 extern "C" int lrvb_hvec_finish(lrvb_ctx* c, const double* point, int64_t n_in, int is_free, const double* g_vec, double* H_out) {
     LRVB_TRY(ctx_bind(c));
     if (!c->hvec_open) LRVB_FAIL(LRVB_ERR_STATE, "call lrvb_hvec_begin first");
+    return hvec_finish_impl(c, point, n_in, is_free, g_vec, H_out);
+}
+// begin + every block + finish in one call: the operands travel in ONE upload, the blocks are launches in stream order
+extern "C" int lrvb_hvec_program(lrvb_ctx* c, const int64_t* ops, int64_t n_ops, const double* data, int64_t n_data,
+                                 const double* point, int64_t n_in, int is_free, const double* g_vec, double* H_out) {
+    LRVB_TRY(ctx_bind(c));
+    if (n_ops < 0 || n_data < 0 || (n_ops > 0 && !ops) || (n_data > 0 && !data)) LRVB_FAIL(LRVB_ERR_INVALID, "bad argument");
+    const i64 V = c->V;
+    // every record is checked before anything is launched
+    for (i64 t = 0; t < n_ops; ++t) {
+        const int64_t* o = ops + 8 * t;
+        const i64 kind = o[0], off = o[1], a = o[2], b = o[3], ro = o[4], co = o[5], mir = o[6], f = o[7];
+        if (off < 0) LRVB_FAIL(LRVB_ERR_INVALID, "record %lld: negative operand offset", (long long)t);
+        if (kind == 0) {
+            if (a <= 0 || b <= 0 || off + a * b > n_data || ro < 0 || co < 0 || ro + a > V || co + b > V || (mir && ro == co))
+                LRVB_FAIL(LRVB_ERR_INVALID, "record %lld: block [%lld+%lld, %lld+%lld) does not fit the %lld x %lld matrix or its operand the data", (long long)t,
+                          (long long)ro, (long long)a, (long long)co, (long long)b, (long long)V, (long long)V);
+        } else if (kind == 1) {
+            if (a <= 0 || b <= 0 || off + a * b + a + b > n_data) LRVB_FAIL(LRVB_ERR_INVALID, "record %lld: indexed block outside the data", (long long)t);
+            for (i64 e = 0; e < a + b; ++e) {
+                const double ix = data[off + a * b + e];
+                if (!(ix >= 0.0) || ix >= (double)V || ix != (double)(i64)ix) LRVB_FAIL(LRVB_ERR_INVALID, "record %lld: index %g outside [0, %lld)", (long long)t, ix, (long long)V);
+            }
+        } else if (kind == 2) {
+            const i64 m = a * (a + 1) / 2;
+            if (a <= 0 || a > 2048 || off + a * a > n_data || f < 0 || f + a * a > n_data || b < 0 || b >= n_data || ro < 0 || co < 0 ||
+                ro + m > V || co + m > V || (mir && ro == co))
+                LRVB_FAIL(LRVB_ERR_INVALID, "record %lld: Kronecker block of order %lld at (%lld, %lld) does not fit", (long long)t, (long long)m, (long long)ro, (long long)co);
+        } else LRVB_FAIL(LRVB_ERR_INVALID, "record %lld: unknown kind %lld", (long long)t, (long long)kind);
+    }
+    LRVB_TRY(buf_reserve(c, c->Heta, (size_t)V * (size_t)V));
+    HIP_TRY(hipMemsetAsync(c->Heta.p, 0, (size_t)V * (size_t)V * sizeof(double), c->stream));
+    if (n_data > 0) {
+        LRVB_TRY(buf_reserve(c, c->hprog, (size_t)n_data));
+        LRVB_TRY(h2d(c, c->hprog.p, data, (size_t)n_data));
+    }
+    const double* dd = c->hprog.p;
+    for (i64 t = 0; t < n_ops; ++t) {
+        const int64_t* o = ops + 8 * t;
+        const i64 kind = o[0], off = o[1], a = o[2], b = o[3], ro = o[4], co = o[5], f = o[7];
+        const int mir = o[6] != 0;
+        if (kind == 0) {
+            EW(hvec_add_block_kernel, a * b, b, dd + off, c->Heta.p, V, ro, co, mir);
+        } else if (kind == 1) {
+            EW(hvec_add_indexed_kernel, a * b, b, dd + off, dd + off + a * b, dd + off + a * b + a, c->Heta.p, V);
+        } else {
+            const i64 m = a * (a + 1) / 2;
+            EW(hvec_symkron_kernel, m * m, m, (int)a, dd + off, dd + f, data[b], c->Heta.p, V, ro, co, mir);
+        }
+    }
+    c->hvec_open = true;
+    return hvec_finish_impl(c, point, n_in, is_free, g_vec, H_out);
+}
+static int hvec_finish_impl(lrvb_ctx* c, const double* point, int64_t n_in, int is_free, const double* g_vec, double* H_out) {
     c->hvec_open = false;
     const i64 D = c->D, V = c->V;
     if (!is_free) {

@@ -75,6 +75,7 @@ struct lrvb_ctx {
     i64 mx_theta_n = 0;            // simplex logits resident in mx_theta (entries; 0 = none)
     DevBuf cgH; i64 cgH_n = 0;     // dense matrix of lrvb_cg_solve_matrix
     DevBuf chol, cholW;            // D x D Cholesky factor (lower); inverses of its 64 x 64 diagonal blocks
+    DevBuf hprog;                  // operands of an lrvb_hvec_program call
     bool chol_valid = false;
     bool hvec_open = false;        // between lrvb_hvec_begin and lrvb_hvec_finish
     i64 chol_n = 0;
@@ -95,7 +96,7 @@ struct lrvb_ctx {
     double* host_pinned = nullptr; size_t host_pinned_n = 0;
     // small host -> device uploads: a ring of pinned slots, so that the copy is a real asynchronous copy in stream order
     // and the call does not have to synchronise the stream (a pageable source has to be consumed before the call returns)
-    static constexpr int UP_SLOTS = 16; static constexpr size_t UP_SLOT_DOUBLES = 8192;
+    static constexpr int UP_SLOTS = 16; static constexpr size_t UP_SLOT_DOUBLES = 16384;
     double* up_ring = nullptr; double* up_ring_dev = nullptr; hipEvent_t up_ev[UP_SLOTS] = {}; int up_next = 0;
 
     int n_splits_user = 0;

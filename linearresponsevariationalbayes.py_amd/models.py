@@ -62,6 +62,7 @@ class DeviceContext(object):
         desc.quad_kind = int(quad_kind)
         self._h = ctypes.c_void_p()
         self.chol_token = 0            # bumped by every factorisation: lets holders of a factor notice a replacement
+        self._hv_ops = None                  # recorded blocks of an hvec assembly (None: not recording)
         self._check(self._lib.lrvb_ctx_create(ctypes.byref(self._h), int(device), ctypes.byref(desc)))
         self.n_obs, self.n_cols = int(n_obs), int(n_cols)
         self.device = int(device)
@@ -311,13 +312,39 @@ class DeviceContext(object):
         return out
 
     # -- vector-coordinate Hessian assembled on the device from small host blocks ---------------------
-    def hvec_begin(self):
-        self._check(self._lib.lrvb_hvec_begin(self._h))
+    # The assembly is RECORDED and sent as one call (lrvb_hvec_program): a begin / add / ... / finish sequence used to cost a
+    # binding call, an upload and a launch per block -- more host time than the kernels of the small configurations need.
+    # `hvec_begin(immediate=True)` keeps the call-per-block entry points of the C ABI (same result; tests/test_gpu_parity.py).
+    def hvec_begin(self, immediate=False):
+        self._hv_ops = None
+        if immediate:
+            self._check(self._lib.lrvb_hvec_begin(self._h))
+            return
+        self._hv_ops, self._hv_data, self._hv_len, self._hv_seen = [], [], 0, {}
+
+    def _hv_put(self, arr):
+        """Position of an operand in the program's data (an array object that was already sent is not sent twice)."""
+        key = id(arr)
+        hit = self._hv_seen.get(key)
+        if hit is not None and hit[1] is arr:
+            return hit[0]
+        off = self._hv_len
+        flat = arr.ravel()
+        self._hv_data.append(flat)
+        self._hv_len += flat.size
+        self._hv_seen[key] = (off, arr)
+        return off
 
     def hvec_add_block(self, block, row_off, col_off, mirror=False):
         B = _hip.as_f64(block)
         B = B.reshape(B.shape[0], -1) if B.ndim > 1 else B.reshape(-1, 1)
-        self._check(self._lib.lrvb_hvec_add_block(self._h, _hip.ptr(B), B.shape[0], B.shape[1], int(row_off), int(col_off), int(bool(mirror))))
+        if self._hv_ops is None:
+            self._check(self._lib.lrvb_hvec_add_block(self._h, _hip.ptr(B), B.shape[0], B.shape[1], int(row_off), int(col_off), int(bool(mirror))))
+            return
+        if row_off < 0 or col_off < 0 or row_off + B.shape[0] > self.V or col_off + B.shape[1] > self.V or (mirror and row_off == col_off):
+            raise ValueError('block [{}+{}, {}+{}) outside the {} x {} matrix (or a mirrored block on the diagonal)'.format(
+                row_off, B.shape[0], col_off, B.shape[1], self.V, self.V))
+        self._hv_ops.append((0, self._hv_put(B), B.shape[0], B.shape[1], int(row_off), int(col_off), int(bool(mirror)), 0))
 
     def hvec_add_indexed(self, block, rows, cols):
         """H[rows[a], cols[b]] += block[a, b] (lrvb_hvec_add_indexed)."""
@@ -326,24 +353,43 @@ class DeviceContext(object):
         cidx = np.ascontiguousarray(cols, dtype=np.int64).ravel()
         if B.shape != (r.size, cidx.size):
             raise ValueError('block must be len(rows) x len(cols)')
-        self._check(self._lib.lrvb_hvec_add_indexed(self._h, _hip.ptr(B), r.size, cidx.size,
-                                                   r.ctypes.data_as(ctypes.c_void_p), cidx.ctypes.data_as(ctypes.c_void_p)))
+        if self._hv_ops is None:
+            self._check(self._lib.lrvb_hvec_add_indexed(self._h, _hip.ptr(B), r.size, cidx.size,
+                                                       r.ctypes.data_as(ctypes.c_void_p), cidx.ctypes.data_as(ctypes.c_void_p)))
+            return
+        if r.size == 0 or cidx.size == 0 or r.min() < 0 or r.max() >= self.V or cidx.min() < 0 or cidx.max() >= self.V:
+            raise ValueError('index outside [0, {})'.format(self.V))
+        pack = np.concatenate([B.ravel(), r.astype(np.float64), cidx.astype(np.float64)])     # block, then the two index lists
+        self._hv_ops.append((1, self._hv_put(pack), r.size, cidx.size, 0, 0, 0, 0))
 
     def hvec_add_symkron(self, A, B, coef, row_off, col_off, mirror=False):
         A, B = _hip.as_f64(A), _hip.as_f64(B)
         if A.ndim != 2 or A.shape[0] != A.shape[1] or A.shape != B.shape:
             raise ValueError('expected two square matrices of the same order')
-        self._check(self._lib.lrvb_hvec_add_symkron(self._h, _hip.ptr(A), _hip.ptr(B), A.shape[0], float(coef),
-                                                   int(row_off), int(col_off), int(bool(mirror))))
+        if self._hv_ops is None:
+            self._check(self._lib.lrvb_hvec_add_symkron(self._h, _hip.ptr(A), _hip.ptr(B), A.shape[0], float(coef),
+                                                       int(row_off), int(col_off), int(bool(mirror))))
+            return
+        m = A.shape[0] * (A.shape[0] + 1) // 2
+        if row_off < 0 or col_off < 0 or row_off + m > self.V or col_off + m > self.V or (mirror and row_off == col_off):
+            raise ValueError('Kronecker block of order {} at ({}, {}) outside the {} x {} matrix'.format(m, row_off, col_off, self.V, self.V))
+        cpos = self._hv_put(np.array([float(coef)]))
+        self._hv_ops.append((2, self._hv_put(A), A.shape[0], cpos, int(row_off), int(col_off), int(bool(mirror)), self._hv_put(B)))
 
     def hvec_finish(self, x, g_vec, is_free=True, want_host=True):
         x = _hip.as_f64(x).ravel()
         g = _hip.as_f64(g_vec).ravel()
         n = self._n(is_free)
         out = np.empty((n, n)) if want_host else None
-        self._check(self._lib.lrvb_hvec_finish(self._h, _hip.ptr(x), x.size, int(bool(is_free)), _hip.ptr(g), _hip.ptr(out)))
-        if is_free:
-            self.chol_token += 0          # (the resident free Hessian is what chol_factor_last factors)
+        if self._hv_ops is None:
+            self._check(self._lib.lrvb_hvec_finish(self._h, _hip.ptr(x), x.size, int(bool(is_free)), _hip.ptr(g), _hip.ptr(out)))
+            return out
+        ops = np.array(self._hv_ops, dtype=np.int64).reshape(-1, 8)
+        data = np.concatenate(self._hv_data) if self._hv_data else np.zeros(0)
+        self._hv_ops = None
+        self._hv_seen = {}
+        self._check(self._lib.lrvb_hvec_program(self._h, ops.ctypes.data_as(ctypes.c_void_p), ops.shape[0], _hip.ptr(data), data.size,
+                                               _hip.ptr(x), x.size, int(bool(is_free)), _hip.ptr(g), _hip.ptr(out)))
         return out
 
     def cross_hessian_tilt(self, free):

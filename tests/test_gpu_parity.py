@@ -676,3 +676,48 @@ def test_device_hessian_assembly_from_kronecker_blocks(vb):
     with pytest.raises(ValueError):
         ctx.hvec_add_block(col, 3, 3, mirror=True)           # mirrored block on the diagonal
     ctx.hvec_finish(theta, g, is_free=True, want_host=False)
+
+
+def test_hvec_program_equals_the_call_per_block_route(vb):
+    """`lrvb_hvec_program` (what the Python assembly sends: every block recorded, ONE call) against the begin / add / finish
+    entry points of the C ABI: dense, mirrored, indexed and Kronecker blocks, an operand shared by two records, both
+    coordinate systems."""
+    rng = np.random.default_rng(11)
+    k = 6
+    spec = [('box', 'a', 5, -np.inf, np.inf), ('psd', 'S', k, 0.0), ('box', 'pos', 4, 0.0, np.inf)]
+    par, lay = make_par(vb, spec)
+    ctx = vb.DeviceContext(par.layout_blocks(), quad_kind=1)
+    V, D = ctx.V, ctx.D
+    m = k * (k + 1) // 2
+    A = rng.normal(size=(k, k)); A = A @ A.T
+    B = rng.normal(size=(k, k)); B = B @ B.T
+    blk = rng.normal(size=(5, 5)); blk = blk + blk.T
+    off = rng.normal(size=(5, 4))
+    rows = np.array([0, 2, 5 + m, 5 + m + 3])
+    sc = rng.normal(size=(4, 4)); sc = sc + sc.T
+    theta = rng.normal(size=D) * 0.3
+    g = rng.normal(size=V)
+
+    def assemble(immediate, is_free):
+        ctx.hvec_begin(immediate=immediate)
+        ctx.hvec_add_block(blk, 0, 0)
+        ctx.hvec_add_block(off, 0, 5 + m, mirror=True)
+        ctx.hvec_add_indexed(sc, rows, rows)
+        ctx.hvec_add_symkron(A, B, 0.5, 5, 5)
+        ctx.hvec_add_symkron(B, A, 0.5, 5, 5)               # A and B are sent once
+        ctx.hvec_add_symkron(A, A, -0.25, 5, 5)
+        return ctx.hvec_finish(theta if is_free else np.zeros(V), g, is_free)
+
+    for is_free in (False, True):
+        H_prog, H_imm = assemble(False, is_free), assemble(True, is_free)
+        assert np.array_equal(H_prog, H_imm)
+        assert np.allclose(H_prog, H_prog.T, rtol=0, atol=1e-12 * np.abs(H_prog).max())
+    # a block that does not fit is refused when it is recorded (and the library checks every record again before it launches anything)
+    ctx.hvec_begin()
+    with pytest.raises(ValueError):
+        ctx.hvec_add_block(blk, V - 2, 0)
+    ops = np.array([[0, 0, 5, 5, V - 2, 0, 0, 0]], dtype=np.int64)
+    import ctypes
+    st = ctx._lib.lrvb_hvec_program(ctx._h, ops.ctypes.data_as(ctypes.c_void_p), 1, vb._hip.ptr(blk.ravel().copy()), 25,
+                                    vb._hip.ptr(np.zeros(V)), V, 0, vb._hip.ptr(g), None)
+    assert st != 0
