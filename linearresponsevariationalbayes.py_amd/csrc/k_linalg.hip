@@ -814,8 +814,11 @@ int launch_gemv(lrvb_ctx* c, bool trans, i64 M, i64 Nn, double alpha, const doub
                 const double* x, double beta, double* y) {
     const i64 nout = trans ? Nn : M;
     if (nout <= 0) return LRVB_OK;
-    if (!trans && M >= 8192 && Nn <= 1024 && !(Nn & 1) && !(lda & 1) && !(((uintptr_t)A) & 15) && !(((uintptr_t)x) & 15)) {
-        const unsigned grid = 2048;
+    // (both streaming kernels were written for tall matrices and are the right ones for the square D x D and V x D products of
+    // the solvers too -- dense preconditioner, packing Jacobian of a PSD / simplex layout, CG on a resident matrix: the
+    // one-wave-per-output kernel below took 25-160 us for a 1024 x 1024 product, its transposed form walking columns)
+    if (!trans && M >= 256 && Nn <= 1024 && !(Nn & 1) && !(lda & 1) && !(((uintptr_t)A) & 15) && !(((uintptr_t)x) & 15)) {
+        const unsigned grid = (unsigned)(M >= 32768 ? 2048 : (M + 15) / 16);
         const int nv = (int)((Nn + 127) / 128);
 #define LRVB_GEMV_N(NVV) hipLaunchKernelGGL(gemv_n_tall_kernel<NVV>, dim3(grid), dim3(256), 0, c->stream, M, Nn, A, lda, x, alpha, beta, y)
         if (nv <= 1) LRVB_GEMV_N(1); else if (nv <= 2) LRVB_GEMV_N(2); else if (nv <= 4) LRVB_GEMV_N(4); else LRVB_GEMV_N(8);
@@ -823,9 +826,11 @@ int launch_gemv(lrvb_ctx* c, bool trans, i64 M, i64 Nn, double alpha, const doub
         HIP_TRY(hipGetLastError());
         return LRVB_OK;
     }
-    if (trans && M >= 8192 && Nn <= 4096) {
-        i64 nblk = (M + 255) / 256; if (nblk > 1024) nblk = 1024;
-        const i64 rpb = (M + nblk - 1) / nblk;
+    if (trans && M >= 64 && Nn <= 8192) {
+        i64 nblk = M >= 8192 ? (M + 255) / 256 : (M + 7) / 8;        // a short matrix still gets a few hundred workgroups
+        if (nblk > 1024) nblk = 1024;
+        i64 rpb = (M + nblk - 1) / nblk;
+        rpb = (rpb + 7) & ~(i64)7;
         nblk = (M + rpb - 1) / rpb;
         LRVB_TRY(buf_reserve(c, c->red_scratch, (size_t)(nblk * Nn)));
         hipLaunchKernelGGL(gemv_t_tall_kernel, dim3((unsigned)nblk), dim3(256), 0, c->stream, M, Nn, A, lda, x, rpb, c->red_scratch.p);
