@@ -269,7 +269,7 @@ void mixture_rows_kernel(const double* __restrict__ theta_z, const double* __res
             v_lin += cat ? -wn * p * s : 0.0;
             v_ent += cat ? wn * p * logp : 0.0;
         }
-        MX_ST(gb, (unsigned)(h * KM + hl - 1) * 8u, p * (g - gdotp), __ballot(valid && loc));     // J^T g:  p_{j+1} (g_{j+1} - g.p)
+        MX_ST(gb, (unsigned)(h * KM + hl - 1) * 8u, p * (g - gdotp), __ballot(valid && loc && gfree != nullptr));     // J^T g:  p_{j+1} (g_{j+1} - g.p); issued (masked) also when nobody asked for it
         // reference category of the row = its arg-max category m (see mixture_row_prelude): categories 0 and m change places
         const unsigned long long bal = __ballot(cat && logit == mxl);
         int m = __ffs((unsigned)(h ? (bal >> 32) : bal)) - 1;

@@ -1629,12 +1629,13 @@ static int mixture_rows_impl(lrvb_ctx* c, int32_t K, const double* theta_z, cons
     if (st == LRVB_OK) st = buf_reserve(c, lam, (size_t)((V + 1) * K));
     if (st == LRVB_OK) st = buf_reserve(c, Amat, (size_t)((N + 16) * lda));      // + 16 rows of zeros: the sliver loads of launch_atb run past N
     if (st == LRVB_OK) st = buf_reserve(c, U, (size_t)(N * 64));
-    if (st == LRVB_OK) st = buf_reserve(c, gfr, (size_t)(N * KM));
+    if (st == LRVB_OK && gfree_out) st = buf_reserve(c, gfr, (size_t)(N * KM));
     if (st == LRVB_OK && theta_z) { c->mx_theta_n = 0; st = h2d(c, thz.p, theta_z, (size_t)(N * KM)); if (st == LRVB_OK) c->mx_theta_n = N * KM; }
     if (st == LRVB_OK) st = h2d(c, lam.p, Lam, (size_t)((V + 1) * K));
     int* bad = reinterpret_cast<int*>(c->scal.p + 8);
     if (st == LRVB_OK && c->prof_on) st = prof_mark(c, PROF_WSYRK);                     // the per-row kernel counts among the statistics kernels
-    if (st == LRVB_OK) st = launch_mixture_rows(c, K, thz.p, lam.p, Amat.p, lda, U.p, gfr.p, c->scal.p, bad);
+    // (the local gradient is 8 N (K - 1) bytes of writes: only formed when the caller takes it)
+    if (st == LRVB_OK) st = launch_mixture_rows(c, K, thz.p, lam.p, Amat.p, lda, U.p, gfree_out ? gfr.p : (double*)nullptr, c->scal.p, bad);
     if (st == LRVB_OK && c->prof_on) st = prof_mark(c, PROF_WSYRK);
     if (st == LRVB_OK && gfree_out) st = d2h(c, gfree_out, gfr.p, (size_t)(N * KM));        // rank-local: this rank's rows
     // Everything that is a SUM OVER OBSERVATIONS goes into one device buffer, [S64 (4096) | val2 (2) | count of
