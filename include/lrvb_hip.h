@@ -167,6 +167,10 @@ int lrvb_set_weights_dev(lrvb_ctx* ctx, const double* w_dev, int64_t n);
 /* Multiplier of the quadratic term (the `z*y` keyword pass-through of
  * LRVB/test_objectives.py:161-217).                                                        */
 int lrvb_set_quad_scale (lrvb_ctx* ctx, double scale);
+/* Precision tau of the Gaussian loss 1/2 tau (y - z)^2 (the `lik_info` of the model description) as a settable
+ * hyper-parameter: LRVB/ModelSensitivity.py:555-612 takes ANY hyper_par, and a likelihood precision is one of the
+ * reference's own examples of it (regression_utils.py:59-132 carries `lik_info` as an argument).                    */
+int lrvb_set_lik_info   (lrvb_ctx* ctx, double lik_info);
 
 /* ---- packing: A15-A18 forward maps ---------------------------------------------------- */
 /* eta = constrain(theta): ModelParamsDict.set_free + get_vector
@@ -264,6 +268,35 @@ int lrvb_obs_influence_vec(lrvb_ctx* ctx, const double* vec_in, int64_t V, const
 /* D x V cross Hessian w.r.t. the linear tilt b of the quadratic term
  * (the `hyper_param @ theta` term of LRVB/test_model_sensitivity.py:56-66).                 */
 int lrvb_cross_hessian_tilt(lrvb_ctx* ctx, const double* free_in, int64_t D, double* C_out);
+/* ---- cross Hessians and gradients with respect to the OTHER hyper-parameters of the declared objective:
+ * TwoParameterObjective.fun_hessian_free1_vector2 / fun_vector_hessian12 / fun_grad2 (LRVB/SparseObjectives.py:381-449)
+ * and the `hyper_par` of ParametricSensitivityLinearApproximation (LRVB/ModelSensitivity.py:555-612, whose defining use
+ * is PRIOR sensitivity) for eps in
+ *   LRVB_HYPER_TILT        b                 (Ph = V)
+ *   LRVB_HYPER_QUAD_M      m, the centre / prior mean of the quadratic term (Ph = V)
+ *   LRVB_HYPER_QUAD_A      A: its diagonal (LRVB_QUAD_DIAG, Ph = V) or the row-major lower triangle of the symmetric
+ *                          matrix (LRVB_QUAD_DENSE, Ph = V (V + 1) / 2, the vector form of LRVB/MatrixParameters.py:16-41)
+ *   LRVB_HYPER_QUAD_SCALE  s                 (Ph = 1)
+ *   LRVB_HYPER_LIK_INFO    tau of the Gaussian loss (Ph = 1; one pass over the observations, summed over the ranks)
+ * all in VECTOR coordinates of the hyper-parameter (a free hyper-parameter chains through its own packing Jacobian on
+ * the caller's side: the objective is differentiated once in eps).  `point` is the free vector (is_free != 0) or the
+ * vector-coordinate point of the input parameter; C_out is n x Ph row-major (n = D or V), g_out has Ph entries.
+ * Closed forms in r = eta - m, A r, b and the data gradient, evaluated on the device with the packing Jacobian of the
+ * input applied there.                                                                                              */
+#define LRVB_HYPER_TILT        0
+#define LRVB_HYPER_QUAD_M      1
+#define LRVB_HYPER_QUAD_A      2
+#define LRVB_HYPER_QUAD_SCALE  3
+#define LRVB_HYPER_LIK_INFO    4
+int lrvb_hyper_size(lrvb_ctx* ctx, int kind, int64_t* n_hyper);
+int lrvb_cross_hessian_hyper(lrvb_ctx* ctx, int kind, const double* point, int64_t n_in, int is_free,
+                             double* C_out, int64_t n_hyper);
+int lrvb_hyper_grad(lrvb_ctx* ctx, int kind, const double* point, int64_t n_in, int is_free,
+                    double* g_out, int64_t n_hyper);
+/* out (D x Q, row-major) = J(theta)^T B for a host matrix B (V x Q): the chain rule d/d theta = J^T d/d eta for cross
+ * Hessians whose vector-coordinate form is an N-independent closed form of the caller's (the priors of the model
+ * families: LRVB/ExponentialFamilies.py:186-204 `mvn_prior`, `gamma_prior`, `dirichlet_prior`).                       */
+int lrvb_jac_t_matmul(lrvb_ctx* ctx, const double* free_in, int64_t D, const double* B, int64_t Q, double* out);
 /* Gram matrix G^T G (D x D) of the per-observation gradient matrix; G is generated on chip
  * and never materialised.                                                                   */
 int lrvb_gram(lrvb_ctx* ctx, const double* free_in, int64_t D, double* GtG_out, int64_t ld);

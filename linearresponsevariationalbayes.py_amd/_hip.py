@@ -18,6 +18,7 @@ BLOCK_BOX, BLOCK_PSD, BLOCK_SIMPLEX = 0, 1, 2
 LOSS_NONE, LOSS_GAUSSIAN, LOSS_LOGISTIC, LOSS_POISSON, LOSS_DATA_ONLY = 0, 1, 2, 3, 4
 QUAD_NONE, QUAD_DIAG, QUAD_DENSE = 0, 1, 2
 SLOT_X, SLOT_Y, SLOT_QUAD_A, SLOT_QUAD_M, SLOT_QUAD_B = 0, 1, 2, 3, 4
+HYPER_TILT, HYPER_QUAD_M, HYPER_QUAD_A, HYPER_QUAD_SCALE, HYPER_LIK_INFO = 0, 1, 2, 3, 4
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_i64 = ctypes.c_int64
@@ -61,6 +62,7 @@ _SIGNATURES = {
     'lrvb_set_weights': [_VP, _VP, c_i64],
     'lrvb_set_weights_dev': [_VP, _VP, c_i64],
     'lrvb_set_quad_scale': [_VP, ctypes.c_double],
+    'lrvb_set_lik_info': [_VP, ctypes.c_double],
     'lrvb_constrain': [_VP, _VP, c_i64, _VP, c_i64],
     'lrvb_unconstrain': [_VP, _VP, c_i64, _VP, c_i64],
     'lrvb_free_to_vector_jac': [_VP, _VP, c_i64, _VP],
@@ -87,6 +89,10 @@ _SIGNATURES = {
     'lrvb_obs_influence': [_VP, _VP, c_i64, _VP, c_i64, c_i64, c_i64, _VP],
     'lrvb_obs_influence_vec': [_VP, _VP, c_i64, _VP, c_i64, c_i64, c_i64, _VP],
     'lrvb_cross_hessian_tilt': [_VP, _VP, c_i64, _VP],
+    'lrvb_hyper_size': [_VP, ctypes.c_int, ctypes.POINTER(c_i64)],
+    'lrvb_cross_hessian_hyper': [_VP, ctypes.c_int, _VP, c_i64, ctypes.c_int, _VP, c_i64],
+    'lrvb_hyper_grad': [_VP, ctypes.c_int, _VP, c_i64, ctypes.c_int, _VP, c_i64],
+    'lrvb_jac_t_matmul': [_VP, _VP, c_i64, _VP, c_i64, _VP],
     'lrvb_gram': [_VP, _VP, c_i64, _VP, c_i64],
     'lrvb_weighted_gram': [_VP, _VP, c_i64],
     'lrvb_weighted_gram_sum': [_VP, _VP, c_i64, _VP],

@@ -38,7 +38,8 @@ void quad_finish_kernel(i64 V, double scale, const double* __restrict__ eta, con
     if (threadIdx.x == 0 && value) *value += scale * sh[0];
 }
 
-int launch_quad_grad_value(lrvb_ctx* c, const double* eta_dev, double* g_eta_dev, double* value_dev) {
+// vtmp = r = eta - m, vtmp2 = A r
+int launch_quad_diff(lrvb_ctx* c, const double* eta_dev) {
     if (c->quad_kind == LRVB_QUAD_NONE) return LRVB_OK;
     const i64 V = c->V;
     LRVB_TRY(buf_reserve(c, c->vtmp, (size_t)V));
@@ -49,6 +50,13 @@ int launch_quad_grad_value(lrvb_ctx* c, const double* eta_dev, double* g_eta_dev
     HIP_TRY(hipGetLastError());
     if (c->quad_kind == LRVB_QUAD_DENSE)
         LRVB_TRY(launch_gemv(c, false, V, V, 1.0, c->quadA.p, V, c->vtmp.p, 0.0, c->vtmp2.p));
+    return LRVB_OK;
+}
+
+int launch_quad_grad_value(lrvb_ctx* c, const double* eta_dev, double* g_eta_dev, double* value_dev) {
+    if (c->quad_kind == LRVB_QUAD_NONE) return LRVB_OK;
+    const i64 V = c->V;
+    LRVB_TRY(launch_quad_diff(c, eta_dev));
     hipLaunchKernelGGL(quad_finish_kernel, dim3(1), dim3(1024), 0, c->stream, V, c->quad_scale, eta_dev,
                        c->vtmp.p, c->vtmp2.p, c->quadB.p, g_eta_dev, value_dev);
     HIP_TRY(hipGetLastError());

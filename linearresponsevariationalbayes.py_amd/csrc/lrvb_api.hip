@@ -363,6 +363,15 @@ extern "C" int lrvb_set_quad_scale(lrvb_ctx* c, double scale) {
     return LRVB_OK;
 }
 
+extern "C" int lrvb_set_lik_info(lrvb_ctx* c, double lik_info) {
+    if (!c) LRVB_FAIL(LRVB_ERR_INVALID, "null context");
+    c->hvp_pt_valid = false;
+    if (c->loss != LRVB_LOSS_GAUSSIAN) LRVB_FAIL(LRVB_ERR_STATE, "lik_info is the precision of the Gaussian loss");
+    if (!(lik_info > 0.0) || !std::isfinite(lik_info)) LRVB_FAIL(LRVB_ERR_INVALID, "lik_info must be positive and finite");
+    c->lik_info = lik_info;
+    return LRVB_OK;
+}
+
 extern "C" int lrvb_set_tuning(lrvb_ctx* c, int n_splits, int reserved) {
     if (!c) LRVB_FAIL(LRVB_ERR_INVALID, "null context");
     if (n_splits < 0 || n_splits > 1024) LRVB_FAIL(LRVB_ERR_INVALID, "n_splits out of range");
@@ -1223,6 +1232,101 @@ extern "C" int lrvb_cross_hessian_tilt(lrvb_ctx* c, const double* free_in, int64
         LRVB_TRY(launch_axpby(c, c->V * c->D, c->quad_scale, c->work1.p, 0.0, c->work1.p));
     }
     return d2h(c, C_out, c->work1.p, (size_t)c->D * (size_t)c->V);
+}
+
+// ---- the other hyper-parameters of the declared objective (kernels: k_hyper.hip) -----------------------------------
+extern "C" int lrvb_hyper_size(lrvb_ctx* c, int kind, int64_t* n_hyper) {
+    if (!c || !n_hyper) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    if (kind == LRVB_HYPER_LIK_INFO) {
+        if (c->loss != LRVB_LOSS_GAUSSIAN) LRVB_FAIL(LRVB_ERR_STATE, "lik_info is the precision of the Gaussian loss");
+        *n_hyper = 1; return LRVB_OK;
+    }
+    if (kind < LRVB_HYPER_TILT || kind > LRVB_HYPER_LIK_INFO) LRVB_FAIL(LRVB_ERR_INVALID, "unknown hyper-parameter kind %d", kind);
+    if (c->quad_kind == LRVB_QUAD_NONE) LRVB_FAIL(LRVB_ERR_STATE, "model has no quadratic term");
+    if (kind == LRVB_HYPER_QUAD_SCALE) *n_hyper = 1;
+    else if (kind == LRVB_HYPER_QUAD_A && c->quad_kind == LRVB_QUAD_DENSE) *n_hyper = c->V * (c->V + 1) / 2;
+    else *n_hyper = c->V;
+    return LRVB_OK;
+}
+// theta / eta (and j1, the dense J of general layouts) at the point; r = eta - m in vtmp, A r in vtmp2 for the quadratic kinds;
+// the data gradient in g_eta and the data value in stats[0] for lik_info
+static int hyper_point(lrvb_ctx* c, int kind, const double* point, i64 n_in, bool is_free, int64_t n_hyper, bool need_J) {
+    LRVB_TRY(ctx_bind(c));
+    if (!point) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    int64_t Ph = 0;
+    LRVB_TRY(lrvb_hyper_size(c, kind, &Ph));
+    LRVB_TRY(check_len(n_hyper, Ph, "hyper-parameter"));
+    const i64 n = is_free ? c->D : c->V;
+    LRVB_TRY(check_len(n_in, n, is_free ? "free vector" : "vector"));
+    LRVB_TRY(h2d(c, c->theta.p, point, (size_t)n));
+    LRVB_TRY(set_point(c, c->theta.p, is_free));
+    if (need_J && is_free && !c->all_box) LRVB_TRY(ensure_dense_J(c, c->theta.p));
+    if (kind == LRVB_HYPER_LIK_INFO) {
+        LRVB_TRY(data_ready(c));
+        LRVB_TRY(eval_grad_eta(c, c->stats.p, false, true));
+    } else {
+        LRVB_TRY(launch_quad_diff(c, c->eta.p));
+    }
+    return LRVB_OK;
+}
+extern "C" int lrvb_cross_hessian_hyper(lrvb_ctx* c, int kind, const double* point, int64_t n_in, int is_free,
+                                        double* C_out, int64_t n_hyper) {
+    if (!C_out) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    LRVB_TRY(hyper_point(c, kind, point, n_in, is_free != 0, n_hyper, true));
+    const i64 V = c->V, D = c->D, Ph = n_hyper, n = is_free ? D : V;
+    if ((double)V * (double)Ph > 2.0e9) LRVB_FAIL(LRVB_ERR_SIZE, "a %lld x %lld cross Hessian does not fit: take a sub-block of the hyper-parameter", (long long)V, (long long)Ph);
+    const double* col = nullptr;
+    if (kind == LRVB_HYPER_QUAD_SCALE) {                      // d/ds of s (A r + b)
+        LRVB_TRY(launch_hyper_col(c, 1.0, c->vtmp2.p, 1.0, c->quadB.p, c->vtmp3.p));
+        col = c->vtmp3.p;
+    } else if (kind == LRVB_HYPER_LIK_INFO) {                 // the data gradient is linear in tau
+        LRVB_TRY(launch_hyper_col(c, 1.0 / c->lik_info, c->g_eta.p, 0.0, nullptr, c->vtmp3.p));
+        col = c->vtmp3.p;
+    }
+    const bool diag_J = is_free && c->all_box;
+    LRVB_TRY(buf_reserve(c, c->work1, (size_t)V * (size_t)Ph));
+    LRVB_TRY(launch_hyper_cross(c, kind, Ph, c->vtmp.p, col, diag_J ? c->j1.p : nullptr, c->work1.p));
+    if (!is_free || diag_J) return d2h(c, C_out, c->work1.p, (size_t)n * (size_t)Ph);
+    LRVB_TRY(buf_reserve(c, c->Hfree, (size_t)D * (size_t)Ph));
+    LRVB_TRY(launch_gemm(c, true, false, D, Ph, V, 1.0, c->Jdense.p, D, c->work1.p, Ph, 0.0, c->Hfree.p, Ph));
+    return d2h(c, C_out, c->Hfree.p, (size_t)D * (size_t)Ph);
+}
+extern "C" int lrvb_hyper_grad(lrvb_ctx* c, int kind, const double* point, int64_t n_in, int is_free,
+                               double* g_out, int64_t n_hyper) {
+    if (!g_out) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    LRVB_TRY(hyper_point(c, kind, point, n_in, is_free != 0, n_hyper, false));
+    if (kind == LRVB_HYPER_LIK_INFO) {                        // sum_n w_n l_n is linear in tau
+        double v = 0.0;
+        LRVB_TRY(d2h(c, &v, c->stats.p, 1));
+        g_out[0] = v / c->lik_info;
+        return LRVB_OK;
+    }
+    if (kind == LRVB_HYPER_QUAD_SCALE) {                      // 1/2 r^T A r + b^T eta: the quadratic term at unit scale
+        const double saved = c->quad_scale;
+        c->quad_scale = 1.0;
+        hipError_t e = hipMemsetAsync(c->scal.p, 0, sizeof(double), c->stream);
+        int st = (e == hipSuccess) ? launch_quad_grad_value(c, c->eta.p, nullptr, c->scal.p) : LRVB_ERR_HIP;
+        c->quad_scale = saved;
+        if (e != hipSuccess) LRVB_FAIL(LRVB_ERR_HIP, "memset failed: %s", hipGetErrorString(e));
+        LRVB_TRY(st);
+        return d2h(c, g_out, c->scal.p, 1);
+    }
+    LRVB_TRY(buf_reserve(c, c->work1, (size_t)n_hyper));
+    LRVB_TRY(launch_hyper_grad(c, kind, n_hyper, c->eta.p, c->vtmp.p, c->vtmp2.p, c->work1.p));
+    return d2h(c, g_out, c->work1.p, (size_t)n_hyper);
+}
+extern "C" int lrvb_jac_t_matmul(lrvb_ctx* c, const double* free_in, int64_t D, const double* B, int64_t Q, double* out) {
+    LRVB_TRY(ctx_bind(c));
+    if (!free_in || !B || !out || Q <= 0) LRVB_FAIL(LRVB_ERR_INVALID, "bad argument");
+    LRVB_TRY(check_len(D, c->D, "free vector"));
+    const i64 V = c->V;
+    LRVB_TRY(h2d(c, c->theta.p, free_in, (size_t)D));
+    LRVB_TRY(buf_reserve(c, c->work1, (size_t)V * (size_t)Q));
+    LRVB_TRY(buf_reserve(c, c->Hfree, (size_t)D * (size_t)Q));
+    LRVB_TRY(h2d(c, c->work1.p, B, (size_t)V * (size_t)Q));
+    LRVB_TRY(ensure_dense_J(c, c->theta.p));
+    LRVB_TRY(launch_gemm(c, true, false, D, Q, V, 1.0, c->Jdense.p, D, c->work1.p, Q, 0.0, c->Hfree.p, Q));
+    return d2h(c, out, c->Hfree.p, (size_t)D * (size_t)Q);
 }
 
 static int gram_dev_impl(lrvb_ctx* c, const double* free_dev, double* G_dev, i64 ld) {

@@ -179,7 +179,13 @@ int launch_cg_update(lrvb_ctx* c, i64 n, double alpha, const double* d, const do
 int launch_gemv(lrvb_ctx* c, bool trans, i64 M, i64 Nn, double alpha, const double* A, i64 lda,
                 const double* x, double beta, double* y);
 
+// k_hyper.hip
+int launch_hyper_cross(lrvb_ctx* c, int kind, i64 Ph, const double* r, const double* col, const double* j1, double* Cv /* V x Ph */);
+int launch_hyper_grad(lrvb_ctx* c, int kind, i64 Ph, const double* eta, const double* r, const double* Ar, double* g /* Ph */);
+int launch_hyper_col(lrvb_ctx* c, double a, const double* x, double bcoef, const double* y, double* out /* V */);
+
 // k_finish.hip
+int launch_quad_diff(lrvb_ctx* c, const double* eta_dev);    // vtmp = eta - m, vtmp2 = A (eta - m)
 int launch_quad_grad_value(lrvb_ctx* c, const double* eta_dev, double* g_eta_dev /* += */, double* value_dev /* += */);
 int launch_quad_hvp(lrvb_ctx* c, const double* u_vec_V, double* out_vec_V /* += scale*A u */);
 int launch_finish_box(lrvb_ctx* c, const double* tiles_dev, const double* g_eta_dev,

@@ -20,9 +20,10 @@ from scipy import special
 from scipy import sparse as sp_sparse
 
 from . import _hip
-from .models import DeviceContext
+from .models import DeviceContext, DeclaredHypers, sym_to_vech, vech_to_sym
 from .packing import VectorParam, HyperVectorParam, ResidentVector
-from .quadform import duplication_matrix
+from .quadform import (duplication_matrix, mvn_prior_hyper_grad, mvn_prior_hyper_cross, gamma_prior_hyper_grad,
+                       gamma_prior_hyper_cross)
 
 
 def _gamma_block(a, b, f_t, f_L):
@@ -39,7 +40,7 @@ def _gamma_entropy(a, b):
     return a - np.log(b) + special.gammaln(a) + (1.0 - a) * special.digamma(a)
 
 
-class LMMObjective(object):
+class LMMObjective(DeclaredHypers):
     _lrvb_device_functor = True
 
     def __init__(self, par, x, y, groups, n_groups, beta_prior_mean=None, beta_prior_info=None,
@@ -52,20 +53,105 @@ class LMMObjective(object):
         self.G = int(n_groups)
         p, G = self.p, self.G
         self._index(par, names)
-        self.beta0 = np.zeros(p) if beta_prior_mean is None else _hip.as_f64(beta_prior_mean).ravel()
-        self.lam0 = np.eye(p) if beta_prior_info is None else _hip.as_f64(beta_prior_info)
-        self.mu0, self.kappa0 = float(mu_prior_mean), float(mu_prior_info)
-        self.a0y, self.b0y = map(float, tau_y_prior)
-        self.a0m, self.b0m = map(float, tau_mu_prior)
+        self._declare_priors(beta_prior_mean, beta_prior_info, mu_prior_mean, mu_prior_info, tau_y_prior, tau_mu_prior)
         self.ctx = DeviceContext(par.layout_blocks(), loss='data_only', n_obs=self.n_obs, n_cols=p + 1, device=device)
         self.ctx.set_data(_hip.SLOT_X, np.hstack([x, y]))
         self.ctx.set_groups(groups, G)
         w0 = np.ones(self.n_obs) if weights is None else _hip.as_f64(weights).ravel().copy()
-        self.weights_par = HyperVectorParam('weights', self.n_obs, val=w0)
+        self._declare_hyper('weights', HyperVectorParam('weights', self.n_obs, val=w0))
         self.tilt_par = None
         self._w_res = ResidentVector()
         self._stats_cache = None
         self._external_stats = None
+
+    # ---- the priors are hyper-parameters (LRVB/ModelSensitivity.py:555-612: prior sensitivity) -------------------------
+    def _declare_priors(self, beta_prior_mean, beta_prior_info, mu_prior_mean, mu_prior_info, tau_y_prior, tau_mu_prior):
+        """beta_prior_mean_par (p), beta_prior_info_par (symmetric matrix in vector form), mu_prior_par = (mean, information)
+        of the normal prior on mu, tau_y_prior_par / tau_mu_prior_par = (shape, rate) of the two gamma priors."""
+        p = self.p
+        self._declare_hyper('beta_prior_mean', HyperVectorParam('beta_prior_mean', p, val=np.zeros(p) if beta_prior_mean is None else _hip.as_f64(beta_prior_mean).ravel()))
+        self._declare_hyper('beta_prior_info', HyperVectorParam('beta_prior_info', p * (p + 1) // 2,
+                                                                val=sym_to_vech(np.eye(p) if beta_prior_info is None else beta_prior_info)))
+        self._declare_hyper('mu_prior', HyperVectorParam('mu_prior', 2, val=np.array([float(mu_prior_mean), float(mu_prior_info)])))
+        self._declare_hyper('tau_y_prior', HyperVectorParam('tau_y_prior', 2, lb=0.0, val=np.array(list(map(float, tau_y_prior)))))
+        self._declare_hyper('tau_mu_prior', HyperVectorParam('tau_mu_prior', 2, lb=0.0, val=np.array(list(map(float, tau_mu_prior)))))
+
+    beta0 = property(lambda self: self._hyper_vec('beta_prior_mean'))
+    lam0 = property(lambda self: vech_to_sym(self._hyper_vec('beta_prior_info')))
+    mu0 = property(lambda self: float(self._hyper_vec('mu_prior')[0]))
+    kappa0 = property(lambda self: float(self._hyper_vec('mu_prior')[1]))
+    a0y = property(lambda self: float(self._hyper_vec('tau_y_prior')[0]))
+    b0y = property(lambda self: float(self._hyper_vec('tau_y_prior')[1]))
+    a0m = property(lambda self: float(self._hyper_vec('tau_mu_prior')[0]))
+    b0m = property(lambda self: float(self._hyper_vec('tau_mu_prior')[1]))
+
+    def _prior_hyper(self, kind, eta_g, want):
+        """d f / d eps (Ph,) or the GLOBAL rows of d2 f / d eta d eps^T (n_global x Ph) in vector coordinates; the priors do not
+        touch the 2 G group parameters, whose rows are zero."""
+        ng = self.n_global
+        if kind in ('beta_prior_mean', 'beta_prior_info'):
+            m = eta_g[self._ms]
+            P = np.linalg.inv(self._sym_from_vech(eta_g[self._ls]))
+            sub = kind[len('beta_prior_'):]
+            if want == 'grad':
+                return mvn_prior_hyper_grad(sub, m - self.beta0, P, self.lam0)
+            return mvn_prior_hyper_cross(sub, ng, self._ms, self._ls, m - self.beta0, P, self.lam0)
+        if kind == 'mu_prior':
+            e_mu, i_mu = eta_g[self._iem], eta_g[self._iim]
+            if want == 'grad':
+                return np.array([-self.kappa0 * (e_mu - self.mu0), 0.5 * ((e_mu - self.mu0) ** 2 + 1.0 / i_mu)])
+            C = np.zeros((ng, 2))
+            C[self._iem, 0] = -self.kappa0
+            C[self._iem, 1] = e_mu - self.mu0
+            C[self._iim, 1] = -0.5 / i_mu ** 2
+            return C
+        ia, ib = (self._iay, self._iby) if kind == 'tau_y_prior' else (self._iam, self._ibm)
+        if kind not in ('tau_y_prior', 'tau_mu_prior'):
+            raise NotImplementedError(kind)
+        if want == 'grad':
+            return gamma_prior_hyper_grad(eta_g[ia], eta_g[ib], special)
+        return gamma_prior_hyper_cross(ng, ia, ib, eta_g[ia], eta_g[ib], special)
+
+    def hyper_grad(self, hyper_par, val1, val1_is_free):
+        kind = self.hyper_kind(hyper_par)
+        if kind == 'weights':
+            raise NotImplementedError('d f / d weights of the hierarchical model is not declared')
+        return self._prior_hyper(kind, self._eta(val1, val1_is_free)[:self.n_global], 'grad')
+
+    @_hip.host_blas
+    def cross_hessian(self, hyper_par, val1, val1_is_free):
+        """d2 f / d par1 d hyper^T for the declared priors, all rows (dense protocol, small G): (n1, Ph)."""
+        kind = self.hyper_kind(hyper_par)
+        if kind == 'weights':
+            raise NotImplementedError('the weight cross Hessian of the hierarchical model is not declared')
+        val1 = _hip.as_f64(val1).ravel()
+        Cg = self.global_cross_hessian(hyper_par, val1, is_free=val1_is_free)
+        return np.vstack([Cg, np.zeros((val1.size - self.n_global, Cg.shape[1]))])
+
+    @_hip.host_blas
+    def global_cross_hessian(self, hyper_par, val, is_free=True):
+        """The n_global rows of the cross Hessian with a prior hyper-parameter (the 2 G local rows are zero): closed form in
+        vector coordinates, J_g^T applied on the device."""
+        kind = self.hyper_kind(hyper_par)
+        ng = self.n_global
+        val = _hip.as_f64(val).ravel()
+        gc = self._ensure_gctx()
+        eta_g = gc.constrain(val[:ng]) if is_free else val[:ng]
+        Cv = self._prior_hyper(kind, eta_g, 'cross')
+        return gc.jac_t_matmul(val[:ng], Cv) if is_free else Cv
+
+    def global_sensitivity(self, hyper_par, free_val):
+        """d theta_global / d hyper^T = -H_S^-1 C_g (n_global x Ph): linear response of the global parameters to a prior
+        (LRVB/ModelSensitivity.py:596-602) through the Schur complement of the arrow Hessian -- the local rows of the cross
+        Hessian are zero, so the local parameters enter through H_S only."""
+        Cg = self.global_cross_hessian(hyper_par, free_val)
+        gc = self._ensure_gctx()
+        if self._device_path and self._external_stats is None:
+            self.global_hessian(free_val, want_host=False)
+            gc.chol_factor_last()
+        else:
+            gc.chol_factor(self.global_hessian(free_val))
+        return -gc.chol_solve(Cg)
 
     def _index(self, par, names):
         p, G = self.p, self.G

@@ -23,7 +23,7 @@ import numpy as np
 from scipy import special, sparse
 
 from . import _hip
-from .models import DeviceContext
+from .models import DeviceContext, DeclaredHypers
 from .packing import VectorParam, HyperVectorParam, ResidentVector
 from .specfun import polygamma12
 
@@ -46,7 +46,7 @@ def _dirichlet_terms(alpha, d):
     return val, grad, hess
 
 
-class MixtureObjective(object):
+class MixtureObjective(DeclaredHypers):
     _lrvb_device_functor = True
 
     def __init__(self, par, x, pi_prior=1.0, phi_prior=1.0, names=('pi', 'phi', 'z'), weights=None, device=0):
@@ -72,8 +72,7 @@ class MixtureObjective(object):
         self._lb[self._iphi.ravel()] = par[nphi]['alpha']._lb
         if np.isfinite(par[npi]['alpha']._ub) or np.isfinite(par[nphi]['alpha']._ub):
             raise ValueError('the Dirichlet parameters must be bounded below only')
-        self.a0 = np.broadcast_to(_hip.as_f64(pi_prior), (K,)).astype(np.float64)
-        self.b0 = np.broadcast_to(_hip.as_f64(phi_prior), (V, K)).astype(np.float64)
+        self._declare_priors(pi_prior, phi_prior)
         # the device context carries the packing of the GLOBAL blocks only: the simplex rows are
         # constrained inside the row kernel and never materialised on the host
         blocks, size = [], 0
@@ -86,7 +85,7 @@ class MixtureObjective(object):
         self.ctx = DeviceContext(blocks, loss='data_only', n_obs=N, n_cols=V, device=device)
         self.ctx.set_data(_hip.SLOT_X, x)
         w0 = np.ones(N) if weights is None else _hip.as_f64(weights).ravel().copy()
-        self.weights_par = HyperVectorParam('weights', N, val=w0)
+        self._declare_hyper('weights', HyperVectorParam('weights', N, val=w0))
         self.tilt_par = None
         self._w_res = ResidentVector()
         self._external_stats = None
@@ -95,6 +94,81 @@ class MixtureObjective(object):
         # not to change them while this is set; `drop_resident_logits()` forces the next upload.
         self.keep_logits_resident = False
         self._fz_on_device = False
+
+    # ---- the Dirichlet priors are hyper-parameters (LRVB/ModelSensitivity.py:555-612: prior sensitivity) ----------------
+    def _declare_priors(self, pi_prior, phi_prior):
+        """pi_prior_par (K) and phi_prior_par (V K, the (V, K) array flattened row-major): the concentration parameters of
+        `dirichlet_prior` (LRVB/ExponentialFamilies.py:201-204) on the mixing weights and on the K topics."""
+        K, V = self.K, self.V
+        self._declare_hyper('pi_prior', HyperVectorParam('pi_prior', K, lb=0.0,
+                                                         val=np.broadcast_to(_hip.as_f64(pi_prior), (K,)).astype(np.float64)))
+        self._declare_hyper('phi_prior', HyperVectorParam('phi_prior', V * K, lb=0.0,
+                                                          val=np.broadcast_to(_hip.as_f64(phi_prior), (V, K)).astype(np.float64).ravel()))
+
+    a0 = property(lambda self: self._hyper_vec('pi_prior'))
+    b0 = property(lambda self: self._hyper_vec('phi_prior').reshape(self.V, self.K))
+
+    def _prior_hyper(self, kind, alpha, beta, want):
+        """d f / d eps (Ph,) or the GLOBAL rows of d2 f / d eta d eps^T (n_global x Ph), vector coordinates: the prior enters
+        through d = C + prior - 1 in `_dirichlet_terms`, so d f / d prior_m = -E log p_m and the gradient e psi1 - sum(e) psi1_0
+        (e = alpha - 1 - d) moves by -psi1 on the diagonal, +psi1_0 inside each Dirichlet."""
+        V, K, ng = self.V, self.K, self.n_global
+        if kind == 'pi_prior':
+            if want == 'grad':
+                return -(special.digamma(alpha) - special.digamma(np.sum(alpha)))
+            C = np.zeros((ng, K))
+            C[np.ix_(self._ipi, np.arange(K))] = -np.diag(special.polygamma(1, alpha)) + special.polygamma(1, np.sum(alpha))
+            return C
+        if kind != 'phi_prior':
+            raise NotImplementedError(kind)
+        b0s = np.sum(beta, axis=0)
+        if want == 'grad':
+            return -(special.digamma(beta) - special.digamma(b0s)[None, :]).ravel()
+        C = np.zeros((ng, V * K))
+        p1, p10 = special.polygamma(1, beta), special.polygamma(1, b0s)
+        cols = np.arange(V * K).reshape(V, K)
+        for k in range(K):
+            C[np.ix_(self._iphi[:, k], cols[:, k])] = -np.diag(p1[:, k]) + p10[k]
+        return C
+
+    def hyper_grad(self, hyper_par, val1, val1_is_free=True):
+        kind = self.hyper_kind(hyper_par)
+        if kind == 'weights':
+            raise NotImplementedError('d f / d weights of the mixture is not declared')
+        fg, _ = self._split(val1)
+        alpha, beta, _ = self._lam(self._lb + np.exp(fg))
+        return self._prior_hyper(kind, alpha, beta, 'grad')
+
+    def global_cross_hessian(self, hyper_par, free_val):
+        """The n_global rows of d2 f / d theta d prior^T in FREE coordinates (the N (K - 1) simplex rows are zero): the closed
+        form in vector coordinates with the packing Jacobian of the Dirichlet blocks applied on the device."""
+        kind = self.hyper_kind(hyper_par)
+        if kind == 'weights':
+            raise NotImplementedError('the weight cross Hessian of the mixture is not declared')
+        fg, _ = self._split(free_val)
+        alpha, beta, _ = self._lam(self._lb + np.exp(fg))
+        return self.ctx.jac_t_matmul(fg, self._prior_hyper(kind, alpha, beta, 'cross'))
+
+    def cross_hessian(self, hyper_par, val1, val1_is_free=True):
+        """Functor protocol (all rows; small N): the global rows over zeros for the simplex logits."""
+        if not val1_is_free:
+            raise NotImplementedError('the mixture objective is evaluated in free coordinates')
+        n_local = self.n_obs * (self.K - 1)
+        if n_local * 8 > 2 ** 31:
+            raise MemoryError('use global_cross_hessian / global_sensitivity: the simplex rows of the cross Hessian are zero')
+        Cg = self.global_cross_hessian(hyper_par, val1)
+        return np.vstack([Cg, np.zeros((n_local, Cg.shape[1]))])
+
+    def global_sensitivity(self, hyper_par, free_val):
+        """d theta_global / d prior^T = -H_S^-1 C_g: linear response of the Dirichlet parameters to a prior through the Schur
+        complement (the N simplex blocks are eliminated on the device; their rows of the cross Hessian are zero)."""
+        Cg = self.global_cross_hessian(hyper_par, free_val)
+        if self._external_stats is None and self._canonical_order():
+            self.global_hessian(free_val, want_host=False)
+            self.ctx.chol_factor_last()
+        else:
+            self.ctx.chol_factor(self.global_hessian(free_val))
+        return -self.ctx.chol_solve(Cg)
 
     def drop_resident_logits(self):
         self._fz_on_device = False

@@ -23,6 +23,22 @@ _LOSSES = {None: _hip.LOSS_NONE, 'none': _hip.LOSS_NONE, 'gaussian': _hip.LOSS_G
            'logistic': _hip.LOSS_LOGISTIC, 'poisson': _hip.LOSS_POISSON, 'data_only': _hip.LOSS_DATA_ONLY}
 
 
+def sym_to_vech(A):
+    """Row-major lower triangle of (the symmetric part of) A: the vector form of a symmetric matrix parameter
+    (LRVB/MatrixParameters.py:16-41, index j + i (i + 1) / 2)."""
+    A = _hip.as_f64(A)
+    A = 0.5 * (A + A.T)
+    return np.ascontiguousarray(A[np.tril_indices(A.shape[0])])
+
+
+def vech_to_sym(v):
+    v = _hip.as_f64(v).ravel()
+    k = int(round((np.sqrt(8.0 * v.size + 1.0) - 1.0) / 2.0))
+    L = np.zeros((k, k))
+    L[np.tril_indices(k)] = v
+    return L + L.T - np.diag(np.diag(L))
+
+
 def _block_array(blocks):
     arr = (_hip.BlockDesc * len(blocks))()
     fo = vo = 0
@@ -100,6 +116,9 @@ class DeviceContext(object):
     def set_quad_scale(self, s):
         self._check(self._lib.lrvb_set_quad_scale(self._h, float(s)))
         self.quad_scale = float(s)
+
+    def set_lik_info(self, tau):
+        self._check(self._lib.lrvb_set_lik_info(self._h, float(tau)))
 
     def set_reduce_hook(self, fn):
         """Install the sum-over-ranks hook of include/lrvb_hip.h (`lrvb_set_reduce_hook`): `fn(dev_ptr, n, hip_stream)`
@@ -398,6 +417,37 @@ class DeviceContext(object):
         self._check(self._lib.lrvb_cross_hessian_tilt(self._h, _hip.ptr(f), f.size, _hip.ptr(C)))
         return C
 
+    def hyper_size(self, kind):
+        n = ctypes.c_int64(0)
+        self._check(self._lib.lrvb_hyper_size(self._h, int(kind), ctypes.byref(n)))
+        return n.value
+
+    def cross_hessian_hyper(self, kind, x, is_free=True):
+        """d2 f / d x d eps^T for the hyper-parameter `kind` (_hip.HYPER_*) in its vector coordinates: (n, Ph)."""
+        x = _hip.as_f64(x).ravel()
+        Ph = self.hyper_size(kind)
+        C = np.empty((self._n(is_free), Ph))
+        self._check(self._lib.lrvb_cross_hessian_hyper(self._h, int(kind), _hip.ptr(x), x.size, 1 if is_free else 0, _hip.ptr(C), Ph))
+        return C
+
+    def hyper_grad(self, kind, x, is_free=True):
+        """d f / d eps for the hyper-parameter `kind` in its vector coordinates: (Ph,)."""
+        x = _hip.as_f64(x).ravel()
+        Ph = self.hyper_size(kind)
+        g = np.empty(Ph)
+        self._check(self._lib.lrvb_hyper_grad(self._h, int(kind), _hip.ptr(x), x.size, 1 if is_free else 0, _hip.ptr(g), Ph))
+        return g
+
+    def jac_t_matmul(self, free, B):
+        """J(free)^T B on the device for a host matrix B (V x Q): the chain rule of a vector-coordinate cross Hessian."""
+        f, B = _hip.as_f64(free).ravel(), _hip.as_f64(B)
+        B2 = B.reshape(B.shape[0], -1)
+        if f.size != self.D or B2.shape[0] != self.V:
+            raise ValueError('expected a free vector of length {} and a matrix with {} rows'.format(self.D, self.V))
+        out = np.empty((self.D, B2.shape[1]))
+        self._check(self._lib.lrvb_jac_t_matmul(self._h, _hip.ptr(f), f.size, _hip.ptr(B2), B2.shape[1], _hip.ptr(out)))
+        return out
+
     def gram(self, free):
         f = _hip.as_f64(free).ravel()
         G = np.empty((self.D, self.D))
@@ -676,7 +726,52 @@ class DeviceContext(object):
         return {name: getattr(p, name) for name, _ in _hip.Prof._fields_}
 
 
-class DeviceObjective(object):
+class DeclaredHypers(object):
+    """Registry of the hyper-parameters a declared objective exposes to `TwoParameterObjective` /
+    `ParametricSensitivityLinearApproximation` / `ParametricSensitivityTaylorExpansion` (the reference accepts ANY
+    parameter object as `hyper_par`, LRVB/ModelSensitivity.py:555-612; a declared objective lists the ones it can
+    differentiate): attribute `<name>_par` per hyper-parameter, `hyper_pars` (name -> parameter), `hyper_kind(par)`."""
+
+    def _declare_hyper(self, name, par):
+        if not hasattr(self, '_hyper_names'):
+            self._hyper_names = []
+        if name not in self._hyper_names:
+            self._hyper_names.append(name)
+        setattr(self, name + '_par', par)
+        return par
+
+    @property
+    def hyper_pars(self):
+        """name -> parameter object of every declared hyper-parameter (an attribute `<name>_par` that the caller replaced
+        by another parameter object of the same size is honoured)."""
+        return {name: getattr(self, name + '_par') for name in getattr(self, '_hyper_names', [])
+                if getattr(self, name + '_par', None) is not None}
+
+    def hyper_kind(self, hyper_par):
+        for name, par in self.hyper_pars.items():
+            if hyper_par is par:
+                return name
+        raise NotImplementedError(
+            'the second parameter must be one of this objective\'s declared hyper-parameters ({}); any other '
+            'hyper-parameter would need tracing of a Python closure, which the device path cannot do'.format(
+                ', '.join(n + '_par' for n in getattr(self, '_hyper_names', []))))
+
+    def _hyper_vec(self, name):
+        return np.asarray(getattr(self, name + '_par').get_vector(), dtype=np.float64).ravel()
+
+    def _hyper_state_key(self, skip=('weights',)):
+        """Cheap identity of the current values of the hyper-parameters (for result memos): version stamps where the
+        parameter has them, contents otherwise."""
+        key = []
+        for name, par in self.hyper_pars.items():
+            if name in skip:
+                continue
+            version = getattr(par, 'version', None)
+            key.append((name, version if version is not None else np.asarray(par.get_vector(), dtype=np.float64).tobytes()))
+        return tuple(key)
+
+
+class DeviceObjective(DeclaredHypers):
     """A declared objective bound to a parameter object `par` (any object with the packing
     protocol and `layout_blocks()`).
 
@@ -727,40 +822,70 @@ class DeviceObjective(object):
             raise ValueError('layout_blocks() of the parameter disagrees with its free/vector sizes')
         self.n_obs = n_obs
         self.scale_fun = scale_fun
-        self.weights_par = None
-        self.tilt_par = None
-        self._w_res = ResidentVector()
-        self._b_res = ResidentVector()
+        self._quad_kind = quad_kind
+        self._hyper_names = []
+        self._res = {}
+        self.weights_par = self.tilt_par = None
+        self.prior_mean_par = self.prior_info_par = self.quad_scale_par = self.lik_info_par = None
         if loss is not None:
             self.ctx.set_data(_hip.SLOT_X, x)
             self.ctx.set_data(_hip.SLOT_Y, _hip.as_f64(y).ravel())
             w0 = np.ones(n_obs) if weights is None else _hip.as_f64(weights).ravel().copy()
-            self.weights_par = HyperVectorParam('weights', n_obs, val=w0)
+            self._declare_hyper('weights', HyperVectorParam('weights', n_obs, val=w0))
+            if _LOSSES[loss] == _hip.LOSS_GAUSSIAN:
+                self._declare_hyper('lik_info', HyperVectorParam('lik_info', 1, lb=0.0, val=np.array([float(lik_info)])))
         if quad_kind != _hip.QUAD_NONE:
-            self.ctx.set_data(_hip.SLOT_QUAD_A, quad_A)
-            if quad_m is not None:
-                self.ctx.set_data(_hip.SLOT_QUAD_M, _hip.as_f64(quad_m).ravel())
             b0 = np.zeros(V) if quad_b is None else _hip.as_f64(quad_b).ravel().copy()
-            self.tilt_par = HyperVectorParam('tilt', V, val=b0)
+            m0 = np.zeros(V) if quad_m is None else _hip.as_f64(quad_m).ravel().copy()
+            self._declare_hyper('tilt', HyperVectorParam('tilt', V, val=b0))
+            self._declare_hyper('prior_mean', HyperVectorParam('prior_mean', V, val=m0))
+            if quad_kind == _hip.QUAD_DIAG:
+                self._declare_hyper('prior_info', HyperVectorParam('prior_info', V, val=quad_A.ravel()))
+            else:       # the symmetric matrix in the reference's vector form: its row-major lower triangle
+                self._declare_hyper('prior_info', HyperVectorParam('prior_info', V * (V + 1) // 2, val=sym_to_vech(quad_A)))
+            self._declare_hyper('quad_scale', HyperVectorParam('quad_scale', 1, val=np.ones(1)))
         self._push_state()
+
+    # ---- declared hyper-parameters ------------------------------------------------------------
+    def _declare_hyper(self, name, par):
+        self._res[name] = ResidentVector()
+        return DeclaredHypers._declare_hyper(self, name, par)
 
     # ---- state pushed before every evaluation ------------------------------------------
     def _push_state(self):
-        if self.weights_par is not None:
-            w = self._w_res.changed(self.weights_par)          # O(1) for the objective's own HyperVectorParam
-            if w is not None:
-                self.ctx.set_weights(w)
-        if self.tilt_par is not None:
-            b = self._b_res.changed(self.tilt_par)
-            if b is not None:
-                self.ctx.set_data(_hip.SLOT_QUAD_B, b)
+        for name in self._hyper_names:
+            par = getattr(self, name + '_par')
+            if par is None:
+                continue
+            v = self._res[name].changed(par)                   # O(1) for the objective's own HyperVectorParams
+            if v is None:
+                continue
+            if name == 'weights':
+                self.ctx.set_weights(v)
+            elif name == 'tilt':
+                self.ctx.set_data(_hip.SLOT_QUAD_B, v)
+            elif name == 'prior_mean':
+                self.ctx.set_data(_hip.SLOT_QUAD_M, v)
+            elif name == 'prior_info':
+                self.ctx.set_data(_hip.SLOT_QUAD_A, v if self._quad_kind == _hip.QUAD_DIAG else vech_to_sym(v))
+            elif name == 'lik_info':
+                self.ctx.set_lik_info(float(np.ravel(v)[0]))
+            # quad_scale: read by _scale() at every evaluation
+
+    def _scale(self, argv=(), argk=None):
+        """The multiplier of the quadratic term: the `quad_scale` hyper-parameter times scale_fun(*argv, **argk)."""
+        s = 1.0 if self.quad_scale_par is None else float(np.ravel(self.quad_scale_par.get_vector())[0])
+        if self.scale_fun is not None:
+            s *= float(self.scale_fun(*argv, **(argk or {})))
+        elif argv or argk:
+            raise TypeError('this objective takes no extra arguments (no scale_fun declared)')
+        return s
 
     def _push(self, argv=(), argk=None):
         self._push_state()
-        if self.scale_fun is not None:
-            self.ctx.set_quad_scale(self.scale_fun(*argv, **(argk or {})))
-        elif argv or argk:
-            raise TypeError('this objective takes no extra arguments (no scale_fun declared)')
+        s = self._scale(argv, argk)
+        if s != self.ctx.quad_scale:
+            self.ctx.set_quad_scale(s)
 
     # ---- the reference's `fun` protocol --------------------------------------------------
     def __call__(self, *argv, **argk):
@@ -788,37 +913,61 @@ class DeviceObjective(object):
         # scalar objective: the Jacobian is the gradient (shape (D,)), as autograd.jacobian gives
         return self.grad(x, is_free, *argv, **argk)
 
-    def hyper_kind(self, hyper_par):
-        if hyper_par is self.weights_par:
-            return 'weights'
-        if hyper_par is self.tilt_par:
-            return 'tilt'
-        raise NotImplementedError(
-            'the second parameter must be this objective\'s `weights_par` or `tilt_par`; other '
-            'hyper-parameters would need tracing of a Python closure, which the device path cannot do')
+    _HYPER_KINDS = {'tilt': _hip.HYPER_TILT, 'prior_mean': _hip.HYPER_QUAD_M, 'prior_info': _hip.HYPER_QUAD_A,
+                    'quad_scale': _hip.HYPER_QUAD_SCALE, 'lik_info': _hip.HYPER_LIK_INFO}
 
     def cross_hessian(self, hyper_par, val1, val1_is_free, *argv, **argk):
-        """d2 f / d par1 d hyper^T with hyper in VECTOR coordinates; shape (n1, hyper size)."""
+        """d2 f / d par1 d hyper^T with hyper in VECTOR coordinates; shape (n1, hyper size).  Closed forms on the device
+        (csrc/k_hyper.hip); the weights' cross Hessian is the per-observation gradient matrix."""
         kind = self.hyper_kind(hyper_par)
         self._push(argv, argk)
         if kind == 'weights':
             return np.ascontiguousarray(self.ctx.obs_grad(val1, 0, self.n_obs, val1_is_free).T)
-        if val1_is_free:
-            return self.ctx.cross_hessian_tilt(val1)
-        s = self.scale_fun(*argv, **argk) if self.scale_fun is not None else 1.0
-        return s * np.eye(self.ctx.V)
+        return self.ctx.cross_hessian_hyper(self._HYPER_KINDS[kind], val1, val1_is_free)
 
     def hyper_grad(self, hyper_par, val1, val1_is_free, *argv, **argk):
         """d f / d hyper with hyper in VECTOR coordinates (TwoParameterObjective.fun_grad2,
-        LRVB/SparseObjectives.py:381-387): the objective is linear in both declared hyper-parameters, so the gradient is
-        the per-observation loss l(y_n, z_n) for the weights (one skinny pass over X) and s * eta for the tilt."""
+        LRVB/SparseObjectives.py:381-387): the per-observation loss l(y_n, z_n) for the weights (one skinny pass over X),
+        closed forms in eta - m for the others (csrc/k_hyper.hip)."""
         kind = self.hyper_kind(hyper_par)
         self._push(argv, argk)
         if kind == 'weights':
             return self.ctx.obs_loss(val1, 0, self.n_obs, val1_is_free)
-        s = self.scale_fun(*argv, **argk) if self.scale_fun is not None else 1.0
-        eta = self.ctx.constrain(val1) if val1_is_free else np.asarray(val1, dtype=np.float64)
-        return s * eta
+        return self.ctx.hyper_grad(self._HYPER_KINDS[kind], val1, val1_is_free)
+
+    def hyper_direction_vec(self, hyper_par, eta, U, eps_dir):
+        """D_eta^r [ d g_eta / d eps [eps_dir] ] [u_1 .. u_r] in vector coordinates (rows of U are the u's; None / empty:
+        r = 0): the mixed directional derivatives `ParametricSensitivityTaylorExpansion` needs (the reference nests
+        autograd JVPs for them, LRVB/ModelSensitivity.py:38-62).  The gradient is linear in every declared
+        hyper-parameter; the O(N) kinds (weights, lik_info) are `lrvb_dk_grad_vec` passes, the others V-sized closed forms."""
+        kind = self.hyper_kind(hyper_par)
+        self._push()
+        eta = _hip.as_f64(eta).ravel()
+        U = None if U is None or np.size(U) == 0 else _hip.as_f64(U).reshape(-1, self.ctx.V)
+        r = 0 if U is None else U.shape[0]
+        eps_dir = _hip.as_f64(eps_dir).ravel()
+        if kind == 'weights':
+            return self.ctx.dk_grad_vec(eta, U, eps_dir, False)
+        if kind == 'lik_info':                               # the data gradient is tau times a tau-free sum
+            tau = float(np.ravel(self.lik_info_par.get_vector())[0])
+            return (eps_dir[0] / tau) * self.ctx.dk_grad_vec(eta, U, None, False)
+        s = self.ctx.quad_scale
+        zero = np.zeros(self.ctx.V)
+        m = np.asarray(self.prior_mean_par.get_vector(), dtype=np.float64)
+        a = np.asarray(self.prior_info_par.get_vector(), dtype=np.float64)
+        diag = self._quad_kind == _hip.QUAD_DIAG
+        A_apply = (lambda v: a * v) if diag else (lambda v: vech_to_sym(a) @ v)
+        if kind == 'tilt':
+            return s * eps_dir if r == 0 else zero
+        if kind == 'prior_mean':
+            return -s * A_apply(eps_dir) if r == 0 else zero
+        if kind == 'prior_info':
+            dA = (lambda v: eps_dir * v) if diag else (lambda v: vech_to_sym(eps_dir) @ v)
+            return s * dA(eta - m) if r == 0 else (s * dA(U[0]) if r == 1 else zero)
+        if kind == 'quad_scale':
+            b = np.asarray(self.tilt_par.get_vector(), dtype=np.float64)
+            return eps_dir[0] * (A_apply(eta - m) + b) if r == 0 else (eps_dir[0] * A_apply(U[0]) if r == 1 else zero)
+        raise NotImplementedError(kind)
 
     def gram(self, free_val):
         self._push_state()

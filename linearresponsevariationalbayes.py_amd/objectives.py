@@ -64,8 +64,9 @@ class _NumericFunctor(object):
 
     def jacobian(self, x, is_free, *argv, **argk):
         f, x = self._f(is_free, argv, argk), self._check(x)
-        J = numeric_jacobian(f, x)
-        return J.reshape(np.shape(f(x)) + (x.size,))            # autograd.jacobian: ans.shape + x.shape
+        shape = np.shape(f(x))
+        J = numeric_jacobian(lambda z: np.ravel(f(z)), x)       # (ans.size, n): flatten first, whatever ans.ndim is
+        return J.reshape(shape + (x.size,))                     # autograd.jacobian: ans.shape + x.shape
 
     def grad(self, x, is_free, *argv, **argk):
         return self.jacobian(x, is_free, *argv, **argk).reshape(np.size(x))
@@ -91,6 +92,58 @@ class _NumericFunctor(object):
         scale = max(np.max(np.abs(v)), 1e-300)
         g = lambda t: self.grad(x + t[0] * v / scale, is_free, *argv, **argk)
         return numeric_jacobian(g, np.zeros(1), rel_step=1e-2)[:, 0] * scale
+
+
+class _NumericTwoParFunctor(object):
+    """Small-D stand-in for autograd on an opaque closure of TWO parameters (`TwoParameterObjective(par1, par2, fun)` as
+    LRVB/SparseObjectives.py:321-449 accepts; the reference's tests at LRVB/test_objectives.py:220-243, 294-381 and the
+    `QuadraticModel` of LRVB/test_model_sensitivity.py:36-88 are written this way): gradients by Richardson-extrapolated
+    central differences, the cross Hessian by Richardson-extrapolated mixed second differences, directly in the
+    coordinates (free or vector) each argument is given in.  Refused above NUMERIC_FALLBACK_MAX_D entries per parameter."""
+
+    def __init__(self, par1, par2, fun):
+        self.par1, self.par2, self.fun = par1, par2, fun
+
+    @staticmethod
+    def _check(x):
+        if np.size(x) > NUMERIC_FALLBACK_MAX_D:
+            raise NotImplementedError('{} parameters: '.format(np.size(x)) + _NO_DERIV)
+        return np.array(x, dtype=np.float64).ravel()
+
+    def _f(self, free1, free2, argv, argk):
+        def f(a, b):
+            set_par(self.par1, a, free1)
+            set_par(self.par2, b, free2)
+            return float(self.fun(*argv, **argk))
+        return f
+
+    def grad1(self, val1, val2, free1, free2, *argv, **argk):
+        a, b, f = self._check(val1), self._check(val2), self._f(free1, free2, argv, argk)
+        return numeric_jacobian(lambda z: f(z, b), a).reshape(a.size)
+
+    def grad2(self, val1, val2, free1, free2, *argv, **argk):
+        a, b, f = self._check(val1), self._check(val2), self._f(free1, free2, argv, argk)
+        return numeric_jacobian(lambda z: f(a, z), b).reshape(b.size)
+
+    def cross12(self, val1, val2, free1, free2, *argv, **argk):
+        a, b, f = self._check(val1), self._check(val2), self._f(free1, free2, argv, argk)
+        ha0, hb0 = 1e-2 * np.maximum(1.0, np.abs(a)), 1e-2 * np.maximum(1.0, np.abs(b))
+        est = []
+        for div in (1.0, 2.0, 4.0):
+            ha, hb = ha0 / div, hb0 / div
+            C = np.empty((a.size, b.size))
+            for i in range(a.size):
+                ap, am = a.copy(), a.copy()
+                ap[i] += ha[i]
+                am[i] -= ha[i]
+                for j in range(b.size):
+                    bp, bm = b.copy(), b.copy()
+                    bp[j] += hb[j]
+                    bm[j] -= hb[j]
+                    C[i, j] = (f(ap, bp) - f(ap, bm) - f(am, bp) + f(am, bm)) / (4.0 * ha[i] * hb[j])
+            est.append(C)
+        r1 = [(4 * est[1] - est[0]) / 3, (4 * est[2] - est[1]) / 3]
+        return (16 * r1[1] - r1[0]) / 15
 
 
 def _functor(fun, par=None):
@@ -437,8 +490,11 @@ def set_par(par, val, is_free):
 
 
 class TwoParameterObjective(object):
-    """Cross Hessians d2 f / d par1 d par2^T (LRVB/SparseObjectives.py:321-449).  `par2` must be a
-    hyper-parameter the declared objective knows (its `weights_par` or `tilt_par`)."""
+    """Cross Hessians d2 f / d par1 d par2^T (LRVB/SparseObjectives.py:321-449).  With a declared objective `par2` is one
+    of the hyper-parameters it declares (`hyper_pars`: observation weights, tilt, prior mean / information / scale,
+    likelihood information, the priors of the model families) and the cross Hessian is a closed form on the device; with a
+    plain closure of up to NUMERIC_FALLBACK_MAX_D entries per parameter it comes from Richardson-extrapolated mixed
+    differences on the host (`_NumericTwoParFunctor`; plumbing for the reference's small test models)."""
 
     def __init__(self, par1, par2, fun):
         self.par1 = par1
@@ -470,8 +526,25 @@ class TwoParameterObjective(object):
             return None
         return self.par2.free_to_vector_jac(np.asarray(val2, dtype=np.float64)).tocsr()
 
+    def _numeric(self):
+        """The host fallback for a plain closure (None for a declared objective)."""
+        if getattr(self.fun, '_lrvb_device_functor', False):
+            return None
+        if not callable(self.fun):
+            raise NotImplementedError(_NO_DERIV)
+        return _NumericTwoParFunctor(self.par1, self.par2, self.fun)
+
+    def _restore(self, result, val1, val2, val1_is_free, val2_is_free):
+        set_par(self.par1, val1, val1_is_free)
+        set_par(self.par2, val2, val2_is_free)
+        return result
+
     def _cross12(self, val1, val2, val1_is_free, val2_is_free, *argv, **argk):
-        f = _functor(self.fun)
+        num = self._numeric()
+        if num is not None:
+            return self._restore(num.cross12(val1, val2, val1_is_free, val2_is_free, *argv, **argk),
+                                 val1, val2, val1_is_free, val2_is_free)
+        f = self.fun
         set_par(self.par2, val2, val2_is_free)
         C = f.cross_hessian(self.par2, np.asarray(val1, dtype=np.float64), val1_is_free, *argv, **argk)
         J2 = self._jac2(val2, val2_is_free)
@@ -482,7 +555,11 @@ class TwoParameterObjective(object):
         return C
 
     def fun_grad1(self, val1, val2, val1_is_free, val2_is_free, *argv, **argk):
-        f = _functor(self.fun)
+        num = self._numeric()
+        if num is not None:
+            return self._restore(num.grad1(val1, val2, val1_is_free, val2_is_free, *argv, **argk),
+                                 val1, val2, val1_is_free, val2_is_free)
+        f = self.fun
         set_par(self.par2, val2, val2_is_free)
         g = f.grad(np.asarray(val1, dtype=np.float64), val1_is_free, *argv, **argk)
         set_par(self.par1, val1, val1_is_free)
@@ -491,7 +568,11 @@ class TwoParameterObjective(object):
     def fun_grad2(self, val1, val2, val1_is_free, val2_is_free, *argv, **argk):
         """d f / d par2 (LRVB/SparseObjectives.py:381-387): per-observation losses for the weights, s * eta for the
         tilt, chained through par2's packing Jacobian when val2 is free."""
-        f = _functor(self.fun)
+        num = self._numeric()
+        if num is not None:
+            return self._restore(num.grad2(val1, val2, val1_is_free, val2_is_free, *argv, **argk),
+                                 val1, val2, val1_is_free, val2_is_free)
+        f = self.fun
         set_par(self.par2, val2, val2_is_free)
         g = np.asarray(f.hyper_grad(self.par2, np.asarray(val1, dtype=np.float64), val1_is_free, *argv, **argk))
         J2 = self._jac2(val2, val2_is_free)

@@ -18,7 +18,7 @@ beta an ArrayParam with lb = 0, Lambda a PosDefMatrixParam) -- BASELINE.json con
 import numpy as np
 
 from . import _hip
-from .models import DeviceContext
+from .models import DeviceContext, DeclaredHypers, sym_to_vech, vech_to_sym
 from .packing import VectorParam, HyperVectorParam, ResidentVector
 
 
@@ -34,11 +34,63 @@ def duplication_matrix(k):
     return D
 
 
-class QuadraticDataObjective(object):
+def vech_dupT(A):
+    """Dup^T vec(A) for a symmetric A (or a stack A[..., k, k]): its row-major lower triangle with the off-diagonal entries
+    doubled -- the gradient with respect to the vector form of a symmetric matrix parameter."""
+    k = A.shape[-1]
+    r, c = np.tril_indices(k)
+    return A[..., r, c] * np.where(r == c, 1.0, 2.0)
+
+
+# ---- priors as hyper-parameters: closed forms shared by the normal-family models -------------------------------------
+# mvn_prior (LRVB/ExponentialFamilies.py:186-189) enters the -ELBO as  1/2 (m - mu0)^T L0 (m - mu0) + 1/2 tr(L0 P),  P the
+# variational covariance; gamma_prior (:194-195) as  -(a0 - 1) E log tau + b0 E tau.  Derivatives with respect to
+# (mu0, vech(L0)) and (a0, b0) -- what `jacobian(grad_1, argnum=hyper)` (LRVB/SparseObjectives.py:333-339) returns.
+def mvn_prior_hyper_grad(kind, dm, P, lam0):
+    if kind == 'mean':
+        return -lam0 @ dm
+    r, c = np.tril_indices(dm.size)
+    return (dm[r] * dm[c] + P[r, c]) * np.where(r == c, 0.5, 1.0)
+
+
+def mvn_prior_hyper_cross(kind, V, ms, ls, dm, P, lam0):
+    """(V x Ph) cross block in vector coordinates; ms / ls the index ranges of the mean and of vech(information)."""
+    k = dm.size
+    if kind == 'mean':
+        C = np.zeros((V, k))
+        C[ms.start:ms.stop, :] = -lam0
+        return C
+    r, c = np.tril_indices(k)
+    n, cols, off = r.size, np.arange(r.size), r != c
+    C = np.zeros((V, n))
+    C[ms.start + r, cols] += dm[c]                               # d/dL0_(ij) of L0 (m - mu0)
+    C[ms.start + c[off], cols[off]] += dm[r[off]]
+    # d/dL0_(ij) of vech-gradient(-1/2 P L0 P): -1/2 P E_(ij) P with E_(ij) = e_i e_j^T + e_j e_i^T (once for i = j)
+    Pi, Pj = P[:, r], P[:, c]
+    M = -0.5 * np.where(off, 1.0, 0.5)[None, None, :] * (Pi[:, None, :] * Pj[None, :, :] + Pj[:, None, :] * Pi[None, :, :])
+    C[ls.start:ls.stop, :] = vech_dupT(np.moveaxis(M, 2, 0)).T
+    return C
+
+
+def gamma_prior_hyper_grad(a, b, special):
+    """[d/da0, d/db0] of -(a0 - 1) (psi(a) - log b) + b0 a / b."""
+    return np.array([-(special.digamma(a) - np.log(b)), a / b])
+
+
+def gamma_prior_hyper_cross(V, ia, ib, a, b, special):
+    """(V x 2): columns a0, b0."""
+    C = np.zeros((V, 2))
+    C[ia, 0], C[ib, 0] = -special.polygamma(1, a), 1.0 / b
+    C[ia, 1], C[ib, 1] = 1.0 / b, -a / b ** 2
+    return C
+
+
+class QuadraticDataObjective(DeclaredHypers):
     """Base functor.  Subclasses provide the N-independent closed forms:
 
       _terms(eta, S, W)   -> (value, grad (V,), hess (V, V)) in vector coordinates
       _obs_terms(eta)     -> (M (V, q, q) symmetric, c (V,)):  d l_n / d eta_k = 1/2 z_n^T M_k z_n + c_k
+      _prior_hyper(kind, eta, want) -> d f / d eps (Ph,) or d2 f / d eta d eps^T (V, Ph) for the priors they declare
     """
     _lrvb_device_functor = True
 
@@ -51,7 +103,7 @@ class QuadraticDataObjective(object):
             raise ValueError('layout_blocks() of the parameter disagrees with its free/vector sizes')
         self.ctx.set_data(_hip.SLOT_X, z)
         w0 = np.ones(self.n_obs) if weights is None else _hip.as_f64(weights).ravel().copy()
-        self.weights_par = HyperVectorParam('weights', self.n_obs, val=w0)
+        self._declare_hyper('weights', HyperVectorParam('weights', self.n_obs, val=w0))
         self.tilt_par = None
         self._w_res = ResidentVector()
         self._S = None
@@ -132,7 +184,7 @@ class QuadraticDataObjective(object):
 
     def _hessian_cached(self, x, is_free):
         self._push_state()
-        key = (bool(is_free), np.asarray(x, dtype=np.float64).tobytes(), self._w_res.key)
+        key = (bool(is_free), np.asarray(x, dtype=np.float64).tobytes(), self._w_res.key, self._hyper_state_key())
         if getattr(self, '_h_key', None) != key:
             self._h_val = self.hessian(x, is_free)
             self._h_key = key
@@ -157,15 +209,25 @@ class QuadraticDataObjective(object):
         self._cg_key = self._h_key
         return out
 
-    def hyper_kind(self, hyper_par):
-        if hyper_par is self.weights_par:
-            return 'weights'
-        raise NotImplementedError('the second parameter must be this objective\'s `weights_par`')
+    def _prior_hyper(self, kind, eta, want):
+        raise NotImplementedError('this objective declares no prior hyper-parameter `{}`'.format(kind))
 
+    def hyper_grad(self, hyper_par, val1, val1_is_free):
+        """d f / d hyper (vector coordinates of the hyper-parameter) for the declared PRIOR hyper-parameters."""
+        kind = self.hyper_kind(hyper_par)
+        if kind == 'weights':
+            raise NotImplementedError('d f / d weights of a quadratic-in-data objective: use the rows of `cross_hessian`')
+        return self._prior_hyper(kind, self._eta(val1, val1_is_free), 'grad')
+
+    @_hip.host_blas
     def cross_hessian(self, hyper_par, val1, val1_is_free):
-        """d2 f / d par1 d w^T: (n1, N).  Rows of G come from the device, the chain rule through
-        the packing Jacobian is one small product."""
-        self.hyper_kind(hyper_par)
+        """d2 f / d par1 d hyper^T.  Weights: (n1, N) -- rows of G come from the device, the chain rule through the packing
+        Jacobian is one small product.  Priors: the N-independent closed form in vector coordinates (V x Ph), multiplied
+        by J^T on the device (`lrvb_jac_t_matmul`)."""
+        kind = self.hyper_kind(hyper_par)
+        if kind != 'weights':
+            Cv = self._prior_hyper(kind, self._eta(val1, val1_is_free), 'cross')
+            return self.ctx.jac_t_matmul(val1, Cv) if val1_is_free else Cv
         self._push_state()
         M, c = self._obs_terms(self._eta(val1, val1_is_free))
         G = self.ctx.obs_quadform(M, c)                          # N x V
@@ -279,17 +341,43 @@ class MVNRegressionObjective(QuadraticDataObjective):
         self._ib = t0 + tsub.vector_indices_dict['rate'].start
         if len(self._ms) != k or len(self._ls) != k * (k + 1) // 2:
             raise ValueError('Wrong size for {}.  Expected dimension {}'.format(beta_name, k))
-        self.mu0 = np.zeros(k) if prior_mean is None else _hip.as_f64(prior_mean).ravel()
-        self.lam0 = np.eye(k) if prior_info is None else _hip.as_f64(prior_info)
-        self.a0, self.b0 = float(prior_shape), float(prior_rate)
         self._dup = duplication_matrix(k)
         super().__init__(par, np.hstack([x, y]), weights=weights, device=device)
+        self._declare_priors(prior_mean, prior_info, prior_shape, prior_rate)
+
+    def _declare_priors(self, prior_mean, prior_info, prior_shape, prior_rate):
+        """The priors are hyper-parameters (LRVB/ModelSensitivity.py:555-612: prior sensitivity is the defining use of
+        the class): prior_mean_par (k), prior_info_par (the symmetric matrix in vector form), prior_shape_par, prior_rate_par."""
+        k = self.k
+        self._declare_hyper('prior_mean', HyperVectorParam('prior_mean', k, val=np.zeros(k) if prior_mean is None else _hip.as_f64(prior_mean).ravel()))
+        self._declare_hyper('prior_info', HyperVectorParam('prior_info', k * (k + 1) // 2,
+                                                           val=sym_to_vech(np.eye(k) if prior_info is None else prior_info)))
+        self._declare_hyper('prior_shape', HyperVectorParam('prior_shape', 1, lb=0.0, val=np.array([float(prior_shape)])))
+        self._declare_hyper('prior_rate', HyperVectorParam('prior_rate', 1, lb=0.0, val=np.array([float(prior_rate)])))
+
+    mu0 = property(lambda self: self._hyper_vec('prior_mean'))
+    lam0 = property(lambda self: vech_to_sym(self._hyper_vec('prior_info')))
+    a0 = property(lambda self: float(self._hyper_vec('prior_shape')[0]))
+    b0 = property(lambda self: float(self._hyper_vec('prior_rate')[0]))
 
     def _unpack(self, eta):
         k = self.k
         m = eta[self._ms.start:self._ms.stop]
         lam = (self._dup @ eta[self._ls.start:self._ls.stop]).reshape(k, k)
         return m, lam, eta[self._ia], eta[self._ib]
+
+    def _prior_hyper(self, kind, eta, want):
+        m, lam, a, b = self._unpack(eta)
+        if kind in ('prior_mean', 'prior_info'):
+            P = np.linalg.inv(lam)
+            sub = kind[len('prior_'):]
+            if want == 'grad':
+                return mvn_prior_hyper_grad(sub, m - self.mu0, P, self.lam0)
+            return mvn_prior_hyper_cross(sub, eta.size, self._ms, self._ls, m - self.mu0, P, self.lam0)
+        col = {'prior_shape': 0, 'prior_rate': 1}[kind]
+        if want == 'grad':
+            return gamma_prior_hyper_grad(a, b, self._special)[col:col + 1]
+        return gamma_prior_hyper_cross(eta.size, self._ia, self._ib, a, b, self._special)[:, col:col + 1]
 
     @_hip.host_blas
     def hessian(self, x, is_free):
@@ -419,12 +507,51 @@ class WishartMVNObjective(QuadraticDataObjective):
         self._vs = range(o + sub.vector_indices_dict['v'].start, o + sub.vector_indices_dict['v'].stop)
         if len(self._ms) != d or len(self._ls) != mm or len(self._vs) != mm:
             raise ValueError('parameter sizes do not match the data dimension {}'.format(d))
-        self.mu0 = np.zeros(d) if prior_mean is None else _hip.as_f64(prior_mean).ravel()
-        self.lam0 = np.eye(d) if prior_info is None else _hip.as_f64(prior_info)
-        self.nu0 = float(d + 2) if prior_df is None else float(prior_df)
-        self.w0 = np.eye(d) if prior_inv_scale is None else _hip.as_f64(prior_inv_scale)
         self._dup = duplication_matrix(d)
         super().__init__(par, np.hstack([y, np.ones((y.shape[0], 1))]), weights=weights, device=device)
+        self._declare_priors(prior_mean, prior_info, prior_df, prior_inv_scale)
+
+    def _declare_priors(self, prior_mean, prior_info, prior_df, prior_inv_scale):
+        """prior_mean_par (d), prior_info_par, prior_inv_scale_par (symmetric matrices in vector form), prior_df_par."""
+        d = self.d
+        mm = d * (d + 1) // 2
+        self._declare_hyper('prior_mean', HyperVectorParam('prior_mean', d, val=np.zeros(d) if prior_mean is None else _hip.as_f64(prior_mean).ravel()))
+        self._declare_hyper('prior_info', HyperVectorParam('prior_info', mm, val=sym_to_vech(np.eye(d) if prior_info is None else prior_info)))
+        self._declare_hyper('prior_df', HyperVectorParam('prior_df', 1, lb=float(d - 1), val=np.array([float(d + 2) if prior_df is None else float(prior_df)])))
+        self._declare_hyper('prior_inv_scale', HyperVectorParam('prior_inv_scale', mm, val=sym_to_vech(np.eye(d) if prior_inv_scale is None else prior_inv_scale)))
+
+    mu0 = property(lambda self: self._hyper_vec('prior_mean'))
+    lam0 = property(lambda self: vech_to_sym(self._hyper_vec('prior_info')))
+    nu0 = property(lambda self: float(self._hyper_vec('prior_df')[0]))
+    w0 = property(lambda self: vech_to_sym(self._hyper_vec('prior_inv_scale')))
+
+    def _prior_hyper(self, kind, eta, want):
+        """Wishart prior (LRVB/ExponentialFamilies.py:72-94 terms): -1/2 (nu0 - d - 1) E log|Lambda| + 1/2 nu tr(W0 V)."""
+        d = self.d
+        m, lam_mu, nu, v = self._unpack(eta)
+        if kind in ('prior_mean', 'prior_info'):
+            P = np.linalg.inv(lam_mu)
+            sub = kind[len('prior_'):]
+            if want == 'grad':
+                return mvn_prior_hyper_grad(sub, m - self.mu0, P, self.lam0)
+            return mvn_prior_hyper_cross(sub, eta.size, self._ms, self._ls, m - self.mu0, P, self.lam0)
+        vs = slice(self._vs.start, self._vs.stop)
+        r, c = np.tril_indices(d)
+        if kind == 'prior_df':
+            kap, kap1, _, _ = self._kappa(nu)
+            if want == 'grad':
+                return np.array([-0.5 * (kap + d * np.log(2.0) + np.linalg.slogdet(v)[1])])
+            C = np.zeros((eta.size, 1))
+            C[self._inu, 0] = -0.5 * kap1
+            C[vs, 0] = -0.5 * vech_dupT(np.linalg.inv(v))
+            return C
+        fac = np.where(r == c, 0.5, 1.0)                         # prior_inv_scale: 1/2 nu tr(W0 V) in the vector form of W0
+        if want == 'grad':
+            return nu * v[r, c] * fac
+        C = np.zeros((eta.size, r.size))
+        C[self._inu, :] = v[r, c] * fac
+        C[self._vs.start + np.arange(r.size), np.arange(r.size)] = nu * fac
+        return C
 
     def _unpack(self, eta):
         d = self.d

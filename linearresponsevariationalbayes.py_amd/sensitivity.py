@@ -7,9 +7,11 @@ LRVB/ModelSensitivity.py:13-17, 555-612:
 
 The Hessian (Objective.fun_free_hessian), the cross Hessian
 (TwoParameterObjective.fun_hessian_free1_vector2), the Cholesky factorisation and the solve all
-run on the device; the factor stays resident in the objective's context.  The higher-order
-`ParametricSensitivityTaylorExpansion` of the reference (:382-515) needs arbitrary-order
-forward-mode AD of a closure and is outside the accelerated path.
+run on the device; the factor stays resident in the objective's context.  `hyper_par` is any
+hyper-parameter the declared objective lists in `hyper_pars` (observation weights, tilt, prior mean /
+information / scale, likelihood information, the priors of the model families), in vector or free
+coordinates; a plain closure of a few parameters is differentiated by the host fallback of
+objectives.py and solved in a scratch device context.  The higher-order class lives in taylor.py.
 """
 from copy import deepcopy
 
@@ -52,11 +54,26 @@ class DeviceCholesky(object):
         return self.ctx.lrvb_cov(moment_jac)
 
 
-def _factor_and_solve(functor, hess, rhs):
+_scratch = {}
+
+
+def _solve_context(functor):
+    """The device context a factorisation for `functor` lives in: the declared objective's own, or -- for a plain
+    closure, whose derivatives came from the host fallback of objectives.py -- one scratch context per process (the
+    Cholesky and the solves still run on the device: there is no host solver in this package)."""
     ctx = getattr(functor, 'ctx', None)
-    if ctx is None:
+    if ctx is not None:
+        return ctx
+    if getattr(functor, '_lrvb_device_functor', False) or not callable(functor):
         raise NotImplementedError('the objective functor exposes no device context for the solve')
-    chol = DeviceCholesky(ctx, hess)
+    if 'ctx' not in _scratch:
+        from .models import scratch_context
+        _scratch['ctx'] = scratch_context()
+    return _scratch['ctx']
+
+
+def _factor_and_solve(functor, hess, rhs):
+    chol = DeviceCholesky(_solve_context(functor), hess)
     return chol, chol.solve(np.asarray(rhs, dtype=np.float64))
 
 
@@ -98,10 +115,7 @@ class ParametricSensitivityLinearApproximation(object):
         else:
             self.hess0 = hess0
         if self.stream_hyper:
-            ctx = getattr(self.objective_functor, 'ctx', None)
-            if ctx is None:
-                raise NotImplementedError('the objective functor exposes no device context for the solve')
-            self.hess0_chol = DeviceCholesky(ctx, self.hess0)
+            self.hess0_chol = DeviceCholesky(_solve_context(self.objective_functor), self.hess0)
             self.hyper_par_cross_hessian0 = None
             self.hyper_par_sensitivity = None
             return
@@ -156,10 +170,7 @@ def get_lrvb_cov(objective, free_val, moment_jac, kl_hessian=None):
     (what Example.ipynb:398-415 computes inline with cho_factor / cho_solve): Hessian build (unless given), Cholesky
     and the solve all on the device; the factor stays resident in the objective's context."""
     hess = get_kl_hessian(objective, free_val) if kl_hessian is None else kl_hessian
-    ctx = getattr(objective.fun, 'ctx', None)
-    if ctx is None:
-        raise NotImplementedError('the objective functor exposes no device context for the solve')
-    return DeviceCholesky(ctx, hess).lrvb_cov(np.asarray(moment_jac, dtype=np.float64))
+    return DeviceCholesky(_solve_context(objective.fun), hess).lrvb_cov(np.asarray(moment_jac, dtype=np.float64))
 
 
 # the k-th order class and its term algebra live in taylor.py; the reference keeps them in this module

@@ -18,8 +18,11 @@ mixed directional derivatives have closed forms that run on the device:
   O(N) contraction -- while the derivatives of the small N-independent map c come from forward-mode AD of c on the
   host (torch.func.jvp, the counterpart of the autograd JVPs the reference applies to the whole objective,
   LRVB/ModelSensitivity.py:38-62), see `PackingJet`.
-* the objective is LINEAR in the two hyper-parameters the device path declares (observation weights, linear tilt),
-  so derivatives of order >= 2 in eps vanish and the first one is g evaluated with the direction as weights / tilt.
+* the GRADIENT is linear in every hyper-parameter the device path declares, taken in its vector coordinates
+  (observation weights, linear tilt, prior mean m, prior information A, quadratic scale s, Gaussian likelihood precision):
+  derivatives of order >= 2 in eps vanish there and the first one is a closed form (`hyper_direction_vec` of the
+  functor; its O(N) leaves are `lrvb_dk_grad_vec` calls).  A hyper-parameter given in FREE coordinates eps = c_h^-1(.)
+  enters through its own packing map: D_eps^j g [d eps^j] = (d g / d eps_vec) [ D^j c_h [d eps^j] ].
 
 The recursion for d^k eta_hat / d eps^k is the implicit-function theorem applied k times to g(eta_hat(eps), eps) = 0.
 `append_jvp` and `generate_two_term_derivative_array` (LRVB/ModelSensitivity.py:38-62, 221-234) are provided for
@@ -335,15 +338,14 @@ class PackingJet(object):
 
 class ParametricSensitivityTaylorExpansion(object):
     """Same constructor and methods as the reference class (LRVB/ModelSensitivity.py:382-515).  `objective_functor`
-    must be a device functor and `hyper_par` its `weights_par` or `tilt_par`, in vector coordinates."""
+    must be a device functor and `hyper_par` one of its declared hyper-parameters (`hyper_pars`), in vector or free
+    coordinates."""
 
     def __init__(self, objective_functor, input_par, hyper_par, input_val0, hyper_val0, order,
                  input_is_free=True, hyper_is_free=False, hess0=None, hyper_par_objective_functor=None):
-        if hyper_is_free:
-            raise NotImplementedError('the declared hyper-parameters (weights, tilt) live in vector coordinates')
         fun = objective_functor if hyper_par_objective_functor is None else hyper_par_objective_functor
         if not hasattr(objective_functor, 'ctx') or not hasattr(objective_functor.ctx, 'dk_grad_vec') \
-                or not hasattr(fun, 'hyper_kind'):
+                or not hasattr(fun, 'hyper_kind') or not hasattr(fun, 'hyper_direction_vec'):
             raise NotImplementedError('higher-order sensitivity needs a device functor (DeviceObjective); an opaque '
                                       'closure would have to be traced')
         if getattr(objective_functor, 'scale_fun', None) is not None:
@@ -455,13 +457,25 @@ class ParametricSensitivityTaylorExpansion(object):
         if eps_dir is None:
             memo[key] = self.ctx.dk_grad_vec(self._eta0(), U, None, True)
             return memo[key]
-        if self.hyper_kind == 'weights':
-            memo[key] = self.ctx.dk_grad_vec(self._eta0(), U, eps_dir, False)
-            return memo[key]
-        # tilt: the objective holds eps^T eta, so d g_eta / d eps [d eps] = d eps, constant in eta
-        if r > 0:
-            return np.zeros(self.input_val0.size if not self.input_is_free else self._eta0().size)
-        return np.asarray(eps_dir, dtype=np.float64).copy()
+        # d g_eta / d eps_vec [eps_dir], differentiated r times in eta: a closed form per hyper-parameter kind
+        key = key + (np.ascontiguousarray(eps_dir, dtype=np.float64).tobytes(),)
+        if key not in memo:
+            memo[key] = self.hyper_par_objective_functor.hyper_direction_vec(self.hyper_par, self._eta0(), U, eps_dir)
+        return memo[key]
+
+    def _eps_direction(self, dhyper, j):
+        """The direction in the hyper-parameter's VECTOR coordinates that carries the j-th eps derivative along dhyper:
+        dhyper itself for j = 1 in vector coordinates (None for j >= 2: the gradient is linear there), D^j c_h [dhyper^j]
+        for a free hyper-parameter with packing map c_h."""
+        if not self.hyper_is_free:
+            return np.asarray(dhyper, dtype=np.float64) if j == 1 else None
+        blocks = self.hyper_par.layout_blocks()
+        if all(b['kind'] == _hip.BLOCK_BOX for b in blocks):
+            return box_map_derivatives(self.hyper_val0, blocks, j)[j] * np.asarray(dhyper, dtype=np.float64) ** j
+        jet = self._cache.get('hjet')
+        if jet is None:
+            jet = self._cache['hjet'] = PackingJet(self.hyper_val0, blocks)
+        return jet.vec([dhyper] * j)
 
     def _dg(self, dirs, eps_dir):
         """D_input^i [gradient in input coordinates] [dirs], the gradient optionally differentiated once along eps."""
@@ -510,13 +524,16 @@ class ParametricSensitivityTaylorExpansion(object):
         return total
 
     def _evaluate_term(self, term, eta_derivs, dhyper):
-        if term.eps_order >= 2:
-            return 0.0                                           # the objective is linear in the declared hyper-parameters
+        eps_dir = None
+        if term.eps_order >= 1:
+            eps_dir = self._eps_direction(dhyper, term.eps_order)
+            if eps_dir is None:
+                return 0.0                                       # the gradient is linear in the hyper-parameter's vector form
         dirs = []
         for i, m in enumerate(term.eta_orders):
             if m > 0:
                 dirs += [eta_derivs[i]] * m
-        return term.prefactor * self._dg(dirs, dhyper if term.eps_order == 1 else None)
+        return term.prefactor * self._dg(dirs, eps_dir)
 
     # ---- the recursion -----------------------------------------------------------------------------------------
     def set_order(self, order):

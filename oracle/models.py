@@ -220,6 +220,101 @@ class DeclaredModel(object):
         """d2 f / d theta d b^T = s J^T  (D x V)."""
         return self.quad_scale * self.layout.jac(theta).T
 
+    # ---- the other hyper-parameters (LRVB/ModelSensitivity.py:555-612 takes any hyper_par) -------------------------
+    # eps in {'tilt': b, 'prior_mean': m, 'prior_info': diag(A) or vech(A) (row-major lower triangle,
+    # LRVB/MatrixParameters.py:16-41), 'quad_scale': s, 'lik_info': tau of the Gaussian loss}, each in its vector
+    # coordinates.  What `jacobian(grad_1, argnum=hyper)` / `grad(argnum=hyper)` of LRVB/SparseObjectives.py:333-339,
+    # 381-387 return for this objective, written out.
+    def hyper_value(self, kind):
+        if kind == 'tilt':
+            return self.quad_b.copy()
+        if kind == 'prior_mean':
+            return self.quad_m.copy()
+        if kind == 'prior_info':
+            A = self.quad_A
+            return A.copy() if A.ndim == 1 else A[np.tril_indices(A.shape[0])].copy()
+        if kind == 'quad_scale':
+            return np.array([float(self.quad_scale)])
+        if kind == 'lik_info':
+            return np.array([float(self.lik_info)])
+        raise ValueError('unknown hyper-parameter ' + str(kind))
+
+    def set_hyper(self, kind, val):
+        val = np.asarray(val, dtype=np.float64).ravel()
+        if kind == 'tilt':
+            self.quad_b = val.copy()
+        elif kind == 'prior_mean':
+            self.quad_m = val.copy()
+        elif kind == 'prior_info':
+            if self.quad_A.ndim == 1:
+                self.quad_A = val.copy()
+            else:
+                V = self.layout.V
+                L = np.zeros((V, V))
+                L[np.tril_indices(V)] = val
+                self.quad_A = L + L.T - np.diag(np.diag(L))
+        elif kind == 'quad_scale':
+            self.quad_scale = float(val[0])
+        elif kind == 'lik_info':
+            self.lik_info = float(val[0])
+        else:
+            raise ValueError('unknown hyper-parameter ' + str(kind))
+
+    def hyper_grad_vec(self, kind, eta):
+        """d f / d eps at the vector-coordinate point eta."""
+        eta = np.asarray(eta, dtype=np.float64)
+        s, r = self.quad_scale, eta - self.quad_m
+        if kind == 'tilt':
+            return s * eta
+        if kind == 'prior_mean':
+            return -s * self._A_apply(r)
+        if kind == 'prior_info':
+            if self.quad_A.ndim == 1:
+                return 0.5 * s * r * r
+            i, j = np.tril_indices(self.layout.V)
+            return s * r[i] * r[j] * np.where(i == j, 0.5, 1.0)
+        if kind == 'quad_scale':
+            return np.array([0.5 * float(r @ self._A_apply(r)) + float(self.quad_b @ eta)])
+        if kind == 'lik_info':
+            z = self.x @ self._beta(eta)
+            return np.array([float(np.sum(self.w * loss_terms(self.loss, self.y, z, self.lik_info)[0])) / self.lik_info])
+        raise ValueError('unknown hyper-parameter ' + str(kind))
+
+    def cross_hessian_hyper_vec(self, kind, eta):
+        """d2 f / d eta d eps^T (V x Ph)."""
+        eta = np.asarray(eta, dtype=np.float64)
+        V, s, r = self.layout.V, self.quad_scale, eta - self.quad_m
+        if kind == 'tilt':
+            return s * np.eye(V)
+        if kind == 'prior_mean':
+            return -s * self._A_dense()
+        if kind == 'prior_info':
+            if self.quad_A.ndim == 1:
+                return s * np.diag(r)
+            i, j = np.tril_indices(V)
+            C = np.zeros((V, i.size))
+            cols = np.arange(i.size)
+            C[i, cols] += s * r[j]
+            off = i != j
+            C[j[off], cols[off]] += s * r[i[off]]
+            return C
+        if kind == 'quad_scale':
+            return (self._A_apply(r) + self.quad_b)[:, None]
+        if kind == 'lik_info':
+            z = self.x @ self._beta(eta)
+            g = np.zeros(V)
+            g[self.glm_off:self.glm_off + self.P] = self.x.T @ (self.w * loss_terms(self.loss, self.y, z, self.lik_info)[1])
+            return (g / self.lik_info)[:, None]
+        raise ValueError('unknown hyper-parameter ' + str(kind))
+
+    def hyper_grad(self, kind, theta):
+        return self.hyper_grad_vec(kind, self.layout.constrain(theta))
+
+    def cross_hessian_hyper(self, kind, theta):
+        """d2 f / d theta d eps^T = J^T (d2 f / d eta d eps^T): the objective is differentiated once in each argument, so no
+        second-order packing term enters."""
+        return self.layout.jac(theta).T @ self.cross_hessian_hyper_vec(kind, self.layout.constrain(theta))
+
     # ---- reference-faithful cost structure -------------------------------------------------
     def hessian_by_hvps(self, theta, n_columns=None):
         """autograd.hessian = jacobian(jacobian(f)): one reverse pass per gradient component.

@@ -43,21 +43,33 @@ class OracleCtx(object):
 class OracleFunctor(object):
     _lrvb_device_functor = True
 
-    def __init__(self, par, model, weights_par=None, tilt_par=None, scale_fun=None):
+    OTHER_HYPERS = ('tilt', 'prior_mean', 'prior_info', 'quad_scale', 'lik_info')
+
+    def __init__(self, par, model, weights_par=None, tilt_par=None, scale_fun=None, **other_hyper_pars):
+        """other_hyper_pars: prior_mean_par=..., prior_info_par=..., quad_scale_par=..., lik_info_par=... (parameter objects
+        whose vector value is pushed into the oracle model before every evaluation, like the device functor does)."""
         self.par = par
         self.model = model
         self.weights_par = weights_par
         self.tilt_par = tilt_par
+        for name in self.OTHER_HYPERS[1:]:
+            setattr(self, name + '_par', other_hyper_pars.pop(name + '_par', None))
+        assert not other_hyper_pars, 'unknown arguments {}'.format(sorted(other_hyper_pars))
         self.scale_fun = scale_fun
         self.ctx = OracleCtx(self)
 
     def _sync(self, argv=(), argk=None):
         if self.weights_par is not None:
             self.model.w = np.asarray(self.weights_par.get_vector(), dtype=np.float64)
-        if self.tilt_par is not None:
-            self.model.quad_b = np.asarray(self.tilt_par.get_vector(), dtype=np.float64)
+        for name in self.OTHER_HYPERS:
+            p = getattr(self, name + '_par')
+            if p is not None and not (name == 'quad_scale' and self.scale_fun is not None):
+                self.model.set_hyper(name, p.get_vector())
         if self.scale_fun is not None:
-            self.model.quad_scale = self.scale_fun(*argv, **(argk or {}))
+            s = self.scale_fun(*argv, **(argk or {}))
+            if self.quad_scale_par is not None:
+                s = s * float(np.ravel(self.quad_scale_par.get_vector())[0])
+            self.model.quad_scale = s
 
     _push_state = _sync
 
@@ -86,9 +98,29 @@ class OracleFunctor(object):
     def hyper_kind(self, hyper_par):
         if hyper_par is self.weights_par:
             return 'weights'
-        if hyper_par is self.tilt_par:
-            return 'tilt'
+        for name in self.OTHER_HYPERS:
+            if hyper_par is getattr(self, name + '_par'):
+                return name
         raise NotImplementedError('unknown hyper-parameter')
+
+    def hyper_direction_vec(self, hyper_par, eta, U, eps_dir):
+        """D_eta^r [d g_eta / d eps [eps_dir]] [rows of U]: by central differences in eps of the oracle's `dk_grad_vec`
+        (exact up to rounding: the gradient is linear in every hyper-parameter's vector form) -- deliberately NOT the
+        closed forms the device functor uses."""
+        self._sync()
+        kind, m = self.hyper_kind(hyper_par), self.model
+        eps_dir = np.asarray(eps_dir, dtype=np.float64).ravel()
+        if kind == 'weights':
+            return m.dk_grad_vec(eta, U, eps_dir, False)
+        h0 = m.hyper_value(kind)
+        try:
+            m.set_hyper(kind, h0 + eps_dir)
+            gp = m.dk_grad_vec(eta, U, None, True)
+            m.set_hyper(kind, h0 - eps_dir)
+            gm = m.dk_grad_vec(eta, U, None, True)
+        finally:
+            m.set_hyper(kind, h0)
+        return 0.5 * (gp - gm)
 
     def hyper_grad(self, hyper_par, val1, val1_is_free, *argv, **argk):
         self._sync(argv, argk)
@@ -97,9 +129,7 @@ class OracleFunctor(object):
         if hyper_par is self.weights_par:
             z = m.x @ eta[m.glm_off:m.glm_off + m.P]
             return om.loss_terms(m.loss, m.y, z, m.lik_info)[0]
-        if hyper_par is self.tilt_par:
-            return m.quad_scale * eta
-        raise NotImplementedError('unknown hyper-parameter')
+        return m.hyper_grad_vec(self.hyper_kind(hyper_par), eta)
 
     def cross_hessian(self, hyper_par, val1, val1_is_free, *argv, **argk):
         self._sync(argv, argk)
@@ -112,8 +142,5 @@ class OracleFunctor(object):
             out = np.zeros((self.model.layout.V, self.model.N))
             out[self.model.glm_off:self.model.glm_off + self.model.P, :] = (l1[:, None] * self.model.x).T
             return out
-        if hyper_par is self.tilt_par:
-            if val1_is_free:
-                return self.model.cross_hessian_tilt(val1)
-            return self.model.quad_scale * np.eye(self.model.layout.V)
-        raise NotImplementedError('unknown hyper-parameter')
+        kind = self.hyper_kind(hyper_par)
+        return self.model.cross_hessian_hyper(kind, val1) if val1_is_free else self.model.cross_hessian_hyper_vec(kind, val1)

@@ -607,3 +607,163 @@ def test_polygamma12_matches_scipy():
     x = np.array([-0.5, 1.5])                                  # outside the series' domain: scipy
     p1, p2 = polygamma12(x)
     assert np.allclose(p1, special.polygamma(1, x), rtol=0, atol=0) and np.allclose(p2, special.polygamma(2, x), rtol=0, atol=0)
+
+
+class _RefTwoParamModel(object):
+    """The reference's own test model, LRVB/test_objectives.py:60-92: fun = exp(sum(x y) / 3) as a PLAIN closure."""
+
+    def __init__(self, dim=3, x_constrained=True, y_constrained=True):
+        self.par = vb.ModelParamsDict()
+        self.par.push_param(vb.VectorParam('x', size=dim, lb=0) if x_constrained else vb.VectorParam('x', size=dim))
+        self.par.push_param(vb.VectorParam('y', size=dim, lb=1) if y_constrained else vb.VectorParam('y', size=dim))
+
+    def set_random(self):
+        self.par.set_free(np.random.random(self.par.free_size()))
+
+    def fun(self):
+        x = self.par['x'].get()
+        y = self.par['y'].get()
+        return np.exp(np.sum(x * y) / 3)
+
+
+def test_reference_two_parameter_tests_on_plain_closures():
+    """The bodies of LRVB/test_objectives.py:220-243 (cross Hessian of sum(x1 x2) z y = z y I) and :294-381
+    (`test_two_parameter_objective`: off-diagonal blocks of the full Hessian in every free / vector combination), as the
+    reference writes them -- plain Python closures, no declared objective -- against this package's classes (the host
+    fallback of objectives.py; the reference's tolerance: assert_array_almost_equal, 6 decimals)."""
+    np_test = np.testing
+    obj_lib = vb.SparseObjectives
+    np.random.seed(42)
+    # ---- :220-243
+    x1 = vb.VectorParam('x1', size=2)
+    x2 = vb.VectorParam('x1', size=2)
+    x1_val = np.array([0., 1.])
+    x2_val = np.array([1., 2.])
+
+    def two_param_objective_fun(y, z=1.):
+        return np.sum(x1.get() * x2.get()) * z * y
+    twopar_obj = obj_lib.TwoParameterObjective(x1, x2, two_param_objective_fun)
+    np_test.assert_array_almost_equal(2 * 2 * 3, twopar_obj.fun_free(x1_val, x2_val, 2, z=3))
+    np_test.assert_array_almost_equal(2 * 2 * 3, twopar_obj.fun_vector(x1_val, x2_val, 2, z=3))
+    np_test.assert_array_almost_equal(np.eye(2) * 2 * 3, twopar_obj.fun_free_hessian12(x1_val, x2_val, 2, z=3))
+    np_test.assert_array_almost_equal(np.eye(2) * 2 * 3, twopar_obj.fun_free_hessian21(x1_val, x2_val, 2, z=3))
+    np_test.assert_array_almost_equal(np.eye(2) * 2 * 3, twopar_obj.fun_vector_hessian12(x1_val, x2_val, 2, z=3))
+    np_test.assert_array_almost_equal(np.eye(2) * 2 * 3, twopar_obj.fun_vector_hessian21(x1_val, x2_val, 2, z=3))
+    np_test.assert_array_almost_equal(x1.get(), x1_val)          # left at the evaluation point (:341-351)
+    np_test.assert_array_almost_equal(x2.get(), x2_val)
+    # gradients in each argument (:373-387): x2 z y and x1 z y
+    np_test.assert_array_almost_equal(x2_val * 6, twopar_obj.fun_grad1(x1_val, x2_val, True, True, 2, z=3))
+    np_test.assert_array_almost_equal(x1_val * 6, twopar_obj.fun_grad2(x1_val, x2_val, False, False, 2, z=3))
+
+    # ---- :294-381
+    model = _RefTwoParamModel()
+    model.set_random()
+    objective_full = obj_lib.Objective(model.par, model.fun)
+    objective = obj_lib.TwoParameterObjective(model.par['x'], model.par['y'], model.fun)
+    par_index = obj_lib.make_index_param(model.par)
+    ind_12 = np.ix_(par_index['x'].get_vector(), par_index['y'].get_vector())
+    ind_21 = np.ix_(par_index['y'].get_vector(), par_index['x'].get_vector())
+    par_free = model.par.get_free()
+    par_vec = model.par.get_vector()
+    x_free = model.par['x'].get_free()
+    y_free = model.par['y'].get_free()
+    x_vec = model.par['x'].get_vector()
+    y_vec = model.par['y'].get_vector()
+    np_test.assert_array_almost_equal(model.fun(), objective.fun_free(x_free, y_free))
+    np_test.assert_array_almost_equal(model.fun(), objective.fun_vector(x_vec, y_vec))
+    np_test.assert_array_almost_equal(model.fun(), objective.eval_fun(x_free, y_vec, val1_is_free=True, val2_is_free=False))
+    np_test.assert_array_almost_equal(model.fun(), objective.eval_fun(x_vec, y_free, val1_is_free=False, val2_is_free=True))
+    full_free_hess = objective_full.fun_free_hessian(par_free)
+    np_test.assert_array_almost_equal(full_free_hess[ind_12], objective.fun_free_hessian12(x_free, y_free))
+    np_test.assert_array_almost_equal(full_free_hess[ind_21], objective.fun_free_hessian21(x_free, y_free))
+    full_vec_hess = objective_full.fun_vector_hessian(par_vec)
+    np_test.assert_array_almost_equal(full_vec_hess[ind_12], objective.fun_vector_hessian12(x_vec, y_vec))
+    np_test.assert_array_almost_equal(full_vec_hess[ind_21], objective.fun_vector_hessian21(x_vec, y_vec))
+    # the closed form of this model: d2 / dx dy of exp(s / 3), s = sum(x y)
+    f0 = model.fun()
+    np_test.assert_allclose(full_vec_hess[ind_12], f0 * (np.outer(y_vec, x_vec) / 9 + np.eye(3) / 3), rtol=1e-8)
+    # mixed free / vector Hessians through an unconstrained x resp. y
+    model = _RefTwoParamModel(x_constrained=False)
+    model.par['x'].set_vector(x_vec)
+    model.par['y'].set_vector(y_vec)
+    np_test.assert_array_almost_equal(model.par['x'].get_vector(), model.par['x'].get_free())
+    objective_full = obj_lib.Objective(model.par, model.fun)
+    objective = obj_lib.TwoParameterObjective(model.par['x'], model.par['y'], model.fun)
+    full_free_hess = objective_full.fun_free_hessian(model.par.get_free())
+    np_test.assert_array_almost_equal(full_free_hess[ind_12], objective.fun_hessian_vector1_free2(x_vec, y_free))
+    model = _RefTwoParamModel(y_constrained=False)
+    model.par['x'].set_vector(x_vec)
+    model.par['y'].set_vector(y_vec)
+    np_test.assert_array_almost_equal(model.par['y'].get_vector(), model.par['y'].get_free())
+    objective_full = obj_lib.Objective(model.par, model.fun)
+    objective = obj_lib.TwoParameterObjective(model.par['x'], model.par['y'], model.fun)
+    full_free_hess = objective_full.fun_free_hessian(model.par.get_free())
+    np_test.assert_array_almost_equal(full_free_hess[ind_12], objective.fun_hessian_free1_vector2(x_free, y_vec))
+    # above the size the host fallback accepts, it refuses (no silent O(D^2) closure calls)
+    big = vb.VectorParam('b', size=65)
+    with pytest.raises(NotImplementedError):
+        obj_lib.TwoParameterObjective(big, x2, lambda: np.sum(big.get()) * np.sum(x2.get())).fun_free_hessian12(np.zeros(65), x2_val)
+
+
+def test_numeric_jacobian_of_matrix_valued_closure():
+    """`Objective.fun_free_jacobian` of a closure that returns a 2-d array: ans.shape + x.shape, entries in place (advisor,
+    round 3: the stacked differences used to be reshaped without moving the axis)."""
+    p = vb.VectorParam('p', size=3)
+    objective = vb.Objective(p, lambda: np.outer(p.get() ** 2, np.array([1.0, 2.0])))          # (3, 2)
+    x = np.array([0.5, -1.0, 2.0])
+    J = objective.fun_free_jacobian(x)
+    assert J.shape == (3, 2, 3)
+    want = np.zeros((3, 2, 3))
+    for i in range(3):
+        want[i, :, i] = 2 * x[i] * np.array([1.0, 2.0])
+    np.testing.assert_allclose(J, want, atol=1e-9)
+
+
+def test_sensitivity_to_prior_hyper_parameters_host_logic():
+    """`ParametricSensitivityLinearApproximation` / `TwoParameterObjective` with the prior mean, the prior information
+    (diagonal), the quadratic scale and the likelihood precision as hyper-parameters, in vector AND free coordinates of the
+    hyper-parameter, on the oracle's arithmetic: the sensitivity equals the Jacobian of a refit (central differences of
+    trust-ncg optima), as LRVB/test_model_sensitivity.py:367-424 checks it for the tilt."""
+    import scipy.optimize
+    rng = np.random.default_rng(77)
+    N, P = 60, 5
+    par, lay = make_par(vb, [('box', 'a', 3, -np.inf, np.inf), ('box', 'b', 2, 0.0, np.inf)])
+    x = rng.normal(size=(N, P)); y = x @ np.array([0.3, -0.2, 0.5, 0.7, 1.1]) + 0.3 * rng.normal(size=N)
+    model = om.DeclaredModel(lay, loss=om.GAUSSIAN, x=x, y=y, w=rng.uniform(0.5, 1.5, N), lik_info=1.3,
+                             quad_A=rng.uniform(0.5, 2.0, P), quad_m=rng.normal(size=P) * 0.2, quad_b=np.zeros(P), quad_scale=0.8)
+    hypers = dict(prior_mean_par=vb.VectorParam('prior_mean', P, val=model.quad_m.copy()),
+                  prior_info_par=vb.VectorParam('prior_info', P, lb=0.0, val=model.quad_A.copy()),
+                  quad_scale_par=vb.VectorParam('quad_scale', 1, lb=0.0, val=np.array([0.8])),
+                  lik_info_par=vb.VectorParam('lik_info', 1, lb=0.0, val=np.array([1.3])))
+    fun = OracleFunctor(par, model, **hypers)
+    objective = vb.Objective(par, fun)
+
+    def refit(start):
+        return scipy.optimize.minimize(objective.fun_free, start, jac=objective.fun_free_grad, hess=objective.fun_free_hessian,
+                                       method='trust-exact', options={'gtol': 1e-11}).x
+    theta0 = refit(np.zeros(P))
+    for name, hp in hypers.items():
+        for hyper_is_free in (False, True):
+            h0 = (hp.get_free() if hyper_is_free else hp.get_vector()).copy()
+            sens = vb.ParametricSensitivityLinearApproximation(fun, par, hp, theta0, h0, hyper_is_free=hyper_is_free)
+            S = sens.get_dinput_dhyper()
+            assert S.shape == (P, h0.size)
+            step = 1e-4
+            for j in range(h0.size):
+                e = np.zeros(h0.size); e[j] = step
+                (hp.set_free if hyper_is_free else hp.set_vector)(h0 + e)
+                tp = refit(theta0)
+                (hp.set_free if hyper_is_free else hp.set_vector)(h0 - e)
+                tm = refit(theta0)
+                np.testing.assert_allclose(S[:, j], (tp - tm) / (2 * step), rtol=2e-6, atol=2e-7, err_msg='{} free={}'.format(name, hyper_is_free))
+            (hp.set_free if hyper_is_free else hp.set_vector)(h0)
+            # first-order prediction of a refit: error second order in the step
+            d = 0.05 * (1.0 + np.abs(h0))
+            (hp.set_free if hyper_is_free else hp.set_vector)(h0 + d)
+            t1 = refit(theta0)
+            (hp.set_free if hyper_is_free else hp.set_vector)(h0 + d / 2)
+            t2 = refit(theta0)
+            (hp.set_free if hyper_is_free else hp.set_vector)(h0)
+            e1 = np.linalg.norm(sens.predict_input_par_from_hyperparameters(h0 + d) - t1)
+            e2 = np.linalg.norm(sens.predict_input_par_from_hyperparameters(h0 + d / 2) - t2)
+            assert e1 < 0.3 * np.linalg.norm(t1 - theta0) + 1e-12 and e2 < 0.3 * e1 + 1e-12, (name, hyper_is_free, e1, e2)

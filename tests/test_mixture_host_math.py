@@ -36,8 +36,7 @@ def shell(par, x, K, a0, b0):
     f._ipi = np.arange(vi['pi'].start, vi['pi'].stop)
     f._iphi = np.arange(vi['phi'].start, vi['phi'].stop).reshape(V, K)
     f._lb = np.full(f.n_global, par['pi']['alpha']._lb)
-    f.a0 = np.broadcast_to(np.asarray(a0, dtype=np.float64), (K,)).copy()
-    f.b0 = np.broadcast_to(np.asarray(b0, dtype=np.float64), (V, K)).copy()
+    f._declare_priors(a0, b0)
     f._external_stats = None
     return f
 
@@ -142,3 +141,32 @@ def test_dirichlet_block_closed_forms():
     # torch's fp64 trigamma is accurate to ~1e-9 only (scipy's agrees with mpmath to 1e-15)
     np.testing.assert_allclose(g, torch.func.grad(t)(ta).numpy(), rtol=1e-7, atol=1e-7)
     np.testing.assert_allclose(H, torch.func.hessian(t)(ta).numpy(), rtol=1e-7, atol=1e-7)
+
+
+@pytest.mark.parametrize('lb', [0.0, 0.5])
+def test_prior_hyper_parameter_closed_forms_match_ad(lb):
+    """Cross Hessians and gradients of the mixture with respect to the two Dirichlet priors against exact AD of the torch
+    restatement with the prior as a variable; the N (K - 1) simplex rows of the cross Hessian are zero."""
+    N, V, K = 12, 3, 3
+    x, w, theta = problem(N, V, K, seed=5, lb=lb)
+    par = make_par(N, V, K, lb)
+    a0 = np.array([1.5, 0.9, 2.0]); b0 = np.random.default_rng(0).uniform(0.5, 2.0, (V, K))
+    f = shell(par, x, K, a0, b0)
+    tt, tw = torch.tensor(theta), torch.tensor(w)
+    ng = f.n_global
+    fg = theta[:ng]
+    eta_g = lb + np.exp(fg)
+    alpha, beta, _ = f._lam(eta_g)
+    jg = eta_g - lb
+    builders = {
+        'pi_prior': (a0, lambda e: tr.mixture_objective(x, K, e, b0, lb=lb)),
+        'phi_prior': (b0.ravel(), lambda e: tr.mixture_objective(x, K, a0, e.reshape(V, K), lb=lb)),
+    }
+    for kind, (e0, build) in builders.items():
+        F = lambda th, e: build(e)(th, tw)
+        te0 = torch.tensor(e0)
+        C = torch.func.jacrev(torch.func.grad(F, argnums=0), argnums=1)(tt, te0).numpy()
+        g = torch.func.grad(F, argnums=1)(tt, te0).numpy()
+        assert np.max(np.abs(C[ng:])) == 0.0
+        np.testing.assert_allclose(jg[:, None] * f._prior_hyper(kind, alpha, beta, 'cross'), C[:ng], rtol=0, atol=1e-9 * max(1.0, np.max(np.abs(C))), err_msg=kind)
+        np.testing.assert_allclose(f._prior_hyper(kind, alpha, beta, 'grad'), g, rtol=0, atol=1e-9 * max(1.0, np.max(np.abs(g))), err_msg=kind)

@@ -307,3 +307,66 @@ def test_append_jvp_and_derivative_array_counterparts():
     for t in terms:
         second += t.differentiate(eval_next_eta_deriv=lambda e0, p0, dp: w)
     assert all(len(t.eval_eta_derivs) == 2 for t in second) and sorted(t.order for t in second) == [2] * len(second)
+
+
+@pytest.mark.parametrize('hyper_is_free', [False, True])
+@pytest.mark.parametrize('kind', ['prior_mean', 'prior_info', 'quad_scale', 'lik_info', 'tilt'])
+def test_taylor_class_with_prior_hyper_parameters(kind, hyper_is_free):
+    """The Taylor class for the OTHER declared hyper-parameters (LRVB/ModelSensitivity.py:382-515 takes any hyper_par), in
+    vector and in free coordinates of the hyper-parameter: d^k/dt^k of the optimality condition along the Taylor polynomial
+    vanishes for k <= K, by exact nested AD of an independent torch restatement with the hyper-parameter as a variable."""
+    import torch_ref as tr
+    from oracle_functor import OracleFunctor
+    from helpers import make_par
+    rng = np.random.default_rng(90)
+    spec = [('box', 'beta', 4, -1.0, np.inf), ('psd', 'm', 2, 0.2), ('box', 'u', 2, -np.inf, np.inf)]
+    par, lay = make_par(vb, spec)
+    N, P = 80, 4
+    x = rng.normal(size=(N, P)) * 0.6
+    y = rng.normal(size=N)
+    a = rng.normal(size=(lay.V, lay.V)); A = a @ a.T / lay.V + 2.0 * np.eye(lay.V)
+    dense = kind == 'prior_info' and not hyper_is_free
+    model = om.DeclaredModel(lay, loss=om.GAUSSIAN, x=x, y=y, w=rng.uniform(0.5, 1.5, N), lik_info=1.4,
+                             quad_A=A if dense else np.diag(A).copy(), quad_m=lay.constrain(rng.normal(size=lay.D) * 0.3),
+                             quad_b=rng.normal(size=lay.V) * 0.1, quad_scale=0.7)
+    h_vec0 = model.hyper_value(kind)
+    lb, ub = {'prior_mean': (-6.0, 6.0), 'tilt': (-np.inf, 2.0)}.get(kind, (0.0, np.inf))
+    if not hyper_is_free:
+        lb, ub = -np.inf, np.inf
+    hp = vb.VectorParam(kind, h_vec0.size, lb=lb, ub=ub, val=h_vec0.copy())
+    fun = OracleFunctor(par, model, **{kind + '_par': hp})
+    phi0 = _optimum(model, np.zeros(lay.D))
+    assert np.linalg.norm(model.grad(phi0)) < 1e-9
+    K = 3
+    hyper0 = hp.get_free().copy() if hyper_is_free else h_vec0.copy()
+    tay = vb.ParametricSensitivityTaylorExpansion(fun, par, hp, phi0, hyper0, K, hyper_is_free=hyper_is_free)
+    de = rng.normal(size=hyper0.size) * (0.3 if kind != 'prior_info' else 0.2)
+    derivs = [tay.evaluate_dkinput_dhyperk(de, k) for k in range(1, K + 1)]
+    np.testing.assert_allclose(hp.get_vector(), h_vec0, rtol=1e-12)              # hyper-parameter left at the base value
+    f = tr.make_hyper_objective(model, kind)
+    coefs = [torch.tensor(phi0)] + [torch.tensor(dk / math.factorial(k)) for k, dk in enumerate(derivs, start=1)]
+    tde, th0 = torch.tensor(de), torch.tensor(hyper0)
+
+    def c_h(e):                                              # the hyper-parameter's own packing map
+        if not hyper_is_free:
+            return e
+        if np.isinf(ub):
+            return torch.exp(e) + lb
+        if np.isinf(lb):
+            return ub - torch.exp(-e)
+        return (ub - lb) * torch.sigmoid(e) + lb
+
+    def residual(t):
+        phi = sum(c * t ** k for k, c in enumerate(coefs))
+        return torch.func.grad(f, argnums=0)(phi, c_h(th0 + t * tde))
+
+    t0, one = torch.zeros((), dtype=torch.float64), torch.ones((), dtype=torch.float64)
+    scale = np.linalg.norm(model.hessian(phi0) @ derivs[0])
+    assert scale > 1e-3
+    h = residual
+    assert torch.linalg.norm(h(t0)).item() < 1e-8 * max(scale, 1.0)
+    for k in range(1, K + 1):
+        h = (lambda g: (lambda t: torch.func.jvp(g, (t,), (one,))[1]))(h)
+        assert torch.linalg.norm(h(t0)).item() < 1e-7 * scale * math.factorial(k), k
+    h = (lambda g: (lambda t: torch.func.jvp(g, (t,), (one,))[1]))(h)
+    assert torch.linalg.norm(h(t0)).item() > 1e-7 * scale          # one order further it does not vanish

@@ -94,7 +94,7 @@ def mvn_regression_objective(x, y, k, mu0, lam0, a0, b0, layout=None):
     """Config 2 (-ELBO of the conjugate-normal regression) in torch as f(point, w); `point` is the
     vector eta = [m (k), tril(Lambda), shape, rate] or, with `layout`, the free vector."""
     xt, yt = torch.tensor(x), torch.tensor(y).reshape(-1)
-    mu0t, lam0t = torch.tensor(mu0), torch.tensor(lam0)
+    mu0t, lam0t = torch.as_tensor(mu0, dtype=torch.float64), torch.as_tensor(lam0, dtype=torch.float64)
     idx = torch.tril_indices(k, k)
     mm = k * (k + 1) // 2
 
@@ -122,7 +122,7 @@ def wishart_mvn_objective(y, d, mu0, lam0, nu0, w0, layout=None):
     """Config 5 (-ELBO of the Wishart + MVN full-covariance model) in torch as f(point, w); point =
     eta = [m (d), tril(Lambda_mu), nu, tril(V)] or the free vector when `layout` is given."""
     yt = torch.tensor(y)
-    mu0t, lam0t, w0t = torch.tensor(mu0), torch.tensor(lam0), torch.tensor(w0)
+    mu0t, lam0t, w0t = (torch.as_tensor(t, dtype=torch.float64) for t in (mu0, lam0, w0))
     idx = torch.tril_indices(d, d)
     mm = d * (d + 1) // 2
     half_i = 0.5 * torch.arange(d, dtype=torch.float64)
@@ -161,7 +161,7 @@ def lmm_objective(x, y, gid, G, beta0, lam0, mu0, kappa0, tau_y_prior, tau_mu_pr
     gt = torch.tensor(gid, dtype=torch.long)
     p = x.shape[1]
     mm = p * (p + 1) // 2
-    b0t, l0t = torch.tensor(beta0), torch.tensor(lam0)
+    b0t, l0t = torch.as_tensor(beta0, dtype=torch.float64), torch.as_tensor(lam0, dtype=torch.float64)
     idx = torch.tril_indices(p, p)
     a0y, b0y = tau_y_prior
     a0m, b0m = tau_mu_prior
@@ -201,8 +201,8 @@ def mixture_objective(x, K, a0, b0, lb=0.0):
     [log(alpha - lb) (K) | log(beta - lb) (V K, row-major) | simplex logits (N (K-1))] and the weights."""
     xt = torch.as_tensor(x, dtype=torch.float64)
     N, V = xt.shape
-    a0t = torch.as_tensor(np.broadcast_to(a0, (K,)).copy(), dtype=torch.float64)
-    b0t = torch.as_tensor(np.broadcast_to(b0, (V, K)).copy(), dtype=torch.float64)
+    a0t = a0 if torch.is_tensor(a0) else torch.as_tensor(np.broadcast_to(a0, (K,)).copy(), dtype=torch.float64)
+    b0t = b0 if torch.is_tensor(b0) else torch.as_tensor(np.broadcast_to(b0, (V, K)).copy(), dtype=torch.float64)
 
     def dir_entropy(al):            # axis 0 is the Dirichlet dimension
         a_sum = al.sum(0)
@@ -222,4 +222,47 @@ def mixture_objective(x, K, a0, b0, lb=0.0):
         ent_z = -(w[:, None] * z * torch.log(z)).sum()
         prior = ((a0t - 1.0) * elog_pi).sum() + ((b0t - 1.0) * elog_phi).sum()
         return -(lik + ent_z + prior + dir_entropy(alpha) + dir_entropy(beta).sum())
+    return f
+
+
+def make_hyper_objective(model, kind):
+    """f(theta, eps) for an oracle.models.DeclaredModel with ONE of its hyper-parameters as a torch variable (the others
+    frozen at the model's values): eps = tilt b | prior_mean m | prior_info diag(A) or vech(A) | quad_scale s | lik_info tau.
+    Written independently of oracle/models.py so that torch.func AD of it pins the oracle's closed-form cross Hessians."""
+    x = None if model.x is None else torch.tensor(model.x)
+    y = None if model.y is None else torch.tensor(model.y)
+    w = None if model.w is None else torch.tensor(model.w)
+    A0 = None if model.quad_A is None else torch.tensor(model.quad_A)
+    m0, b0 = torch.tensor(model.quad_m), torch.tensor(model.quad_b)
+    V = model.layout.V
+    tri = torch.tril_indices(V, V)
+
+    def f(theta, eps):
+        eta = constrain(theta, model.layout)
+        tau = eps[0] if kind == 'lik_info' else model.lik_info
+        val = torch.zeros((), dtype=eta.dtype)
+        if model.loss:
+            z = x @ eta[model.glm_off:model.glm_off + model.P]
+            if model.loss == 1:
+                l = 0.5 * tau * (y - z) ** 2
+            elif model.loss == 2:
+                l = torch.nn.functional.softplus(z) - y * z
+            else:
+                l = torch.exp(z) - y * z
+            val = val + torch.sum(w * l)
+        if A0 is not None:
+            m = eps if kind == 'prior_mean' else m0
+            b = eps if kind == 'tilt' else b0
+            s = eps[0] if kind == 'quad_scale' else model.quad_scale
+            A = A0
+            if kind == 'prior_info':
+                if A0.dim() == 1:
+                    A = eps
+                else:
+                    L = torch.zeros(V, V, dtype=eps.dtype).index_put((tri[0], tri[1]), eps)
+                    A = L + L.T - torch.diag(torch.diagonal(L))
+            d = eta - m
+            Ad = A * d if A.dim() == 1 else A @ d
+            val = val + s * (0.5 * torch.dot(d, Ad) + torch.dot(b, eta))
+        return val
     return f
