@@ -2907,7 +2907,7 @@ __global__ void cg_multi_alpha_kernel(int Q, double* __restrict__ s) {
 }
 
 // ---- blocked CG, fused form (box layouts, no preconditioner): an iteration is FIVE launches and no host round trip ------
-// s: [ |b|^2 (Q) | rho_prev (Q) | r.r (Q) | live (Q) | iterations (Q) ].  head: r.r, the convergence test, beta, p = r + beta p
+// s: [ |b|^2 (Q) | rho_prev (Q) | r.r (Q) | live (Q) | iterations (Q) | live after even iterations (Q) | after odd ones (Q) ].  head: r.r, the convergence test, beta, p = r + beta p
 // and the product's operand u = eta' o p in one kernel (one workgroup per system); tail: q = eta' (W + s A u) + g eta'' p
 // formed on the fly, p.q, alpha, x += alpha p, r -= alpha q.  The host runs ONE ITERATION AHEAD of its convergence test
 // (the status of iteration k is read on a side stream while iteration k + 1 is already queued); when every system has
@@ -2934,6 +2934,9 @@ void cg_multi_head_kernel(i64 D, i64 it, double tol, const double* __restrict__ 
             else { const double rp = s[Q + q]; beta = (it > 0 && rp != 0.0) ? rr / rp : 0.0; s[Q + q] = rr; s[4 * Q + q] = (double)(it + 1); }
         }
         s[2 * Q + q] = rr; s[3 * Q + q] = live;
+        // the flag of THIS iteration's test, in the slot of its parity: what the host reads back (the live flags themselves are
+        // rewritten by the head kernel of iteration it + 1, which may already be queued -- a copy of s[3Q..] could hold either state)
+        s[(5 + (it & 1)) * Q + q] = live;
         bc[0] = live; bc[1] = beta;
     }
     __syncthreads();
@@ -2992,7 +2995,9 @@ static int cg_multi_fused_loop(lrvb_ctx* c, i64 Q, i64 D, double tol, i64 maxite
         // status of THIS iteration's test, copied on the side stream as soon as the head kernel is done
         HIP_TRY(hipEventRecord(c->aux_ev[0], c->stream));
         HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->aux_ev[0], 0));
-        HIP_TRY(hipMemcpyAsync(status + (it & 1) * 1024, s + 3 * Q, (size_t)Q * sizeof(double), hipMemcpyDeviceToHost, c->aux_stream));
+        // the per-parity snapshot, not the live flags: head(it + 2) -- the next writer of this slot -- is queued only after the host has
+        // consumed this copy, so every rank reads the same flags for iteration `it` and queues the same number of reductions
+        HIP_TRY(hipMemcpyAsync(status + (it & 1) * 1024, s + (5 + (it & 1)) * Q, (size_t)Q * sizeof(double), hipMemcpyDeviceToHost, c->aux_stream));
         HIP_TRY(hipMemsetAsync(W, 0, (size_t)(Q * D) * sizeof(double), c->stream));
         for (i64 q0 = 0; q0 < Q; q0 += 16) {
             const i64 qn = (Q - q0 < 16) ? Q - q0 : 16;
@@ -3001,7 +3006,8 @@ static int cg_multi_fused_loop(lrvb_ctx* c, i64 Q, i64 D, double tol, i64 maxite
             c->hm_live = nullptr;
             LRVB_TRY(st);
         }
-        LRVB_TRY(obs_reduce(c, W, Q * D));                            // every rank queues the same iterations (identical scalars)
+        LRVB_TRY(obs_reduce(c, W, Q * D));                            // every rank queues the same iterations: the stop decision below
+                                                                      // reads per-iteration snapshots of reduced (rank-identical) scalars
         hipLaunchKernelGGL(cg_multi_tail_kernel, dim3((unsigned)Q), dim3(256), 0, c->stream, D, c->quad_scale, quadA, (const double*)c->j1.p,
                            (const double*)c->j2.p, (const double*)c->g_eta.p, (const double*)W, (const double*)U, (const double*)Pd, Xd, Rd,
                            (const double*)s, Q);

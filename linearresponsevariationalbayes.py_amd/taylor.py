@@ -549,6 +549,9 @@ class ParametricSensitivityTaylorExpansion(object):
         dhyper = np.asarray(dhyper, dtype=np.float64).ravel()
         if dhyper.size != self.hyper_val0.size:
             raise ValueError('dhyper is the wrong size')
+        # the derivatives are those AT THE BASE VALUES, whatever the parameter objects hold at the moment (the reference
+        # evaluates its closures at (input_val0, hyper_val0) explicitly, LRVB/ModelSensitivity.py:452-470)
+        self.set_par_to_base_values()
         self._cache['h'] = {}                                    # leaves are memoised per direction dhyper
         derivs = []
         for j in range(1, k + 1):

@@ -431,3 +431,79 @@ def test_statistics_calls_reduce_once_and_fail_together():
     for f, _ in objs:
         f.ctx.set_reduce_hook(None)
         assert not f.ctx.has_reduce_hook
+
+
+_WORKER_CG = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, 'tests'))
+import torch
+import torch.distributed as dist
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = sys.argv[3]
+dist.init_process_group('gloo', rank=rank, world_size=world)
+import lrvb_amd as vb
+from lrvb_amd.distributed import torch_reduce_hook, shard_rows
+rng = np.random.default_rng(5)
+N, P, Q = 67, 8, 5                                  # tiny: a product takes about as long as the status copy
+x = rng.normal(size=(N, P)); y = rng.normal(size=N); theta = rng.normal(size=P) * 0.1
+r0, r1 = shard_rows(N, rank, world)
+dev = torch.device('cuda', 0); torch.cuda.set_device(0)
+par = vb.ModelParamsDict('par'); par.push_param(vb.VectorParam('b', P))
+fun = vb.DeviceObjective(par, x=x[r0:r1], y=y[r0:r1], loss='gaussian', quad_A=np.full(P, 0.5))
+fun._push_state()
+ctx = fun.ctx
+ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+inner = torch_reduce_hook(dev, None)
+calls = [0]
+def counting(buf, n, stream):
+    calls[0] += 1
+    inner(buf, n, stream)
+ctx.set_reduce_hook(counting)
+sols, counts = [], []
+for rep in range(40):
+    B = rng.normal(size=(Q, P)) * np.array([1.0, 1e-3, 10.0, 0.0, 1.0])[:, None]      # systems stop at different iterations; one is zero
+    before = calls[0]
+    X, info, its = ctx.cg_solve_multi(theta, B, tol=10.0 ** -(4 + rep % 7))
+    counts.append(calls[0] - before)
+    sols.append(np.concatenate([X.ravel(), info.astype(float), its.astype(float)]))
+ctx.set_reduce_hook(None)
+t = torch.from_numpy(np.concatenate([np.array(counts, dtype=float)] + sols))
+gathered = [torch.empty_like(t) for _ in range(world)]
+dist.all_gather(gathered, t)
+if rank == 0:
+    assert all(torch.equal(gathered[0], q) for q in gathered), 'ranks disagree (reduction counts or solutions)'
+    np.save(sys.argv[4], gathered[0].numpy())
+dist.destroy_process_group()
+'''
+
+
+def test_blocked_cg_queues_the_same_reductions_on_every_rank(tmp_path):
+    """Advisor finding, round 3: the host of the fused blocked CG runs one iteration ahead of its convergence test and used
+    to read the LIVE flags, which the next iteration's head kernel rewrites in place -- ranks could then stop at different
+    iterations and queue different numbers of all-reduces.  The stop decision now reads a per-iteration snapshot.  Two ranks,
+    a shape so small that a product takes about as long as the status copy, 40 solves with systems that stop at different
+    iterations: the number of hook calls per solve and the solutions are identical on both ranks, and the solutions are right."""
+    world = 2
+    port = _free_port()
+    out_path = str(tmp_path / 'cg.npy')
+    script = tmp_path / 'worker_cg.py'
+    script.write_text(_WORKER_CG.format(root=ROOT))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), str(port), out_path], env=env) for r in range(world)]
+    codes = [p.wait(timeout=600) for p in procs]
+    assert codes == [0] * world
+    flat = np.load(out_path)
+    rng = np.random.default_rng(5)
+    N, P, Q = 67, 8, 5
+    x = rng.normal(size=(N, P)); y = rng.normal(size=N); theta = rng.normal(size=P) * 0.1
+    H = x.T @ x + 0.5 * np.eye(P)
+    counts, rest = flat[:40], flat[40:].reshape(40, Q * P + 2 * Q)
+    assert np.all(counts >= 2) and np.all(counts <= P + 3)              # [value | gradient] state + one block product per iteration
+    for rep in range(40):
+        B = rng.normal(size=(Q, P)) * np.array([1.0, 1e-3, 10.0, 0.0, 1.0])[:, None]
+        X = rest[rep, :Q * P].reshape(Q, P)
+        tol = 10.0 ** -(4 + rep % 7)
+        for q in range(Q):
+            assert np.linalg.norm(H @ X[q] - B[q]) <= 10 * tol * np.linalg.norm(B[q]) + 1e-300
+        assert np.all(rest[rep, Q * P:Q * P + Q] == 0)

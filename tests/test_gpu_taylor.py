@@ -245,7 +245,13 @@ def test_refusals(vb):
     with pytest.raises(NotImplementedError):
         vb.ParametricSensitivityTaylorExpansion(host, p2, p2, np.zeros(3), np.zeros(3), 2)
     f2 = vb.QuadraticObjective(p2, A=np.eye(3))
-    with pytest.raises(NotImplementedError):
-        vb.ParametricSensitivityTaylorExpansion(f2, p2, f2.tilt_par, np.zeros(3), np.zeros(3), 2, hyper_is_free=True)
+    with pytest.raises(NotImplementedError):          # a hyper-parameter the objective does not declare
+        vb.ParametricSensitivityTaylorExpansion(f2, p2, vb.VectorParam('stranger', 3), np.zeros(3), np.zeros(3), 2)
+    # free coordinates of the hyper-parameter are accepted since round 4 (an unbounded tilt: free = vector, same derivatives)
+    tf = vb.ParametricSensitivityTaylorExpansion(f2, p2, f2.tilt_par, np.zeros(3), np.zeros(3), 2, hyper_is_free=True)
+    tv = vb.ParametricSensitivityTaylorExpansion(f2, p2, f2.tilt_par, np.zeros(3), np.zeros(3), 2)
+    de = np.array([0.3, -0.2, 0.1])
+    np.testing.assert_allclose(tf.evaluate_dkinput_dhyperk(de, 1), tv.evaluate_dkinput_dhyperk(de, 1), rtol=1e-13)
+    np.testing.assert_allclose(tv.evaluate_dkinput_dhyperk(de, 1), -de, rtol=1e-12)
     with pytest.raises(ValueError):
         vb.ParametricSensitivityTaylorExpansion(f2, p2, f2.tilt_par, np.zeros(3), np.zeros(3), 0)
