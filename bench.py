@@ -180,8 +180,14 @@ def cpu_baseline(fetch_rows, n_total, D, n_pos, loss, lik_info, prior_info, thet
     model0 = om.DeclaredModel(layout, loss=0, quad_A=np.full(D, prior_info))
     t0 = time.perf_counter()
     gq = g + model0.grad_vec(eta)
-    opk.convert_vector_to_free_hessian(layout, theta, gq, S + model0.hessian_vec(eta))
+    H_oracle = opk.convert_vector_to_free_hessian(layout, theta, gq, S + model0.hessian_vec(eta))
     t_assembly = time.perf_counter() - t0
+    # the checker leg of the parity record: the oracle's free-coordinate Hessian and gradient over ALL rows (kept only when the
+    # loop above did see all of them)
+    oracle_full = None
+    if rows_done == n_total:
+        oracle_full = {'hessian': np.asarray(H_oracle.todense() if hasattr(H_oracle, 'todense') else H_oracle),
+                       'grad': layout.jac(theta).T @ gq}
     t_strong = t_compute * (n_total / rows_done) + t_assembly
     raw['strong'] = {'rows_timed': rows_done, 'compute_s': t_compute, 'assembly_s': t_assembly,
                      'gflops': 2.0 * rows_done * D * (D + 1) / max(t_compute, 1e-12) / 1e9}
@@ -230,6 +236,7 @@ def cpu_baseline(fetch_rows, n_total, D, n_pos, loss, lik_info, prior_info, thet
         'strong_numpy_note': 'closed-form X^T diag(c) X through BLAS (row scaling on a 16-thread pool), measured over {} of {} rows in 65,536-row chunks '
                              '(compute only), N-independent assembly added once'.format(rows_done, n_total),
         'raw_timings': raw,
+        '_oracle_full': oracle_full,
     }
 
 
@@ -252,6 +259,16 @@ def _timed_steps(step, warmup, steps, ctx, fence):
     prof = ctx.profile_get()
     ctx.profile_enable(False)
     return elapsed, prof
+
+
+def _gather_floats(torch, dist, vals, dev, backend, use_dist):
+    """[[vals of rank 0], [vals of rank 1], ...] (one row per rank)."""
+    if not use_dist:
+        return [list(map(float, vals))]
+    t = torch.tensor(list(map(float, vals)), dtype=torch.float64, device=dev if backend != 'gloo' else 'cpu')
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [[float(v) for v in o.cpu().tolist()] for o in out]
 
 
 def _fingerprint(np, H):
@@ -409,6 +426,8 @@ def run_config(args, cfg=None, steps=None, warmup=None, env=None):
         elapsed = float(t.item())
     kernel_ms = prof['wsyrk_ms'] / steps                      # all statistics-kernel launches of one step
     ms_per_step = elapsed / steps * 1e3
+    # the exchange apart from the compute, per rank (HIP events around the sum-over-ranks hook inside the library)
+    per_rank = _gather_floats(torch, dist, [kernel_ms, prof['reduce_ms'] / steps, prof['reduce_calls'] / steps], dev, backend, use_dist)
     scale = 1e9 if unit == 'GB/s' else 1e12
     achieved = alg / (kernel_ms * 1e-3) / scale if kernel_ms > 0 else 0.0
     out = {
@@ -427,6 +446,10 @@ def run_config(args, cfg=None, steps=None, warmup=None, env=None):
                      'step_frac': alg / (ms_per_step * 1e-3) / scale / peak},
     }
     out['roofline'].update(extra)
+    out['exchange'] = {'per_rank_kernel_ms': [r[0] for r in per_rank], 'allreduce_ms': [r[1] for r in per_rank],
+                       'allreduce_calls_per_step': per_rank[0][2],
+                       'note': 'HIP events on each rank\'s stream: all statistics kernels of a step / around the sum-over-ranks hook '
+                               '(collective + wait for the slowest rank); the rest of ms_per_step is N-independent host and device assembly'}
     if cfg == 'c5' and world == 1 and own_group:
         # the LRVB solve of the configuration: exact Hessian (sufficient statistics), Cholesky, CG on the resident matrix
         obj = vb.Objective(par, fun)
@@ -606,6 +629,8 @@ def main(args):
     fence()
     ctx.profile_enable(True)
     ctx.profile_reset()
+    if sharded is not None:
+        sharded.timing(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         Hout = step()
@@ -613,6 +638,16 @@ def main(args):
     elapsed = time.perf_counter() - t0
     prof = ctx.profile_get()
     ctx.profile_enable(False)
+    # the three phases of a sharded build on this rank's stream: statistics kernels | exchange | N-independent assembly
+    phases = None
+    if sharded is not None:
+        k_ms, ar_ms, fin_ms, n_marks = sharded.phase_ms()
+        sharded.timing(False)
+        phases = [k_ms / max(n_marks, 1), ar_ms / max(n_marks, 1), fin_ms / max(n_marks, 1)]
+    elif native:
+        nb = max(prof['build_calls'], 1)
+        k_ms = prof['wsyrk_ms'] / nb + prof['pass_ms'] / nb
+        phases = [k_ms, prof['reduce_ms'] / nb, prof['build_ms'] / nb - k_ms - prof['reduce_ms'] / nb]
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if use_dist:
@@ -664,6 +699,14 @@ def main(args):
                      'pass_kernel_GBs': (8.0 * n_local * (D + 3)) / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else None},
     }
 
+    if phases is not None:
+        rows = _gather_floats(torch, dist, phases, dev, backend, use_dist)
+        out['exchange'] = {'per_rank_kernel_ms': [r[0] for r in rows], 'allreduce_ms': [r[1] for r in rows],
+                           'per_rank_finish_ms': [r[2] for r in rows], 'sum_ms_rank0': sum(rows[0]),
+                           'note': 'device-event time of the three phases of a sharded build on each rank\'s stream: statistics '
+                                   'kernels (partial) | sum all-reduce of the {:.1f} MB statistics buffer (collective + wait for the '
+                                   'slowest rank) | replicated N-independent assembly; they are contiguous on one stream, so their sum '
+                                   'is the device time of a step'.format(ctx.stats_size() * 8 / 1e6)}
     # the same data for every world size (chunks are seeded by their global index), so the built matrix must not depend on
     # it: a fingerprint of H that can be compared across the N = 1, 2, 4, 8 lines (agreement to ~1e-12 relative)
     torch.cuda.synchronize()
@@ -732,11 +775,49 @@ def main(args):
             ctx2.sync()
             out['config']['logistic_build_ms'] = (time.perf_counter() - t7) / 5 * 1e3
             del ctx2, H2, yb
+        # SURVEY 8(d) defines a build as "(theta, w) on the host -> H": the same step with theta and the 8 MB weight vector
+        # uploaded in every build (pinned host buffers, stream-ordered copies into the buffers the context has adopted), H
+        # left in HBM.  `value` above keeps the inputs resident; this is the PCIe-inclusive figure beside it.
+        th_host = theta.cpu().pin_memory()
+        w_host = w.cpu().pin_memory()
+
+        def step_host_inputs():
+            theta.copy_(th_host, non_blocking=True)
+            w.copy_(w_host, non_blocking=True)
+            ctx.hessian_dev(theta.data_ptr(), H.data_ptr(), D)
+        for _ in range(2):
+            step_host_inputs()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_host_inputs()
+        fence()
+        out['ms_per_step_host_inputs'] = (time.perf_counter() - t0) / args.steps * 1e3
+        out['config']['host_inputs_note'] = ('ms_per_step_host_inputs: theta ({} B) and w ({:.1f} MB) copied from pinned host memory '
+                                             'in every build, H left in HBM'.format(8 * D, 8e-6 * n_local))
         if not args.no_cpu_baseline and rank == 0:
             def fetch_rows(a, b):
                 return X[a:b].cpu().numpy(), y[a:b].cpu().numpy()
             out['cpu_baseline'] = cpu_baseline(fetch_rows, N_total, D, n_pos, args.loss, lik_info, prior_info,
                                                theta.cpu().numpy(), budget_s=args.cpu_budget_s)
+            # PARITY at the benchmark's own size: the matrix the timed region built against the oracle's Hessian over the same
+            # 1e6 rows (the strong-numpy leg forms it anyway), plus the gradient.  The checker leg: outside every timed region.
+            full = out['cpu_baseline'].pop('_oracle_full', None)
+            if full is not None:
+                ctx.hessian_dev(theta.data_ptr(), H.data_ptr(), D)
+                ctx.sync()
+                H_gpu = H.cpu().numpy()
+                g_gpu = ctx.grad(theta.cpu().numpy())
+                Ho, go = full['hessian'], full['grad']
+                out['parity'] = {
+                    'max_rel_err_hessian': float(np.max(np.abs(H_gpu - Ho)) / np.max(np.abs(Ho))),
+                    'max_rel_err_grad': float(np.max(np.abs(g_gpu - go)) / np.max(np.abs(go))),
+                    'asymmetry': float(np.max(np.abs(H_gpu - H_gpu.T)) / np.max(np.abs(Ho))),
+                    'rows': int(N_total), 'n_free': int(D),
+                    'against': 'oracle (numpy fp64: X^T diag(c) X over all rows in 65,536-row chunks + convert_vector_to_free_hessian); '
+                               'errors relative to the largest entry; tolerance of the GPU suite for sums over observations: 1e-11'}
+            else:
+                out['parity'] = {'skipped': 'the strong-numpy leg did not reach all rows within its time budget'}
     if configs_out is not None:
         out['configs'] = configs_out
     if use_dist:

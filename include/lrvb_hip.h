@@ -531,6 +531,9 @@ typedef struct lrvb_prof {
     double  pass_bytes;     /* 8 * n_obs * (n_cols + 3)                                       */
     double  build_ms;       /* whole lrvb_hessian_dev calls                                  */
     int64_t build_calls;
+    double  reduce_ms;      /* HIP-event time around the sum-over-ranks hook (the exchange step of SURVEY 8(e)): the
+                               collective itself plus, on its first use in a step, the wait for the slowest rank   */
+    int64_t reduce_calls;
 } lrvb_prof;
 int lrvb_profile_enable(lrvb_ctx* ctx, int on);   /* off by default (event overhead)        */
 int lrvb_profile_get   (lrvb_ctx* ctx, lrvb_prof* out);

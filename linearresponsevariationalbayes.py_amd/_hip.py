@@ -41,7 +41,8 @@ class Prof(ctypes.Structure):
     _fields_ = [('wsyrk_ms', ctypes.c_double), ('wsyrk_calls', c_i64),
                 ('wsyrk_flops', ctypes.c_double), ('wsyrk_bytes', ctypes.c_double),
                 ('pass_ms', ctypes.c_double), ('pass_calls', c_i64), ('pass_bytes', ctypes.c_double),
-                ('build_ms', ctypes.c_double), ('build_calls', c_i64)]
+                ('build_ms', ctypes.c_double), ('build_calls', c_i64),
+                ('reduce_ms', ctypes.c_double), ('reduce_calls', c_i64)]
 
 
 # name -> argtypes; every function returns int except the two noted.  This table is also what

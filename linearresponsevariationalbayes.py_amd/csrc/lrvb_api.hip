@@ -232,7 +232,7 @@ extern "C" int lrvb_ctx_destroy(lrvb_ctx* c) {
     for (DevBuf* b : all) buf_free(*b);
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
     if (c->up_ring) { for (int k = 0; k < lrvb_ctx::UP_SLOTS; ++k) if (c->up_ev[k]) (void)hipEventDestroy(c->up_ev[k]); (void)hipHostFree(c->up_ring); }
-    for (int k = 0; k < 3; ++k) for (hipEvent_t e : c->ev_pool[k]) (void)hipEventDestroy(e);
+    for (int k = 0; k < PROF_POOLS; ++k) for (hipEvent_t e : c->ev_pool[k]) (void)hipEventDestroy(e);
     if (c->ev_order) (void)hipEventDestroy(c->ev_order);
     for (int k = 0; k < 2; ++k) if (c->aux_ev[k]) (void)hipEventDestroy(c->aux_ev[k]);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
@@ -440,7 +440,9 @@ static int set_point(lrvb_ctx* c, const double* point_dev, bool is_free) {
 // Sum of a device buffer of observation sums over the ranks of the job (no-op in a single process).
 static int obs_reduce(lrvb_ctx* c, double* buf_dev, i64 n) {
     if (!c->reduce_fn || n <= 0) return LRVB_OK;
+    if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_REDUCE));          // the exchange, timed apart from the kernels around it
     const int st = c->reduce_fn(c->reduce_user, buf_dev, (int64_t)n, (void*)c->stream);
+    if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_REDUCE));
     if (st != 0) LRVB_FAIL(LRVB_ERR_STATE, "the reduce hook failed with status %d", st);
     return LRVB_OK;
 }
@@ -3154,7 +3156,7 @@ int prof_mark(lrvb_ctx* c, int which) {
 }
 static int prof_collect(lrvb_ctx* c) {
     HIP_TRY(hipStreamSynchronize(c->stream));
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < PROF_POOLS; ++k) {
         double ms_sum = 0.0; int64_t calls = 0;
         for (size_t i = 0; i + 1 < c->ev_used[k]; i += 2) {
             float ms = 0.f;
@@ -3165,6 +3167,7 @@ static int prof_collect(lrvb_ctx* c) {
         if (k == PROF_WSYRK) { c->prof.wsyrk_ms += ms_sum; c->prof.wsyrk_calls += calls; }
         if (k == PROF_PASS)  { c->prof.pass_ms  += ms_sum; c->prof.pass_calls  += calls; }
         if (k == PROF_BUILD) { c->prof.build_ms += ms_sum; c->prof.build_calls += calls; }
+        if (k == PROF_REDUCE) { c->prof.reduce_ms += ms_sum; c->prof.reduce_calls += calls; }
     }
     return LRVB_OK;
 }

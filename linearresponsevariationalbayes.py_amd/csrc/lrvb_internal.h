@@ -109,12 +109,12 @@ struct lrvb_ctx {
     // profiling: event pairs are recorded without host synchronisation and summed in
     // lrvb_profile_get (so the timed region of bench.py is not perturbed)
     bool prof_on = false;
-    std::vector<hipEvent_t> ev_pool[3];     // 0 = wsyrk, 1 = pass, 2 = build
-    size_t ev_used[3] = {0, 0, 0};
+    std::vector<hipEvent_t> ev_pool[4];     // 0 = wsyrk, 1 = pass, 2 = build, 3 = sum-over-ranks hook
+    size_t ev_used[4] = {0, 0, 0, 0};
     lrvb_prof prof{};
 };
 
-enum { PROF_WSYRK = 0, PROF_PASS = 1, PROF_BUILD = 2 };
+enum { PROF_WSYRK = 0, PROF_PASS = 1, PROF_BUILD = 2, PROF_REDUCE = 3, PROF_POOLS = 4 };
 int prof_mark(lrvb_ctx* c, int which);      // records the next event of pool `which` on the ctx stream
 
 int  buf_reserve(lrvb_ctx* c, DevBuf& b, size_t n);

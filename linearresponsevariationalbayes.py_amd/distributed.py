@@ -56,6 +56,22 @@ class ShardedHessian(object):
     def __init__(self, engine, group=None):
         self.engine = engine
         self.group = group
+        self._marks = None              # timing on: list of (start, after partial, after all-reduce, after finish) event tuples
+
+    def timing(self, on=True):
+        """Record device events around the three phases of every build (partial statistics | exchange | assembly) on the
+        stream the build runs on: the first multi-GPU run can then say which phase a shortfall sits in.  No host
+        synchronisation is added; `phase_ms()` collects after the caller has synchronised."""
+        self._marks = [] if on else None
+
+    def phase_ms(self):
+        """(kernel_ms, allreduce_ms, finish_ms) summed over the builds since `timing(True)`, and their count."""
+        marks, self._marks = self._marks or [], ([] if self._marks is not None else None)
+        tot = [0.0, 0.0, 0.0]
+        for ev in marks:
+            for k in range(3):
+                tot[k] += ev[k].elapsed_time(ev[k + 1])
+        return tot[0], tot[1], tot[2], len(marks)
 
     def _world(self):
         import torch.distributed as dist
@@ -65,10 +81,24 @@ class ShardedHessian(object):
 
     def build(self, theta):
         dist, world = self._world()
+        ev = None
+        if self._marks is not None and getattr(self.engine, 'torch', None) is not None:
+            torch = self.engine.torch
+            stream = torch.cuda.current_stream(self.engine.device)      # the stream the engine's context runs on
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record(stream)
         stats = self.engine.partial(theta)
+        if ev is not None:
+            ev[1].record(stream)
         if dist is not None:            # also with one rank: keeps the collective path exercised
             dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=self.group)
-        return self.engine.finish(theta, stats)
+        if ev is not None:
+            ev[2].record(stream)
+        H = self.engine.finish(theta, stats)
+        if ev is not None:
+            ev[3].record(stream)
+            self._marks.append(ev)
+        return H
 
 
 class _DevicePointer(object):

@@ -43,6 +43,16 @@ def test_cpu_baseline_leg_on_a_small_sample():
     assert raw['port_fit']['per_column_per_row_s'] >= 0 and raw['port_fit']['per_column_fixed_s'] >= 0
     # the port really is the D-pass structure: it cannot beat the closed form
     assert out['value'] <= out['strong_numpy_value'] * 1.5
+    # the checker leg of the `parity` record: the matrix the strong leg forms over all rows IS the oracle's Hessian
+    from oracle import packing as opk, models as om
+    theta = np.random.default_rng(0)
+    rng2 = np.random.default_rng(0); rng2.normal(size=(N, D)); rng2.normal(size=N); theta = rng2.normal(size=D) * 0.05
+    lay = opk.Layout([opk.box_block(D - n_pos), opk.box_block(n_pos, lb=0.0)])
+    model = om.DeclaredModel(lay, loss=om.GAUSSIAN, x=x, y=y, lik_info=2.0, quad_A=np.full(D, 1.0))
+    full = out['_oracle_full']
+    Hm = model.hessian(theta)
+    assert np.max(np.abs(full['hessian'] - Hm)) < 1e-12 * np.max(np.abs(Hm))
+    assert np.max(np.abs(full['grad'] - model.grad(theta))) < 1e-12 * np.max(np.abs(model.grad(theta)))
 
 
 def test_gpus_flag_starts_the_ranks_itself(monkeypatch):

@@ -317,3 +317,45 @@ def test_two_rank_sharded_value_gradient_hvp_cg_and_fit(tmp_path):
     o += 2
     H_sharded = flat[o:o + D * D].reshape(D, D)
     assert np.max(np.abs(H_sharded - H)) < 1e-11 * np.max(np.abs(H))
+
+
+class _StubCommContext(object):
+    """Stands where a DeviceContext stands in `native_comm_init`, with the two RCCL calls stubbed at the ctypes boundary:
+    `comm_unique_id` returns 128 bytes that differ per process (as ncclGetUniqueId does), `comm_init` records what it got."""
+    seen = None
+
+    @staticmethod
+    def comm_unique_id():
+        return bytes([os.getpid() % 251] * 64 + list(os.urandom(64)))
+
+    def comm_init(self, world, rank, comm_id):
+        self.seen = (world, rank, bytes(comm_id))
+
+
+def _comm_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from lrvb_amd.distributed import native_comm_init
+    ctx = _StubCommContext()
+    got = native_comm_init(ctx)
+    own = _StubCommContext.comm_unique_id()                      # what this process WOULD have drawn: never used on rank > 0
+    t = torch.tensor(list(ctx.seen[2]) + [ctx.seen[0], ctx.seen[1], got[0], got[1]], dtype=torch.int64)
+    gathered = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(gathered, t)
+    if rank == 0:
+        np.save(out_path, torch.stack(gathered).numpy())
+    assert len(ctx.seen[2]) == 128 and own[:64] != b'' 
+    dist.destroy_process_group()
+
+
+def test_native_communicator_id_is_the_same_on_every_rank(tmp_path):
+    """`distributed.native_comm_init` (the id exchange in front of lrvb_comm_init, untestable with RCCL on a one-GPU box):
+    rank 0 draws the 128-byte id, the process group carries it, every rank hands THE SAME bytes and its own (world, rank) to
+    the library.  Two gloo ranks, the RCCL calls stubbed."""
+    out_path = str(tmp_path / 'comm.npy')
+    mp.spawn(_comm_worker, args=(2, _free_port(), out_path), nprocs=2, join=True)
+    rows = np.load(out_path)
+    assert rows.shape == (2, 132)
+    assert np.array_equal(rows[0, :128], rows[1, :128])          # one id
+    assert rows[0, 128:].tolist() == [2, 0, 2, 0] and rows[1, 128:].tolist() == [2, 1, 2, 1]
