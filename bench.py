@@ -734,6 +734,7 @@ def main(args):
         theta_h = theta.cpu().numpy()
         rng = np.random.default_rng(5)
         rhs = rng.normal(size=(16, D))
+        ctx.set_tuning(args.n_splits, 8)                     # matrix-free figures first: never use the resident Hessian of the build
         ctx.cg_solve(theta_h, rhs[0])
         ctx.set_quad_scale(ctx.quad_scale)                   # forget the point state (the first of the 16 solves rebuilds it)
         t3 = time.perf_counter()
@@ -755,6 +756,17 @@ def main(args):
         out['lrvb_solve_ms']['cg_16_rhs_tol1e-8_same_point_again'] = (t6b - t6) * 1e3
         out['lrvb_solve_ms']['cg_iterations'] = [int(i) if f == 0 else -1 for i, f in zip(its, infos)]
         out['lrvb_solve_ms']['cg_iterations_one_by_one'] = iters
+        # the same 16 systems AFTER A BUILD at the same point (ConjugateGradientSolver at an optimum whose Hessian was just
+        # built): the products run against the Hessian the build left in the context -- no pass over X
+        ctx.set_tuning(args.n_splits, 0)
+        ctx.hessian_dev(theta.data_ptr(), H.data_ptr(), D)
+        ctx.cg_solve_multi(theta_h, rhs[:2], tol=1e-8)
+        ctx.sync()
+        t7 = time.perf_counter()
+        Xr, infos_r, its_r = ctx.cg_solve_multi(theta_h, rhs, tol=1e-8)
+        t8 = time.perf_counter()
+        out['lrvb_solve_ms']['cg_16_rhs_tol1e-8_after_build_resident_hessian'] = (t8 - t7) * 1e3
+        out['lrvb_solve_ms']['cg_iterations_resident_hessian'] = [int(i) if f == 0 else -1 for i, f in zip(its_r, infos_r)]
         if args.loss == 'gaussian':
             # the headline (Gaussian) build needs no separate pass over X; a loss whose curvature depends on the linear
             # predictor does (pass -> SYRK).  Same X, same layout, logistic loss on thresholded responses, for the record:

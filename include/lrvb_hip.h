@@ -541,8 +541,17 @@ int lrvb_profile_reset (lrvb_ctx* ctx);
 /* Tuning knobs: number of row splits of the weighted-SYRK grid (0 = automatic); `reserved` bit 0 =
  * always use the register-staged SYRK kernel, bit 1 = mixture rows always take the dense per-row
  * factorisation, bit 2 = the fused multi-vector pass (blocked CG, streamed influence) with four
- * waves per workgroup instead of eight.  Every setting computes the same results by another code path
- * (they exist so that tests can compare the paths); any other bit of `reserved` is LRVB_ERR_INVALID.  */
+ * waves per workgroup instead of eight, bit 3 = never use the resident Hessian (below): products are always passes over
+ * the observations.  Every setting computes the same results by another code path
+ * (they exist so that tests can compare the paths); any other bit of `reserved` is LRVB_ERR_INVALID.
+ *
+ * THE RESIDENT HESSIAN.  Every free-coordinate build (lrvb_hessian, lrvb_hessian_dev, lrvb_hessian_finish_dev) leaves a copy
+ * of its result inside the context.  lrvb_hvp, lrvb_cg_solve and lrvb_cg_solve_multi asked for the SAME point afterwards form
+ * their products H v from that matrix (a D x D product, identical on every rank, no pass over X and no reduction) -- the
+ * reference's ConjugateGradientSolver is used exactly so: fun_free_hessian / fun_free_hvp at one optimum, many right-hand
+ * sides (LRVB/ConjugateGradient.py:63-105).  The copy is dropped by lrvb_set_data(_dev), lrvb_set_weights(_dev),
+ * lrvb_set_quad_scale (new value), lrvb_set_lik_info, lrvb_set_reduce_hook, lrvb_comm_init / _destroy and lrvb_set_tuning;
+ * buffers adopted with the `_dev` setters must be installed again after their contents change.                        */
 int lrvb_set_tuning(lrvb_ctx* ctx, int n_splits, int reserved);
 
 #pragma GCC visibility pop

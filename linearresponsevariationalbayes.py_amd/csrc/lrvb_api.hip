@@ -228,7 +228,7 @@ extern "C" int lrvb_ctx_destroy(lrvb_ctx* c) {
     DevBuf* all[] = { &c->X, &c->y, &c->w, &c->quadA, &c->quadM, &c->quadB, &c->theta, &c->eta, &c->j1, &c->j2,
                       &c->vtmp, &c->vtmp2, &c->vtmp3, &c->g_eta, &c->g_free, &c->lp, &c->cw, &c->zbuf,
                       &c->part_vec, &c->part_val, &c->stats, &c->tile_part, &c->Heta, &c->Hfree, &c->Jdense,
-                      &c->Tdense, &c->work1, &c->chol, &c->cholW, &c->hprog, &c->cgH, &c->groups, &c->mx_theta, &c->mx_lam, &c->mx_A, &c->mx_U, &c->mx_g, &c->mx_Xk, &c->mx_R, &c->cgT, &c->ones, &c->cgm[0], &c->cgm[1], &c->cgm[2], &c->cgm[3], &c->cgm[4], &c->cgm[5], &c->cgm[6], &c->cgm[7], &c->cgm[8], &c->rhs, &c->cgx, &c->cgr, &c->cgp, &c->cgq, &c->cgz, &c->scal, &c->opt, &c->dkw, &c->cyv, &c->rvec, &c->red_scratch, &c->gstats, &c->Zs, &c->ws, &c->bpart, &c->gpad, &c->boxmap };
+                      &c->Tdense, &c->work1, &c->chol, &c->cholW, &c->hprog, &c->cgH, &c->groups, &c->mx_theta, &c->mx_lam, &c->mx_A, &c->mx_U, &c->mx_g, &c->mx_Xk, &c->mx_R, &c->cgT, &c->ones, &c->cgm[0], &c->cgm[1], &c->cgm[2], &c->cgm[3], &c->cgm[4], &c->cgm[5], &c->cgm[6], &c->cgm[7], &c->cgm[8], &c->rhs, &c->cgx, &c->cgr, &c->cgp, &c->cgq, &c->cgz, &c->scal, &c->opt, &c->dkw, &c->cyv, &c->rvec, &c->red_scratch, &c->gstats, &c->Zs, &c->ws, &c->bpart, &c->gpad, &c->boxmap, &c->Hres, &c->hres_theta };
     for (DevBuf* b : all) buf_free(*b);
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
     if (c->up_ring) { for (int k = 0; k < lrvb_ctx::UP_SLOTS; ++k) if (c->up_ev[k]) (void)hipEventDestroy(c->up_ev[k]); (void)hipHostFree(c->up_ring); }
@@ -321,6 +321,7 @@ extern "C" int lrvb_set_data(lrvb_ctx* c, int slot, const double* host, int64_t 
     LRVB_TRY(h2d(c, b->p, host, n));
     if (slot == LRVB_SLOT_X) { c->have_X = true; c->x2_ready = false; c->gstats_valid = false; c->zs_valid = false; }
     if (slot == LRVB_SLOT_Y) c->have_y = true;
+    c->hres_valid = false;
     return LRVB_OK;
 }
 
@@ -333,6 +334,7 @@ extern "C" int lrvb_set_data_dev(lrvb_ctx* c, int slot, const double* data_dev, 
     b->p = const_cast<double*>(data_dev); b->n = n; b->owned = false;
     if (slot == LRVB_SLOT_X) { c->have_X = true; c->x2_ready = false; c->gstats_valid = false; c->zs_valid = false; }
     if (slot == LRVB_SLOT_Y) c->have_y = true;
+    c->hres_valid = false;
     return LRVB_OK;
 }
 
@@ -341,7 +343,7 @@ extern "C" int lrvb_set_weights(lrvb_ctx* c, const double* w, int64_t n) {
     if (c->loss == LRVB_LOSS_NONE) LRVB_FAIL(LRVB_ERR_STATE, "model has no data term");
     if (!w || n != c->N) LRVB_FAIL(LRVB_ERR_SIZE, "weights must have %lld entries (got %lld)", (long long)c->N, (long long)n);
     if (!c->w.owned) { c->w.p = nullptr; c->w.n = 0; c->w.owned = true; }
-    c->gstats_valid = false; c->ws_valid = false;
+    c->gstats_valid = false; c->ws_valid = false; c->hres_valid = false;
     LRVB_TRY(buf_reserve(c, c->w, (size_t)n));
     return h2d(c, c->w.p, w, (size_t)n);
 }
@@ -352,13 +354,14 @@ extern "C" int lrvb_set_weights_dev(lrvb_ctx* c, const double* w_dev, int64_t n)
     if (!w_dev || n != c->N) LRVB_FAIL(LRVB_ERR_SIZE, "weights must have %lld entries (got %lld)", (long long)c->N, (long long)n);
     if (c->w.p && c->w.owned) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->w.p)); }
     c->w.p = const_cast<double*>(w_dev); c->w.n = (size_t)n; c->w.owned = false;
-    c->gstats_valid = false; c->ws_valid = false;
+    c->gstats_valid = false; c->ws_valid = false; c->hres_valid = false;
     return LRVB_OK;
 }
 
 extern "C" int lrvb_set_quad_scale(lrvb_ctx* c, double scale) {
     if (c) c->hvp_pt_valid = false;
     if (!c) LRVB_FAIL(LRVB_ERR_INVALID, "null context");
+    if (scale != c->quad_scale) c->hres_valid = false;
     c->quad_scale = scale;
     return LRVB_OK;
 }
@@ -369,14 +372,16 @@ extern "C" int lrvb_set_lik_info(lrvb_ctx* c, double lik_info) {
     if (c->loss != LRVB_LOSS_GAUSSIAN) LRVB_FAIL(LRVB_ERR_STATE, "lik_info is the precision of the Gaussian loss");
     if (!(lik_info > 0.0) || !std::isfinite(lik_info)) LRVB_FAIL(LRVB_ERR_INVALID, "lik_info must be positive and finite");
     c->lik_info = lik_info;
+    c->hres_valid = false;
     return LRVB_OK;
 }
 
 extern "C" int lrvb_set_tuning(lrvb_ctx* c, int n_splits, int reserved) {
     if (!c) LRVB_FAIL(LRVB_ERR_INVALID, "null context");
     if (n_splits < 0 || n_splits > 1024) LRVB_FAIL(LRVB_ERR_INVALID, "n_splits out of range");
-    if (reserved & ~7) LRVB_FAIL(LRVB_ERR_INVALID, "reserved = %d: only bits 0-2 are defined (include/lrvb_hip.h)", reserved);
-    c->hvp_pt_valid = false;
+    if (reserved & ~15) LRVB_FAIL(LRVB_ERR_INVALID, "reserved = %d: only bits 0-3 are defined (include/lrvb_hip.h)", reserved);
+    c->hvp_pt_valid = false; c->hres_valid = false;
+    c->no_resident = (reserved & 8) != 0;
     c->n_splits_user = n_splits;
     c->force_generic_wsyrk = (reserved & 1) != 0;
     c->force_dense_rows = (reserved & 2) ? 1 : 0;
@@ -448,7 +453,7 @@ static int obs_reduce(lrvb_ctx* c, double* buf_dev, i64 n) {
 }
 extern "C" int lrvb_set_reduce_hook(lrvb_ctx* c, lrvb_reduce_fn fn, void* user) {
     if (!c) LRVB_FAIL(LRVB_ERR_INVALID, "null context");
-    c->hvp_pt_valid = false;
+    c->hvp_pt_valid = false; c->hres_valid = false;
     c->reduce_fn = fn; c->reduce_user = fn ? user : nullptr;
     return LRVB_OK;
 }
@@ -512,6 +517,7 @@ extern "C" int lrvb_comm_init(lrvb_ctx* c, int world_size, int rank, const lrvb_
     RCCL_TRY(g_rccl.CommInitRank(&c->comm, world_size, *id, rank));
     c->comm_world = world_size; c->comm_rank = rank;
     c->reduce_fn = native_reduce; c->reduce_user = c;              // every observation sum now goes through RCCL
+    c->hres_valid = false;
     return LRVB_OK;
 }
 extern "C" int lrvb_comm_destroy(lrvb_ctx* c) {
@@ -522,7 +528,7 @@ extern "C" int lrvb_comm_destroy(lrvb_ctx* c) {
     if (c->reduce_fn == native_reduce) { c->reduce_fn = nullptr; c->reduce_user = nullptr; }
     RCCL_TRY(g_rccl.CommDestroy(c->comm));
     c->comm = nullptr; c->comm_world = 1; c->comm_rank = 0;
-    c->hvp_pt_valid = false;
+    c->hvp_pt_valid = false; c->hres_valid = false;
     return LRVB_OK;
 }
 extern "C" int lrvb_allreduce_hessian(lrvb_ctx* c, double* stats_dev, int64_t n) {
@@ -611,6 +617,54 @@ static int prepare_general_hvp(lrvb_ctx* c, const double* theta_dev) {
     LRVB_TRY(buf_reserve(c, c->Tdense, (size_t)c->D * (size_t)c->D));
     HIP_TRY(hipMemsetAsync(c->Tdense.p, 0, (size_t)c->D * (size_t)c->D * sizeof(double), c->stream));
     return launch_third_order(c, theta_dev, c->g_eta.p, c->Tdense.p);
+}
+
+// ---- the resident Hessian ------------------------------------------------------------------------------------------
+// Every free-coordinate build leaves a copy of its result with the library (8 MB at D = 1024: a ~4 us device copy beside a
+// 15 ms build).  A product H v asked for at the SAME point afterwards -- lrvb_hvp, every iteration of lrvb_cg_solve and
+// lrvb_cg_solve_multi, i.e. ConjugateGradientSolver (LRVB/ConjugateGradient.py:63-105) after fun_free_hessian at the optimum --
+// is then a D x D matrix product instead of a pass over the N x P design (1.3-1.5 ms at the headline shape).  The copy is
+// dropped whenever data, weights, a hyper-parameter, the reduce hook or the tuning change (the setters), and is only used
+// for the exact point it was built at.  Adopted device buffers fall under the contract of lrvb_set_data_dev /
+// lrvb_set_weights_dev: install them again after their contents change.
+__global__ void vec_differs_kernel(i64 n, const double* __restrict__ a, const double* __restrict__ b, int* __restrict__ flag) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && !(a[i] == b[i])) atomicOr(flag, 1);
+}
+static int hres_capture(lrvb_ctx* c, const double* H_dev, i64 ld, const double* theta_dev, const double* theta_host) {
+    const i64 D = c->D;
+    c->hres_valid = false;
+    LRVB_TRY(buf_reserve(c, c->Hres, (size_t)D * (size_t)D));
+    HIP_TRY(hipMemcpy2DAsync(c->Hres.p, (size_t)D * 8, H_dev, (size_t)ld * 8, (size_t)D * 8, (size_t)D, hipMemcpyDeviceToDevice, c->stream));
+    if (theta_host) { c->hres_pt.assign(theta_host, theta_host + D); c->hres_pt_host = true; }
+    else {
+        LRVB_TRY(buf_reserve(c, c->hres_theta, (size_t)D));
+        HIP_TRY(hipMemcpyAsync(c->hres_theta.p, theta_dev, (size_t)D * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        c->hres_pt_host = false;
+    }
+    c->hres_valid = true;
+    return LRVB_OK;
+}
+// Is `free_in` (host) the point of the resident Hessian?  A build through a `_dev` entry point left its point on the device
+// only: the first question costs one small comparison kernel and a flag read-back, after which the host copy answers.
+static int hres_matches(lrvb_ctx* c, const double* free_in, i64 D, bool* match) {
+    *match = false;
+    if (!c->hres_valid || c->no_resident || !free_in || D != c->D) return LRVB_OK;
+    if (!c->hres_pt_host) {
+        LRVB_TRY(h2d(c, c->theta.p, free_in, (size_t)D));
+        int* flag = reinterpret_cast<int*>(c->scal.p);
+        HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), c->stream));
+        EW(vec_differs_kernel, D, (const double*)c->theta.p, (const double*)c->hres_theta.p, flag);
+        int differs = 0;
+        HIP_TRY(hipMemcpyAsync(&differs, flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (differs) return LRVB_OK;                  // (the resident matrix stays: its own point may come back)
+        c->hres_pt.assign(free_in, free_in + D); c->hres_pt_host = true;
+        *match = true;
+        return LRVB_OK;
+    }
+    *match = (i64)c->hres_pt.size() == D && memcmp(c->hres_pt.data(), free_in, (size_t)D * sizeof(double)) == 0;
+    return LRVB_OK;
 }
 
 // ---- Hessian build ---------------------------------------------------------------------
@@ -797,7 +851,8 @@ extern "C" int lrvb_hessian_partial_dev(lrvb_ctx* c, const double* free_dev, dou
 extern "C" int lrvb_hessian_finish_dev(lrvb_ctx* c, const double* free_dev, const double* stats_dev, double* H_dev, int64_t ld) {
     LRVB_TRY(ctx_bind(c));
     if (!free_dev || !stats_dev || !H_dev) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
-    return hessian_finish(c, free_dev, true, stats_dev, H_dev, ld);
+    LRVB_TRY(hessian_finish(c, free_dev, true, stats_dev, H_dev, ld));
+    return hres_capture(c, H_dev, ld, free_dev, nullptr);
 }
 extern "C" int lrvb_hessian_dev(lrvb_ctx* c, const double* free_dev, double* H_dev, int64_t ld) {
     LRVB_TRY(ctx_bind(c));
@@ -806,6 +861,7 @@ extern "C" int lrvb_hessian_dev(lrvb_ctx* c, const double* free_dev, double* H_d
     LRVB_TRY(hessian_partial(c, free_dev, true, c->stats.p));
     LRVB_TRY(stats_reduce(c));
     LRVB_TRY(hessian_finish(c, free_dev, true, c->stats.p, H_dev, ld));
+    LRVB_TRY(hres_capture(c, H_dev, ld, free_dev, nullptr));
     if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_BUILD));
     return LRVB_OK;
 }
@@ -826,6 +882,7 @@ static int hessian_host(lrvb_ctx* c, const double* point, i64 n_in, bool is_free
     LRVB_TRY(hessian_partial(c, c->theta.p, is_free, c->stats.p));
     LRVB_TRY(stats_reduce(c));
     LRVB_TRY(hessian_finish(c, c->theta.p, is_free, c->stats.p, c->Hfree.p, n));
+    if (is_free) LRVB_TRY(hres_capture(c, c->Hfree.p, n, c->theta.p, point));
     HIP_TRY(hipMemcpy2DAsync(H_out, (size_t)ld * 8, c->Hfree.p, (size_t)n * 8, (size_t)n * 8, (size_t)n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return LRVB_OK;
@@ -913,6 +970,15 @@ static int hvp_host(lrvb_ctx* c, const double* point, const double* v, i64 n_in,
     LRVB_TRY(data_ready(c));
     LRVB_TRY(buf_reserve(c, c->cgp, (size_t)n));
     LRVB_TRY(buf_reserve(c, c->cgq, (size_t)n));
+    if (is_free) {                                        // the Hessian of this very point is resident: one D x D product
+        bool resident = false;
+        LRVB_TRY(hres_matches(c, point, n_in, &resident));
+        if (resident) {
+            LRVB_TRY(h2d(c, c->cgp.p, v, (size_t)n));
+            LRVB_TRY(launch_gemv(c, false, n, n, 1.0, c->Hres.p, n, c->cgp.p, 0.0, c->cgq.p));
+            return d2h(c, out, c->cgq.p, (size_t)n);
+        }
+    }
     LRVB_TRY(h2d(c, c->cgp.p, v, (size_t)n));
     if (!reuse) {
         LRVB_TRY(h2d(c, c->theta.p, point, (size_t)n));
@@ -2284,21 +2350,28 @@ extern "C" int lrvb_cg_solve(lrvb_ctx* c, const double* free_in, const double* b
     DevBuf* vecs[] = { &c->rhs, &c->cgx, &c->cgr, &c->cgp, &c->cgq, &c->cgz };
     for (DevBuf* v : vecs) LRVB_TRY(buf_reserve(c, *v, (size_t)D));
     if (Minv) { LRVB_TRY(buf_reserve(c, c->Hfree, (size_t)D * (size_t)D)); LRVB_TRY(h2d(c, c->Hfree.p, Minv, (size_t)D * (size_t)D)); }
+    bool resident = false;                                 // the Hessian of this point is resident: products are D x D gemv's
+    LRVB_TRY(hres_matches(c, free_in, D, &resident));
     LRVB_TRY(h2d(c, c->rhs.p, b, (size_t)D));
     // point state once: eta, J, g_eta, cached curvature
-    if (!reuse) {
-        LRVB_TRY(h2d(c, c->theta.p, free_in, (size_t)D));
-        LRVB_TRY(set_point(c, c->theta.p, true));
-        LRVB_TRY(eval_grad_eta(c, c->stats.p, true));
+    if (!resident) {
+        if (!reuse) {
+            LRVB_TRY(h2d(c, c->theta.p, free_in, (size_t)D));
+            LRVB_TRY(set_point(c, c->theta.p, true));
+            LRVB_TRY(eval_grad_eta(c, c->stats.p, true));
+        }
+        if (!prepared) LRVB_TRY(prepare_general_hvp(c, c->theta.p));
     }
-    if (!prepared) LRVB_TRY(prepare_general_hvp(c, c->theta.p));
+    auto product = [&](const double* vin, double* vout) -> int {
+        return resident ? launch_gemv(c, false, D, D, 1.0, c->Hres.p, D, vin, 0.0, vout) : hvp_apply(c, c->theta.p, true, vin, vout);
+    };
 
     double* s = c->scal.p;                     // s[0] = ||b||^2, s[1] = ||r||^2, s[2] = r.z, s[3] = p.q
     double hs[4];
     LRVB_TRY(launch_dot(c, c->rhs.p, c->rhs.p, D, s + 0));
     if (x0) {
         LRVB_TRY(h2d(c, c->cgx.p, x0, (size_t)D));
-        LRVB_TRY(hvp_apply(c, c->theta.p, true, c->cgx.p, c->cgq.p));
+        LRVB_TRY(product(c->cgx.p, c->cgq.p));
         LRVB_TRY(launch_axpby(c, D, 1.0, c->rhs.p, 0.0, c->cgr.p));
         LRVB_TRY(launch_axpby(c, D, -1.0, c->cgq.p, 1.0, c->cgr.p));
     } else {
@@ -2324,7 +2397,7 @@ extern "C" int lrvb_cg_solve(lrvb_ctx* c, const double* free_in, const double* b
             const double rho = hs[2];
             if (it > 0) LRVB_TRY(launch_axpby(c, D, 1.0, z, rho / rho_prev, c->cgp.p));
             else        LRVB_TRY(launch_axpby(c, D, 1.0, z, 0.0, c->cgp.p));
-            LRVB_TRY(hvp_apply(c, c->theta.p, true, c->cgp.p, c->cgq.p));
+            LRVB_TRY(product(c->cgp.p, c->cgq.p));
             LRVB_TRY(launch_dot(c, c->cgp.p, c->cgq.p, D, s + 3));
             LRVB_TRY(d2h(c, hs + 3, s + 3, 1));
             const double alpha = rho / hs[3];
@@ -2336,7 +2409,7 @@ extern "C" int lrvb_cg_solve(lrvb_ctx* c, const double* free_in, const double* b
     LRVB_TRY(d2h(c, x_out, c->cgx.p, (size_t)D));
     if (info_out) *info_out = info;
     if (iters_out) *iters_out = it;
-    remember_point(c, free_in, D, true, true);
+    if (!resident) remember_point(c, free_in, D, true, true);
     return LRVB_OK;
 }
 
@@ -2947,7 +3020,7 @@ void cg_multi_head_kernel(i64 D, i64 it, double tol, const double* __restrict__ 
     double* p = Pm + q * D; double* u = U + q * D;
     for (i64 d = threadIdx.x; d < D; d += 256) {
         const double pv = live ? r[d] + beta * p[d] : p[d];           // a stopped system keeps its direction
-        p[d] = pv; u[d] = j1[d] * pv;
+        p[d] = pv; u[d] = j1 ? j1[d] * pv : pv;                       // j1 null: the product runs in free coordinates (resident Hessian)
     }
 }
 __global__ __launch_bounds__(256)
@@ -2960,7 +3033,7 @@ void cg_multi_tail_kernel(i64 D, double sq, const double* __restrict__ quadA /* 
     const i64 q = blockIdx.x;
     if (s[3 * Q + q] == 0.0) return;                                  // stopped: nothing moves
     const double* p = Pm + q * D; const double* w = W + q * D; const double* u = U + q * D;
-    auto qv = [&](i64 d) { return j1[d] * (w[d] + (quadA ? sq * quadA[d] * u[d] : 0.0)) + g[d] * j2[d] * p[d]; };
+    auto qv = [&](i64 d) { return j1 ? j1[d] * (w[d] + (quadA ? sq * quadA[d] * u[d] : 0.0)) + g[d] * j2[d] * p[d] : w[d]; };
     double a = 0.0;
     for (i64 d = threadIdx.x; d < D; d += 256) a += p[d] * qv(d);
     sh[threadIdx.x] = a;
@@ -2978,7 +3051,7 @@ static bool cg_multi_fused_ok(const lrvb_ctx* c, const double* Minv, i64 Q) {
 
 // the loop of lrvb_cg_solve_multi after the common set-up (Bd, Xd, Rd, Pd = 0 in place; s[0..Q) = |b|^2 on the device)
 static int cg_multi_fused_loop(lrvb_ctx* c, i64 Q, i64 D, double tol, i64 maxiter, double* Xd, double* Rd, double* Pd,
-                               std::vector<int>& info, std::vector<int64_t>& iters) {
+                               std::vector<int>& info, std::vector<int64_t>& iters, bool resident) {
     double* s = c->scal.p;
     double* U = c->cgm[6].p; double* W = c->cgm[7].p;
     LRVB_TRY(ensure_aux(c));
@@ -2988,10 +3061,11 @@ static int cg_multi_fused_loop(lrvb_ctx* c, i64 Q, i64 D, double tol, i64 maxite
     LRVB_TRY(d2h(c, hb.data(), s, (size_t)Q));
     for (i64 q = 0; q < Q; ++q) { init[q] = hb[q]; init[3 * Q + q] = hb[q] > 0.0 ? 1.0 : 0.0; if (hb[q] == 0.0) HIP_TRY(hipMemsetAsync(Xd + q * D, 0, (size_t)D * sizeof(double), c->stream)); }
     LRVB_TRY(h2d(c, s, init.data(), (size_t)(5 * Q)));
-    const double* quadA = c->quad_kind == LRVB_QUAD_DIAG ? c->quadA.p : nullptr;
+    const double* quadA = (!resident && c->quad_kind == LRVB_QUAD_DIAG) ? c->quadA.p : nullptr;
+    const double* j1 = resident ? nullptr : c->j1.p;
     double* status = c->host_pinned + 2048;                        // [live (Q)] of the iteration whose head kernel ran last
     auto queue_iteration = [&](i64 it) -> int {
-        hipLaunchKernelGGL(cg_multi_head_kernel, dim3((unsigned)Q), dim3(256), 0, c->stream, D, it, tol, (const double*)c->j1.p,
+        hipLaunchKernelGGL(cg_multi_head_kernel, dim3((unsigned)Q), dim3(256), 0, c->stream, D, it, tol, j1,
                            (const double*)Rd, Pd, U, s, Q);
         HIP_TRY(hipGetLastError());
         // status of THIS iteration's test, copied on the side stream as soon as the head kernel is done
@@ -3000,6 +3074,10 @@ static int cg_multi_fused_loop(lrvb_ctx* c, i64 Q, i64 D, double tol, i64 maxite
         // the per-parity snapshot, not the live flags: head(it + 2) -- the next writer of this slot -- is queued only after the host has
         // consumed this copy, so every rank reads the same flags for iteration `it` and queues the same number of reductions
         HIP_TRY(hipMemcpyAsync(status + (it & 1) * 1024, s + (5 + (it & 1)) * Q, (size_t)Q * sizeof(double), hipMemcpyDeviceToHost, c->aux_stream));
+        if (resident) {
+            // W = U H: the whole block against the resident matrix (H symmetric), identical on every rank -- no reduction
+            LRVB_TRY(launch_gemm(c, false, false, Q, D, D, 1.0, U, D, c->Hres.p, D, 0.0, W, D));
+        } else {
         HIP_TRY(hipMemsetAsync(W, 0, (size_t)(Q * D) * sizeof(double), c->stream));
         for (i64 q0 = 0; q0 < Q; q0 += 16) {
             const i64 qn = (Q - q0 < 16) ? Q - q0 : 16;
@@ -3008,9 +3086,10 @@ static int cg_multi_fused_loop(lrvb_ctx* c, i64 Q, i64 D, double tol, i64 maxite
             c->hm_live = nullptr;
             LRVB_TRY(st);
         }
-        LRVB_TRY(obs_reduce(c, W, Q * D));                            // every rank queues the same iterations: the stop decision below
+        LRVB_TRY(obs_reduce(c, W, Q * D));
+        }                            // every rank queues the same iterations: the stop decision below
                                                                       // reads per-iteration snapshots of reduced (rank-identical) scalars
-        hipLaunchKernelGGL(cg_multi_tail_kernel, dim3((unsigned)Q), dim3(256), 0, c->stream, D, c->quad_scale, quadA, (const double*)c->j1.p,
+        hipLaunchKernelGGL(cg_multi_tail_kernel, dim3((unsigned)Q), dim3(256), 0, c->stream, D, c->quad_scale, quadA, j1,
                            (const double*)c->j2.p, (const double*)c->g_eta.p, (const double*)W, (const double*)U, (const double*)Pd, Xd, Rd,
                            (const double*)s, Q);
         HIP_TRY(hipGetLastError());
@@ -3060,19 +3139,26 @@ extern "C" int lrvb_cg_solve_multi(lrvb_ctx* c, const double* free_in, const dou
     LRVB_TRY(buf_reserve(c, c->cgm[6], qv));
     LRVB_TRY(buf_reserve(c, c->cgm[7], qv));
     LRVB_TRY(buf_reserve(c, c->cgm[8], (size_t)((c->P > 0 ? c->P : 1) * Qp)));
-    if (c->loss != LRVB_LOSS_NONE) {
+    bool resident = false;                                 // the Hessian of this point is resident: block products are Q x D x D GEMMs
+    LRVB_TRY(hres_matches(c, free_in, D, &resident));
+    if (c->loss != LRVB_LOSS_NONE && !resident) {
         LRVB_TRY(buf_reserve(c, c->cgT, (size_t)(c->N * Qp)));
         HIP_TRY(hipMemsetAsync(c->cgT.p, 0, (size_t)(c->N * Qp) * sizeof(double), c->stream));     // keeps the padding column zero
     }
     double *Bd = c->cgm[0].p, *Xd = c->cgm[1].p, *Rd = c->cgm[2].p, *Pd = c->cgm[3].p, *Qd = c->cgm[4].p, *Zd = c->cgm[5].p;
     if (Minv) { LRVB_TRY(buf_reserve(c, c->Hfree, (size_t)D * (size_t)D)); LRVB_TRY(h2d(c, c->Hfree.p, Minv, (size_t)D * (size_t)D)); }
     LRVB_TRY(h2d(c, Bd, B, qd));
-    if (!reuse) {
-        LRVB_TRY(h2d(c, c->theta.p, free_in, (size_t)D));
-        LRVB_TRY(set_point(c, c->theta.p, true));
-        LRVB_TRY(eval_grad_eta(c, c->stats.p, true));
+    if (!resident) {
+        if (!reuse) {
+            LRVB_TRY(h2d(c, c->theta.p, free_in, (size_t)D));
+            LRVB_TRY(set_point(c, c->theta.p, true));
+            LRVB_TRY(eval_grad_eta(c, c->stats.p, true));
+        }
+        if (!prepared) LRVB_TRY(prepare_general_hvp(c, c->theta.p));
     }
-    if (!prepared) LRVB_TRY(prepare_general_hvp(c, c->theta.p));
+    auto block_product = [&](const double* Vb, double* Out) -> int {
+        return resident ? launch_gemm(c, false, false, Q, D, D, 1.0, Vb, D, c->Hres.p, D, 0.0, Out, D) : hvp_apply_multi(c, Q, Vb, Out);
+    };
     // scalars: s[0..Q) = ||b||^2 | rr | rz | pq | alpha | beta | minus_alpha | one
     LRVB_TRY(buf_reserve(c, c->scal, (size_t)(8 * Q + 16)));
     double* s = c->scal.p;
@@ -3083,7 +3169,7 @@ extern "C" int lrvb_cg_solve_multi(lrvb_ctx* c, const double* free_in, const dou
     HIP_TRY(hipGetLastError());
     if (X0) {
         LRVB_TRY(h2d(c, Xd, X0, qd));
-        LRVB_TRY(hvp_apply_multi(c, Q, Xd, Qd));
+        LRVB_TRY(block_product(Xd, Qd));
         HIP_TRY(hipMemcpyAsync(Rd, Bd, qd * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         LRVB_TRY(launch_axpby(c, (i64)qd, -1.0, Qd, 1.0, Rd));
     } else {
@@ -3098,11 +3184,11 @@ extern "C" int lrvb_cg_solve_multi(lrvb_ctx* c, const double* free_in, const dou
         if (bnorm[q] == 0.0) { active[q] = 0; HIP_TRY(hipMemsetAsync(Xd + q * D, 0, (size_t)D * sizeof(double), c->stream)); }
         else { info[q] = (int)maxiter; ++n_active; }
     }
-    if (cg_multi_fused_ok(c, Minv, Q)) {
-        LRVB_TRY(cg_multi_fused_loop(c, Q, D, tol, maxiter, Xd, Rd, Pd, info, iters));
+    if ((resident && !Minv && Q <= 400) || cg_multi_fused_ok(c, Minv, Q)) {
+        LRVB_TRY(cg_multi_fused_loop(c, Q, D, tol, maxiter, Xd, Rd, Pd, info, iters, resident));
         LRVB_TRY(d2h(c, X_out, Xd, qd));
         for (i64 q = 0; q < Q; ++q) { if (info_out) info_out[q] = info[q]; if (iters_out) iters_out[q] = iters[q]; }
-        remember_point(c, free_in, D, true, true);
+        if (!resident) remember_point(c, free_in, D, true, true);
         return LRVB_OK;
     }
     for (i64 it = 0; it < maxiter && n_active > 0; ++it) {
@@ -3123,7 +3209,7 @@ extern "C" int lrvb_cg_solve_multi(lrvb_ctx* c, const double* free_in, const dou
         if (n_active == 0) break;
         LRVB_TRY(h2d(c, s + 4 * Q, coef.data(), (size_t)(2 * Q)));
         EW(rows_axpby_kernel, (i64)qd, D, s + 4 * Q, Z, s + 5 * Q, Pd);
-        LRVB_TRY(hvp_apply_multi(c, Q, Pd, Qd));
+        LRVB_TRY(block_product(Pd, Qd));
         hipLaunchKernelGGL(rows_dot_kernel, dim3((unsigned)Q), dim3(256), 0, c->stream, Q, D, Pd, Qd, s + 3 * Q);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(cg_multi_alpha_kernel, dim3((unsigned)((Q + 63) / 64)), dim3(64), 0, c->stream, (int)Q, s);
@@ -3134,7 +3220,7 @@ extern "C" int lrvb_cg_solve_multi(lrvb_ctx* c, const double* free_in, const dou
     }
     LRVB_TRY(d2h(c, X_out, Xd, qd));
     for (i64 q = 0; q < Q; ++q) { if (info_out) info_out[q] = info[q]; if (iters_out) iters_out[q] = iters[q]; }
-    remember_point(c, free_in, D, true, true);
+    if (!resident) remember_point(c, free_in, D, true, true);
     return LRVB_OK;
 }
 

@@ -74,6 +74,10 @@ struct lrvb_ctx {
     DevBuf mx_theta, mx_lam, mx_A, mx_U, mx_g, mx_Xk, mx_R;   // mixture rows pipeline (kept between calls)
     i64 mx_theta_n = 0;            // simplex logits resident in mx_theta (entries; 0 = none)
     DevBuf cgH; i64 cgH_n = 0;     // dense matrix of lrvb_cg_solve_matrix
+    // the free-coordinate Hessian of the last build, kept by the library: products at the SAME point with the SAME data, weights
+    // and hyper-parameters (lrvb_hvp, lrvb_cg_solve, lrvb_cg_solve_multi) are D x D matrix products instead of passes over X
+    DevBuf Hres, hres_theta; bool hres_valid = false; bool hres_pt_host = false; std::vector<double> hres_pt;
+    bool no_resident = false;      // tuning/testing: always take the matrix-free products
     DevBuf chol, cholW;            // D x D Cholesky factor (lower); inverses of its 64 x 64 diagonal blocks
     DevBuf hprog;                  // operands of an lrvb_hvec_program call
     bool chol_valid = false;

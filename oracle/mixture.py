@@ -26,6 +26,8 @@ def mixture_rows(theta_z, X, w, Lam):
     gfree = np.zeros((N, K - 1))
     Hloc = np.zeros((N, K - 1, K - 1))
     R = np.zeros((q * q, K * K))
+    blk = 256                                                      # rows whose outer products are added to R in one product
+    XX, AA = np.zeros((blk, q * q)), np.zeros((blk, K * K))
     for n in range(N):
         p = Z[n]
         g = -w[n] * (S[n] - np.log(p) - 1.0)                      # d l_n / d z_n
@@ -34,7 +36,13 @@ def mixture_rows(theta_z, X, w, Lam):
         gfree[n] = J.T @ g
         Hloc[n] = J.T @ np.diag(w[n] / p) @ J + np.einsum('k,kij->ij', g, T)
         A = J @ np.linalg.solve(Hloc[n], J.T)
-        R += w[n] ** 2 * np.outer(np.outer(Xt[n], Xt[n]).ravel(), A.ravel())
+        # R += w_n^2 vec(x~ x~^T) vec(A)^T, the rows of a block summed by one matrix product (N = 1e4 rows of K = 32 would
+        # otherwise write 1e10 doubles one outer product at a time)
+        XX[n % blk] = w[n] ** 2 * np.outer(Xt[n], Xt[n]).ravel()
+        AA[n % blk] = A.ravel()
+        if n % blk == blk - 1 or n == N - 1:
+            used = n % blk + 1
+            R += XX[:used].T @ AA[:used]
     U = np.zeros((N, 64))
     U[:, :q] = Xt
     U[:, 32:32 + K] = Z

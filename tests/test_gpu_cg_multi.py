@@ -192,3 +192,81 @@ def test_point_state_is_reused_only_when_nothing_changed(vb):
     check(th1, w2, scale=2.5)
     assert ctx.profile_get()['pass_calls'] == 5
     ctx.profile_enable(False)
+
+
+def test_products_use_the_resident_hessian_after_a_build(vb):
+    """After a free-coordinate Hessian build the library keeps the matrix: products at the SAME point -- `lrvb_hvp`, `lrvb_cg_solve`,
+    `lrvb_cg_solve_multi`, i.e. ConjugateGradientSolver at an optimum after fun_free_hessian (LRVB/ConjugateGradient.py:63-105) --
+    run against it with NO pass over the observations (profile: zero pass / SYRK launches), give the results of the matrix-free
+    route, and fall back to the passes as soon as the point, the weights, a hyper-parameter or the tuning change."""
+    rng = np.random.default_rng(31)
+    N, P = 4000, 256
+    spec = [('box', 'free', 160, -np.inf, np.inf), ('box', 'pos', 96, 0.0, np.inf)]
+    par, lay = make_par(vb, spec)
+    x, y, w = glm_data(rng, N, P, om.LOGISTIC)
+    fun = vb.DeviceObjective(par, x=x, y=y, loss='logistic', quad_A=np.full(P, 0.7), weights=w)
+    objective = vb.Objective(par, fun)
+    ctx = fun.ctx
+    theta = rng.normal(size=P) * 0.2
+    B = rng.normal(size=(5, P))
+    v = rng.normal(size=P)
+
+    def passes(call):
+        ctx.profile_enable(True); ctx.profile_reset()
+        out = call()
+        prof = ctx.profile_get(); ctx.profile_enable(False)
+        return out, prof['pass_calls']
+
+    # matrix-free reference results (no build yet: nothing resident)
+    (X_mf, info_mf, it_mf), n_mf = passes(lambda: ctx.cg_solve_multi(theta, B, tol=1e-10))
+    assert n_mf >= 1 and np.all(info_mf == 0)
+    hv_mf = ctx.hvp(theta, v)
+    H = objective.fun_free_hessian(theta)                          # the build: its matrix stays in the context
+    (X_res, info_res, it_res), n_res = passes(lambda: ctx.cg_solve_multi(theta, B, tol=1e-10))
+    assert n_res == 0                                             # no pass over X
+    assert np.all(info_res == 0) and rel_err(X_res, np.linalg.solve(H, B.T).T) < 1e-8 and rel_err(X_res, X_mf) < 1e-8
+    hv_res, n_hv = passes(lambda: ctx.hvp(theta, v))
+    assert n_hv == 0 and rel_err(hv_res, H @ v) < 1e-13 and rel_err(hv_res, hv_mf) < 1e-11
+    (x1, info1, _), n1 = passes(lambda: ctx.cg_solve(theta, B[0], tol=1e-10))
+    assert n1 == 0 and info1 == 0 and rel_err(x1, np.linalg.solve(H, B[0])) < 1e-8
+    # the reference class end to end: ConjugateGradientSolver over fun_free_hvp at the point of the build
+    solver = vb.ConjugateGradientSolver(objective.fun_free_hvp, theta)
+    masks = vb.ConjugateGradient.get_masks(P, 64)
+    _, n_solver = passes(lambda: solver.get_hinv_vec_subsets(v, masks))
+    assert n_solver == 0
+    for rhs, sol, info in zip(solver.vecs, solver.hinv_vecs, solver.cg_infos):
+        assert info == 0 and np.max(np.abs(sol - np.linalg.solve(H, rhs))) < 1e-8
+    # another point: the resident matrix is not that point's -- matrix-free again, correct answer
+    theta2 = theta + 1e-3
+    model = om.DeclaredModel(lay, loss=om.LOGISTIC, x=x, y=y, w=w, quad_A=np.full(P, 0.7))
+    hv2, n2 = passes(lambda: ctx.hvp(theta2, v))
+    assert n2 >= 1 and rel_err(hv2, model.hessian(theta2) @ v) < 1e-11
+    # ... and the original point is still served from the matrix
+    _, n_back = passes(lambda: ctx.hvp(theta, v))
+    assert n_back == 0
+    # new weights: the matrix is dropped
+    w2 = w * rng.uniform(0.9, 1.1, N)
+    fun.weights_par.set_vector(w2)
+    fun._push_state()
+    model.w = w2
+    hv3, n3 = passes(lambda: ctx.hvp(theta, v))
+    assert n3 >= 1 and rel_err(hv3, model.hessian(theta) @ v) < 1e-11
+    # a new prior (hyper-parameter) after a rebuild: dropped again
+    H2 = objective.fun_free_hessian(theta)
+    assert passes(lambda: ctx.hvp(theta, v))[1] == 0
+    fun.prior_info_par.set_vector(np.full(P, 0.9))
+    model.quad_A = np.full(P, 0.9)
+    hv4, n4 = passes(lambda: objective.fun_free_hvp(theta, v))
+    assert n4 >= 1 and rel_err(hv4, model.hessian(theta) @ v) < 1e-11
+    # the tuning switch: never use the resident matrix
+    objective.fun_free_hessian(theta)
+    ctx.set_tuning(0, 8)
+    assert passes(lambda: ctx.hvp(theta, v))[1] >= 1
+    ctx.set_tuning(0, 0)
+    assert passes(lambda: ctx.hvp(theta, v))[1] >= 1              # set_tuning itself drops the matrix
+    objective.fun_free_hessian(theta)
+    assert passes(lambda: ctx.hvp(theta, v))[1] == 0
+    # vector coordinates are never served from the free-coordinate matrix
+    eta = lay.constrain(theta)
+    hvv, nv = passes(lambda: ctx.hvp(eta, v, is_free=False))
+    assert nv >= 1 and rel_err(hvv, model.hessian_vec(eta) @ v) < 1e-11
