@@ -399,6 +399,14 @@ int lrvb_mixture_schur_dirichlet(lrvb_ctx* ctx, int32_t K, int32_t q, const doub
  * materialised (BASELINE.json config 5).  n_cols <= 64.                                        */
 int lrvb_quadform_gram(lrvb_ctx* ctx, const double* M, const double* c, int64_t K,
                        const double* free_in, double* GtG_out, int64_t ld);
+/* The same Gram matrix for the Wishart + MVN model (BASELINE.json configuration 5: y_n ~ N(mu, Lambda^-1), q(mu) = MVNParam(d),
+ * q(Lambda) = WishartParam(d); LRVB/NormalParams.py:6-23, WishartParams.py:6-35) with the V matrices M_k GENERATED ON THE
+ * DEVICE from (nu, m, V): the 8 V (d + 1)^2-byte operand (134 MB at d = 63) no longer crosses PCIe, and with GtG_out == NULL the
+ * result stays in HBM as well (lrvb_chol_factor_last factors it; a sharded step then moves nothing over PCIe but c and theta).
+ * offsets = vector-coordinate positions of [mean of q(mu), vech(information of q(mu)), nu, vech(V)]; v is d x d row-major;
+ * cvec (V) the constants c_k of the per-observation gradient, as for lrvb_quadform_gram.                                  */
+int lrvb_wishart_gram(lrvb_ctx* ctx, int64_t d, const int64_t* offsets, double nu, const double* m, const double* v,
+                      const double* cvec, const double* free_in, double* GtG_out, int64_t ld);
 
 /* ---- linear-response solve ------------------------------------------------------------ */
 /* scipy.linalg.cho_factor at LRVB/ModelSensitivity.py:594 / SparseObjectives.py:539.
@@ -550,7 +558,7 @@ int lrvb_profile_reset (lrvb_ctx* ctx);
  * their products H v from that matrix (a D x D product, identical on every rank, no pass over X and no reduction) -- the
  * reference's ConjugateGradientSolver is used exactly so: fun_free_hessian / fun_free_hvp at one optimum, many right-hand
  * sides (LRVB/ConjugateGradient.py:63-105).  The copy is dropped by lrvb_set_data(_dev), lrvb_set_weights(_dev),
- * lrvb_set_quad_scale (new value), lrvb_set_lik_info, lrvb_set_reduce_hook, lrvb_comm_init / _destroy and lrvb_set_tuning;
+ * lrvb_set_quad_scale (new value), lrvb_set_lik_info, lrvb_set_reduce_hook and lrvb_comm_init / _destroy;
  * buffers adopted with the `_dev` setters must be installed again after their contents change.                        */
 int lrvb_set_tuning(lrvb_ctx* ctx, int n_splits, int reserved);
 

@@ -380,8 +380,8 @@ extern "C" int lrvb_set_tuning(lrvb_ctx* c, int n_splits, int reserved) {
     if (!c) LRVB_FAIL(LRVB_ERR_INVALID, "null context");
     if (n_splits < 0 || n_splits > 1024) LRVB_FAIL(LRVB_ERR_INVALID, "n_splits out of range");
     if (reserved & ~15) LRVB_FAIL(LRVB_ERR_INVALID, "reserved = %d: only bits 0-3 are defined (include/lrvb_hip.h)", reserved);
-    c->hvp_pt_valid = false; c->hres_valid = false;
-    c->no_resident = (reserved & 8) != 0;
+    c->hvp_pt_valid = false;
+    c->no_resident = (reserved & 8) != 0;      // (the resident matrix itself stays: it is the Hessian whichever kernels would form it)
     c->n_splits_user = n_splits;
     c->force_generic_wsyrk = (reserved & 1) != 0;
     c->force_dense_rows = (reserved & 2) ? 1 : 0;
@@ -2035,10 +2035,78 @@ __global__ void rank_terms_kernel(i64 V, const double* __restrict__ n_obs_dev, c
     A[i * V + j] = 0.25 * A[i * V + j] + 0.5 * (t[i] * cvec[j] + cvec[i] * t[j]) + n_obs * cvec[i] * cvec[j];
 }
 
+// The per-coordinate matrices M_k of the Wishart + MVN model's per-observation term (LRVB/NormalParams.py:6-23,
+// WishartParams.py:6-35;  l_n = 1/2 z^T Q z + c with z = [y; 1], Q = nu [[V, -V m], [-m^T V, m^T V m]]), written on the device
+// from (nu, m, V m, V): V q^2 doubles (134 MB at d = 63) that the host used to build and send over PCIe in every call.
+struct WishartGen { i64 d, ms, ls, inu, vs; double nu, mvm; const double* m; const double* vm; const double* v; };
+__global__ __launch_bounds__(256)
+void wishart_obs_matrices_kernel(i64 total, i64 V, WishartGen g, double* __restrict__ M)
+{
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const i64 d = g.d, q = d + 1;
+    const i64 k = e / (q * q), rem = e - k * q * q;
+    const i64 a = rem / q, b = rem - a * q;
+    double val = 0.0;
+    if (k >= g.ms && k < g.ms + d) {                          // d/d m_i
+        const i64 i = k - g.ms;
+        if (a < d && b == d) val = -g.nu * g.v[a * d + i];
+        else if (a == d && b < d) val = -g.nu * g.v[b * d + i];
+        else if (a == d && b == d) val = 2.0 * g.nu * g.vm[i];
+    } else if (k == g.inu) {                                  // d/d nu: Q / nu
+        if (a < d && b < d) val = g.v[a * d + b];
+        else if (a < d) val = -g.vm[a];
+        else if (b < d) val = -g.vm[b];
+        else val = g.mvm;
+    } else if (k >= g.vs && k < g.vs + d * (d + 1) / 2) {     // d/d V_(rc) in the vector form of V (row-major lower triangle)
+        const i64 kk = k - g.vs;
+        i64 r = (i64)((sqrt(8.0 * (double)kk + 1.0) - 1.0) * 0.5);
+        while (r * (r + 1) / 2 > kk) --r;
+        while ((r + 1) * (r + 2) / 2 <= kk) ++r;
+        const i64 cc = kk - r * (r + 1) / 2;
+        const bool off = r != cc;
+        auto em = [&](i64 t) { return (t == r ? g.m[cc] : 0.0) + ((off && t == cc) ? g.m[r] : 0.0); };
+        if (a < d && b < d) val = g.nu * (((a == r && b == cc) ? 1.0 : 0.0) + ((off && a == cc && b == r) ? 1.0 : 0.0));
+        else if (a < d) val = -g.nu * em(a);
+        else if (b < d) val = -g.nu * em(b);
+        else val = g.nu * (g.m[r] * g.m[cc] * (off ? 2.0 : 1.0));
+    }
+    M[e] = val;                                               // the information block of q(mu) (ls) enters through c only: M = 0
+}
+
+static int quadform_gram_impl(lrvb_ctx* c, const double* M, const WishartGen* gen, const double* cvec, int64_t K,
+                              const double* free_in, double* GtG_out, int64_t ld);
 extern "C" int lrvb_quadform_gram(lrvb_ctx* c, const double* M, const double* cvec, int64_t K,
                                   const double* free_in, double* GtG_out, int64_t ld) {
     LRVB_TRY(ctx_bind(c));
     if (!M || !cvec || !free_in || !GtG_out) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    return quadform_gram_impl(c, M, nullptr, cvec, K, free_in, GtG_out, ld);
+}
+extern "C" int lrvb_wishart_gram(lrvb_ctx* c, int64_t d, const int64_t* offsets, double nu, const double* m, const double* v,
+                                 const double* cvec, const double* free_in, double* GtG_out, int64_t ld) {
+    LRVB_TRY(ctx_bind(c));
+    if (!offsets || !m || !v || !cvec || !free_in) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    const i64 mm = d * (d + 1) / 2;
+    if (d < 1 || d + 1 != c->P) LRVB_FAIL(LRVB_ERR_SIZE, "the data rows are [y; 1]: expected n_cols = d + 1 = %lld, got %lld", (long long)(d + 1), (long long)c->P);
+    const i64 ms = offsets[0], ls = offsets[1], inu = offsets[2], vs = offsets[3];
+    if (ms < 0 || ms + d > c->V || ls < 0 || ls + mm > c->V || inu < 0 || inu >= c->V || vs < 0 || vs + mm > c->V)
+        LRVB_FAIL(LRVB_ERR_INVALID, "parameter offsets outside the %lld vector coordinates", (long long)c->V);
+    // (m, V m, V) -> the device, in stream order (small uploads: no synchronisation)
+    std::vector<double> pack((size_t)(2 * d + d * d));
+    double mvm = 0.0;
+    for (i64 i = 0; i < d; ++i) {
+        double t = 0.0;
+        for (i64 j = 0; j < d; ++j) t += v[i * d + j] * m[j];
+        pack[(size_t)i] = m[i]; pack[(size_t)(d + i)] = t; mvm += m[i] * t;
+    }
+    memcpy(pack.data() + 2 * d, v, (size_t)(d * d) * sizeof(double));
+    LRVB_TRY(buf_reserve(c, c->vtmp, pack.size() > (size_t)(c->V > c->D ? c->V : c->D) ? pack.size() : (size_t)(c->V > c->D ? c->V : c->D)));
+    LRVB_TRY(h2d(c, c->vtmp.p, pack.data(), pack.size()));
+    WishartGen gen{ d, ms, ls, inu, vs, nu, mvm, c->vtmp.p, c->vtmp.p + d, c->vtmp.p + 2 * d };
+    return quadform_gram_impl(c, nullptr, &gen, cvec, c->V, free_in, GtG_out, ld);
+}
+static int quadform_gram_impl(lrvb_ctx* c, const double* M, const WishartGen* gen, const double* cvec, int64_t K,
+                              const double* free_in, double* GtG_out, int64_t ld) {
     if (c->loss == LRVB_LOSS_NONE || !c->have_X) LRVB_FAIL(LRVB_ERR_STATE, "no data matrix: call lrvb_set_data(LRVB_SLOT_X) first");
     if (K != c->V) LRVB_FAIL(LRVB_ERR_SIZE, "expected one matrix per vector coordinate (%lld), got %lld", (long long)c->V, (long long)K);
     if (c->P > 64) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "Kronecker Gram kernel supports n_cols <= 64");
@@ -2072,7 +2140,13 @@ extern "C" int lrvb_quadform_gram(lrvb_ctx* c, const double* M, const double* cv
     LRVB_TRY(buf_reserve(c, c->vtmp3, (size_t)(V > D ? V : D)));
     LRVB_TRY(buf_reserve(c, c->Hfree, (size_t)D * (size_t)D));
     LRVB_TRY(launch_wsyrk_kron(c, c->zbuf.p, c->Tdense.p));
-    LRVB_TRY(h2d_beside(c, c->work1.p, M, (size_t)V * (size_t)q * (size_t)q));
+    if (M) {
+        LRVB_TRY(h2d_beside(c, c->work1.p, M, (size_t)V * (size_t)q * (size_t)q));
+    } else {                                              // the matrices are written on the device, behind the Kronecker kernel
+        const i64 total = V * (i64)q * q;
+        hipLaunchKernelGGL(wishart_obs_matrices_kernel, dim3(nb256(total)), dim3(256), 0, c->stream, total, V, *gen, c->work1.p);
+        HIP_TRY(hipGetLastError());
+    }
     LRVB_TRY(h2d_beside(c, c->g_eta.p, cvec, (size_t)V));
     LRVB_TRY(h2d_beside(c, c->theta.p, free_in, (size_t)D));
     LRVB_TRY(obs_reduce(c, c->Tdense.p, (i64)(tiles_n + (size_t)q * q + 1)));
@@ -2105,11 +2179,11 @@ extern "C" int lrvb_quadform_gram(lrvb_ctx* c, const double* M, const double* cv
     if (st == LRVB_OK) st = launch_dense_jac(c, c->theta.p, c->Jdense.p);
     if (st == LRVB_OK) st = gemm_tn(c, V, V, D, Av.p, c->Jdense.p, T1.p);             // Av is symmetric
     if (st == LRVB_OK) st = gemm_tn(c, V, D, D, c->Jdense.p, T1.p, c->Hfree.p);
-    if (st == LRVB_OK) {
+    if (st == LRVB_OK && GtG_out) {
         if (hipMemcpy2DAsync(GtG_out, (size_t)ld * 8, c->Hfree.p, (size_t)D * 8, (size_t)D * 8, (size_t)D, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
             hipStreamSynchronize(c->stream) != hipSuccess) { lrvb_set_error("copy back failed"); st = LRVB_ERR_HIP; }
     } else {
-        (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamSynchronize(c->stream);               // (the scoped buffers below are freed: their users must be done)
     }
     buf_free(Mt); buf_free(T1); buf_free(Av);
     return st;

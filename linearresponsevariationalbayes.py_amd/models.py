@@ -573,6 +573,18 @@ class DeviceContext(object):
                                                 _hip.ptr(out), self.D))
         return out
 
+    def wishart_gram(self, d, offsets, nu, m, v, c, free, want_host=True):
+        """G^T G of the Wishart + MVN model with the per-coordinate matrices generated on the device (lrvb_wishart_gram);
+        want_host=False leaves the result in HBM (for `chol_factor_last`) and returns None."""
+        m, v, c, f = _hip.as_f64(m).ravel(), _hip.as_f64(v), _hip.as_f64(c).ravel(), _hip.as_f64(free).ravel()
+        if m.size != d or v.shape != (d, d) or c.size != self.V or f.size != self.D:
+            raise ValueError('expected m of length {0}, v of shape ({0}, {0}), c of length {1} and a free vector of length {2}'.format(d, self.V, self.D))
+        offs = np.ascontiguousarray(offsets, dtype=np.int64).ravel()
+        out = np.empty((self.D, self.D)) if want_host else None
+        self._check(self._lib.lrvb_wishart_gram(self._h, int(d), offs.ctypes.data_as(ctypes.c_void_p), float(nu), _hip.ptr(m), _hip.ptr(v),
+                                               _hip.ptr(c), _hip.ptr(f), _hip.ptr(out), self.D))
+        return out
+
     def cg_solve_matrix(self, H, b, x0=None, Minv=None, tol=1e-8, maxiter=0):
         b = _hip.as_f64(b).ravel()
         D = b.size

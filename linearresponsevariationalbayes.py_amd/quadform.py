@@ -664,6 +664,31 @@ class WishartMVNObjective(QuadraticDataObjective):
                 self.ctx.hvec_add_symkron(blk[1], blk[2], blk[3], blk[4], blk[5], blk[6])
         return self.ctx.hvec_finish(x, g, is_free)
 
+    def _obs_constants(self, eta):
+        """c (V,): the constant part of d l_n / d eta_k = 1/2 z_n^T M_k z_n + c_k (everything that needs the d x d inverses and
+        the polygamma sum; the matrices M_k themselves are written by the device, `lrvb_wishart_gram`)."""
+        d = self.d
+        m, lam_mu, nu, v = self._unpack(eta)
+        P = np.linalg.inv(lam_mu)
+        Vi = np.linalg.inv(v)
+        _, kap1, _, _ = self._kappa(nu)
+        c = np.zeros(eta.size)
+        r, cidx = np.tril_indices(d)
+        fac = np.where(r == cidx, 1.0, 2.0)
+        c[self._ls.start:self._ls.stop] = -0.5 * nu * (P @ v @ P)[r, cidx] * fac
+        c[self._inu] = 0.5 * np.sum(v * P) - 0.5 * kap1
+        c[self._vs.start:self._vs.stop] = (0.5 * nu * P - 0.5 * Vi)[r, cidx] * fac
+        return c, m, nu, v
+
+    @_hip.host_blas
+    def gram(self, free_val, want_host=True):
+        """G^T G in free coordinates.  The V = (d + 1)^2 matrices of the per-observation gradient are generated on the device
+        from (nu, m, V) -- nothing of size V q^2 is built on the host or sent over PCIe -- and with want_host=False the D x D
+        result stays in HBM too (returns None; `ctx.chol_factor_last()` factors it)."""
+        c, m, nu, v = self._obs_constants(self._eta(free_val, True))
+        return self.ctx.wishart_gram(self.d, [self._ms.start, self._ls.start, self._inu, self._vs.start], nu, m, v, c, free_val,
+                                     want_host=want_host)
+
     def _obs_terms(self, eta):
         d, q = self.d, self.q
         m, lam_mu, nu, v = self._unpack(eta)

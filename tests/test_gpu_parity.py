@@ -110,11 +110,12 @@ def test_glm_box_layout(vb, loss, N, P):
     v = rng.normal(size=lay.D)
     assert abs(obj.fun_free(theta) - model.value(theta)) <= 1e-12 * max(1.0, abs(model.value(theta)))
     assert rel_err(obj.fun_free_grad(theta), model.grad(theta)) < TOL
-    H = obj.fun_free_hessian(theta)
     Hw = model.hessian(theta)
+    assert rel_err(obj.fun_free_hvp(theta, v), Hw @ v) < TOL          # before any build: the matrix-free pass over X
+    H = obj.fun_free_hessian(theta)
     assert rel_err(H, Hw) < TOL
     assert np.array_equal(H, H.T)
-    assert rel_err(obj.fun_free_hvp(theta, v), Hw @ v) < TOL
+    assert rel_err(obj.fun_free_hvp(theta, v), Hw @ v) < TOL          # after the build: against the resident Hessian
     # vector coordinates
     eta = lay.constrain(theta)
     assert rel_err(obj.fun_vector_grad(eta), model.grad_vec(eta)) < TOL
@@ -145,8 +146,9 @@ def test_glm_general_layout(vb):
     Hw = model.hessian(theta)
     assert abs(obj.fun_free(theta) - model.value(theta)) < 1e-11 * abs(model.value(theta))
     assert rel_err(obj.fun_free_grad(theta), model.grad(theta)) < TOL
+    assert rel_err(obj.fun_free_hvp(theta, v), Hw @ v) < TOL          # matrix-free (nothing built yet)
     assert rel_err(obj.fun_free_hessian(theta), Hw) < TOL
-    assert rel_err(obj.fun_free_hvp(theta, v), Hw @ v) < TOL
+    assert rel_err(obj.fun_free_hvp(theta, v), Hw @ v) < TOL          # resident Hessian
     assert rel_err(fun.ctx.obs_grad(theta), model.obs_grad(theta)) < TOL
     assert rel_err(fun.gram(theta), model.gram(theta)) < TOL
     assert rel_err(fun.ctx.cross_hessian_tilt(theta), model.cross_hessian_tilt(theta)) < 1e-14
@@ -422,8 +424,8 @@ def test_full_size_properties_headline_shape(vb):
     Hg = build(w1)
     ctx.set_tuning(0, 0)
     assert (Hg - H1).abs().max().item() < 1e-12 * scale
-    # only the three documented bits exist; anything else is refused and changes nothing
-    for bad in (8, 1 << 8, 7 << 8, 1 << 16, -1):
+    # only the four documented bits exist; anything else is refused and changes nothing
+    for bad in (16, 1 << 8, 7 << 8, 1 << 16, -1):
         with pytest.raises(ValueError):
             ctx.set_tuning(0, bad)
     assert torch.equal(build(w1), H1)

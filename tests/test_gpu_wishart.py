@@ -177,3 +177,29 @@ def test_config5_full_size_gram_properties(vb):
     assert rel_err(parts[0], cross @ cross.T) < 1e-9
     lam = np.linalg.eigvalsh(full)
     assert lam[0] > -1e-9 * lam[-1]
+
+
+@pytest.mark.parametrize('d,N', [(1, 50), (4, 700), (17, 3000)])
+def test_gram_with_device_generated_matrices(vb, d, N):
+    """`WishartMVNObjective.gram` writes the V = (d + 1)^2 per-coordinate matrices of the per-observation gradient on the device
+    (lrvb_wishart_gram) instead of building V q^2 doubles on the host: the same G^T G as the generic entry point fed with the
+    host-built matrices (`_obs_terms`, pinned against exact AD in tests/test_wishart_mvn_host_math.py), and with
+    want_host=False the result stays in HBM, where the Cholesky factors it."""
+    rng = np.random.default_rng(100 + d)
+    y, par, fun, lay, ft = _build(vb, rng, N, d)
+    theta = lay.unconstrain(random_point(rng, d))
+    got = fun.gram(theta)
+    eta = lay.constrain(theta)
+    M, c = fun._obs_terms(eta)
+    want = fun.ctx.quadform_gram(M, c, theta)
+    assert rel_err(got, want) < 1e-13
+    c2, m, nu, v = fun._obs_constants(eta)
+    np.testing.assert_allclose(c2, c, rtol=1e-14, atol=1e-15)
+    assert fun.gram(theta, want_host=False) is None
+    shift = 1e-3 * np.abs(got).max()
+    # the resident matrix is the one that came back: factor a shifted copy both ways and compare the covariances
+    fun.ctx.chol_factor(got + shift * np.eye(lay.D))
+    cov_host = fun.ctx.lrvb_cov(np.eye(lay.D)[:3])
+    assert rel_err(cov_host, np.linalg.inv(got + shift * np.eye(lay.D))[:3, :3]) < 1e-7
+    with pytest.raises(ValueError):
+        fun.ctx.wishart_gram(d, [0, d, d + d * (d + 1) // 2, d + d * (d + 1) // 2 + 1], nu, m[:-1] if d > 1 else np.zeros(2), v, c2, theta)
