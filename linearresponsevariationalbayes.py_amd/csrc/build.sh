@@ -5,7 +5,7 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 OUT=../liblrvb_hip.so
-SRCS="lrvb_api.hip k_wsyrk.hip k_glm.hip k_pack.hip k_linalg.hip k_finish.hip k_hyper.hip k_mixture.hip k_hvp_multi.hip k_lmm.hip \
+SRCS="lrvb_api.hip k_elementwise.hip k_gauss.hip k_hvec.hip k_models.hip k_cg.hip k_wsyrk.hip k_glm.hip k_pack.hip k_linalg.hip k_finish.hip k_hyper.hip k_mixture.hip k_hvp_multi.hip k_lmm.hip \
       k_mixture_inst0.hip k_mixture_inst1.hip k_mixture_inst2.hip k_mixture_inst3.hip"
 OBJDIR=.obj
 mkdir -p "$OBJDIR"

@@ -32,9 +32,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
     :: "v"(voff), "s"(sbase), "s"(ldsaddr) : "memory")
 
 constexpr int HM_ROWS = 8;               // observations per chunk
-#ifndef HM_REGIONS
-#define HM_REGIONS 1
-#endif
+constexpr int HM_REGIONS = 1;           // chunk order: one chip-wide window (regions of 8 / 32 / 64 workgroups measured: no effect)
 
 // TONLY = true stops after step A and writes the scaled rows of T instead (out[n][q] = c_n (X U)[n][q]):
 // the streamed weight-sensitivity product of lrvb_obs_influence.
@@ -149,9 +147,6 @@ void hvp_multi_kernel(const double* __restrict__ X, int Preal, i64 N, const doub
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < 8; t += 2) {
-#ifdef HM_LAB_NO_A
-                tpa[0] += fr[cur][t >> 1][0] + fr[cur][4 + (t >> 1)][0]; tpb[0] += fr[cur][t >> 1][1] + fr[cur][4 + (t >> 1)][1]; continue;
-#endif
                 tpa[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(fr[cur][t >> 1][0], uf[b][t], tpa[0], 0, 0, 0);
                 tpa[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(fr[cur][4 + (t >> 1)][0], uf[b][t], tpa[1], 0, 0, 0);
                 tpb[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(fr[cur][t >> 1][1], uf[b][t + 1], tpb[0], 0, 0, 0);
@@ -224,9 +219,6 @@ void hvp_multi_kernel(const double* __restrict__ X, int Preal, i64 N, const doub
         // one 16-byte fragment feeds two tiles: tile m takes the columns pc0 + 32 (m >> 1) + 2 i + (m & 1)
 #pragma unroll
         for (int h = 0; h < NT / 2; ++h) {
-#ifdef HM_LAB_NO_B
-            acc[2 * h][0] += xb[h][0][0] * t0 + xb[h][1][0] * t1; acc[2 * h + 1][0] += xb[h][0][1] * t0 + xb[h][1][1] * t1; continue;
-#endif
             acc[2 * h]     = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[h][0][0], t0, acc[2 * h], 0, 0, 0);
             acc[2 * h + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[h][0][1], t0, acc[2 * h + 1], 0, 0, 0);
             acc[2 * h]     = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[h][1][0], t1, acc[2 * h], 0, 0, 0);
@@ -240,11 +232,7 @@ void hvp_multi_kernel(const double* __restrict__ X, int Preal, i64 N, const doub
         double c0, c1;
         load_weights(buf, c0, c1);
         const i64 nxt = ch + step;
-#ifdef HM_LAB_NO_DMA
-        if (nxt < cend && nxt < cbeg + 4 * step) issue(nxt, buf ^ 1);      // lab: only the first stages are loaded (compute-only time)
-#else
         if (nxt < cend) issue(nxt, buf ^ 1);
-#endif
         if (have_prev) {
             double t0, t1;
             gather_t(Tpart + (slot ^ 1) * (NW * 2 * 64), c0p, c1p, t0, t1);

@@ -21,12 +21,7 @@
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
-#ifndef LRVB_GS_WAVES_ATTR
-#define LRVB_GS_WAVES_ATTR
-#endif
-#ifndef LRVB_GS_DEPTH
-#define LRVB_GS_DEPTH 6          // k-steps of 4 rows in flight per wave (8 waves per CU: ~68 KB of loads in flight per CU at 44 columns)
-#endif
+constexpr int LRVB_GS_DEPTH = 6; // k-steps of 4 rows in flight per wave (8 waves per CU: ~68 KB of loads in flight per CU at 44 columns)
 
 // ---- one-time: group-sorted copy of the rows; per call: weights in the same order ------------------------------------
 __global__ __launch_bounds__(256)
@@ -65,7 +60,7 @@ template <int N_> struct GsWait { static __device__ __forceinline__ void vm() {
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N_) : "memory"); } };
 
 template <int NPG, int SINGLE>      // NPG pair groups of 32 columns, SINGLE trailing block of <= 16 columns
-__global__ __launch_bounds__(256) LRVB_GS_WAVES_ATTR
+__global__ __launch_bounds__(256)
 void grouped_stats_kernel(const double* __restrict__ Zs, int q, const double* __restrict__ ws,
                           const i64* __restrict__ offs, const i64* __restrict__ wg0, i64 N, i64 R, i64 NW,
                           double* __restrict__ gs, double* __restrict__ bpart /* NW x 2 x 128 */, double* __restrict__ partial)
@@ -167,7 +162,6 @@ void grouped_stats_kernel(const double* __restrict__ Zs, int q, const double* __
             }
             if (SINGLE) { b[2 * NPG] = sl[offs_s]; a[2 * NPG] = b[2 * NPG] * wk; }
             int idx = 0;
-#ifndef LRVB_GS_LAB_NO_MFMA
 #pragma unroll
             for (int ta = 0; ta < NB; ++ta)
 #pragma unroll
@@ -175,13 +169,6 @@ void grouped_stats_kernel(const double* __restrict__ Zs, int q, const double* __
                     acc[idx] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ta], b[tb], acc[idx], 0, 0, 0);
                     ++idx;
                 }
-#else
-            acc[0][0] += a[0] + b[NB - 1];
-#endif
-#ifdef LRVB_GS_LAB_NO_GROUPS
-            gw += wk; (void)row0;
-            return;
-#endif
             const int ge = gE < r1 ? gE : r1;                  // this wave's share of the current group ends here
             if (row0 + 4 <= ge - 1 || step >= nsteps) {        // the whole step lies strictly inside the group (or is a dead slot: weights zero)
 #pragma unroll
@@ -319,7 +306,6 @@ void grouped_dense_kernel(const double* __restrict__ lvl, int S, int elems, int 
 
 // rows per wave of the fused pass: ~3072 waves (12 per CU), a multiple of 4 rows, at least 64
 i64 grouped_rows_per_wave(i64 N) {
-    if (const char* e = getenv("LRVB_GS_ROWS")) { const i64 r = atoll(e); if (r >= 4) return (r + 3) & ~(i64)3; }   // lab knob
     i64 R = (N + 3071) / 3072;                    // three waves per SIMD (the kernel's register budget), all resident at once
     R = (R + 3) & ~(i64)3;
     if (R < 64) R = 64;

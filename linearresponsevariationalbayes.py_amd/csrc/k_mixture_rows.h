@@ -141,34 +141,13 @@ __device__ __forceinline__ double mx_half_max(double v) {
 //    arrive by LDS-DMA, every store is ALWAYS issued (rows or lanes that must not be written are masked through EXEC,
 //    never branched around), exactly MX_STORES stores follow the DMAs of a pair and the wait for them is vmcnt(MX_STORES).
 //    (hipcc cannot count stores behind branches and waits vmcnt(0) for any load -- draining the stores in every iteration.)
-#ifndef MX_WAVES_ATTR
-#define MX_WAVES_ATTR
-#endif
 // stores and LDS-DMA loads under an explicit EXEC mask (call sites are wave-uniform control flow: EXEC is all ones there)
 #define MX_ST(sbase, voff, val, mask) asm volatile("s_mov_b64 exec, %3\n\tglobal_store_dwordx2 %0, %1, %2\n\ts_mov_b64 exec, -1" \
     :: "v"(voff), "v"(val), "s"(sbase), "s"(mask) : "memory")
-#ifndef MX_ST16_MODE                  // lab knob: cache-policy bits of the 16-byte stores of A_n
-#define MX_ST16_MODE 0
-#endif
-#if MX_ST16_MODE == 1
-#define MX_ST16_MOD "nt"
-#elif MX_ST16_MODE == 2
-#define MX_ST16_MOD "sc0"
-#elif MX_ST16_MODE == 3
-#define MX_ST16_MOD "sc1"
-#elif MX_ST16_MODE == 4
-#define MX_ST16_MOD "sc0 sc1"
-#elif MX_ST16_MODE == 5
-#define MX_ST16_MOD "nt sc1"
-#else
-#define MX_ST16_MOD ""
-#endif
-#define MX_ST16(sbase, voff, val, mask) asm volatile("s_mov_b64 exec, %3\n\tglobal_store_dwordx4 %0, %1, %2 " MX_ST16_MOD "\n\ts_mov_b64 exec, -1" \
+// (cache-policy bits on these stores -- nt, sc0, sc1, both, nt sc1 -- were measured in round 3: 1.148-1.18 ms, inside the noise)
+#define MX_ST16(sbase, voff, val, mask) asm volatile("s_mov_b64 exec, %3\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_mov_b64 exec, -1" \
     :: "v"(voff), "v"(val), "s"(sbase), "s"(mask) : "memory")
-#ifndef MX_DMA_MOD                    // lab knob: cache-policy bits of the input DMAs
-#define MX_DMA_MOD ""
-#endif
-#define MX_DMA4(sbase, voff, ldsaddr, mask) asm volatile("s_mov_b32 m0, %2\n\ts_mov_b64 exec, %3\n\tglobal_load_lds_dword %0, %1 " MX_DMA_MOD "\n\ts_mov_b64 exec, -1" \
+#define MX_DMA4(sbase, voff, ldsaddr, mask) asm volatile("s_mov_b32 m0, %2\n\ts_mov_b64 exec, %3\n\tglobal_load_lds_dword %0, %1\n\ts_mov_b64 exec, -1" \
     :: "v"(voff), "s"(sbase), "s"(ldsaddr), "s"(mask) : "memory")
 template <int N_> struct MxWait { static __device__ __forceinline__ void vm() {
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N_) : "memory"); } };
@@ -178,7 +157,7 @@ typedef double mx_d2 __attribute__((ext_vector_type(2)));
 __host__ __device__ constexpr int mixture_rows_lda(int K) { return K * (K + 1) / 2 + ((K * (K + 1) / 2) & 1); }
 
 template <int K>
-__global__ __launch_bounds__(256) MX_WAVES_ATTR
+__global__ __launch_bounds__(256)
 void mixture_rows_kernel(const double* __restrict__ theta_z, const double* __restrict__ X, int V,
                          const double* __restrict__ w, const double* __restrict__ Lam, i64 N,
                          double* __restrict__ Amat, double* __restrict__ U,
@@ -344,11 +323,7 @@ void mixture_rows_kernel(const double* __restrict__ theta_z, const double* __res
             for (int sg = 0; sg < NSEG; ++sg) {
                 const int e2 = sg * 64 + lane;                            // pair of doubles
                 const mx_d2 val = *reinterpret_cast<const mx_d2*>(rbw + 2 * (e2 < LDA / 2 ? e2 : 0));
-#ifdef MX_LAB_NO_ASTORE                                                    // ablation: the compute without the 4.2 KB row of A_n
-                MX_ST16(arow, (unsigned)e2 * 16u, val, __ballot(on && e2 < LDA / 2 && val[0] == 1.2345e300));
-#else
                 MX_ST16(arow, (unsigned)e2 * 16u, val, __ballot(on && e2 < LDA / 2));
-#endif
             }
             __builtin_amdgcn_wave_barrier();
         }

@@ -1,0 +1,354 @@
+// k_models.hip -- per-model kernels of the BASELINE.json configurations: per-observation quadratic forms, group sums and the
+// elimination of the 2G local parameters of the hierarchical model, the Dirichlet blocks and the Schur assembly of the mixture,
+// the operands of the Wishart model's G^T G, higher-order loss derivatives, the Gauss-Hermite logistic term.
+#include "lrvb_internal.h"
+#include "k_kernels.h"
+#include <math.h>
+
+__global__ __launch_bounds__(256)
+void obs_quadform_kernel(const double* __restrict__ Z, i64 ldz, int q, const double* __restrict__ M,
+                         const double* __restrict__ cvec, i64 K, i64 n0, i64 n1, double* __restrict__ out)
+{
+    const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 n = n0 + blockIdx.y;
+    if (k >= K || n >= n1) return;
+    const double* z = Z + n * ldz;
+    const double* Mk = M + k * (i64)q * q;
+    double s = 0.0;
+    for (int a = 0; a < q; ++a) {
+        double t = 0.0;
+        for (int b = 0; b < q; ++b) t += Mk[a * q + b] * z[b];
+        s += z[a] * t;
+    }
+    out[(n - n0) * K + k] = 0.5 * s + (cvec ? cvec[k] : 0.0);
+}
+
+// out[g, 0] = sum_{n in g} w_n,  out[g, 1 + j] = sum_{n in g} w_n z_nj.  One wavefront per group walks
+// the group's rows in a fixed order (counting-sort permutation built once on the host when the group
+// ids are set), lane = column: deterministic, no atomics.  These are the per-group Sigma w, Sigma w y,
+// Sigma w x of doc/lmm.lyx:105-160.
+__global__ __launch_bounds__(256)
+void group_sums_kernel(const double* __restrict__ Z, i64 ldz, int q, const double* __restrict__ w,
+                       const i64* __restrict__ perm, const i64* __restrict__ offs, i64 n_groups,
+                       double* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const i64 g = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= n_groups) return;
+    const i64 b = offs[g], e = offs[g + 1];
+    double sw = 0.0, s0 = 0.0;                  // lane j < q accumulates column j; every lane tracks sum w
+    i64 k = b;
+    for (; k + 1 < e; k += 2) {                 // two rows in flight
+        const i64 n0 = perm[k], n1 = perm[k + 1];
+        const double w0 = w[n0], w1 = w[n1];
+        const double z0 = lane < q ? Z[n0 * ldz + lane] : 0.0;
+        const double z1 = lane < q ? Z[n1 * ldz + lane] : 0.0;
+        sw += w0; s0 += w0 * z0;
+        sw += w1; s0 += w1 * z1;
+    }
+    if (k < e) {
+        const i64 n0 = perm[k];
+        const double w0 = w[n0];
+        sw += w0; s0 += w0 * (lane < q ? Z[n0 * ldz + lane] : 0.0);
+    }
+    double* dst = out + g * (i64)(q + 1);
+    if (lane == 0) dst[0] = sw;
+    if (lane < q) dst[1 + lane] = s0;
+}
+
+// One wavefront per batch of groups, lane = column of the group's row [W_g | sum w x (p) | sum w y] of the resident
+// statistics.  For group g (doc/lmm.lyx:105-160; e_g, i_g the mean and information of q(u_g)):
+//   r_g = sum w y - (sum w x) . m,   a_g = W_g e_g - r_g,   d_g = e_g - e_mu,   D_g = ty W_g + tm,
+// the two columns of the arrow Hessian's cross block that belong to (e_g, i_g), in vector coordinates of the p + 5
+// coupled global rows [mean of q(beta) (p) | e_mu | a_y | b_y | a_mu | b_mu], times d local / d free,
+//   c_e = [ty sum w x | -tm | a_g tay | a_g tby | d_g tam | d_g tbm],
+//   c_i = [0 | 0 | -W_g tay / (2 i_g^2) | -W_g tby / (2 i_g^2) | -tam / (2 i_g^2) | -tbm / (2 i_g^2)] * (i_g - lb),
+// go to rows 2g and 2g + 1 of C (width ldc), the reciprocals of the free local diagonal to the weights; the sums over
+// groups that the global gradient and the scalars of the ELBO need are accumulated per wave (fixed order) in `part`.
+//   sums[0 .. p) = sum_g e_g sum w x;  sums[64 + k]: 0 sum e_g r_g, 1 sum W_g (e_g^2 + 1 / i_g), 2 sum d_g^2 + 1 / i_g,
+//   3 sum d_g, 4 sum log i_g, 5 sum W_g, 6 sum (local free gradient)^2 (a stationarity diagnostic)
+__global__ __launch_bounds__(256)
+void lmm_group_kernel(const double* __restrict__ gs, i64 G, int p, const double* __restrict__ par, const double* __restrict__ floc,
+                      double* __restrict__ C, int ldc, double* __restrict__ wts, double* __restrict__ part)
+{
+    const int lane = threadIdx.x & 63;
+    const i64 gw = (i64)blockIdx.x * 4 + (threadIdx.x >> 6), GW = (i64)gridDim.x * 4;
+    const double ty = par[0], tm = par[1], e_mu = par[2], tay = par[3], tby = par[4], tam = par[5], tbm = par[6], lb = par[7];
+    const double mj = (lane >= 1 && lane <= p) ? par[8 + lane - 1] : 0.0;       // m aligned with the sum w x lanes
+    const int q1 = p + 2;                                                     // entries of a statistics row
+    double v1 = 0.0;                                                          // lane 1 + j: sum_g e_g (sum w x)_j
+    double sc[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (i64 g = gw; g < G; g += GW) {
+        const double val = lane < q1 ? gs[g * q1 + lane] : 0.0;
+        double dotv = val * mj;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dotv += __shfl_xor(dotv, off);
+        const double W = __shfl(val, 0), sy = __shfl(val, p + 1);
+        const double eg = floc[g], ig = lb + exp(floc[G + g]), jl = ig - lb;
+        const double rg = sy - dotv, a = W * eg - rg, d = eg - e_mu, Dg = ty * W + tm;
+        const double i2 = 1.0 / (ig * ig);
+        const double dl_i = Dg * i2 / ig - 0.5 * i2, g_i = -0.5 * Dg * i2 + 0.5 / ig, g_e = ty * a + tm * d;
+        const double dfe = Dg, dfi = dl_i * jl * jl + g_i * jl;
+        const double sx = __shfl(val, lane + 1 < 64 ? lane + 1 : 63);           // lane r < p: (sum w x)_r
+        double ce, ci;
+        if (lane < p) { ce = ty * sx; ci = 0.0; }
+        else if (lane == p) { ce = -tm; ci = 0.0; }
+        else if (lane == p + 1) { ce = a * tay; ci = -0.5 * W * i2 * tay * jl; }
+        else if (lane == p + 2) { ce = a * tby; ci = -0.5 * W * i2 * tby * jl; }
+        else if (lane == p + 3) { ce = d * tam; ci = -0.5 * i2 * tam * jl; }
+        else if (lane == p + 4) { ce = d * tbm; ci = -0.5 * i2 * tbm * jl; }
+        else { ce = 0.0; ci = 0.0; }
+        if (lane < ldc) { C[(2 * g) * (i64)ldc + lane] = ce; C[(2 * g + 1) * (i64)ldc + lane] = ci; }
+        if (lane == 0) { wts[2 * g] = 1.0 / dfe; wts[2 * g + 1] = 1.0 / dfi; }
+        v1 += val * eg;
+        sc[0] += eg * rg; sc[1] += W * (eg * eg + 1.0 / ig); sc[2] += d * d + 1.0 / ig; sc[3] += d;
+        sc[4] += log(ig); sc[5] += W; sc[6] += g_e * g_e + (g_i * jl) * (g_i * jl);
+    }
+    double* dst = part + gw * 128;
+    dst[lane] = (lane >= 1 && lane <= p) ? v1 : 0.0;          // shifted by one: slot 1 + j
+    if (lane < 7) dst[64 + lane] = sc[lane];
+    else dst[64 + lane] = 0.0;
+}
+
+// sums[k] = sum over the wave partials in a fixed order (eight interleaved slices, then the slices in order); the vector
+// part is moved down by one slot
+__global__ __launch_bounds__(1024)
+void lmm_sums_kernel(const double* __restrict__ part, int n_waves, double* __restrict__ sums) {
+    __shared__ double sh[8][128];
+    const int k = threadIdx.x & 127, sl = threadIdx.x >> 7;
+    double a0 = 0.0, a1 = 0.0;
+    int wv = sl;
+    for (; wv + 8 < n_waves; wv += 16) { a0 += part[(i64)wv * 128 + k]; a1 += part[(i64)(wv + 8) * 128 + k]; }
+    if (wv < n_waves) a0 += part[(i64)wv * 128 + k];
+    sh[sl][k] = a0 + a1;
+    __syncthreads();
+    if (sl == 0) {
+        double a = 0.0;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) a += sh[s][k];
+        if (k < 64) { if (k >= 1) sums[k - 1] = a; if (k == 63) sums[63] = 0.0; }
+        else sums[k] = a;
+    }
+}
+
+// tail[0..1] = val2, tail[2] = number of rows whose local block was not positive definite, tail[3] = 0
+__global__ void mixture_tail_kernel(i64 n, const double* __restrict__ val2, const int* __restrict__ bad, double* __restrict__ tail) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    tail[i] = (i < 2) ? val2[i] : (i == 2 ? (double)(*bad) : 0.0);
+}
+
+// Rm[(j K + k), (j' K + k')] = R[(j q + j'), (k K + k')]: the (q^2 x K^2) operand re-indexed as the square
+// matrix that sits between d vec(Lam) / d free and its transpose
+__global__ void mixture_permute_kernel(i64 total, int q, int K, const double* __restrict__ R, double* __restrict__ Rm)
+{
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const i64 n = (i64)q * K;
+    const i64 r = e / n, cc = e - r * n;
+    const int j = (int)(r / K), k = (int)(r - (i64)j * K), jp = (int)(cc / K), kp = (int)(cc - (i64)jp * K);
+    Rm[e] = R[((i64)j * q + jp) * ((i64)K * K) + (i64)k * K + kp];
+}
+
+// H = diag(s) Hgg diag(s) + diag(d) - 1/2 (S + S^T)
+__global__ void mixture_schur_finish_kernel(i64 total, i64 n, const double* __restrict__ Hgg, const double* __restrict__ sc,
+                                            const double* __restrict__ dg, const double* __restrict__ S, double* __restrict__ H)
+{
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const i64 r = e / n, cc = e - r * n;
+    double v = Hgg[e];
+    if (sc) v *= sc[r] * sc[cc];
+    if (dg && r == cc) v += dg[r];
+    H[e] = v - 0.5 * (S[e] + S[cc * n + r]);
+}
+
+// A matrix that is diagonal plus a constant on the blocks of a partition, times a column scaling:
+//   out[r, c] = ( [r == c] diag[r] + [group(r) == group(c)] gconst[group(r)] ) * colscale[c],
+// group(r) = 0 for r < K (the Dirichlet over the K mixture weights), 1 + (r mod K) otherwise (the K Dirichlets over the
+// vocabulary, parameter (v, k) at index K + v K + k): the shape of d E log p / d alpha and of the Dirichlet entropy /
+// expectation Hessians (diag(psi1(alpha)) - psi1(alpha_0): LRVB/ExponentialFamilies.py:118-120, DirichletParams.py:19-26).
+__global__ void dirichlet_blocks_kernel(i64 total, i64 n, int K, const double* __restrict__ diag, const double* __restrict__ gconst,
+                                        const double* __restrict__ colscale, double* __restrict__ out)
+{
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const i64 r = e / n, cc = e - r * n;
+    const int gr = r < K ? 0 : 1 + (int)(r % K), gc = cc < K ? 0 : 1 + (int)(cc % K);
+    double v = (gr == gc) ? gconst[gr] : 0.0;
+    if (r == cc) v += diag[r];
+    out[e] = colscale ? v * colscale[cc] : v;
+}
+
+// M~ (64 q x V) holds vec(M_k) in the virtual index v = 64 a + b.  Everything stays on the device.
+__global__ void mtilde_kernel(const double* __restrict__ M, i64 V, int q, double* __restrict__ Mt /* (64 q) x V */) {
+    const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 v = blockIdx.y;                       // virtual row index 64 a + b
+    if (k >= V) return;
+    const int a = (int)(v >> 6), b = (int)(v & 63);
+    Mt[v * V + k] = (b < q) ? M[k * (i64)q * q + a * q + b] : 0.0;
+}
+
+__global__ void svec_kernel(const double* __restrict__ S1 /* q x q */, int q, double* __restrict__ sv /* 64 q */) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= 64 * q) return;
+    const int a = v >> 6, b = v & 63;
+    sv[v] = (b < q) ? S1[a * q + b] : 0.0;
+}
+
+__global__ void rank_terms_kernel(i64 V, const double* __restrict__ n_obs_dev, const double* __restrict__ t, const double* __restrict__ cvec,
+                                  double* __restrict__ A /* V x V, holds M~^T K4 M~ */) {
+    const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 i = blockIdx.y;
+    if (j >= V) return;
+    const double n_obs = *n_obs_dev;                 // the number of observations of ALL shards (summed with the statistics)
+    A[i * V + j] = 0.25 * A[i * V + j] + 0.5 * (t[i] * cvec[j] + cvec[i] * t[j]) + n_obs * cvec[i] * cvec[j];
+}
+
+__global__ __launch_bounds__(256)
+void wishart_obs_matrices_kernel(i64 total, i64 V, WishartGen g, double* __restrict__ M)
+{
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const i64 d = g.d, q = d + 1;
+    const i64 k = e / (q * q), rem = e - k * q * q;
+    const i64 a = rem / q, b = rem - a * q;
+    double val = 0.0;
+    if (k >= g.ms && k < g.ms + d) {                          // d/d m_i
+        const i64 i = k - g.ms;
+        if (a < d && b == d) val = -g.nu * g.v[a * d + i];
+        else if (a == d && b < d) val = -g.nu * g.v[b * d + i];
+        else if (a == d && b == d) val = 2.0 * g.nu * g.vm[i];
+    } else if (k == g.inu) {                                  // d/d nu: Q / nu
+        if (a < d && b < d) val = g.v[a * d + b];
+        else if (a < d) val = -g.vm[a];
+        else if (b < d) val = -g.vm[b];
+        else val = g.mvm;
+    } else if (k >= g.vs && k < g.vs + d * (d + 1) / 2) {     // d/d V_(rc) in the vector form of V (row-major lower triangle)
+        const i64 kk = k - g.vs;
+        i64 r = (i64)((sqrt(8.0 * (double)kk + 1.0) - 1.0) * 0.5);
+        while (r * (r + 1) / 2 > kk) --r;
+        while ((r + 1) * (r + 2) / 2 <= kk) ++r;
+        const i64 cc = kk - r * (r + 1) / 2;
+        const bool off = r != cc;
+        auto em = [&](i64 t) { return (t == r ? g.m[cc] : 0.0) + ((off && t == cc) ? g.m[r] : 0.0); };
+        if (a < d && b < d) val = g.nu * (((a == r && b == cc) ? 1.0 : 0.0) + ((off && a == cc && b == r) ? 1.0 : 0.0));
+        else if (a < d) val = -g.nu * em(a);
+        else if (b < d) val = -g.nu * em(b);
+        else val = g.nu * (g.m[r] * g.m[cc] * (off ? 2.0 : 1.0));
+    }
+    M[e] = val;                                               // the information block of q(mu) (ls) enters through c only: M = 0
+}
+
+// D^j g_eta [u_1 .. u_j] for the declared objective: the building block of the reference's higher-order
+// sensitivity (`ParametricSensitivityTaylorExpansion`, LRVB/ModelSensitivity.py:382-515, which obtains the
+// same quantity from j nested autograd JVPs of the gradient closure, :38-62, 221-234).  In vector coordinates
+// the linear predictor is linear in eta, so the mixed derivative has the closed form
+//   X^T ( w o loss^(j+1)(z) o (X u_2) o ... o (X u_j) o (X u_1) )   [+ s A u_1 when j = 1],
+// i.e. the cached-curvature Hessian-vector pass with a different per-observation coefficient: one skinny
+// product for z and the X u_k, one elementwise kernel, one fused pass.  j = 0 is the gradient itself.
+__device__ __forceinline__ double loss_derivative(int loss, double lik, int m, double y, double z) {
+    if (loss == LRVB_LOSS_GAUSSIAN) return m == 1 ? lik * (z - y) : (m == 2 ? lik : 0.0);
+    if (loss == LRVB_LOSS_POISSON) { const double e = exp(z); return m == 1 ? e - y : e; }
+    // logistic: loss' = sigma - y, loss^(m) = sigma^(m-1), polynomials in s = sigma(z) from
+    // P_1 = s - s^2, P_(k+1) = P_k' (s - s^2)
+    const double s = 1.0 / (1.0 + exp(-z));
+    switch (m) {
+    case 1: return s - y;
+    case 2: return s * (1.0 - s);
+    case 3: return s * (1.0 + s * (-3.0 + s * 2.0));
+    case 4: return s * (1.0 + s * (-7.0 + s * (12.0 - s * 6.0)));
+    case 5: return s * (1.0 + s * (-15.0 + s * (50.0 + s * (-60.0 + s * 24.0))));
+    case 6: return s * (1.0 + s * (-31.0 + s * (180.0 + s * (-390.0 + s * (360.0 - s * 120.0)))));
+    case 7: return s * (1.0 + s * (-63.0 + s * (602.0 + s * (-2100.0 + s * (3360.0 + s * (-2520.0 + s * 720.0))))));
+    default: return 0.0;
+    }
+}
+
+__global__ void dk_coef_kernel(i64 n, int loss, double lik, int m, const double* __restrict__ w, const double* __restrict__ y,
+                               const double* __restrict__ T, int Q, double* __restrict__ coef) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double p = w[i] * loss_derivative(loss, lik, m, y[i], T[i * Q]);
+    for (int k = 1; k < Q; ++k) p *= T[i * Q + k];
+    coef[i] = p;
+}
+
+__global__ void obs_loss_kernel(i64 n, int loss, double lik, const double* __restrict__ y, const double* __restrict__ z,
+                                double* __restrict__ out) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double zi = z[i], yi = y[i];
+    double v;
+    if (loss == LRVB_LOSS_GAUSSIAN) { const double d = zi - yi; v = 0.5 * lik * d * d; }
+    else if (loss == LRVB_LOSS_POISSON) v = exp(zi) - yi * zi;
+    else v = (zi > 0.0 ? zi + log1p(exp(-zi)) : log1p(exp(zi))) - yi * zi;       // log(1 + e^z) - y z, overflow-free
+    out[i] = v;
+}
+
+// phi(m, s) = sum_k w_k log(1 + exp(m + sqrt(2) s x_k)) / sqrt(pi) and the derivatives of THIS SUM with respect to (m, s)
+// (what autograd forms from the reference's expression), up to second order.  log(1 + e^t) in the overflow-free form.
+__device__ __forceinline__ void gh_logistic_point(double m, double sd, const double* __restrict__ gx, const double* __restrict__ gw, int K,
+                                                  double& v, double& dm, double& ds, double& dmm, double& dms, double& dss) {
+    const double r2 = 1.4142135623730951, ispi = 0.5641895835477563;     // sqrt(2), 1 / sqrt(pi)
+    v = dm = ds = dmm = dms = dss = 0.0;
+    for (int k = 0; k < K; ++k) {
+        const double xk = r2 * gx[k], wk = gw[k] * ispi;
+        const double t = m + sd * xk;
+        const double e = exp(-fabs(t));
+        const double sp = (t > 0.0 ? t : 0.0) + log1p(e);                // log(1 + e^t)
+        const double sg = t >= 0.0 ? 1.0 / (1.0 + e) : e / (1.0 + e);     // sigmoid(t)
+        const double s2 = sg * (1.0 - sg);
+        v += wk * sp; dm += wk * sg; ds += wk * sg * xk;
+        dmm += wk * s2; dms += wk * s2 * xk; dss += wk * s2 * xk * xk;
+    }
+}
+
+__global__ __launch_bounds__(256)
+void gh_logistic_kernel(i64 n, const double* __restrict__ zm, const double* __restrict__ zs, const double* __restrict__ gx,
+                        const double* __restrict__ gw, int K, int order, double* __restrict__ val, double* __restrict__ d1, double* __restrict__ d2)
+{
+    __shared__ double sx[128], sw[128];
+    if ((int)threadIdx.x < K) { sx[threadIdx.x] = gx[threadIdx.x]; sw[threadIdx.x] = gw[threadIdx.x]; }
+    __syncthreads();
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double v, dm, ds, dmm, dms, dss;
+    gh_logistic_point(zm[i], zs[i], sx, sw, K, v, dm, ds, dmm, dms, dss);
+    val[i] = v;
+    if (order >= 1) { d1[2 * i] = dm; d1[2 * i + 1] = ds; }
+    if (order >= 2) { d2[3 * i] = dmm; d2[3 * i + 1] = dms; d2[3 * i + 2] = dss; }
+}
+
+// z_n ~ N(mu_n, v_n), mu = X mean, v = (X o X) var.  Per observation psi(mu, v) = phi(mu, sqrt(v)) - y mu; this kernel turns
+// (mu, v) into the weighted coefficient vectors of the gradient and of the three Hessian products, and block sums of w psi.
+__global__ __launch_bounds__(256)
+void logitnormal_coef_kernel(i64 n, const double* __restrict__ mu, const double* __restrict__ vv, const double* __restrict__ y,
+                             const double* __restrict__ w, const double* __restrict__ gx, const double* __restrict__ gw, int K,
+                             double* __restrict__ a1, double* __restrict__ a2, double* __restrict__ c11, double* __restrict__ c12,
+                             double* __restrict__ c22, double* __restrict__ vpart)
+{
+    __shared__ double sx[128], sw[128], red[4];
+    if ((int)threadIdx.x < K) { sx[threadIdx.x] = gx[threadIdx.x]; sw[threadIdx.x] = gw[threadIdx.x]; }
+    __syncthreads();
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    double contrib = 0.0;
+    if (i < n) {
+        const double m = mu[i], var = vv[i], sd = sqrt(var), wi = w[i];
+        double v, dm, ds, dmm, dms, dss;
+        gh_logistic_point(m, sd, sx, sw, K, v, dm, ds, dmm, dms, dss);
+        // chain sd = sqrt(var): sd' = 1 / (2 sd), sd'' = -1 / (4 sd^3)
+        const double s1 = 0.5 / sd, s2 = -0.25 / (sd * var);
+        contrib = wi * (v - y[i] * m);
+        a1[i] = wi * (dm - y[i]);
+        a2[i] = wi * ds * s1;
+        c11[i] = wi * dmm;
+        c12[i] = wi * dms * s1;
+        c22[i] = wi * (dss * s1 * s1 + ds * s2);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) contrib += __shfl_xor(contrib, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = contrib;
+    __syncthreads();
+    if (threadIdx.x == 0) vpart[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}

@@ -30,10 +30,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 
 // (stride mod 32 doubles) == 16: the two 16-lane halves of a ds_read_b64 lane group read
 // consecutive observations and land on disjoint banks.
-#ifndef LRVB_WS_STRIDE
-#define LRVB_WS_STRIDE (WS_TILE + 16)
-#endif
-constexpr int WS_LDS_STRIDE = LRVB_WS_STRIDE;
+constexpr int WS_LDS_STRIDE = WS_TILE + 16;      // (strides 130 .. 152 measured in round 3: the kernel time does not move)
 
 int wsyrk_num_tiles(i64 P) {
     i64 nb = (P + WS_TILE - 1) / WS_TILE;

@@ -1,6 +1,7 @@
 // lrvb_api.hip -- the C ABI declared in include/lrvb_hip.h (context, orchestration, host<->device
-// staging).  Kernels live in the k_*.hip files.
+// staging).  Every kernel lives in a k_*.hip file; the ones this file launches itself are declared in k_kernels.h.
 #include "lrvb_internal.h"
+#include "k_kernels.h"
 #include <vector>
 #include <stdarg.h>
 #include <stdio.h>
@@ -86,12 +87,6 @@ static int h2d_beside(lrvb_ctx* c, double* dst, const double* src, size_t n) {
     HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyHostToDevice, c->aux_stream));
     HIP_TRY(hipStreamSynchronize(c->aux_stream));
     return LRVB_OK;
-}
-// small upload: the device reads the pinned slot itself (a kernel in stream order; a copy-engine transfer would put a
-// cross-queue dependency in front of the next kernel -- measured: configuration 2's step 0.66 -> 1.36 ms)
-__global__ void upload_kernel(double* __restrict__ dst, const double* __restrict__ slot, i64 n) {
-    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < n) dst[e] = slot[e];
 }
 static int h2d(lrvb_ctx* c, double* dst, const double* src, size_t n) {
     if (n == 0) return LRVB_OK;
@@ -398,36 +393,6 @@ static int data_ready(lrvb_ctx* c) {
 }
 
 // ---- small elementwise kernels used only by the orchestration -------------------------
-__global__ void mul_kernel(i64 n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ o) {
-    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) o[i] = a[i] * b[i];
-}
-__global__ void fma3_kernel(i64 n, const double* __restrict__ a, const double* __restrict__ b, const double* __restrict__ v,
-                            const double* __restrict__ j1, const double* __restrict__ he, double* __restrict__ o) {
-    // o = j1 * he + a * b * v     (box HVP epilogue: j1 (H_eta u) + g_eta eta'' v)
-    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) o[i] = j1[i] * he[i] + a[i] * b[i] * v[i];
-}
-__global__ void square_kernel(i64 n, const double* __restrict__ a, double* __restrict__ o) {
-    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) o[i] = a[i] * a[i];
-}
-__global__ void transpose_kernel(i64 rows, i64 cols, const double* __restrict__ a, double* __restrict__ o) {
-    // o (cols x rows) = a^T (a is rows x cols)
-    const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    const i64 i = blockIdx.y;
-    if (j < cols && i < rows) o[j * rows + i] = a[i * cols + j];
-}
-__global__ void diag_scale_kernel(i64 D, i64 V, double scale, const double* __restrict__ j1, double* __restrict__ C) {
-    const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    const i64 i = blockIdx.y;
-    if (j < V && i < D) C[i * V + j] = (i == j) ? scale * j1[i] : 0.0;
-}
-__global__ void symmetrize_lower_kernel(i64 n, double* __restrict__ A, i64 ld) {
-    const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    const i64 i = blockIdx.y;
-    if (j < n && i < n && j > i) A[i * ld + j] = A[j * ld + i];
-}
 static inline unsigned nb256(i64 n) { return (unsigned)((n + 255) / 256); }
 #define EW(kernel, n, ...) do { if ((n) > 0) { hipLaunchKernelGGL(kernel, dim3(nb256(n)), dim3(256), 0, c->stream, n, __VA_ARGS__); HIP_TRY(hipGetLastError()); } } while (0)
 
@@ -620,17 +585,6 @@ static int prepare_general_hvp(lrvb_ctx* c, const double* theta_dev) {
 }
 
 // ---- the resident Hessian ------------------------------------------------------------------------------------------
-// Every free-coordinate build leaves a copy of its result with the library (8 MB at D = 1024: a ~4 us device copy beside a
-// 15 ms build).  A product H v asked for at the SAME point afterwards -- lrvb_hvp, every iteration of lrvb_cg_solve and
-// lrvb_cg_solve_multi, i.e. ConjugateGradientSolver (LRVB/ConjugateGradient.py:63-105) after fun_free_hessian at the optimum --
-// is then a D x D matrix product instead of a pass over the N x P design (1.3-1.5 ms at the headline shape).  The copy is
-// dropped whenever data, weights, a hyper-parameter, the reduce hook or the tuning change (the setters), and is only used
-// for the exact point it was built at.  Adopted device buffers fall under the contract of lrvb_set_data_dev /
-// lrvb_set_weights_dev: install them again after their contents change.
-__global__ void vec_differs_kernel(i64 n, const double* __restrict__ a, const double* __restrict__ b, int* __restrict__ flag) {
-    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && !(a[i] == b[i])) atomicOr(flag, 1);
-}
 static int hres_capture(lrvb_ctx* c, const double* H_dev, i64 ld, const double* theta_dev, const double* theta_host) {
     const i64 D = c->D;
     c->hres_valid = false;
@@ -676,91 +630,6 @@ extern "C" int lrvb_stats_size(lrvb_ctx* c, int64_t* n) {
 }
 
 // ---- Gaussian loss: the build needs no pass over X besides the SYRK ------------------------------------------------
-// l = 1/2 tau (z - y)^2: the curvature c_n = w_n tau does not depend on theta, and with S = X^T diag(c) X,
-// r = X^T (c o y):   d f / d beta = S beta - r,   sum_n w_n l_n = 1/2 beta^T S beta - beta^T r + 1/2 sum c y^2.
-// r rides on the SYRK's diagonal tiles (k_wsyrk.hip), so a Hessian build reads X exactly once.
-// c = w tau, c y, and the block's share of sum c y^2 (2048 observations per block; shares summed in a fixed order later)
-__global__ __launch_bounds__(256)
-void gauss_coef_kernel(i64 n, double tau, const double* __restrict__ w, const double* __restrict__ y,
-                       double* __restrict__ cw, double* __restrict__ cy, double* __restrict__ cyy_part) {
-    __shared__ double sh[256];
-    double s = 0.0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const i64 i = (i64)blockIdx.x * 2048 + k * 256 + threadIdx.x;
-        if (i < n) { const double cv = w[i] * tau, yv = y[i]; cw[i] = cv; cy[i] = cv * yv; s += cv * yv * yv; }
-    }
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) { if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off]; __syncthreads(); }
-    if (threadIdx.x == 0) cyy_part[blockIdx.x] = sh[0];
-}
-// S beta from the tile-packed lower triangle, one workgroup per tile (bi >= bj), every tile row read once, coalesced:
-// wave w takes rows w, w + 4, ...; the row dot products are the tile's share of (S beta) in block row bi, and -- off
-// the diagonal, or below it inside a diagonal tile -- the same loaded values accumulate the share of block row bj
-// (the transposed tile).  part: [2 nb][nb * 128], zeroed by the caller; slot [bj] holds row shares, [nb + bi] column shares.
-__global__ __launch_bounds__(1024)
-void tiles_symv_kernel(const double* __restrict__ tiles, int nb, i64 P, const double* __restrict__ beta, double* __restrict__ part)
-{
-    __shared__ double colsh[16][128];         // sixteen waves: eight rows of the tile each (four waves were a 32-step latency chain)
-    const int t = blockIdx.x;
-    int bi = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
-    while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
-    while (bi * (bi + 1) / 2 > t) --bi;
-    const int bj = t - bi * (bi + 1) / 2;
-    const bool diag = bi == bj;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const double* tile = tiles + (i64)t * (WS_TILE * WS_TILE);
-    const i64 width = (i64)nb * WS_TILE;
-    const i64 j0 = (i64)bj * WS_TILE + lane, j1 = j0 + 64;
-    const double b0 = j0 < P ? beta[j0] : 0.0, b1 = j1 < P ? beta[j1] : 0.0;
-    double c0 = 0.0, c1 = 0.0;
-    for (int ii = wave; ii < WS_TILE; ii += 16) {
-        const i64 i = (i64)bi * WS_TILE + ii;
-        double s0 = tile[ii * WS_TILE + lane], s1 = tile[ii * WS_TILE + lane + 64];
-        if (i >= P) { s0 = 0.0; s1 = 0.0; }
-        if (diag) { if (lane > ii) s0 = 0.0; if (lane + 64 > ii) s1 = 0.0; }        // lower triangle incl. the diagonal
-        double d = s0 * b0 + s1 * b1;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) d += __shfl_xor(d, off);
-        if (lane == 0 && i < P) part[(i64)bj * width + i] = d;
-        const double bi_val = i < P ? beta[i] : 0.0;
-        // transposed share: strictly below the diagonal inside a diagonal tile (the diagonal itself is in the row share)
-        c0 += ((diag && lane == ii) ? 0.0 : s0) * bi_val;
-        c1 += ((diag && lane + 64 == ii) ? 0.0 : s1) * bi_val;
-    }
-    colsh[wave][lane] = c0; colsh[wave][lane + 64] = c1;
-    __syncthreads();
-    if (threadIdx.x < 128) {
-        const i64 j = (i64)bj * WS_TILE + threadIdx.x;
-        if (j < P) {
-            double cs = colsh[0][threadIdx.x];
-#pragma unroll
-            for (int g = 1; g < 16; ++g) cs += colsh[g][threadIdx.x];
-            part[(i64)(nb + bi) * width + j] = cs;
-        }
-    }
-}
-// one block: g = S beta - r from the shares, value = 1/2 beta^T S beta - beta^T r + 1/2 sum c y^2
-__global__ __launch_bounds__(1024)
-void gauss_finish_kernel(const double* __restrict__ part, int nb, i64 P, const double* __restrict__ beta, const double* __restrict__ r,
-                         const double* __restrict__ cyy_part, int n_cyy, double* __restrict__ value_out, double* __restrict__ g_out)
-{
-    __shared__ double sh[1024];
-    const i64 width = (i64)nb * WS_TILE;
-    double acc_v = 0.0;
-    for (int k = threadIdx.x; k < n_cyy; k += 1024) acc_v += 0.5 * cyy_part[k];
-    for (i64 i = threadIdx.x; i < P; i += 1024) {
-        double acc = 0.0;
-        for (int k = 0; k < 2 * nb; ++k) acc += part[(i64)k * width + i];
-        g_out[i] = acc - r[i];
-        acc_v += beta[i] * (0.5 * acc - r[i]);
-    }
-    sh[threadIdx.x] = acc_v;
-    __syncthreads();
-    for (int off = 512; off > 0; off >>= 1) { if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off]; __syncthreads(); }
-    if (threadIdx.x == 0) *value_out = sh[0];
-}
 
 static bool gauss_shortcut(const lrvb_ctx* c) {
     return c->loss == LRVB_LOSS_GAUSSIAN && wsyrk_fast_path(c) && c->P <= 4096;
@@ -1052,41 +921,6 @@ extern "C" int lrvb_free_hessian_from_vector(lrvb_ctx* c, const double* free_in,
 static int gemm_tn(lrvb_ctx* c, i64 K, i64 PA, i64 PB, const double* A, const double* B, double* C);
 
 // ---- vector-coordinate Hessian assembled on the device from small host blocks ------------------------------
-// The N-independent closed forms of the quadratic-in-data objectives are Kronecker products of k x k
-// matrices sandwiched between duplication matrices: D^T (A (x) B) D is a k(k+1)/2-square block (4 M entries
-// at k = 63) that is cheap to WRITE but expensive to form with dense host algebra.  The host sends A and B.
-__global__ void hvec_symkron_kernel(i64 total, i64 m, int k, const double* __restrict__ A, const double* __restrict__ B, double coef,
-                                    double* __restrict__ H, i64 ld, i64 row_off, i64 col_off, int mirror)
-{
-    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= total) return;                                  // total = m * m (the EW launcher passes the element count first)
-    const i64 r = e / m, cidx = e - r * m;
-    // vech index -> (i, j), j <= i, row-major lower triangle (SymIndex of LRVB/MatrixParameters.py:16-23)
-    int i = (int)((sqrt(8.0 * (double)r + 1.0) - 1.0) * 0.5);
-    while ((i64)i * (i + 1) / 2 > r) --i;
-    while ((i64)(i + 1) * (i + 2) / 2 <= r) ++i;
-    const int j = (int)(r - (i64)i * (i + 1) / 2);
-    int p = (int)((sqrt(8.0 * (double)cidx + 1.0) - 1.0) * 0.5);
-    while ((i64)p * (p + 1) / 2 > cidx) --p;
-    while ((i64)(p + 1) * (p + 2) / 2 <= cidx) ++p;
-    const int q = (int)(cidx - (i64)p * (p + 1) / 2);
-    double v = A[i * k + p] * B[j * k + q];
-    if (i != j) v += A[j * k + p] * B[i * k + q];
-    if (p != q) v += A[i * k + q] * B[j * k + p];
-    if (i != j && p != q) v += A[j * k + q] * B[i * k + p];
-    v *= coef;
-    H[(row_off + r) * ld + col_off + cidx] += v;
-    if (mirror) H[(col_off + cidx) * ld + row_off + r] += v;
-}
-__global__ void hvec_add_block_kernel(i64 total, i64 cols, const double* __restrict__ Bk, double* __restrict__ H, i64 ld,
-                                      i64 row_off, i64 col_off, int mirror)
-{
-    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= total) return;                                  // total = rows * cols
-    const i64 r = e / cols, cidx = e - r * cols;
-    H[(row_off + r) * ld + col_off + cidx] += Bk[e];
-    if (mirror) H[(col_off + cidx) * ld + row_off + r] += Bk[e];
-}
 extern "C" int lrvb_hvec_begin(lrvb_ctx* c) {
     LRVB_TRY(ctx_bind(c));
     LRVB_TRY(buf_reserve(c, c->Heta, (size_t)c->V * (size_t)c->V));
@@ -1106,16 +940,6 @@ extern "C" int lrvb_hvec_add_block(lrvb_ctx* c, const double* block, int64_t row
     LRVB_TRY(h2d(c, c->work1.p, block, (size_t)(rows * cols)));
     EW(hvec_add_block_kernel, rows * cols, cols, c->work1.p, c->Heta.p, c->V, row_off, col_off, mirror);
     return LRVB_OK;
-}
-// H[rows[a], cols[b]] += block[a, b]: a dense block scattered over index lists (the coupled rows of an arrow Hessian
-// are not contiguous).  The index lists travel as doubles behind the block (one upload).
-__global__ void hvec_add_indexed_kernel(i64 total, i64 nc, const double* __restrict__ Bk, const double* __restrict__ ridx,
-                                        const double* __restrict__ cidx, double* __restrict__ H, i64 ld)
-{
-    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= total) return;
-    const i64 a = e / nc, b = e - a * nc;
-    H[(i64)ridx[a] * ld + (i64)cidx[b]] += Bk[e];
 }
 extern "C" int lrvb_hvec_add_indexed(lrvb_ctx* c, const double* block, int64_t nr, int64_t nc, const int64_t* rows, const int64_t* cols) {
     LRVB_TRY(ctx_bind(c));
@@ -1236,10 +1060,6 @@ static int hvec_finish_impl(lrvb_ctx* c, const double* point, int64_t n_in, int 
 }
 
 // ---- cross Hessians ----------------------------------------------------------------------
-__global__ void fill_kernel(i64 n, double v, double* __restrict__ o) {
-    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) o[i] = v;
-}
 
 static int obs_grad_impl(lrvb_ctx* c, const double* point, i64 n_in, bool is_free, i64 n0, i64 n1, double* G_out) {
     LRVB_TRY(ctx_bind(c));
@@ -1443,41 +1263,7 @@ extern "C" int lrvb_gram(lrvb_ctx* c, const double* free_in, int64_t D, double* 
 }
 
 // ---- objectives quadratic in the data -----------------------------------------------------------
-__global__ __launch_bounds__(256)
-void obs_quadform_kernel(const double* __restrict__ Z, i64 ldz, int q, const double* __restrict__ M,
-                         const double* __restrict__ cvec, i64 K, i64 n0, i64 n1, double* __restrict__ out)
-{
-    const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    const i64 n = n0 + blockIdx.y;
-    if (k >= K || n >= n1) return;
-    const double* z = Z + n * ldz;
-    const double* Mk = M + k * (i64)q * q;
-    double s = 0.0;
-    for (int a = 0; a < q; ++a) {
-        double t = 0.0;
-        for (int b = 0; b < q; ++b) t += Mk[a * q + b] * z[b];
-        s += z[a] * t;
-    }
-    out[(n - n0) * K + k] = 0.5 * s + (cvec ? cvec[k] : 0.0);
-}
 
-// part[b] = sum of v over block b's contiguous slice (fixed tree); the partials are summed by sum_partials_kernel
-__global__ __launch_bounds__(256)
-void vec_block_sums_kernel(i64 n, const double* __restrict__ v, double* __restrict__ part) {
-    __shared__ double sh[256];
-    const i64 per = (n + gridDim.x - 1) / gridDim.x;
-    const i64 a = (i64)blockIdx.x * per, b = a + per < n ? a + per : n;
-    double s = 0.0;
-    for (i64 i = a + threadIdx.x; i < b; i += 256) s += v[i];
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
-}
-__global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ part, i64 n, double* __restrict__ out);
 
 static int weighted_gram_impl(lrvb_ctx* c, double* S_out, int64_t ld, double* wsum_out);
 extern "C" int lrvb_weighted_gram(lrvb_ctx* c, double* S_out, int64_t ld) { return weighted_gram_impl(c, S_out, ld, nullptr); }
@@ -1537,38 +1323,6 @@ extern "C" int lrvb_obs_quadform(lrvb_ctx* c, const double* M, const double* cve
 }
 
 // ---- grouped sufficient statistics (hierarchical models: BASELINE.json config 4) -----------------
-// out[g, 0] = sum_{n in g} w_n,  out[g, 1 + j] = sum_{n in g} w_n z_nj.  One wavefront per group walks
-// the group's rows in a fixed order (counting-sort permutation built once on the host when the group
-// ids are set), lane = column: deterministic, no atomics.  These are the per-group Sigma w, Sigma w y,
-// Sigma w x of doc/lmm.lyx:105-160.
-__global__ __launch_bounds__(256)
-void group_sums_kernel(const double* __restrict__ Z, i64 ldz, int q, const double* __restrict__ w,
-                       const i64* __restrict__ perm, const i64* __restrict__ offs, i64 n_groups,
-                       double* __restrict__ out)
-{
-    const int lane = threadIdx.x & 63;
-    const i64 g = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (g >= n_groups) return;
-    const i64 b = offs[g], e = offs[g + 1];
-    double sw = 0.0, s0 = 0.0;                  // lane j < q accumulates column j; every lane tracks sum w
-    i64 k = b;
-    for (; k + 1 < e; k += 2) {                 // two rows in flight
-        const i64 n0 = perm[k], n1 = perm[k + 1];
-        const double w0 = w[n0], w1 = w[n1];
-        const double z0 = lane < q ? Z[n0 * ldz + lane] : 0.0;
-        const double z1 = lane < q ? Z[n1 * ldz + lane] : 0.0;
-        sw += w0; s0 += w0 * z0;
-        sw += w1; s0 += w1 * z1;
-    }
-    if (k < e) {
-        const i64 n0 = perm[k];
-        const double w0 = w[n0];
-        sw += w0; s0 += w0 * (lane < q ? Z[n0 * ldz + lane] : 0.0);
-    }
-    double* dst = out + g * (i64)(q + 1);
-    if (lane == 0) dst[0] = sw;
-    if (lane < q) dst[1 + lane] = s0;
-}
 
 extern "C" int lrvb_set_groups(lrvb_ctx* c, const int32_t* gid, int64_t n, int64_t n_groups) {
     LRVB_TRY(ctx_bind(c));
@@ -1652,79 +1406,6 @@ extern "C" int lrvb_grouped_stats(lrvb_ctx* c, double* S_out, double* gs_out) {
     return LRVB_OK;
 }
 
-// One wavefront per batch of groups, lane = column of the group's row [W_g | sum w x (p) | sum w y] of the resident
-// statistics.  For group g (doc/lmm.lyx:105-160; e_g, i_g the mean and information of q(u_g)):
-//   r_g = sum w y - (sum w x) . m,   a_g = W_g e_g - r_g,   d_g = e_g - e_mu,   D_g = ty W_g + tm,
-// the two columns of the arrow Hessian's cross block that belong to (e_g, i_g), in vector coordinates of the p + 5
-// coupled global rows [mean of q(beta) (p) | e_mu | a_y | b_y | a_mu | b_mu], times d local / d free,
-//   c_e = [ty sum w x | -tm | a_g tay | a_g tby | d_g tam | d_g tbm],
-//   c_i = [0 | 0 | -W_g tay / (2 i_g^2) | -W_g tby / (2 i_g^2) | -tam / (2 i_g^2) | -tbm / (2 i_g^2)] * (i_g - lb),
-// go to rows 2g and 2g + 1 of C (width ldc), the reciprocals of the free local diagonal to the weights; the sums over
-// groups that the global gradient and the scalars of the ELBO need are accumulated per wave (fixed order) in `part`.
-//   sums[0 .. p) = sum_g e_g sum w x;  sums[64 + k]: 0 sum e_g r_g, 1 sum W_g (e_g^2 + 1 / i_g), 2 sum d_g^2 + 1 / i_g,
-//   3 sum d_g, 4 sum log i_g, 5 sum W_g, 6 sum (local free gradient)^2 (a stationarity diagnostic)
-__global__ __launch_bounds__(256)
-void lmm_group_kernel(const double* __restrict__ gs, i64 G, int p, const double* __restrict__ par, const double* __restrict__ floc,
-                      double* __restrict__ C, int ldc, double* __restrict__ wts, double* __restrict__ part)
-{
-    const int lane = threadIdx.x & 63;
-    const i64 gw = (i64)blockIdx.x * 4 + (threadIdx.x >> 6), GW = (i64)gridDim.x * 4;
-    const double ty = par[0], tm = par[1], e_mu = par[2], tay = par[3], tby = par[4], tam = par[5], tbm = par[6], lb = par[7];
-    const double mj = (lane >= 1 && lane <= p) ? par[8 + lane - 1] : 0.0;       // m aligned with the sum w x lanes
-    const int q1 = p + 2;                                                     // entries of a statistics row
-    double v1 = 0.0;                                                          // lane 1 + j: sum_g e_g (sum w x)_j
-    double sc[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    for (i64 g = gw; g < G; g += GW) {
-        const double val = lane < q1 ? gs[g * q1 + lane] : 0.0;
-        double dotv = val * mj;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) dotv += __shfl_xor(dotv, off);
-        const double W = __shfl(val, 0), sy = __shfl(val, p + 1);
-        const double eg = floc[g], ig = lb + exp(floc[G + g]), jl = ig - lb;
-        const double rg = sy - dotv, a = W * eg - rg, d = eg - e_mu, Dg = ty * W + tm;
-        const double i2 = 1.0 / (ig * ig);
-        const double dl_i = Dg * i2 / ig - 0.5 * i2, g_i = -0.5 * Dg * i2 + 0.5 / ig, g_e = ty * a + tm * d;
-        const double dfe = Dg, dfi = dl_i * jl * jl + g_i * jl;
-        const double sx = __shfl(val, lane + 1 < 64 ? lane + 1 : 63);           // lane r < p: (sum w x)_r
-        double ce, ci;
-        if (lane < p) { ce = ty * sx; ci = 0.0; }
-        else if (lane == p) { ce = -tm; ci = 0.0; }
-        else if (lane == p + 1) { ce = a * tay; ci = -0.5 * W * i2 * tay * jl; }
-        else if (lane == p + 2) { ce = a * tby; ci = -0.5 * W * i2 * tby * jl; }
-        else if (lane == p + 3) { ce = d * tam; ci = -0.5 * i2 * tam * jl; }
-        else if (lane == p + 4) { ce = d * tbm; ci = -0.5 * i2 * tbm * jl; }
-        else { ce = 0.0; ci = 0.0; }
-        if (lane < ldc) { C[(2 * g) * (i64)ldc + lane] = ce; C[(2 * g + 1) * (i64)ldc + lane] = ci; }
-        if (lane == 0) { wts[2 * g] = 1.0 / dfe; wts[2 * g + 1] = 1.0 / dfi; }
-        v1 += val * eg;
-        sc[0] += eg * rg; sc[1] += W * (eg * eg + 1.0 / ig); sc[2] += d * d + 1.0 / ig; sc[3] += d;
-        sc[4] += log(ig); sc[5] += W; sc[6] += g_e * g_e + (g_i * jl) * (g_i * jl);
-    }
-    double* dst = part + gw * 128;
-    dst[lane] = (lane >= 1 && lane <= p) ? v1 : 0.0;          // shifted by one: slot 1 + j
-    if (lane < 7) dst[64 + lane] = sc[lane];
-    else dst[64 + lane] = 0.0;
-}
-// sums[k] = sum over the wave partials in a fixed order (eight interleaved slices, then the slices in order); the vector
-// part is moved down by one slot
-__global__ __launch_bounds__(1024)
-void lmm_sums_kernel(const double* __restrict__ part, int n_waves, double* __restrict__ sums) {
-    __shared__ double sh[8][128];
-    const int k = threadIdx.x & 127, sl = threadIdx.x >> 7;
-    double a0 = 0.0, a1 = 0.0;
-    int wv = sl;
-    for (; wv + 8 < n_waves; wv += 16) { a0 += part[(i64)wv * 128 + k]; a1 += part[(i64)(wv + 8) * 128 + k]; }
-    if (wv < n_waves) a0 += part[(i64)wv * 128 + k];
-    sh[sl][k] = a0 + a1;
-    __syncthreads();
-    if (sl == 0) {
-        double a = 0.0;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) a += sh[s][k];
-        if (k < 64) { if (k >= 1) sums[k - 1] = a; if (k == 63) sums[63] = 0.0; }
-        else sums[k] = a;
-    }
-}
 
 // par (host, 8 + p): [ty, tm, e_mu, d ty / d a_y, d ty / d b_y, d tm / d a_mu, d tm / d b_mu, lower bound of the local
 // informations, m (p)]; f_local (host, 2 G): the FREE local parameters [e_1..e_G | log(i_g - lb)].  out (host,
@@ -1768,12 +1449,6 @@ extern "C" int lrvb_lmm_group_terms(lrvb_ctx* c, const double* par, int64_t n_pa
     return d2h(c, out, sums, (size_t)(128 + R * R));
 }
 
-// tail[0..1] = val2, tail[2] = number of rows whose local block was not positive definite, tail[3] = 0
-__global__ void mixture_tail_kernel(i64 n, const double* __restrict__ val2, const int* __restrict__ bad, double* __restrict__ tail) {
-    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    tail[i] = (i < 2) ? val2[i] : (i == 2 ? (double)(*bad) : 0.0);
-}
 // ---- mixture model: per-row simplex blocks eliminated on the device (config 3) --------------------
 // Inputs: free local parameters theta_z (N x (K-1)), Lam ((V+1) x K) = [E log pi; E log phi].
 // Outputs: val2 = [-sum w z.s, sum w z log z], the free local gradient (N x (K-1)), the weighted
@@ -1865,29 +1540,6 @@ extern "C" int lrvb_mixture_stats(lrvb_ctx* c, int32_t K, const double* theta_z,
 }
 
 // ---- Schur complement of the mixture's global block, assembled on the device -------------------------
-// Rm[(j K + k), (j' K + k')] = R[(j q + j'), (k K + k')]: the (q^2 x K^2) operand re-indexed as the square
-// matrix that sits between d vec(Lam) / d free and its transpose
-__global__ void mixture_permute_kernel(i64 total, int q, int K, const double* __restrict__ R, double* __restrict__ Rm)
-{
-    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= total) return;
-    const i64 n = (i64)q * K;
-    const i64 r = e / n, cc = e - r * n;
-    const int j = (int)(r / K), k = (int)(r - (i64)j * K), jp = (int)(cc / K), kp = (int)(cc - (i64)jp * K);
-    Rm[e] = R[((i64)j * q + jp) * ((i64)K * K) + (i64)k * K + kp];
-}
-// H = diag(s) Hgg diag(s) + diag(d) - 1/2 (S + S^T)
-__global__ void mixture_schur_finish_kernel(i64 total, i64 n, const double* __restrict__ Hgg, const double* __restrict__ sc,
-                                            const double* __restrict__ dg, const double* __restrict__ S, double* __restrict__ H)
-{
-    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= total) return;
-    const i64 r = e / n, cc = e - r * n;
-    double v = Hgg[e];
-    if (sc) v *= sc[r] * sc[cc];
-    if (dg && r == cc) v += dg[r];
-    H[e] = v - 0.5 * (S[e] + S[cc * n + r]);
-}
 
 // Shared tail of the two Schur entry points: Jd (n x n) and Hd (n x n) are on the device, sc / dg (nullable) too.
 static int mixture_schur_core(lrvb_ctx* c, int32_t K, int32_t q, const double* sc, const double* dg, double* H_out) {
@@ -1929,22 +1581,6 @@ extern "C" int lrvb_mixture_schur(lrvb_ctx* c, int32_t K, int32_t q, const doubl
     return mixture_schur_core(c, K, q, sc, dg, H_out);
 }
 
-// A matrix that is diagonal plus a constant on the blocks of a partition, times a column scaling:
-//   out[r, c] = ( [r == c] diag[r] + [group(r) == group(c)] gconst[group(r)] ) * colscale[c],
-// group(r) = 0 for r < K (the Dirichlet over the K mixture weights), 1 + (r mod K) otherwise (the K Dirichlets over the
-// vocabulary, parameter (v, k) at index K + v K + k): the shape of d E log p / d alpha and of the Dirichlet entropy /
-// expectation Hessians (diag(psi1(alpha)) - psi1(alpha_0): LRVB/ExponentialFamilies.py:118-120, DirichletParams.py:19-26).
-__global__ void dirichlet_blocks_kernel(i64 total, i64 n, int K, const double* __restrict__ diag, const double* __restrict__ gconst,
-                                        const double* __restrict__ colscale, double* __restrict__ out)
-{
-    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= total) return;
-    const i64 r = e / n, cc = e - r * n;
-    const int gr = r < K ? 0 : 1 + (int)(r % K), gc = cc < K ? 0 : 1 + (int)(cc % K);
-    double v = (gr == gc) ? gconst[gr] : 0.0;
-    if (r == cc) v += diag[r];
-    out[e] = colscale ? v * colscale[cc] : v;
-}
 
 // The same Schur complement with BOTH n x n inputs generated on the device from their O(n) description (six n-vectors
 // and two (K + 1)-vectors instead of two 8 MB matrices at n = 1024), the operand R taken from the lrvb_mixture_rows /
@@ -2012,67 +1648,10 @@ static int gemm_tn(lrvb_ctx* c, i64 K, i64 PA, i64 PB, const double* A, const do
     return launch_atb(c, A, PA, B, PB, K, c->ones.p, C);
 }
 
-// M~ (64 q x V) holds vec(M_k) in the virtual index v = 64 a + b.  Everything stays on the device.
-__global__ void mtilde_kernel(const double* __restrict__ M, i64 V, int q, double* __restrict__ Mt /* (64 q) x V */) {
-    const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    const i64 v = blockIdx.y;                       // virtual row index 64 a + b
-    if (k >= V) return;
-    const int a = (int)(v >> 6), b = (int)(v & 63);
-    Mt[v * V + k] = (b < q) ? M[k * (i64)q * q + a * q + b] : 0.0;
-}
-__global__ void svec_kernel(const double* __restrict__ S1 /* q x q */, int q, double* __restrict__ sv /* 64 q */) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= 64 * q) return;
-    const int a = v >> 6, b = v & 63;
-    sv[v] = (b < q) ? S1[a * q + b] : 0.0;
-}
-__global__ void rank_terms_kernel(i64 V, const double* __restrict__ n_obs_dev, const double* __restrict__ t, const double* __restrict__ cvec,
-                                  double* __restrict__ A /* V x V, holds M~^T K4 M~ */) {
-    const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    const i64 i = blockIdx.y;
-    if (j >= V) return;
-    const double n_obs = *n_obs_dev;                 // the number of observations of ALL shards (summed with the statistics)
-    A[i * V + j] = 0.25 * A[i * V + j] + 0.5 * (t[i] * cvec[j] + cvec[i] * t[j]) + n_obs * cvec[i] * cvec[j];
-}
 
 // The per-coordinate matrices M_k of the Wishart + MVN model's per-observation term (LRVB/NormalParams.py:6-23,
 // WishartParams.py:6-35;  l_n = 1/2 z^T Q z + c with z = [y; 1], Q = nu [[V, -V m], [-m^T V, m^T V m]]), written on the device
 // from (nu, m, V m, V): V q^2 doubles (134 MB at d = 63) that the host used to build and send over PCIe in every call.
-struct WishartGen { i64 d, ms, ls, inu, vs; double nu, mvm; const double* m; const double* vm; const double* v; };
-__global__ __launch_bounds__(256)
-void wishart_obs_matrices_kernel(i64 total, i64 V, WishartGen g, double* __restrict__ M)
-{
-    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= total) return;
-    const i64 d = g.d, q = d + 1;
-    const i64 k = e / (q * q), rem = e - k * q * q;
-    const i64 a = rem / q, b = rem - a * q;
-    double val = 0.0;
-    if (k >= g.ms && k < g.ms + d) {                          // d/d m_i
-        const i64 i = k - g.ms;
-        if (a < d && b == d) val = -g.nu * g.v[a * d + i];
-        else if (a == d && b < d) val = -g.nu * g.v[b * d + i];
-        else if (a == d && b == d) val = 2.0 * g.nu * g.vm[i];
-    } else if (k == g.inu) {                                  // d/d nu: Q / nu
-        if (a < d && b < d) val = g.v[a * d + b];
-        else if (a < d) val = -g.vm[a];
-        else if (b < d) val = -g.vm[b];
-        else val = g.mvm;
-    } else if (k >= g.vs && k < g.vs + d * (d + 1) / 2) {     // d/d V_(rc) in the vector form of V (row-major lower triangle)
-        const i64 kk = k - g.vs;
-        i64 r = (i64)((sqrt(8.0 * (double)kk + 1.0) - 1.0) * 0.5);
-        while (r * (r + 1) / 2 > kk) --r;
-        while ((r + 1) * (r + 2) / 2 <= kk) ++r;
-        const i64 cc = kk - r * (r + 1) / 2;
-        const bool off = r != cc;
-        auto em = [&](i64 t) { return (t == r ? g.m[cc] : 0.0) + ((off && t == cc) ? g.m[r] : 0.0); };
-        if (a < d && b < d) val = g.nu * (((a == r && b == cc) ? 1.0 : 0.0) + ((off && a == cc && b == r) ? 1.0 : 0.0));
-        else if (a < d) val = -g.nu * em(a);
-        else if (b < d) val = -g.nu * em(b);
-        else val = g.nu * (g.m[r] * g.m[cc] * (off ? 2.0 : 1.0));
-    }
-    M[e] = val;                                               // the information block of q(mu) (ls) enters through c only: M = 0
-}
 
 static int quadform_gram_impl(lrvb_ctx* c, const double* M, const WishartGen* gen, const double* cvec, int64_t K,
                               const double* free_in, double* GtG_out, int64_t ld);
@@ -2329,17 +1908,6 @@ extern "C" int lrvb_lrvb_cov(lrvb_ctx* c, const double* M, int64_t Q, int64_t D,
 }
 
 // ---- weight sensitivity of moments, streamed over the observations ------------
-// out[n - n0, q] = -(G H^-1 M^T)[n, q] = d (moment q) / d w_n  by linear response, for rows n0..n1 of G.
-// G = diag(l') X J_glm is never formed: W = H^-1 M^T (D x Q) from the resident Cholesky factor,
-// Z = J_glm W (P x Q), and the rows of X are multiplied by Z in one pass, scaled by -l'_n.
-__global__ void row_scale_rows_kernel(i64 total, i64 Q, const double* __restrict__ rowscale, double alpha, double* __restrict__ C) {
-    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;      // total = rows * Q (the EW launcher passes the element count first)
-    if (e < total) C[e] *= alpha * rowscale[e / Q];
-}
-__global__ void scale_slice_rows_kernel(i64 total, i64 Q, const double* __restrict__ j1, const double* __restrict__ W, double* __restrict__ Z) {
-    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;      // total = P * Q
-    if (e < total) Z[e] = (j1 ? j1[e / Q] : 1.0) * W[e];
-}
 static int obs_influence_impl(lrvb_ctx* c, const double* point, i64 n_in, bool is_free, const double* M, i64 Q,
                               i64 n0, i64 n1, double* out) {
     LRVB_TRY(ctx_bind(c));
@@ -2488,51 +2056,8 @@ extern "C" int lrvb_cg_solve(lrvb_ctx* c, const double* free_in, const double* b
 }
 
 // ---- higher-order directional derivatives of the gradient (vector coordinates) -------------------------
-// D^j g_eta [u_1 .. u_j] for the declared objective: the building block of the reference's higher-order
-// sensitivity (`ParametricSensitivityTaylorExpansion`, LRVB/ModelSensitivity.py:382-515, which obtains the
-// same quantity from j nested autograd JVPs of the gradient closure, :38-62, 221-234).  In vector coordinates
-// the linear predictor is linear in eta, so the mixed derivative has the closed form
-//   X^T ( w o loss^(j+1)(z) o (X u_2) o ... o (X u_j) o (X u_1) )   [+ s A u_1 when j = 1],
-// i.e. the cached-curvature Hessian-vector pass with a different per-observation coefficient: one skinny
-// product for z and the X u_k, one elementwise kernel, one fused pass.  j = 0 is the gradient itself.
-__device__ __forceinline__ double loss_derivative(int loss, double lik, int m, double y, double z) {
-    if (loss == LRVB_LOSS_GAUSSIAN) return m == 1 ? lik * (z - y) : (m == 2 ? lik : 0.0);
-    if (loss == LRVB_LOSS_POISSON) { const double e = exp(z); return m == 1 ? e - y : e; }
-    // logistic: loss' = sigma - y, loss^(m) = sigma^(m-1), polynomials in s = sigma(z) from
-    // P_1 = s - s^2, P_(k+1) = P_k' (s - s^2)
-    const double s = 1.0 / (1.0 + exp(-z));
-    switch (m) {
-    case 1: return s - y;
-    case 2: return s * (1.0 - s);
-    case 3: return s * (1.0 + s * (-3.0 + s * 2.0));
-    case 4: return s * (1.0 + s * (-7.0 + s * (12.0 - s * 6.0)));
-    case 5: return s * (1.0 + s * (-15.0 + s * (50.0 + s * (-60.0 + s * 24.0))));
-    case 6: return s * (1.0 + s * (-31.0 + s * (180.0 + s * (-390.0 + s * (360.0 - s * 120.0)))));
-    case 7: return s * (1.0 + s * (-63.0 + s * (602.0 + s * (-2100.0 + s * (3360.0 + s * (-2520.0 + s * 720.0))))));
-    default: return 0.0;
-    }
-}
-__global__ void dk_coef_kernel(i64 n, int loss, double lik, int m, const double* __restrict__ w, const double* __restrict__ y,
-                               const double* __restrict__ T, int Q, double* __restrict__ coef) {
-    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double p = w[i] * loss_derivative(loss, lik, m, y[i], T[i * Q]);
-    for (int k = 1; k < Q; ++k) p *= T[i * Q + k];
-    coef[i] = p;
-}
 
 // ---- per-observation loss values: the gradient of the objective with respect to the weights -----------------
-__global__ void obs_loss_kernel(i64 n, int loss, double lik, const double* __restrict__ y, const double* __restrict__ z,
-                                double* __restrict__ out) {
-    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const double zi = z[i], yi = y[i];
-    double v;
-    if (loss == LRVB_LOSS_GAUSSIAN) { const double d = zi - yi; v = 0.5 * lik * d * d; }
-    else if (loss == LRVB_LOSS_POISSON) v = exp(zi) - yi * zi;
-    else v = (zi > 0.0 ? zi + log1p(exp(-zi)) : log1p(exp(zi))) - yi * zi;       // log(1 + e^z) - y z, overflow-free
-    out[i] = v;
-}
 
 extern "C" int lrvb_obs_loss(lrvb_ctx* c, const double* point, int64_t n_in, int is_free, int64_t n0, int64_t n1, double* out) {
     LRVB_TRY(ctx_bind(c));
@@ -2561,38 +2086,6 @@ extern "C" int lrvb_obs_loss(lrvb_ctx* c, const double* point, int64_t n_in, int
 }
 
 // ---- non-conjugate logistic term by Gauss-Hermite quadrature (LRVB/Modeling.py:36-52) ------------------------------------
-// phi(m, s) = sum_k w_k log(1 + exp(m + sqrt(2) s x_k)) / sqrt(pi) and the derivatives of THIS SUM with respect to (m, s)
-// (what autograd forms from the reference's expression), up to second order.  log(1 + e^t) in the overflow-free form.
-__device__ __forceinline__ void gh_logistic_point(double m, double sd, const double* __restrict__ gx, const double* __restrict__ gw, int K,
-                                                  double& v, double& dm, double& ds, double& dmm, double& dms, double& dss) {
-    const double r2 = 1.4142135623730951, ispi = 0.5641895835477563;     // sqrt(2), 1 / sqrt(pi)
-    v = dm = ds = dmm = dms = dss = 0.0;
-    for (int k = 0; k < K; ++k) {
-        const double xk = r2 * gx[k], wk = gw[k] * ispi;
-        const double t = m + sd * xk;
-        const double e = exp(-fabs(t));
-        const double sp = (t > 0.0 ? t : 0.0) + log1p(e);                // log(1 + e^t)
-        const double sg = t >= 0.0 ? 1.0 / (1.0 + e) : e / (1.0 + e);     // sigmoid(t)
-        const double s2 = sg * (1.0 - sg);
-        v += wk * sp; dm += wk * sg; ds += wk * sg * xk;
-        dmm += wk * s2; dms += wk * s2 * xk; dss += wk * s2 * xk * xk;
-    }
-}
-__global__ __launch_bounds__(256)
-void gh_logistic_kernel(i64 n, const double* __restrict__ zm, const double* __restrict__ zs, const double* __restrict__ gx,
-                        const double* __restrict__ gw, int K, int order, double* __restrict__ val, double* __restrict__ d1, double* __restrict__ d2)
-{
-    __shared__ double sx[128], sw[128];
-    if ((int)threadIdx.x < K) { sx[threadIdx.x] = gx[threadIdx.x]; sw[threadIdx.x] = gw[threadIdx.x]; }
-    __syncthreads();
-    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double v, dm, ds, dmm, dms, dss;
-    gh_logistic_point(zm[i], zs[i], sx, sw, K, v, dm, ds, dmm, dms, dss);
-    val[i] = v;
-    if (order >= 1) { d1[2 * i] = dm; d1[2 * i + 1] = ds; }
-    if (order >= 2) { d2[3 * i] = dmm; d2[3 * i + 1] = dms; d2[3 * i + 2] = dss; }
-}
 
 extern "C" int lrvb_gh_logistic(lrvb_ctx* c, int64_t n, const double* z_mean, const double* z_sd, const double* gh_x, const double* gh_w,
                                 int32_t n_nodes, int32_t order, double* val, double* d1, double* d2) {
@@ -2615,56 +2108,6 @@ extern "C" int lrvb_gh_logistic(lrvb_ctx* c, int64_t n, const double* z_mean, co
 }
 
 // ---- logistic regression with a mean-field Gaussian variational posterior (the model that expectation is written for) -------
-// z_n ~ N(mu_n, v_n), mu = X mean, v = (X o X) var.  Per observation psi(mu, v) = phi(mu, sqrt(v)) - y mu; this kernel turns
-// (mu, v) into the weighted coefficient vectors of the gradient and of the three Hessian products, and block sums of w psi.
-__global__ __launch_bounds__(256)
-void logitnormal_coef_kernel(i64 n, const double* __restrict__ mu, const double* __restrict__ vv, const double* __restrict__ y,
-                             const double* __restrict__ w, const double* __restrict__ gx, const double* __restrict__ gw, int K,
-                             double* __restrict__ a1, double* __restrict__ a2, double* __restrict__ c11, double* __restrict__ c12,
-                             double* __restrict__ c22, double* __restrict__ vpart)
-{
-    __shared__ double sx[128], sw[128], red[4];
-    if ((int)threadIdx.x < K) { sx[threadIdx.x] = gx[threadIdx.x]; sw[threadIdx.x] = gw[threadIdx.x]; }
-    __syncthreads();
-    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    double contrib = 0.0;
-    if (i < n) {
-        const double m = mu[i], var = vv[i], sd = sqrt(var), wi = w[i];
-        double v, dm, ds, dmm, dms, dss;
-        gh_logistic_point(m, sd, sx, sw, K, v, dm, ds, dmm, dms, dss);
-        // chain sd = sqrt(var): sd' = 1 / (2 sd), sd'' = -1 / (4 sd^3)
-        const double s1 = 0.5 / sd, s2 = -0.25 / (sd * var);
-        contrib = wi * (v - y[i] * m);
-        a1[i] = wi * (dm - y[i]);
-        a2[i] = wi * ds * s1;
-        c11[i] = wi * dmm;
-        c12[i] = wi * dms * s1;
-        c22[i] = wi * (dss * s1 * s1 + ds * s2);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) contrib += __shfl_xor(contrib, off);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = contrib;
-    __syncthreads();
-    if (threadIdx.x == 0) vpart[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-}
-// out[0] = sum of part[0 .. n) in a fixed order (one workgroup: strided partial sums, then a tree)
-__global__ __launch_bounds__(256)
-void sum_partials_kernel(const double* __restrict__ part, i64 n, double* __restrict__ out) {
-    __shared__ double sh[256];
-    double a = 0.0;
-    for (i64 i = threadIdx.x; i < n; i += 256) a += part[i];
-    sh[threadIdx.x] = a;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[0] = sh[0];
-}
-__global__ void rowscale_kernel(i64 n, i64 P, const double* __restrict__ cvec, const double* __restrict__ B, double* __restrict__ o) {
-    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) o[i] = cvec[i / P] * B[i];
-}
 // C (P x P) = A^T diag(cvec) B over N rows: the LDS-DMA MFMA kernel when the operands allow, the generic tile GEMM on a
 // row-scaled copy otherwise
 static int weighted_tn(lrvb_ctx* c, const double* A, const double* B, i64 P, i64 N, const double* cvec_padded, double* C, DevBuf& scratch) {
@@ -2957,43 +2400,6 @@ extern "C" int lrvb_minimize_trust_ncg(lrvb_ctx* c, const double* y0, int64_t D,
 }
 
 // ---- blocked conjugate gradients: Q right-hand sides share every pass over the observations ------------
-// Q independent CG recurrences (the ones `ConjugateGradientSolver.get_hinv_vec_subsets` runs one after the
-// other, LRVB/ConjugateGradient.py:87-105) advance in lockstep, so that the Hessian-vector products of an
-// iteration become ONE pair of skinny MFMA GEMMs over X -- T = X U_glm^T (N x Q), then X^T diag(c) T (P x Q)
-// -- instead of Q fused passes.  Block vectors are Q x D row-major (one right-hand side per row).
-__global__ void mul_rows_kernel(i64 n, i64 D, const double* __restrict__ a, const double* __restrict__ v, double* __restrict__ o) {
-    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < n) o[e] = a[e % D] * v[e];
-}
-__global__ void fma3_rows_kernel(i64 n, i64 D, const double* __restrict__ g, const double* __restrict__ j2, const double* __restrict__ v,
-                                 const double* __restrict__ j1, const double* __restrict__ he, double* __restrict__ o) {
-    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < n) { const i64 d = e % D; o[e] = j1[d] * he[e] + g[d] * j2[d] * v[e]; }
-}
-__global__ void diag_mul_add_rows_kernel(i64 n, i64 V, double scale, const double* __restrict__ a, const double* __restrict__ u, double* __restrict__ out) {
-    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < n) out[e] += scale * a[e % V] * u[e];
-}
-__global__ void scatter_rows_T_kernel(i64 n, i64 Q, i64 V, i64 P, i64 off, const double* __restrict__ Rt, i64 ldr, double* __restrict__ out) {
-    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;        // e over Q x P
-    if (e < n) { const i64 q = e / P, p = e - q * P; out[q * V + off + p] = Rt[p * ldr + q]; }
-}
-// per-row scalars of the block recurrences
-__global__ void rows_dot_kernel(i64 Q, i64 D, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out) {
-    __shared__ double sh[256];
-    const i64 q = blockIdx.x;
-    double s = 0.0;
-    for (i64 d = threadIdx.x; d < D; d += 256) s += a[q * D + d] * b[q * D + d];
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) { if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off]; __syncthreads(); }
-    if (threadIdx.x == 0) out[q] = sh[0];
-}
-__global__ void rows_axpby_kernel(i64 n, i64 D, const double* __restrict__ alpha, const double* __restrict__ x,
-                                  const double* __restrict__ beta, double* __restrict__ y) {
-    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;        // y = alpha[q] x + beta[q] y
-    if (e < n) { const i64 q = e / D; y[e] = alpha[q] * x[e] + beta[q] * y[e]; }
-}
 
 static int heta_apply_multi(lrvb_ctx* c, i64 Q, const double* U /* Q x V */, double* Out /* Q x V */) {
     const i64 V = c->V, P = c->P, N = c->N;
@@ -3044,79 +2450,8 @@ static int hvp_apply_multi(lrvb_ctx* c, i64 Q, const double* Vb, double* Out) {
     return launch_gemm(c, false, false, Q, D, D, 1.0, Vb, D, c->Tdense.p, D, 1.0, Out, D);        // + Vb T (T symmetric)
 }
 
-// step lengths of the blocked CG on the device: alpha_q = (r.z)_q / (p.Hp)_q for the systems still running (the ones whose
-// direction was updated in this iteration: z coefficient 1), 0 for the frozen ones; the coefficient rows of the two updates
-// x += alpha p, r -= alpha q are written in place.  Saves the second host round trip of every iteration.
-__global__ void cg_multi_alpha_kernel(int Q, double* __restrict__ s) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= Q) return;
-    const bool act = s[4 * Q + q] != 0.0;
-    const double alpha = act ? s[2 * Q + q] / s[3 * Q + q] : 0.0;
-    s[4 * Q + q] = alpha; s[5 * Q + q] = 1.0; s[6 * Q + q] = -alpha; s[7 * Q + q] = 1.0;
-}
 
 // ---- blocked CG, fused form (box layouts, no preconditioner): an iteration is FIVE launches and no host round trip ------
-// s: [ |b|^2 (Q) | rho_prev (Q) | r.r (Q) | live (Q) | iterations (Q) | live after even iterations (Q) | after odd ones (Q) ].  head: r.r, the convergence test, beta, p = r + beta p
-// and the product's operand u = eta' o p in one kernel (one workgroup per system); tail: q = eta' (W + s A u) + g eta'' p
-// formed on the fly, p.q, alpha, x += alpha p, r -= alpha q.  The host runs ONE ITERATION AHEAD of its convergence test
-// (the status of iteration k is read on a side stream while iteration k + 1 is already queued); when every system has
-// stopped, the queued product is skipped on the device by the `live` flags.  Round 2's loop had twelve launches, a
-// device-to-host and a host-to-device copy per iteration: ~135 us beside the 1.52 ms product.
-__global__ __launch_bounds__(256)
-void cg_multi_head_kernel(i64 D, i64 it, double tol, const double* __restrict__ j1, const double* __restrict__ R,
-                          double* __restrict__ Pm, double* __restrict__ U, double* __restrict__ s, i64 Q)
-{
-    __shared__ double sh[256];
-    __shared__ double bc[2];
-    const i64 q = blockIdx.x;
-    const double* r = R + q * D;
-    double a = 0.0;
-    for (i64 d = threadIdx.x; d < D; d += 256) a += r[d] * r[d];
-    sh[threadIdx.x] = a;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) { if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off]; __syncthreads(); }
-    if (threadIdx.x == 0) {
-        const double rr = sh[0];
-        double live = s[3 * Q + q], beta = 0.0;
-        if (live != 0.0) {
-            if (sqrt(rr) < tol * sqrt(s[q])) { live = 0.0; s[4 * Q + q] = (double)it; }
-            else { const double rp = s[Q + q]; beta = (it > 0 && rp != 0.0) ? rr / rp : 0.0; s[Q + q] = rr; s[4 * Q + q] = (double)(it + 1); }
-        }
-        s[2 * Q + q] = rr; s[3 * Q + q] = live;
-        // the flag of THIS iteration's test, in the slot of its parity: what the host reads back (the live flags themselves are
-        // rewritten by the head kernel of iteration it + 1, which may already be queued -- a copy of s[3Q..] could hold either state)
-        s[(5 + (it & 1)) * Q + q] = live;
-        bc[0] = live; bc[1] = beta;
-    }
-    __syncthreads();
-    const bool live = bc[0] != 0.0;
-    const double beta = bc[1];
-    double* p = Pm + q * D; double* u = U + q * D;
-    for (i64 d = threadIdx.x; d < D; d += 256) {
-        const double pv = live ? r[d] + beta * p[d] : p[d];           // a stopped system keeps its direction
-        p[d] = pv; u[d] = j1 ? j1[d] * pv : pv;                       // j1 null: the product runs in free coordinates (resident Hessian)
-    }
-}
-__global__ __launch_bounds__(256)
-void cg_multi_tail_kernel(i64 D, double sq, const double* __restrict__ quadA /* nullable */, const double* __restrict__ j1,
-                          const double* __restrict__ j2, const double* __restrict__ g, const double* __restrict__ W,
-                          const double* __restrict__ U, const double* __restrict__ Pm, double* __restrict__ X,
-                          double* __restrict__ R, const double* __restrict__ s, i64 Q)
-{
-    __shared__ double sh[256];
-    const i64 q = blockIdx.x;
-    if (s[3 * Q + q] == 0.0) return;                                  // stopped: nothing moves
-    const double* p = Pm + q * D; const double* w = W + q * D; const double* u = U + q * D;
-    auto qv = [&](i64 d) { return j1 ? j1[d] * (w[d] + (quadA ? sq * quadA[d] * u[d] : 0.0)) + g[d] * j2[d] * p[d] : w[d]; };
-    double a = 0.0;
-    for (i64 d = threadIdx.x; d < D; d += 256) a += p[d] * qv(d);
-    sh[threadIdx.x] = a;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) { if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off]; __syncthreads(); }
-    const double alpha = s[2 * Q + q] / sh[0];
-    double* x = X + q * D; double* r = R + q * D;
-    for (i64 d = threadIdx.x; d < D; d += 256) { x[d] += alpha * p[d]; r[d] -= alpha * qv(d); }
-}
 
 static bool cg_multi_fused_ok(const lrvb_ctx* c, const double* Minv, i64 Q) {
     return Q <= 400 && c->all_box && !Minv && c->loss != LRVB_LOSS_NONE && c->quad_kind != LRVB_QUAD_DENSE && c->V == c->D &&
