@@ -20,7 +20,7 @@ from scipy import special
 from scipy import sparse as sp_sparse
 
 from . import _hip
-from .models import DeviceContext, DeclaredHypers, sym_to_vech, vech_to_sym
+from .models import DeviceContext, DeclaredHypers, sym_to_vech, vech_to_sym, refuse_double_reduction
 from .packing import VectorParam, HyperVectorParam, ResidentVector
 from .quadform import (duplication_matrix, mvn_prior_hyper_grad, mvn_prior_hyper_cross, gamma_prior_hyper_grad,
                        gamma_prior_hyper_cross)
@@ -206,15 +206,24 @@ class LMMObjective(DeclaredHypers):
         """S (q x q, host copy) with the group sums left ON THE DEVICE, both summed over the ranks inside the library
         when the context carries a reduce hook (`ShardedObjective`, `native_comm_init`)."""
         self._push_state()
+        self._check_hook_epoch()
         if getattr(self, '_S_dev', None) is None:
             self._S_dev = self.ctx.grouped_stats(want_S=True, want_gs=False)[0]
         return self._S_dev
+
+    def _check_hook_epoch(self):
+        """A reduce hook installed or removed since the statistics were cached makes them stale (local vs global sums)."""
+        if getattr(self, '_epoch', None) != self.ctx.hook_epoch:
+            self._stats_cache = None
+            self._S_dev = None
+            self._epoch = self.ctx.hook_epoch
 
     def local_stats(self):
         """The statistics as one flat host vector [S (q*q) | group sums (G*(q+1))]: this process's own rows -- the
         buffer a host-side all-reduce (`allreduce_stats`, the gloo tests) sums over shards -- or, when the context carries
         a reduce hook, already the sum over all ranks (one reduction of the device buffer inside `lrvb_grouped_stats`)."""
         self._push_state()
+        self._check_hook_epoch()
         if self._stats_cache is None:
             S, gs = self.ctx.grouped_stats(want_S=True, want_gs=True)
             self._stats_cache = np.concatenate([S.ravel(), gs.ravel()])
@@ -222,6 +231,7 @@ class LMMObjective(DeclaredHypers):
 
     def set_reduced_stats(self, flat):
         """Install statistics summed over all shards (None = use this process's own)."""
+        refuse_double_reduction(getattr(self, "ctx", None), flat)
         self._external_stats = None if flat is None else np.asarray(flat, dtype=np.float64).copy()
 
     def _stats(self):

@@ -23,7 +23,7 @@ import numpy as np
 from scipy import special, sparse
 
 from . import _hip
-from .models import DeviceContext, DeclaredHypers
+from .models import DeviceContext, DeclaredHypers, refuse_double_reduction
 from .packing import VectorParam, HyperVectorParam, ResidentVector
 from .specfun import polygamma12
 
@@ -261,8 +261,9 @@ class MixtureObjective(DeclaredHypers):
         return flat[:2], flat[2:2 + 4096].reshape(64, 64), flat[2 + 4096:].reshape((self.V + 1) ** 2, self.K ** 2)
 
     def local_stats(self, free_val):
-        """[val2 (2) | S64 (4096) | R ((V+1)^2 K^2)] of THIS process's rows at free_val: the buffer
-        that is all-reduced when observations (and their simplex rows) are sharded over GPUs."""
+        """[val2 (2) | S64 (4096) | R ((V+1)^2 K^2)] at free_val: of THIS process's rows (the buffer a host-side exchange
+        all-reduces when observations and their simplex rows are sharded over GPUs), or -- with a reduce hook on the
+        context -- already the sums over all ranks, reduced on the device inside the statistics call."""
         self._push_state()
         fg, fz = self._split(free_val)
         _, _, lam = self._lam(self._lb + np.exp(fg))
@@ -271,6 +272,7 @@ class MixtureObjective(DeclaredHypers):
 
     def set_reduced_stats(self, flat):
         """Install statistics summed over all shards (None = use this process's own)."""
+        refuse_double_reduction(getattr(self, "ctx", None), flat)
         self._external_stats = None if flat is None else np.asarray(flat, dtype=np.float64).copy()
 
     # ---- functor protocol ------------------------------------------------------------------------------

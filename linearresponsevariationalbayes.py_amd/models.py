@@ -84,6 +84,7 @@ class DeviceContext(object):
         self.device = int(device)
         self.quad_scale = 1.0
         self.has_reduce_hook = False   # a sum-over-ranks hook is installed: the statistics calls return GLOBAL sums
+        self.hook_epoch = 0            # bumped whenever a hook / communicator is installed or removed: host caches of statistics key on it
         self._hook_cb = None
 
     def close(self):
@@ -126,6 +127,7 @@ class DeviceContext(object):
         hip_stream (the context's stream).  None removes it.  An exception raised by `fn` fails the library call
         that triggered it and is re-raised from there."""
         self._hook_error = None
+        self.hook_epoch += 1
         if fn is None:
             self._check(self._lib.lrvb_set_reduce_hook(self._h, None, None))
             self._hook_cb = None
@@ -160,9 +162,11 @@ class DeviceContext(object):
         self._check(self._lib.lrvb_comm_init(self._h, int(world_size), int(rank), ctypes.cast(buf, ctypes.c_void_p)))
         self._hook_cb = None          # only now: a failed call leaves the C side pointing at the old trampoline
         self.has_reduce_hook = True
+        self.hook_epoch += 1
 
     def comm_destroy(self):
         self._check(self._lib.lrvb_comm_destroy(self._h))
+        self.hook_epoch += 1
         if self._hook_cb is None:
             self.has_reduce_hook = False
 
@@ -342,16 +346,18 @@ class DeviceContext(object):
         self._hv_ops, self._hv_data, self._hv_len, self._hv_seen = [], [], 0, {}
 
     def _hv_put(self, arr):
-        """Position of an operand in the program's data (an array object that was already sent is not sent twice)."""
-        key = id(arr)
-        hit = self._hv_seen.get(key)
-        if hit is not None and hit[1] is arr:
-            return hit[0]
+        """Position of an operand in the program's data.  The operand is COPIED at record time (the caller may reuse its
+        array for the next block, as the call-per-block entry points allow); an operand with the same contents as one
+        already recorded travels once."""
+        flat = np.array(arr, dtype=np.float64).ravel()          # private copy
+        key = (flat.size, flat.tobytes()) if flat.size <= 8192 else None
+        if key is not None and key in self._hv_seen:
+            return self._hv_seen[key]
         off = self._hv_len
-        flat = arr.ravel()
         self._hv_data.append(flat)
         self._hv_len += flat.size
-        self._hv_seen[key] = (off, arr)
+        if key is not None:
+            self._hv_seen[key] = off
         return off
 
     def hvec_add_block(self, block, row_off, col_off, mirror=False):
@@ -372,6 +378,8 @@ class DeviceContext(object):
         cidx = np.ascontiguousarray(cols, dtype=np.int64).ravel()
         if B.shape != (r.size, cidx.size):
             raise ValueError('block must be len(rows) x len(cols)')
+        if np.unique(r).size != r.size or np.unique(cidx).size != cidx.size:
+            raise ValueError('an index list names an element twice (the device adds the entries in parallel)')
         if self._hv_ops is None:
             self._check(self._lib.lrvb_hvec_add_indexed(self._h, _hip.ptr(B), r.size, cidx.size,
                                                        r.ctypes.data_as(ctypes.c_void_p), cidx.ctypes.data_as(ctypes.c_void_p)))
@@ -736,6 +744,14 @@ class DeviceContext(object):
         p = _hip.Prof()
         self._check(self._lib.lrvb_profile_get(self._h, ctypes.byref(p)))
         return {name: getattr(p, name) for name, _ in _hip.Prof._fields_}
+
+
+def refuse_double_reduction(ctx, flat):
+    """`set_reduced_stats(...)` installs statistics that the CALLER summed over the ranks.  With a sum-over-ranks hook on the
+    context the statistics calls already return global sums: summing those again multiplies them by the world size."""
+    if flat is not None and getattr(ctx, 'has_reduce_hook', False):
+        raise RuntimeError('this context reduces inside the library (reduce hook / in-library communicator): its statistics '
+                           'are already sums over all ranks -- do not all-reduce and install them again')
 
 
 class DeclaredHypers(object):

@@ -21,6 +21,7 @@ import numbers
 from collections import OrderedDict
 
 import numpy as np
+from copy import deepcopy
 from scipy.sparse import coo_matrix, block_diag
 
 from . import _hip
@@ -253,6 +254,23 @@ class HyperVectorParam(VectorParam):
         self._val = val
         HyperVectorParam._stamp[0] += 1
         self.version = HyperVectorParam._stamp[0]
+
+    def __deepcopy__(self, memo):
+        """A copy is a parameter of its own: a fresh version stamp and a frozen private array (copy.deepcopy would
+        otherwise hand out the original's stamp with a WRITEABLE array, and an in-place write to the clone would go
+        unnoticed by `ResidentVector`)."""
+        clone = self.__class__.__new__(self.__class__)
+        memo[id(self)] = clone
+        for k, v in self.__dict__.items():
+            if k not in ('_val', 'version'):
+                setattr(clone, k, deepcopy(v, memo))
+        clone.set(self._val)
+        return clone
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        if '_val' in state:
+            self.set(state['_val'])                              # re-freeze and re-stamp after unpickling
 
 
 class ResidentVector(object):

@@ -18,7 +18,7 @@ beta an ArrayParam with lb = 0, Lambda a PosDefMatrixParam) -- BASELINE.json con
 import numpy as np
 
 from . import _hip
-from .models import DeviceContext, DeclaredHypers, sym_to_vech, vech_to_sym
+from .models import DeviceContext, DeclaredHypers, sym_to_vech, vech_to_sym, refuse_double_reduction
 from .packing import VectorParam, HyperVectorParam, ResidentVector
 
 
@@ -121,23 +121,28 @@ class QuadraticDataObjective(DeclaredHypers):
         if ext is not None:
             return ext[:-1].reshape(self.q, self.q), float(ext[-1])
         self._push_state()
-        if self._S is None:
+        if self._S is None or getattr(self, '_S_epoch', None) != self.ctx.hook_epoch:
             # GPU: sum_n w_n z_n z_n^T and sum_n w_n in one buffer -- with a reduce hook on the context (observations sharded
-            # over ranks) both arrive summed over all ranks, one reduction
+            # over ranks) both arrive summed over all ranks, one reduction.  (A hook installed or removed since the last
+            # evaluation makes the cached statistics stale: they key on the context's hook epoch.)
             self._S, self._W = self.ctx.weighted_gram(with_sum=True)
+            self._S_epoch = self.ctx.hook_epoch
         return self._S, self._W
 
     # ---- observations sharded over GPUs: the statistics are sums over rows ---------------------------
     def local_stats(self):
-        """[S (q*q) | W] of THIS process's rows: the buffer of the one sum all-reduce per evaluation
-        (SURVEY.md section 8(e)); value, gradient and Hessian are then replicated host closed forms.
-        G^T G (`gram`) is additive over shards as well: all-reduce the matrices the ranks return."""
+        """[S (q*q) | W]: the statistics every evaluation is a closed form of.  Without a reduce hook these are THIS
+        process's rows -- the buffer of the one sum all-reduce per evaluation that a host-side
+        exchange (`distributed.allreduce_stats` + `set_reduced_stats`) performs.  With a hook on the context
+        (`ShardedObjective`, `native_comm_init`) they are ALREADY the sums over all ranks, reduced on the device inside
+        the statistics call; `gram` likewise returns the global G^T G then."""
         self._external_stats = None
         S, W = self._stats()
         return np.concatenate([np.asarray(S, dtype=np.float64).ravel(), [W]])
 
     def set_reduced_stats(self, flat):
         """Install statistics summed over all shards (None = use this process's own)."""
+        refuse_double_reduction(getattr(self, "ctx", None), flat)
         if flat is None:
             self._external_stats = None
             return
@@ -184,7 +189,7 @@ class QuadraticDataObjective(DeclaredHypers):
 
     def _hessian_cached(self, x, is_free):
         self._push_state()
-        key = (bool(is_free), np.asarray(x, dtype=np.float64).tobytes(), self._w_res.key, self._hyper_state_key())
+        key = (bool(is_free), np.asarray(x, dtype=np.float64).tobytes(), self._w_res.key, self._hyper_state_key(), self.ctx.hook_epoch)
         if getattr(self, '_h_key', None) != key:
             self._h_val = self.hessian(x, is_free)
             self._h_key = key

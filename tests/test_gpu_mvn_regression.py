@@ -90,3 +90,34 @@ def test_config2_full_size(vb):
     e_tau = par['tau'].e()
     np.testing.assert_allclose(np.linalg.inv(par['beta']['info'].get()),
                                np.linalg.inv(e_tau * x.T @ x + 0.1 * np.eye(k)), rtol=1e-4, atol=1e-10)
+
+
+def test_statistics_are_not_reduced_twice_under_a_hook(vb):
+    """Advisor finding, round 3: with a sum-over-ranks hook on the context the statistics calls return GLOBAL sums; the host flow
+    `set_reduced_stats(allreduce_stats(local_stats()))` would multiply them by the world size.  It is refused, and the host
+    caches of the statistics follow the hook (installed / removed) instead of going stale."""
+    rng = np.random.default_rng(5)
+    x, y, par, fun, lay, ft = _build(vb, rng, 500, 3)
+    local = fun.local_stats().copy()
+    calls = []
+
+    def doubling_hook(ptr, n, stream):                      # stands for "sum over two identical ranks"
+        import torch
+        from lrvb_amd.distributed import _DevicePointer
+        t = torch.as_tensor(_DevicePointer(ptr, n), device='cuda:0')
+        t.mul_(2.0)
+        calls.append(n)
+    import torch
+    fun.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    fun.ctx.set_reduce_hook(doubling_hook)
+    try:
+        under_hook = fun.local_stats()
+        assert calls and np.allclose(under_hook, 2.0 * local, rtol=1e-14)      # not the cached local statistics
+        with pytest.raises(RuntimeError):
+            fun.set_reduced_stats(under_hook)
+    finally:
+        fun.ctx.set_reduce_hook(None)
+        fun.ctx.set_stream(None)
+    np.testing.assert_allclose(fun.local_stats(), local, rtol=1e-14)          # hook removed: local again, not the doubled cache
+    fun.set_reduced_stats(local)                                               # the host-side exchange is fine without a hook
+    fun.set_reduced_stats(None)

@@ -714,6 +714,22 @@ def test_hvec_program_equals_the_call_per_block_route(vb):
         H_prog, H_imm = assemble(False, is_free), assemble(True, is_free)
         assert np.array_equal(H_prog, H_imm)
         assert np.allclose(H_prog, H_prog.T, rtol=0, atol=1e-12 * np.abs(H_prog).max())
+    # operands are copied when they are recorded: a caller that reuses ONE scratch array for several blocks gets each block's
+    # contents at the time of its call, as with the call-per-block entry points (advisor finding, round 3)
+    def assemble_with_scratch(immediate):
+        scratch = np.empty((5, 5))
+        ctx.hvec_begin(immediate=immediate)
+        scratch[:] = blk
+        ctx.hvec_add_block(scratch, 0, 0)
+        scratch[:] = 2.0 * blk                                 # overwritten before finish
+        ctx.hvec_add_block(scratch[:, :4].copy(), 0, 5 + m, mirror=True)
+        scratch[:] = -7.0
+        return ctx.hvec_finish(np.zeros(V), g, False)
+    assert np.array_equal(assemble_with_scratch(False), assemble_with_scratch(True))
+    # an index list that names an element twice is refused (the device adds the entries in parallel)
+    ctx.hvec_begin()
+    with pytest.raises(ValueError):
+        ctx.hvec_add_indexed(sc, np.array([0, 2, 2, 3]), rows)
     # a block that does not fit is refused when it is recorded (and the library checks every record again before it launches anything)
     ctx.hvec_begin()
     with pytest.raises(ValueError):

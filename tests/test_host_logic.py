@@ -767,3 +767,24 @@ def test_sensitivity_to_prior_hyper_parameters_host_logic():
             e1 = np.linalg.norm(sens.predict_input_par_from_hyperparameters(h0 + d) - t1)
             e2 = np.linalg.norm(sens.predict_input_par_from_hyperparameters(h0 + d / 2) - t2)
             assert e1 < 0.3 * np.linalg.norm(t1 - theta0) + 1e-12 and e2 < 0.3 * e1 + 1e-12, (name, hyper_is_free, e1, e2)
+
+
+def test_hyper_vector_param_copies_are_parameters_of_their_own():
+    """Advisor finding, round 3: `copy.deepcopy` of a HyperVectorParam handed out the original's version stamp with a
+    WRITEABLE array -- an in-place write to the clone would have gone unnoticed by the resident-copy check.  A copy (deep
+    copy, pickle round trip) now carries a fresh stamp and a frozen private array."""
+    import pickle
+    from copy import deepcopy
+    from lrvb_amd.packing import ResidentVector
+    p = vb.HyperVectorParam('w', 4, lb=0.0, val=np.arange(1.0, 5.0))
+    for q in (deepcopy(p), pickle.loads(pickle.dumps(p))):
+        assert q.version != p.version and q.name == 'w' and q._lb == 0.0
+        np.testing.assert_array_equal(q.get_vector(), p.get_vector())
+        assert not q.get().flags.writeable and q.get() is not p.get()
+        with pytest.raises(ValueError):
+            q.get()[0] = 9.0
+        res = ResidentVector()
+        assert res.changed(p) is not None and res.changed(p) is None
+        assert res.changed(q) is not None                        # the copy is a different resident state
+        q.set_vector(np.full(4, 2.0))
+        np.testing.assert_array_equal(p.get_vector(), np.arange(1.0, 5.0))     # the original is untouched
