@@ -357,6 +357,25 @@ int lrvb_grouped_stats(lrvb_ctx* ctx, double* S_out, double* gs_out);
  * diagonal for this model) -- what the reference would obtain from the D x D autograd Hessian and a sparse solve
  * (LRVB/SparseObjectives.py:581-657).                                                                                  */
 int lrvb_lmm_group_terms(lrvb_ctx* ctx, const double* par, int64_t n_par, const double* f_local, int64_t n_local, double* out);
+/* ---- a whole step of configurations 2 and 4 as ONE call (round 4) --------------------------------------------------------
+ * The N-independent closed forms of these models are affine in the sufficient statistics, with coefficients that depend on
+ * theta only.  The caller sends those coefficients (`hp`: P = Lambda^-1, polygamma values, priors -- see csrc/k_lmm.hip for
+ * the layout) together with theta in ONE upload; the library forms the statistics (summed over the ranks), combines them
+ * with the coefficients in a single-workgroup kernel where they lie, writes the Kronecker block of the information matrix,
+ * and converts to free coordinates (LRVB/Parameters.py:397-424) -- no device-to-host copy inside the call.  The result
+ * stays in HBM (lrvb_chol_factor_last factors it); H_out / value_out / sums_out may be NULL.
+ *
+ * lrvb_mvnreg_hessian: MVNParam regression (configuration 2; LRVB/NormalParams.py:6-23, GammaParams.py:4-16,
+ *   regression_utils.py:59-132), the context holds the rows [x | y]; idx = vector positions of [mean, vech(information),
+ *   shape, rate].
+ * lrvb_lmm_global_hessian: hierarchical LMM (configuration 4; doc/lmm.lyx:77-160): `data_ctx` holds the rows [x | y] and the
+ *   groups, `global_ctx` the packing of the global parameters; idx = vector positions of [mean, vech(information), e_mu,
+ *   i_mu, a_y, b_y, a_mu, b_mu]; free_val = [global free parameters | e_1..e_G | log(i_g - info_lb)].  Result: the Schur
+ *   complement of the arrow Hessian onto the global block, in free coordinates, in global_ctx.                         */
+int lrvb_mvnreg_hessian(lrvb_ctx* ctx, const double* free_in, int64_t D, const double* hp, int64_t n_hp, const int32_t* idx,
+                        double* value_out, double* H_out);
+int lrvb_lmm_global_hessian(lrvb_ctx* data_ctx, lrvb_ctx* global_ctx, const double* free_val, int64_t n_free, const double* hp,
+                            int64_t n_hp, const int32_t* idx, double info_lb, double* sums_out, double* H_out);
 
 /* Mixture models with a SimplexParam row per observation (LRVB/SimplexParams.py:69-175): for every
  * row, on one wavefront, the simplex map and its closed-form Jacobian / Hessian (:33-63), the local

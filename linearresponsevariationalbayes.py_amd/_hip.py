@@ -109,6 +109,8 @@ _SIGNATURES = {
     'lrvb_group_sums': [_VP, _VP],
     'lrvb_grouped_stats': [_VP, _VP, _VP],
     'lrvb_lmm_group_terms': [_VP, _VP, c_i64, _VP, c_i64, _VP],
+    'lrvb_mvnreg_hessian': [_VP, _VP, c_i64, _VP, c_i64, _VP, _VP, _VP],
+    'lrvb_lmm_global_hessian': [_VP, _VP, _VP, c_i64, _VP, c_i64, _VP, ctypes.c_double, _VP, _VP],
     'lrvb_quadform_gram': [_VP, _VP, _VP, c_i64, _VP, _VP, c_i64],
     'lrvb_wishart_gram': [_VP, c_i64, _VP, ctypes.c_double, _VP, _VP, _VP, _VP, _VP, c_i64],
     'lrvb_cg_solve_matrix': [_VP, _VP, _VP, _VP, _VP, ctypes.c_double, c_i64, c_i64, _VP,

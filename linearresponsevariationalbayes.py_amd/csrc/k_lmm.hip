@@ -377,3 +377,262 @@ int launch_grouped_stats_fused(lrvb_ctx* c, double* S_dense_dev, double* gs_dev)
     }
     return LRVB_OK;
 }
+
+// ---- N-independent closed forms ON THE DEVICE (round 4) -----------------------------------------------------------------------
+// Round 3 evaluated the closed forms of configurations 2 and 4 on the host: every step copied the reduced statistics back
+// (three synchronous round trips in configuration 4), did 43 x 43 algebra in numpy and sent the blocks up again -- 0.55 ms of
+// host time around 0.2 ms of kernels.  The vector-coordinate Hessian and gradient are AFFINE in the statistics with
+// coefficients that depend on theta only (P = Lambda^-1, polygamma values, the prior), so the host now sends those
+// coefficients ONCE per step, before anything is computed, and one workgroup combines them with the statistics where they
+// lie: no device-to-host copy inside a step.
+//
+// hp (host pack), doubles: [0] ty [1] tm [2] e_mu [3] i_mu [4] a_y [5] b_y [6] a_mu [7] b_mu [8] d ty/d a_y [9] d ty/d b_y
+// [10] d tm/d a_mu [11] d tm/d b_mu [12] kappa0 [13] mu0 [14] a0y [15] b0y [16] a0m [17] b0m [18] G [19] psi1(a_y)
+// [20] psi2(a_y) [21] psi1(a_mu) [22] psi2(a_mu); from [32]: m (p), beta0 (p), P (p x p), Lambda0 (p x p), P Lambda0 P (p x p).
+// sums / Md: the output of the group elimination (lmm_group_kernel + lmm_sums_kernel + Gram), S the q x q weighted Gram.
+// Formulas: LMMObjective._arrow / _global_hessian_device of hierarchical.py (doc/lmm.lyx:105-160), pinned against exact AD in
+// tests/test_lmm_host_math.py.
+__device__ __forceinline__ double block_sum_1024(double v, double* sh) {
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) { if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off]; __syncthreads(); }
+    const double r = sh[0];
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ void vech_rc(int k, int& r, int& c) {
+    int a = (int)((sqrt(8.0 * (double)k + 1.0) - 1.0) * 0.5);
+    while (a * (a + 1) / 2 > k) --a;
+    while ((a + 1) * (a + 2) / 2 <= k) ++a;
+    r = a; c = k - a * (a + 1) / 2;
+}
+__global__ __launch_bounds__(1024)
+void lmm_closed_forms_kernel(LmmIdx ix, const double* __restrict__ S, const double* __restrict__ sums, const double* __restrict__ Md,
+                             const double* __restrict__ hp, double* __restrict__ T /* scratch: p^2 */, double* __restrict__ PSP /* scratch: p^2 */,
+                             double* __restrict__ g, double* __restrict__ H, double* __restrict__ Gc)
+{
+    __shared__ double sh[1024];
+    __shared__ double um[64];
+    __shared__ double sc[16];
+    const int p = ix.p, q = p + 1, tid = threadIdx.x;
+    const i64 ld = ix.ld;
+    const double ty = hp[0], tm = hp[1], e_mu = hp[2], i_mu = hp[3], ay = hp[4], by = hp[5], am = hp[6], bm = hp[7];
+    const double tay = hp[8], tby = hp[9], tam = hp[10], tbm = hp[11], kappa0 = hp[12], mu0 = hp[13];
+    const double a0y = hp[14], b0y = hp[15], a0m = hp[16], b0m = hp[17], Gn = hp[18];
+    const double* m = hp + 32; const double* beta0 = m + p; const double* P = beta0 + p; const double* lam0 = P + p * p; const double* PL0P = lam0 + p * p;
+    // T = Sxx P; um = Sxx m - Sxy + v1; rss; trace(T)
+    double tr = 0.0;
+    for (int e = tid; e < p * p; e += 1024) {
+        const int i = e / p, j = e - i * p;
+        double a = 0.0;
+        for (int k = 0; k < p; ++k) a += S[i * q + k] * P[k * p + j];
+        T[e] = a;
+        if (i == j) tr += a;
+    }
+    double rs = 0.0;
+    if (tid < p) {
+        double a = 0.0;
+        for (int k = 0; k < p; ++k) a += S[tid * q + k] * m[k];
+        rs = m[tid] * (a - 2.0 * S[tid * q + p]);
+        um[tid] = a - S[tid * q + p] + sums[tid];
+    }
+    const double trT = block_sum_1024(tr, sh);
+    const double rss = block_sum_1024(rs, sh) + S[p * q + p];
+    // PSP = P T; Gc = ty PSP + P Lambda0 P
+    for (int e = tid; e < p * p; e += 1024) {
+        const int i = e / p, j = e - i * p;
+        double a = 0.0;
+        for (int k = 0; k < p; ++k) a += P[i * p + k] * T[k * p + j];
+        PSP[e] = a;
+        Gc[e] = ty * a + PL0P[e];
+    }
+    if (tid == 0) {
+        const double s_eg_rg = sums[64], s_W_e2 = sums[65], s_d2 = sums[66], W = sums[69];
+        const double Ay = rss + trT - 2.0 * s_eg_rg + s_W_e2, Am = s_d2 + Gn / i_mu;
+        sc[0] = 0.5 * Ay + b0y; sc[1] = 0.5 * Am + b0m;                 // f_ty, f_tm
+        sc[2] = -0.5 * W - (a0y - 1.0); sc[3] = -0.5 * Gn - (a0m - 1.0);  // f_Ly, f_Lm
+    }
+    __syncthreads();
+    const double f_ty = sc[0], f_tm = sc[1], f_Ly = sc[2], f_Lm = sc[3], dsum = sums[67];
+    const double p1y = hp[19], p2y = hp[20], p1m = hp[21], p2m = hp[22];
+    // gamma blocks: gradient (2) and Hessian (2 x 2) in (shape, rate) of f_t a / b + f_L (psi(a) - log b) - entropy
+    const double gy0 = f_ty / by + f_Ly * p1y - (1.0 + (1.0 - ay) * p1y), gy1 = -f_ty * ay / (by * by) - f_Ly / by + 1.0 / by;
+    const double Hy00 = f_Ly * p2y + p1y - (1.0 - ay) * p2y, Hy01 = -f_ty / (by * by), Hy11 = 2.0 * f_ty * ay / (by * by * by) + f_Ly / (by * by) - 1.0 / (by * by);
+    const double gm0 = f_tm / bm + f_Lm * p1m - (1.0 + (1.0 - am) * p1m), gm1 = -f_tm * am / (bm * bm) - f_Lm / bm + 1.0 / bm;
+    const double Hm00 = f_Lm * p2m + p1m - (1.0 - am) * p2m, Hm01 = -f_tm / (bm * bm), Hm11 = 2.0 * f_tm * am / (bm * bm * bm) + f_Lm / (bm * bm) - 1.0 / (bm * bm);
+    // gradient of the global parameters (vector coordinates): feeds the second-order packing term
+    if (tid < p) {
+        double a = ty * um[tid];
+        for (int k = 0; k < p; ++k) a += lam0[tid * p + k] * (m[k] - beta0[k]);
+        g[ix.ms + tid] = a;
+    }
+    const int mm = p * (p + 1) / 2;
+    for (int k = tid; k < mm; k += 1024) {
+        int r, c; vech_rc(k, r, c);
+        const double fac = r == c ? 1.0 : 2.0;
+        g[ix.ls + k] = (-0.5 * Gc[r * p + c] + 0.5 * P[r * p + c]) * fac;
+        const double gl = -0.5 * PSP[r * p + c] * fac;                   // d g_vech(Lambda) / d E tau
+        H[(i64)(ix.ls + k) * ld + ix.iay] = gl * tay; H[(i64)ix.iay * ld + ix.ls + k] = gl * tay;
+        H[(i64)(ix.ls + k) * ld + ix.iby] = gl * tby; H[(i64)ix.iby * ld + ix.ls + k] = gl * tby;
+    }
+    if (tid == 0) {
+        g[ix.iem] = -tm * dsum + kappa0 * (e_mu - mu0);
+        g[ix.iim] = -0.5 * (tm * Gn + kappa0) / (i_mu * i_mu) + 0.5 / i_mu;
+        g[ix.iay] = gy0; g[ix.iby] = gy1; g[ix.iam] = gm0; g[ix.ibm] = gm1;
+    }
+    // the dense part of the global block on the p + 6 rows [mean of q(beta) | e_mu, i_mu, a_y, b_y, a_mu, b_mu], the Schur
+    // term of the eliminated group parameters (Md, on the p + 5 coupled rows) already subtracted
+    const int n6 = p + 6, R = p + 5;
+    for (int e = tid; e < n6 * n6; e += 1024) {
+        const int a = e / n6, b = e - a * n6;
+        auto row_of = [&](int t) { return t < p ? ix.ms + t : (t == p ? ix.iem : (t == p + 1 ? ix.iim : (t == p + 2 ? ix.iay : (t == p + 3 ? ix.iby : (t == p + 4 ? ix.iam : ix.ibm))))); };
+        auto m_of = [&](int t) { return t < p ? t : (t == p ? p : (t == p + 1 ? -1 : t - 1)); };
+        double v = 0.0;
+        const int jem = p, jim = p + 1, jay = p + 2, jby = p + 3, jam = p + 4, jbm = p + 5;
+        if (a < p && b < p) v = ty * S[a * q + b] + lam0[a * p + b];
+        else if (a < p && b == jay) v = um[a] * tay;
+        else if (a < p && b == jby) v = um[a] * tby;
+        else if (b < p && a == jay) v = um[b] * tay;
+        else if (b < p && a == jby) v = um[b] * tby;
+        else if (a == jem && b == jem) v = tm * Gn + kappa0;
+        else if ((a == jem && b == jam) || (a == jam && b == jem)) v = -dsum * tam;
+        else if ((a == jem && b == jbm) || (a == jbm && b == jem)) v = -dsum * tbm;
+        else if (a == jim && b == jim) v = (tm * Gn + kappa0) / (i_mu * i_mu * i_mu) - 0.5 / (i_mu * i_mu);
+        else if ((a == jim && b == jam) || (a == jam && b == jim)) v = -0.5 * Gn / (i_mu * i_mu) * tam;
+        else if ((a == jim && b == jbm) || (a == jbm && b == jim)) v = -0.5 * Gn / (i_mu * i_mu) * tbm;
+        else if (a == jay && b == jay) v = Hy00;
+        else if ((a == jay && b == jby) || (a == jby && b == jay)) v = Hy01;
+        else if (a == jby && b == jby) v = Hy11;
+        else if (a == jam && b == jam) v = Hm00;
+        else if ((a == jam && b == jbm) || (a == jbm && b == jam)) v = Hm01;
+        else if (a == jbm && b == jbm) v = Hm11;
+        const int ma = m_of(a), mb = m_of(b);
+        if (ma >= 0 && mb >= 0) v -= Md[ma * R + mb];
+        H[(i64)row_of(a) * ld + row_of(b)] = v;
+    }
+}
+int launch_lmm_closed_forms(lrvb_ctx* c, const LmmIdx& ix, const double* S, const double* sums, const double* Md, const double* hp,
+                            double* scratch, double* g, double* H, double* Gc) {
+    hipLaunchKernelGGL(lmm_closed_forms_kernel, dim3(1), dim3(1024), 0, c->stream, ix, S, sums, Md, hp, scratch, scratch + (size_t)ix.p * ix.p, g, H, Gc);
+    HIP_TRY(hipGetLastError());
+    return LRVB_OK;
+}
+
+// The (k (k + 1) / 2)^2 block of the information matrix of a MVNParam in one launch:
+//   D^T ( 1/2 (G (x) P + P (x) G) - 1/2 P (x) P ) D     (three lrvb_hvec_add_symkron calls before)
+__device__ __forceinline__ double symkron_entry(const double* __restrict__ A, const double* __restrict__ B, int k, int i, int j, int p, int q) {
+    double v = A[i * k + p] * B[j * k + q];
+    if (i != j) v += A[j * k + p] * B[i * k + q];
+    if (p != q) v += A[i * k + q] * B[j * k + p];
+    if (i != j && p != q) v += A[j * k + q] * B[i * k + p];
+    return v;
+}
+__global__ __launch_bounds__(256)
+void symkron3_kernel(i64 total, int m, int k, const double* __restrict__ G, const double* __restrict__ P, double* __restrict__ H, i64 ld, i64 off)
+{
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int r = (int)(e / m), cidx = (int)(e - (i64)r * m);
+    int i, j, p, q;
+    vech_rc(r, i, j); vech_rc(cidx, p, q);
+    H[(off + r) * ld + off + cidx] = 0.5 * (symkron_entry(G, P, k, i, j, p, q) + symkron_entry(P, G, k, i, j, p, q)) - 0.5 * symkron_entry(P, P, k, i, j, p, q);
+}
+int launch_symkron3(lrvb_ctx* c, int k, const double* G, const double* P, double* H, i64 ld, i64 off) {
+    const int m = k * (k + 1) / 2;
+    const i64 total = (i64)m * m;
+    hipLaunchKernelGGL(symkron3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, total, m, k, G, P, H, ld, off);
+    HIP_TRY(hipGetLastError());
+    return LRVB_OK;
+}
+__global__ void add_padded_kernel(i64 total, i64 n, const double* __restrict__ src, i64 lds, double* __restrict__ dst, i64 ldd) {
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const i64 i = e / n, j = e - i * n;
+    dst[i * ldd + j] += src[i * lds + j];
+}
+int launch_add_padded(lrvb_ctx* c, i64 n, const double* src, i64 lds, double* dst, i64 ldd) {
+    const i64 total = n * n;
+    hipLaunchKernelGGL(add_padded_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, total, n, src, lds, dst, ldd);
+    HIP_TRY(hipGetLastError());
+    return LRVB_OK;
+}
+
+// Configuration 2 (MVNRegressionObjective of quadform.py; LRVB/NormalParams.py:6-23, GammaParams.py:4-16): value, gradient and the
+// vector-coordinate Hessian from [S ((k + 1)^2) | W] where they lie.  hp: [0] a [1] b [2] a0 [3] b0 [4] psi(a) [5] psi1(a)
+// [6] psi2(a) [7] gammaln(a) [8] log|Lambda|; from [32]: m (k), mu0 (k), P (k x k), Lambda0 (k x k), P Lambda0 P (k x k).
+__global__ __launch_bounds__(1024)
+void mvnreg_closed_forms_kernel(MvnRegIdx ix, const double* __restrict__ S, const double* __restrict__ hp, double* __restrict__ T,
+                                double* __restrict__ PSP, double* __restrict__ g, double* __restrict__ H, double* __restrict__ Gc,
+                                double* __restrict__ value_out)
+{
+    __shared__ double sh[1024];
+    __shared__ double u[64];
+    const int k = ix.k, q = k + 1, tid = threadIdx.x;
+    const i64 ld = ix.ld;
+    const double a = hp[0], b = hp[1], a0 = hp[2], b0 = hp[3], dig = hp[4], p1 = hp[5], p2 = hp[6], lgam = hp[7], logdet = hp[8];
+    const double* m = hp + 32; const double* mu0 = m + k; const double* P = mu0 + k; const double* lam0 = P + k * k; const double* PL0P = lam0 + k * k;
+    const double W = S[q * q];
+    const double e = a / b, L = dig - log(b);
+    double tr = 0.0, trl = 0.0;
+    for (int t = tid; t < k * k; t += 1024) {
+        const int i = t / k, j = t - i * k;
+        double s = 0.0;
+        for (int r = 0; r < k; ++r) s += S[i * q + r] * P[r * k + j];
+        T[t] = s;
+        if (i == j) tr += s;
+        trl += lam0[t] * P[j * k + i];                                  // tr(Lambda0 P)
+    }
+    double rs = 0.0, pq = 0.0;
+    if (tid < k) {
+        double s = 0.0, l = 0.0;
+        for (int r = 0; r < k; ++r) { s += S[tid * q + r] * m[r]; l += lam0[tid * k + r] * (m[r] - mu0[r]); }
+        rs = m[tid] * (s - 2.0 * S[tid * q + k]);
+        pq = (m[tid] - mu0[tid]) * l;
+        u[tid] = s - S[tid * q + k];
+        g[ix.ms + tid] = e * u[tid] + l;
+    }
+    const double trT = block_sum_1024(tr, sh), trLP = block_sum_1024(trl, sh), prior_q = block_sum_1024(pq, sh);
+    const double rss = block_sum_1024(rs, sh) + S[k * q + k];
+    for (int t = tid; t < k * k; t += 1024) {
+        const int i = t / k, j = t - i * k;
+        double s = 0.0;
+        for (int r = 0; r < k; ++r) s += P[i * k + r] * T[r * k + j];
+        PSP[t] = s;
+        Gc[t] = e * s + PL0P[t];
+    }
+    __syncthreads();
+    const double f_e = 0.5 * rss + 0.5 * trT + b0, f_L = -0.5 * W - (a0 - 1.0);
+    if (tid == 0) {
+        const double entropy_gamma = a - log(b) + lgam + (1.0 - a) * dig;
+        if (value_out) *value_out = 0.5 * e * rss + 0.5 * (e * trT + trLP) - 0.5 * W * L + 0.5 * prior_q - (a0 - 1.0) * L + b0 * e + 0.5 * logdet
+                                    - entropy_gamma - 0.5 * ((double)k + (double)k * log(2.0 * M_PI));
+        g[ix.ia] = f_e / b + f_L * p1 - (1.0 + (1.0 - a) * p1);
+        g[ix.ib] = -f_e * a / (b * b) - f_L / b + 1.0 / b;
+        H[(i64)ix.ia * ld + ix.ia] = f_L * p2 + p1 - (1.0 - a) * p2;
+        H[(i64)ix.ia * ld + ix.ib] = -f_e / (b * b); H[(i64)ix.ib * ld + ix.ia] = -f_e / (b * b);
+        H[(i64)ix.ib * ld + ix.ib] = 2.0 * f_e * a / (b * b * b) + f_L / (b * b) - 1.0 / (b * b);
+    }
+    for (int t = tid; t < k * k; t += 1024) {                            // H[ms, ms] = C = e Sxx + Lambda0
+        const int i = t / k, j = t - i * k;
+        H[(i64)(ix.ms + i) * ld + ix.ms + j] = e * S[i * q + j] + lam0[t];
+    }
+    if (tid < k) {
+        H[(i64)(ix.ms + tid) * ld + ix.ia] = u[tid] / b; H[(i64)ix.ia * ld + ix.ms + tid] = u[tid] / b;
+        H[(i64)(ix.ms + tid) * ld + ix.ib] = -u[tid] * a / (b * b); H[(i64)ix.ib * ld + ix.ms + tid] = -u[tid] * a / (b * b);
+    }
+    const int mm = k * (k + 1) / 2;
+    for (int t = tid; t < mm; t += 1024) {
+        int r, c; vech_rc(t, r, c);
+        const double fac = r == c ? 1.0 : 2.0;
+        g[ix.ls + t] = (-0.5 * Gc[r * k + c] + 0.5 * P[r * k + c]) * fac;
+        const double gl = -0.5 * PSP[r * k + c] * fac;
+        H[(i64)(ix.ls + t) * ld + ix.ia] = gl / b; H[(i64)ix.ia * ld + ix.ls + t] = gl / b;
+        H[(i64)(ix.ls + t) * ld + ix.ib] = -gl * a / (b * b); H[(i64)ix.ib * ld + ix.ls + t] = -gl * a / (b * b);
+    }
+}
+int launch_mvnreg_closed_forms(lrvb_ctx* c, const MvnRegIdx& ix, const double* S, const double* hp, double* scratch,
+                               double* g, double* H, double* Gc, double* value_out) {
+    hipLaunchKernelGGL(mvnreg_closed_forms_kernel, dim3(1), dim3(1024), 0, c->stream, ix, S, hp, scratch, scratch + (size_t)ix.k * ix.k, g, H, Gc, value_out);
+    HIP_TRY(hipGetLastError());
+    return LRVB_OK;
+}

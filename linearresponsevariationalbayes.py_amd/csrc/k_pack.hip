@@ -366,9 +366,10 @@ int launch_unconstrain(lrvb_ctx* c, const double* eta_dev, double* theta_dev, in
     return LRVB_OK;
 }
 
-int launch_dense_jac(lrvb_ctx* c, const double* theta_dev, double* J_dev) {
-    HIP_TRY(hipMemsetAsync(J_dev, 0, sizeof(double) * (size_t)c->V * (size_t)c->D, c->stream));
-    const i64 ldj = c->D;
+int launch_dense_jac(lrvb_ctx* c, const double* theta_dev, double* J_dev, i64 ld, i64 rows_alloc) {
+    // ld / rows_alloc: the caller's (zero-padded, even-width) allocation; 0 = the plain V x D matrix
+    const i64 ldj = ld > 0 ? ld : c->D;
+    HIP_TRY(hipMemsetAsync(J_dev, 0, sizeof(double) * (size_t)(rows_alloc > 0 ? rows_alloc : c->V) * (size_t)ldj, c->stream));
     const bool fused = box_fused(c);
     if (fused) LRVB_TRY(launch_box_all<1>(c, theta_dev, nullptr, J_dev, nullptr, nullptr, ldj, nullptr));
     for (const auto& b : c->blocks) {

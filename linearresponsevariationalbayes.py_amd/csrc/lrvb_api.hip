@@ -223,7 +223,7 @@ extern "C" int lrvb_ctx_destroy(lrvb_ctx* c) {
     DevBuf* all[] = { &c->X, &c->y, &c->w, &c->quadA, &c->quadM, &c->quadB, &c->theta, &c->eta, &c->j1, &c->j2,
                       &c->vtmp, &c->vtmp2, &c->vtmp3, &c->g_eta, &c->g_free, &c->lp, &c->cw, &c->zbuf,
                       &c->part_vec, &c->part_val, &c->stats, &c->tile_part, &c->Heta, &c->Hfree, &c->Jdense,
-                      &c->Tdense, &c->work1, &c->chol, &c->cholW, &c->hprog, &c->cgH, &c->groups, &c->mx_theta, &c->mx_lam, &c->mx_A, &c->mx_U, &c->mx_g, &c->mx_Xk, &c->mx_R, &c->cgT, &c->ones, &c->cgm[0], &c->cgm[1], &c->cgm[2], &c->cgm[3], &c->cgm[4], &c->cgm[5], &c->cgm[6], &c->cgm[7], &c->cgm[8], &c->rhs, &c->cgx, &c->cgr, &c->cgp, &c->cgq, &c->cgz, &c->scal, &c->opt, &c->dkw, &c->cyv, &c->rvec, &c->red_scratch, &c->gstats, &c->Zs, &c->ws, &c->bpart, &c->gpad, &c->boxmap, &c->Hres, &c->hres_theta };
+                      &c->Tdense, &c->work1, &c->chol, &c->cholW, &c->hprog, &c->cgH, &c->groups, &c->mx_theta, &c->mx_lam, &c->mx_A, &c->mx_U, &c->mx_g, &c->mx_Xk, &c->mx_R, &c->cgT, &c->ones, &c->cgm[0], &c->cgm[1], &c->cgm[2], &c->cgm[3], &c->cgm[4], &c->cgm[5], &c->cgm[6], &c->cgm[7], &c->cgm[8], &c->rhs, &c->cgx, &c->cgr, &c->cgp, &c->cgq, &c->cgz, &c->scal, &c->opt, &c->dkw, &c->cyv, &c->rvec, &c->red_scratch, &c->gstats, &c->Zs, &c->ws, &c->bpart, &c->gpad, &c->boxmap, &c->Hres, &c->hres_theta, &c->qstats };
     for (DevBuf* b : all) buf_free(*b);
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
     if (c->up_ring) { for (int k = 0; k < lrvb_ctx::UP_SLOTS; ++k) if (c->up_ev[k]) (void)hipEventDestroy(c->up_ev[k]); (void)hipHostFree(c->up_ring); }
@@ -1059,6 +1059,117 @@ static int hvec_finish_impl(lrvb_ctx* c, const double* point, int64_t n_in, int 
     return H_out ? d2h(c, H_out, c->Hfree.p, (size_t)D * (size_t)D) : LRVB_OK;
 }
 
+// ---- configurations 2 and 4 as ONE call: statistics, closed forms, assembly, free conversion -- no host round trip ------------
+static int grouped_stats_device(lrvb_ctx* c);
+static int lmm_group_terms_device(lrvb_ctx* c, const double* par, int64_t n_par, const double* f_local, int64_t n_local, double** sums_dev);
+// J^T H_vec J + sum_k g_k d2 eta_k for the vector-coordinate matrix in c->Heta (leading dimension Vp = V rounded up to even,
+// the padding zero) with theta on the device and g in c->g_eta; the result in c->Hfree (leading dimension D), where
+// lrvb_chol_factor_last finds it.  Even widths throughout: the two products run on the LDS-DMA MFMA kernel without the padded
+// copies of gemm_tn (three rectangular copies and a memset per product at the 995 parameters of configuration 4).
+static int free_conversion_padded(lrvb_ctx* c, const double* theta_dev, i64 Vp) {
+    const i64 D = c->D, Dp = D + (D & 1);
+    LRVB_TRY(buf_reserve(c, c->Jdense, (size_t)Vp * (size_t)Dp));
+    LRVB_TRY(buf_reserve(c, c->work1, (size_t)Vp * (size_t)Dp));
+    LRVB_TRY(buf_reserve(c, c->Tdense, (size_t)Dp * (size_t)Dp));
+    LRVB_TRY(buf_reserve(c, c->Hfree, (size_t)D * (size_t)D));
+    LRVB_TRY(launch_dense_jac(c, theta_dev, c->Jdense.p, Dp, Vp));
+    LRVB_TRY(gemm_tn(c, Vp, Vp, Dp, c->Heta.p, c->Jdense.p, c->work1.p));          // H_vec is symmetric: H J = H^T J
+    LRVB_TRY(gemm_tn(c, Vp, Dp, Dp, c->Jdense.p, c->work1.p, c->Tdense.p));        // J^T (H J)
+    HIP_TRY(hipMemsetAsync(c->Hfree.p, 0, (size_t)D * (size_t)D * sizeof(double), c->stream));
+    LRVB_TRY(launch_third_order(c, theta_dev, c->g_eta.p, c->Hfree.p));
+    return launch_add_padded(c, D, c->Tdense.p, Dp, c->Hfree.p, D);
+}
+
+extern "C" int lrvb_mvnreg_hessian(lrvb_ctx* c, const double* free_in, int64_t D, const double* hp, int64_t n_hp, const int32_t* idx,
+                                   double* value_out, double* H_out) {
+    LRVB_TRY(ctx_bind(c));
+    if (!free_in || !hp || !idx) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    LRVB_TRY(check_len(D, c->D, "free vector"));
+    if (c->loss == LRVB_LOSS_NONE || !c->have_X) LRVB_FAIL(LRVB_ERR_STATE, "no data matrix: call lrvb_set_data(LRVB_SLOT_X) first");
+    const i64 q = c->P, k = q - 1, V = c->V, Vp = V + (V & 1), mm = k * (k + 1) / 2;
+    if (k < 1 || k > 63) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "1 <= k <= 63 regressors");
+    LRVB_TRY(check_len(n_hp, 32 + 2 * k + 3 * k * k, "host pack"));
+    MvnRegIdx ix{ (int)k, idx[0], idx[1], idx[2], idx[3], Vp };
+    if (ix.ms < 0 || ix.ms + k > V || ix.ls < 0 || ix.ls + mm > V || ix.ia < 0 || ix.ia >= V || ix.ib < 0 || ix.ib >= V || V != k + mm + 2)
+        LRVB_FAIL(LRVB_ERR_INVALID, "parameter positions do not describe [mean, information, shape, rate] of %lld + %lld + 2 vector coordinates", (long long)k, (long long)mm);
+    // one upload: [theta | hp]
+    std::vector<double> pack((size_t)(D + n_hp));
+    memcpy(pack.data(), free_in, (size_t)D * sizeof(double));
+    memcpy(pack.data() + D, hp, (size_t)n_hp * sizeof(double));
+    LRVB_TRY(buf_reserve(c, c->hprog, pack.size()));
+    LRVB_TRY(buf_reserve(c, c->qstats, (size_t)(q * q) + 1 + 256));
+    LRVB_TRY(buf_reserve(c, c->Heta, (size_t)Vp * (size_t)Vp));
+    LRVB_TRY(buf_reserve(c, c->vtmp3, (size_t)(3 * k * k + 1) > (size_t)(V > D ? V : D) ? (size_t)(3 * k * k + 1) : (size_t)(V > D ? V : D)));
+    LRVB_TRY(h2d(c, c->hprog.p, pack.data(), pack.size()));
+    // statistics [S | sum w] (weights resident), summed over the ranks once
+    LRVB_TRY(reserve_obs_vec(c, c->zbuf));
+    HIP_TRY(hipMemcpyAsync(c->zbuf.p, c->w.p, (size_t)c->N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    double* tiles = c->stats.p + 1 + c->P;
+    LRVB_TRY(launch_wsyrk(c, c->zbuf.p, tiles));
+    LRVB_TRY(launch_tiles_to_dense(c, tiles, q, c->qstats.p, q, 0, 0, false));
+    hipLaunchKernelGGL(vec_block_sums_kernel, dim3(256), dim3(256), 0, c->stream, c->N, (const double*)c->w.p, c->qstats.p + q * q + 1);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)(c->qstats.p + q * q + 1), (i64)256, c->qstats.p + q * q);
+    HIP_TRY(hipGetLastError());
+    LRVB_TRY(obs_reduce(c, c->qstats.p, q * q + 1));
+    // closed forms where the statistics lie, the Kronecker block, the conversion to free coordinates
+    HIP_TRY(hipMemsetAsync(c->Heta.p, 0, (size_t)Vp * (size_t)Vp * sizeof(double), c->stream));
+    const double* hp_dev = c->hprog.p + D;
+    double* scratch = c->vtmp3.p; double* Gc = scratch + 2 * k * k; double* val = Gc + k * k;
+    LRVB_TRY(launch_mvnreg_closed_forms(c, ix, c->qstats.p, hp_dev, scratch, c->g_eta.p, c->Heta.p, Gc, val));
+    LRVB_TRY(launch_symkron3(c, (int)k, Gc, hp_dev + 32 + 2 * k, c->Heta.p, Vp, ix.ls));
+    LRVB_TRY(free_conversion_padded(c, c->hprog.p, Vp));
+    if (value_out) LRVB_TRY(d2h(c, value_out, val, 1));
+    if (H_out) LRVB_TRY(d2h(c, H_out, c->Hfree.p, (size_t)D * (size_t)D));
+    return LRVB_OK;
+}
+
+extern "C" int lrvb_lmm_global_hessian(lrvb_ctx* c, lrvb_ctx* gc, const double* free_val, int64_t n_free, const double* hp, int64_t n_hp,
+                                       const int32_t* idx, double info_lb, double* sums_out, double* H_out) {
+    LRVB_TRY(ctx_bind(c));
+    LRVB_TRY(ctx_bind(gc));
+    if (!free_val || !hp || !idx) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    if (c->device != gc->device) LRVB_FAIL(LRVB_ERR_INVALID, "the two contexts must live on one device");
+    if (c->loss == LRVB_LOSS_NONE || !c->have_X) LRVB_FAIL(LRVB_ERR_STATE, "no data matrix: call lrvb_set_data(LRVB_SLOT_X) first");
+    const i64 G = c->n_groups, q = c->P, p = q - 1, ng = gc->D, V = gc->V, Vp = V + (V & 1), mm = p * (p + 1) / 2;
+    if (p < 1 || p + 7 > 64) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "1 <= p <= 57 regressors");
+    if (V != ng || V != p + mm + 6) LRVB_FAIL(LRVB_ERR_INVALID, "the global context must hold the %lld global parameters of the model", (long long)(p + mm + 6));
+    LRVB_TRY(check_len(n_free, ng + 2 * G, "free vector"));
+    LRVB_TRY(check_len(n_hp, 32 + 2 * p + 3 * p * p, "host pack"));
+    LmmIdx ix{ (int)p, idx[0], idx[1], idx[2], idx[3], idx[4], idx[5], idx[6], idx[7], Vp };
+    const int32_t* ip = idx;
+    if (ip[0] < 0 || ip[0] + p > V || ip[1] < 0 || ip[1] + mm > V) LRVB_FAIL(LRVB_ERR_INVALID, "parameter positions outside the global block");
+    for (int t = 2; t < 8; ++t) if (ip[t] < 0 || ip[t] >= V) LRVB_FAIL(LRVB_ERR_INVALID, "parameter positions outside the global block");
+    // every buffer first (an allocation may synchronise)
+    LRVB_TRY(buf_reserve(gc, gc->hprog, (size_t)(ng + n_hp)));
+    LRVB_TRY(buf_reserve(gc, gc->Heta, (size_t)Vp * (size_t)Vp));
+    LRVB_TRY(buf_reserve(gc, gc->vtmp3, (size_t)(3 * p * p) > (size_t)V ? (size_t)(3 * p * p) : (size_t)V));
+    // (a) the data context: [S | group sums] in one pass, summed over the ranks; the 2 G local parameters eliminated there
+    LRVB_TRY(grouped_stats_device(c));
+    std::vector<double> par((size_t)(8 + p));
+    par[0] = hp[0]; par[1] = hp[1]; par[2] = hp[2]; par[3] = hp[8]; par[4] = hp[9]; par[5] = hp[10]; par[6] = hp[11]; par[7] = info_lb;
+    memcpy(par.data() + 8, hp + 32, (size_t)p * sizeof(double));
+    double* sums = nullptr;
+    LRVB_TRY(lmm_group_terms_device(c, par.data(), 8 + p, free_val + ng, 2 * G, &sums));
+    // (b) the global context continues in stream order behind it: one upload [theta_g | hp], the closed forms where the
+    // statistics lie, the Kronecker block, the conversion to free coordinates
+    std::vector<double> pack((size_t)(ng + n_hp));
+    memcpy(pack.data(), free_val, (size_t)ng * sizeof(double));
+    memcpy(pack.data() + ng, hp, (size_t)n_hp * sizeof(double));
+    LRVB_TRY(h2d(gc, gc->hprog.p, pack.data(), pack.size()));
+    HIP_TRY(hipMemsetAsync(gc->Heta.p, 0, (size_t)Vp * (size_t)Vp * sizeof(double), gc->stream));
+    LRVB_TRY(stream_handoff(c, c->stream, gc->stream));
+    const double* hp_dev = gc->hprog.p + ng;
+    double* scratch = gc->vtmp3.p; double* Gc = scratch + 2 * p * p;
+    LRVB_TRY(launch_lmm_closed_forms(gc, ix, c->gstats.p, sums, sums + 128, hp_dev, scratch, gc->g_eta.p, gc->Heta.p, Gc));
+    LRVB_TRY(stream_handoff(gc, gc->stream, c->stream));        // the data context's next call may overwrite what was just read
+    LRVB_TRY(launch_symkron3(gc, (int)p, Gc, hp_dev + 32 + 2 * p, gc->Heta.p, Vp, ix.ls));
+    LRVB_TRY(free_conversion_padded(gc, gc->hprog.p, Vp));
+    if (sums_out) LRVB_TRY(d2h(c, sums_out, sums, 128));
+    if (H_out) LRVB_TRY(d2h(gc, H_out, gc->Hfree.p, (size_t)ng * (size_t)ng));
+    return LRVB_OK;
+}
+
 // ---- cross Hessians ----------------------------------------------------------------------
 
 static int obs_grad_impl(lrvb_ctx* c, const double* point, i64 n_in, bool is_free, i64 n0, i64 n1, double* G_out) {
@@ -1374,8 +1485,18 @@ extern "C" int lrvb_group_sums(lrvb_ctx* c, double* out) {
 // ---- hierarchical LMM (config 4): statistics resident on the device, group effects eliminated there ---------------
 // [S (q x q) | group sums (G x (q + 1))] in ONE device buffer, handed to the sum-over-ranks hook once and kept
 // resident for lrvb_lmm_group_terms; both host copies are optional.
+static int grouped_stats_device(lrvb_ctx* c);
 extern "C" int lrvb_grouped_stats(lrvb_ctx* c, double* S_out, double* gs_out) {
     LRVB_TRY(ctx_bind(c));
+    LRVB_TRY(grouped_stats_device(c));
+    const i64 G = c->n_groups, q = c->P;
+    const size_t n_s = (size_t)q * q, n_g = (size_t)G * (size_t)(q + 1);
+    if (S_out) LRVB_TRY(d2h(c, S_out, c->gstats.p, n_s));
+    if (gs_out) LRVB_TRY(d2h(c, gs_out, c->gstats.p + n_s, n_g));
+    return LRVB_OK;
+}
+// [S | group sums] of the context's rows and weights into c->gstats, summed over the ranks: no host copy
+static int grouped_stats_device(lrvb_ctx* c) {
     if (c->n_groups <= 0) LRVB_FAIL(LRVB_ERR_STATE, "no groups: call lrvb_set_groups first");
     if (c->loss == LRVB_LOSS_NONE || !c->have_X) LRVB_FAIL(LRVB_ERR_STATE, "no data matrix: call lrvb_set_data(LRVB_SLOT_X) first");
     const i64 G = c->n_groups, q = c->P;
@@ -1401,8 +1522,6 @@ extern "C" int lrvb_grouped_stats(lrvb_ctx* c, double* S_out, double* gs_out) {
     }
     LRVB_TRY(obs_reduce(c, c->gstats.p, (i64)(n_s + n_g)));
     c->gstats_valid = true;
-    if (S_out) LRVB_TRY(d2h(c, S_out, c->gstats.p, n_s));
-    if (gs_out) LRVB_TRY(d2h(c, gs_out, c->gstats.p + n_s, n_g));
     return LRVB_OK;
 }
 
@@ -1412,9 +1531,18 @@ extern "C" int lrvb_grouped_stats(lrvb_ctx* c, double* S_out, double* gs_out) {
 // 128 + (p + 5)^2): the sums of lmm_group_kernel, then M = sum_g c_e c_e^T / dfe + c_i c_i^T / dfi -- the Schur
 // complement of the 2 G local parameters onto the coupled global rows, in vector coordinates of the globals and free
 // coordinates of the locals (H_gl diag(H_ll)^-1 H_lg; the G independent 2 x 2 local blocks of this model are diagonal).
+static int lmm_group_terms_device(lrvb_ctx* c, const double* par, int64_t n_par, const double* f_local, int64_t n_local, double** sums_dev);
 extern "C" int lrvb_lmm_group_terms(lrvb_ctx* c, const double* par, int64_t n_par, const double* f_local, int64_t n_local, double* out) {
     LRVB_TRY(ctx_bind(c));
     if (!par || !f_local || !out) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
+    double* sums = nullptr;
+    LRVB_TRY(lmm_group_terms_device(c, par, n_par, f_local, n_local, &sums));
+    const i64 R = c->P - 1 + 5;
+    // [sums (128) | M (R x R)] are adjacent: one copy
+    return d2h(c, out, sums, (size_t)(128 + R * R));
+}
+// the same, the result [sums (128) | M (R x R)] left on the device (in c->work1; valid until the next use of that buffer)
+static int lmm_group_terms_device(lrvb_ctx* c, const double* par, int64_t n_par, const double* f_local, int64_t n_local, double** sums_dev) {
     if (!c->gstats_valid) LRVB_FAIL(LRVB_ERR_STATE, "no grouped statistics resident: call lrvb_grouped_stats first");
     const i64 G = c->n_groups, q = c->P, p = q - 1, R = p + 5;
     if (p < 1 || p + 7 > 64) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "1 <= p <= 57 regressors");
@@ -1445,8 +1573,8 @@ extern "C" int lrvb_lmm_group_terms(lrvb_ctx* c, const double* par, int64_t n_pa
     LRVB_TRY(buf_reserve(c, c->Tdense, (size_t)WS_TILE * WS_TILE));
     LRVB_TRY(launch_gram_small_on(c, Cm, 2 * G, ldc, wts, c->Tdense.p));
     LRVB_TRY(launch_tiles_to_dense(c, c->Tdense.p, R, Md, R, 0, 0, false));
-    // [sums (128) | M (R x R)] are adjacent: one copy
-    return d2h(c, out, sums, (size_t)(128 + R * R));
+    *sums_dev = sums;
+    return LRVB_OK;
 }
 
 // ---- mixture model: per-row simplex blocks eliminated on the device (config 3) --------------------

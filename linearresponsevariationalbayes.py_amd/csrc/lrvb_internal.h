@@ -70,6 +70,7 @@ struct lrvb_ctx {
     DevBuf Heta, Hfree, Jdense, Tdense, work1;   // dense V x V / D x D scratch
     DevBuf groups; i64 n_groups = 0;   // [perm (N) | offsets (G+1)] as int64
     DevBuf Zs, ws, bpart; bool zs_valid = false, ws_valid = false;   // fused grouped statistics (k_lmm.hip): group-sorted rows (+4 zero rows), weights in that order, pieces of groups cut by wave boundaries
+    DevBuf qstats;                 // [S (q x q) | sum w] of lrvb_mvnreg_hessian
     DevBuf gstats; bool gstats_valid = false;   // [S (q x q) | group sums (G x (q+1))] of lrvb_grouped_stats, summed over ranks
     DevBuf mx_theta, mx_lam, mx_A, mx_U, mx_g, mx_Xk, mx_R;   // mixture rows pipeline (kept between calls)
     i64 mx_theta_n = 0;            // simplex logits resident in mx_theta (entries; 0 = none)
@@ -100,7 +101,7 @@ struct lrvb_ctx {
     double* host_pinned = nullptr; size_t host_pinned_n = 0;
     // small host -> device uploads: a ring of pinned slots, so that the copy is a real asynchronous copy in stream order
     // and the call does not have to synchronise the stream (a pageable source has to be consumed before the call returns)
-    static constexpr int UP_SLOTS = 16; static constexpr size_t UP_SLOT_DOUBLES = 16384;
+    static constexpr int UP_SLOTS = 16; static constexpr size_t UP_SLOT_DOUBLES = 65536;   // 512 KB per slot: the 2 G local parameters of config 4 fit one
     double* up_ring = nullptr; double* up_ring_dev = nullptr; hipEvent_t up_ev[UP_SLOTS] = {}; int up_next = 0;
 
     int n_splits_user = 0;
@@ -130,7 +131,7 @@ void buf_free(DevBuf& b);
 int upload_boxmap(lrvb_ctx* c);
 int launch_constrain(lrvb_ctx* c, const double* theta_dev, double* eta_dev, double* j1_dev, double* j2_dev);
 int launch_unconstrain(lrvb_ctx* c, const double* eta_dev, double* theta_dev, int* bad_flag_dev);
-int launch_dense_jac(lrvb_ctx* c, const double* theta_dev, double* J_dev /* V x D */);
+int launch_dense_jac(lrvb_ctx* c, const double* theta_dev, double* J_dev /* V x D */, i64 ld = 0, i64 rows_alloc = 0);
 int launch_third_order(lrvb_ctx* c, const double* theta_dev, const double* g_eta_dev, double* T_dev /* D x D */);
 
 // k_glm.hip
@@ -163,6 +164,14 @@ int  launch_tiles_to_dense(lrvb_ctx* c, const double* tiles_dev, i64 P, double* 
                            i64 row_off, i64 col_off, bool accumulate);
 
 // k_lmm.hip
+struct LmmIdx { int p, ms, ls, iem, iim, iay, iby, iam, ibm; i64 ld; };    // vector-coordinate positions of the global parameters
+int  launch_lmm_closed_forms(lrvb_ctx* c, const LmmIdx& ix, const double* S, const double* sums, const double* Md, const double* hp,
+                             double* scratch /* 2 p^2 */, double* g, double* H, double* Gc);
+int  launch_symkron3(lrvb_ctx* c, int k, const double* G, const double* P, double* H, i64 ld, i64 off);
+struct MvnRegIdx { int k, ms, ls, ia, ib; i64 ld; };
+int  launch_mvnreg_closed_forms(lrvb_ctx* c, const MvnRegIdx& ix, const double* S /* (k+1)^2 | W */, const double* hp, double* scratch,
+                                double* g, double* H, double* Gc, double* value_out);
+int  launch_add_padded(lrvb_ctx* c, i64 n, const double* src, i64 lds, double* dst, i64 ldd);
 i64  grouped_rows_per_wave(i64 N);
 bool grouped_fused_supported(const lrvb_ctx* c);
 int  launch_grouped_stats_fused(lrvb_ctx* c, double* S_dense_dev /* q x q */, double* gs_dev /* G x (q + 1) */);

@@ -52,6 +52,7 @@ class LMMObjective(DeclaredHypers):
         self.n_obs, self.p = x.shape
         self.G = int(n_groups)
         p, G = self.p, self.G
+        self._names = tuple(names)
         self._index(par, names)
         self._declare_priors(beta_prior_mean, beta_prior_info, mu_prior_mean, mu_prior_info, tau_y_prior, tau_mu_prior)
         self.ctx = DeviceContext(par.layout_blocks(), loss='data_only', n_obs=self.n_obs, n_cols=p + 1, device=device)
@@ -467,7 +468,57 @@ class LMMObjective(DeclaredHypers):
             return self._global_hessian_device(_hip.as_f64(free_val).ravel(), want_host)
         return self._global_hessian_host(free_val)
 
+    def _host_pack(self, fv):
+        """The theta-only coefficients of the closed forms (`lmm_closed_forms_kernel`, csrc/k_lmm.hip): the global parameters
+        are constrained by the host parameter objects -- no device round trip -- and P = Lambda^-1, P Lambda0 P and the four
+        polygamma values are formed here; everything that touches the statistics happens on the device."""
+        p = self.p
+        fi = self.par.free_indices_dict
+        sub = []
+        for name in self._names[:4]:
+            q = self.par[name]
+            q.set_free(fv[fi[name].start:fi[name].stop])
+            sub.append(q)
+        beta, mu, tau_y, tau_mu = sub
+        m = np.asarray(beta['mean'].get(), dtype=np.float64).ravel()
+        lam = np.asarray(beta['info'].get(), dtype=np.float64)
+        e_mu, i_mu = float(np.ravel(mu['mean'].get())[0]), float(np.ravel(mu['info'].get())[0])
+        ay, by = float(np.ravel(tau_y['shape'].get())[0]), float(np.ravel(tau_y['rate'].get())[0])
+        am, bm = float(np.ravel(tau_mu['shape'].get())[0]), float(np.ravel(tau_mu['rate'].get())[0])
+        if np.linalg.slogdet(lam)[0] <= 0:
+            raise ValueError('Matrix is not positive definite')
+        P = np.linalg.inv(lam)
+        lam0 = self.lam0
+        hp = np.zeros(32 + 2 * p + 3 * p * p)
+        hp[:23] = [ay / by, am / bm, e_mu, i_mu, ay, by, am, bm, 1.0 / by, -ay / by ** 2, 1.0 / bm, -am / bm ** 2,
+                   self.kappa0, self.mu0, self.a0y, self.b0y, self.a0m, self.b0m, float(self.G),
+                   special.polygamma(1, ay), special.polygamma(2, ay), special.polygamma(1, am), special.polygamma(2, am)]
+        o = 32
+        for arr in (m, self.beta0, P, lam0, P @ lam0 @ P):
+            hp[o:o + arr.size] = np.ravel(arr)
+            o += arr.size
+        return hp
+
     def _global_hessian_device(self, fv, want_host):
+        """ONE library call (lrvb_lmm_global_hessian, round 4): statistics in one pass, the 2 G local parameters eliminated,
+        the closed forms evaluated where the statistics lie (they are affine in them, with theta-only coefficients sent up in
+        the call's single upload), Kronecker block, free conversion -- no device-to-host copy inside a step."""
+        ng, G = self.n_global, self.G
+        if fv.size != ng + 2 * G:
+            raise ValueError('Free value is the wrong length')
+        gc = self._ensure_gctx()
+        self._push_state()
+        self._check_hook_epoch()
+        idx = [self._ms.start, self._ls.start, self._iem, self._iim, self._iay, self._iby, self._iam, self._ibm]
+        want_sums = bool(getattr(self, 'want_diagnostics', False))
+        H, sums = self.ctx.lmm_global_hessian(gc, fv, self._host_pack(fv), idx, self._info_lb, want_sums=want_sums, want_host=want_host)
+        self._S_dev = None                                       # (the statistics were formed inside the call, not cached here)
+        self.last_local_grad_norm = float(np.sqrt(sums[70])) if want_sums else None
+        return H
+
+    def _global_hessian_device_stepwise(self, fv, want_host):
+        """Round 3's route, call by call (statistics to the host, numpy closed forms, blocks back up): kept as the
+        independent path the one-call route is tested against."""
         p, G, ng = self.p, self.G, self.n_global
         if fv.size != ng + 2 * G:
             raise ValueError('Free value is the wrong length')

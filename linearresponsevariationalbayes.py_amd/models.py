@@ -547,6 +547,29 @@ class DeviceContext(object):
         self._check(self._lib.lrvb_lmm_group_terms(self._h, _hip.ptr(par), par.size, _hip.ptr(fl), fl.size, _hip.ptr(out)))
         return out[:128], out[128:].reshape(R, R)
 
+    def mvnreg_hessian(self, free, hp, idx, want_value=False, want_host=True):
+        """A whole Hessian build of the MVNParam regression as one call (lrvb_mvnreg_hessian): statistics, closed forms,
+        Kronecker block and free conversion on the device, no copy back inside.  Returns (H or None, value or None)."""
+        f, hp = _hip.as_f64(free).ravel(), _hip.as_f64(hp).ravel()
+        ix = np.ascontiguousarray(idx, dtype=np.int32).ravel()
+        out = np.empty((self.D, self.D)) if want_host else None
+        val = np.empty(1) if want_value else None
+        self._check(self._lib.lrvb_mvnreg_hessian(self._h, _hip.ptr(f), f.size, _hip.ptr(hp), hp.size, ix.ctypes.data_as(ctypes.c_void_p),
+                                                 _hip.ptr(val), _hip.ptr(out)))
+        return out, (None if val is None else float(val[0]))
+
+    def lmm_global_hessian(self, gctx, free, hp, idx, info_lb, want_sums=False, want_host=True):
+        """The Schur complement of the hierarchical model's arrow Hessian onto its global block as one call
+        (lrvb_lmm_global_hessian): `self` holds the rows and groups, `gctx` the packing of the global parameters and, afterwards,
+        the result.  Returns (H or None, sums (128,) or None)."""
+        f, hp = _hip.as_f64(free).ravel(), _hip.as_f64(hp).ravel()
+        ix = np.ascontiguousarray(idx, dtype=np.int32).ravel()
+        out = np.empty((gctx.D, gctx.D)) if want_host else None
+        sums = np.empty(128) if want_sums else None
+        self._check(self._lib.lrvb_lmm_global_hessian(self._h, gctx._h, _hip.ptr(f), f.size, _hip.ptr(hp), hp.size,
+                                                     ix.ctypes.data_as(ctypes.c_void_p), float(info_lb), _hip.ptr(sums), _hip.ptr(out)))
+        return out, sums
+
     def mixture_stats(self, K, theta_z, lam, want_schur=True):
         """`mixture_rows` without the per-row gradient and with the Schur operand left on the device (summed over the
         ranks there): returns (val2, S64)."""

@@ -347,6 +347,7 @@ class MVNRegressionObjective(QuadraticDataObjective):
         if len(self._ms) != k or len(self._ls) != k * (k + 1) // 2:
             raise ValueError('Wrong size for {}.  Expected dimension {}'.format(beta_name, k))
         self._dup = duplication_matrix(k)
+        self._names = (beta_name, tau_name)
         super().__init__(par, np.hstack([x, y]), weights=weights, device=device)
         self._declare_priors(prior_mean, prior_info, prior_shape, prior_rate)
 
@@ -389,6 +390,9 @@ class MVNRegressionObjective(QuadraticDataObjective):
         """The (k(k+1)/2)^2 block of q(beta)'s information matrix is three Kronecker products of k x k matrices: the device
         writes it from the factors (lrvb_hvec_add_symkron) and converts the assembled matrix to free coordinates; the host
         sends the rest of the vector-coordinate Hessian (its other blocks are O(V k) numbers)."""
+        if is_free and getattr(self, '_external_stats', None) is None and not getattr(self, 'stepwise', False) and hasattr(self.ctx, 'mvnreg_hessian') \
+                and self._ia == self._ls.stop and self._ib == self._ia + 1 and self._ms.stop == self._ls.start:
+            return self.device_hessian(x)[0]
         S, W = self._stats()
         eta = self._eta(x, is_free)
         _, g, H = self._terms(eta, S, W, kron=False)
@@ -400,6 +404,42 @@ class MVNRegressionObjective(QuadraticDataObjective):
         c.hvec_add_symkron(P, G, 0.5, l0, l0)
         c.hvec_add_symkron(P, P, -0.5, l0, l0)
         return c.hvec_finish(x if is_free else eta, g, is_free)
+
+    def _host_pack(self, free_val):
+        """The theta-only coefficients of the closed forms (csrc/k_lmm.hip, `mvnreg_closed_forms_kernel`): the point is
+        constrained by the host parameter objects -- no device round trip -- and P = Lambda^-1, P Lambda0 P, the polygamma
+        values and log|Lambda| are formed here; everything that touches the statistics happens on the device."""
+        sp, k = self._special, self.k
+        beta, tau = self.par[self._names[0]], self.par[self._names[1]]
+        fi = self.par.free_indices_dict
+        x = np.asarray(free_val, dtype=np.float64)
+        beta.set_free(x[fi[self._names[0]].start:fi[self._names[0]].stop])
+        tau.set_free(x[fi[self._names[1]].start:fi[self._names[1]].stop])
+        m = np.asarray(beta['mean'].get(), dtype=np.float64).ravel()
+        lam = np.asarray(beta['info'].get(), dtype=np.float64)
+        a, b = float(np.ravel(tau['shape'].get())[0]), float(np.ravel(tau['rate'].get())[0])
+        sign, logdet = np.linalg.slogdet(lam)
+        if sign <= 0:
+            raise ValueError('Matrix is not positive definite')
+        P = np.linalg.inv(lam)
+        lam0 = self.lam0
+        hp = np.zeros(32 + 2 * k + 3 * k * k)
+        hp[:9] = [a, b, self.a0, self.b0, sp.digamma(a), sp.polygamma(1, a), sp.polygamma(2, a), sp.gammaln(a), logdet]
+        o = 32
+        for arr in (m, self.mu0, P, lam0, P @ lam0 @ P):
+            hp[o:o + arr.size] = np.ravel(arr)
+            o += arr.size
+        return hp
+
+    @_hip.host_blas
+    def device_hessian(self, free_val, want_value=False, want_host=True):
+        """The free-coordinate Hessian (and, if asked, the value) as ONE library call: the weighted Gram of [x | y] and the sum
+        of the weights, the closed forms in (m, Lambda, a, b) where the statistics lie, the Kronecker block of Lambda and
+        the free conversion -- nothing is copied back inside the call (round 3: statistics to the host, ~40 numpy calls on
+        21 x 21 matrices, blocks back up).  want_host=False leaves the matrix in HBM (`ctx.chol_factor_last()`)."""
+        self._push_state()
+        return self.ctx.mvnreg_hessian(free_val, self._host_pack(free_val), [self._ms.start, self._ls.start, self._ia, self._ib],
+                                       want_value=want_value, want_host=want_host)
 
     def _terms(self, eta, S, W, kron=True):
         sp = self._special

@@ -215,6 +215,8 @@ def test_device_elimination_matches_host_assembly(vb, N, p, G):
     H_host = fun._global_hessian_host(theta)
     assert rel_err(H_dev, H_host) < 1e-11
     assert np.max(np.abs(H_dev - H_dev.T)) < 1e-12 * np.max(np.abs(H_dev))
+    # the ONE-CALL route (closed forms on the device, round 4) against round 3's call-by-call route with numpy closed forms
+    assert rel_err(H_dev, fun._global_hessian_device_stepwise(theta, True)) < 1e-12
     # the grouped statistics call against the two separate calls, and against numpy
     S, gs = fun.ctx.grouped_stats(want_S=True, want_gs=True)
     assert rel_err(S, fun.ctx.weighted_gram()) < 1e-13 and rel_err(gs, fun.ctx.group_sums()) < 1e-13   # other kernels, other summation order
@@ -228,6 +230,7 @@ def test_device_elimination_matches_host_assembly(vb, N, p, G):
     fun.weights_par.set_vector(np.ones(N))
     eta = _cavi_optimum(x, y, gid, G, np.zeros(p), 0.2 * np.eye(p), 0.1, 0.3, (2.0, 1.0), (1.5, 0.5))
     theta_opt = _layout(p, G).unconstrain(eta)
+    fun.want_diagnostics = True                                # the sums of the elimination come back with the call
     assert fun.global_hessian(theta_opt, want_host=False) is None
     assert fun.last_local_grad_norm < 1e-6 * N                 # the kernel's own stationarity diagnostic
     fun._gctx.chol_factor_last()

@@ -121,3 +121,38 @@ def test_statistics_are_not_reduced_twice_under_a_hook(vb):
     np.testing.assert_allclose(fun.local_stats(), local, rtol=1e-14)          # hook removed: local again, not the doubled cache
     fun.set_reduced_stats(local)                                               # the host-side exchange is fine without a hook
     fun.set_reduced_stats(None)
+
+
+@pytest.mark.parametrize('N,k', [(300, 1), (5000, 6), (20000, 21)])
+def test_one_call_hessian_matches_the_stepwise_route_and_ad(vb, N, k):
+    """`MVNRegressionObjective.device_hessian` (lrvb_mvnreg_hessian: statistics, closed forms in (m, Lambda, a, b) evaluated on
+    the device where the statistics lie, Kronecker block, free conversion -- one call, no copy back inside) against round 3's
+    stepwise route (statistics to the host, numpy closed forms, blocks sent up) and against exact AD; the value comes from the
+    same kernel; want_host=False leaves the matrix where the Cholesky finds it."""
+    rng = np.random.default_rng(N + k)
+    x, y, par, fun, lay, ft = _build(vb, rng, N, k)
+    w = rng.uniform(0.5, 1.5, N)
+    fun.weights_par.set_vector(w)
+    theta = rng.normal(size=lay.D) * 0.3
+    H1, val = fun.device_hessian(theta, want_value=True)
+    fun.stepwise = True
+    H0 = vb.Objective(par, fun).fun_free_hessian(theta)
+    fun.stepwise = False
+    assert rel_err(H1, H0) < 1e-12
+    assert np.max(np.abs(H1 - H1.T)) < 1e-12 * np.max(np.abs(H1))
+    tt, tw = torch.tensor(theta), torch.tensor(w)
+    assert rel_err(H1, torch.func.hessian(ft)(tt, tw).numpy()) < 1e-9
+    assert abs(val - ft(tt, tw).item()) < 1e-11 * abs(ft(tt, tw).item())
+    assert rel_err(vb.Objective(par, fun).fun_free_hessian(theta), H1) == 0.0          # the Objective route IS the one call
+    # resident result: factor it where it lies (shifted copy on the host for the comparison)
+    assert fun.device_hessian(theta, want_host=False)[0] is None
+    ev = np.linalg.eigvalsh(H1).min()
+    if ev > 1e-8 * np.abs(H1).max():
+        fun.ctx.chol_factor_last()
+        M = np.eye(lay.D)[:2]
+        assert rel_err(fun.ctx.lrvb_cov(M), M @ np.linalg.solve(H1, M.T)) < 1e-7
+    # new weights and a new prior reach the next call
+    fun.weights_par.set_vector(w * 1.5)
+    fun.prior_mean_par.set_vector(np.full(k, 0.3))
+    ft2 = tr.mvn_regression_objective(x, y, k, np.full(k, 0.3), 0.1 * np.eye(k), 2.0, 1.5, layout=lay)
+    assert rel_err(fun.device_hessian(theta)[0], torch.func.hessian(ft2)(tt, 1.5 * tw).numpy()) < 1e-9
