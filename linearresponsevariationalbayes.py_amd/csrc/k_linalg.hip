@@ -845,3 +845,32 @@ int launch_gemv(lrvb_ctx* c, bool trans, i64 M, i64 Nn, double alpha, const doub
     HIP_TRY(hipGetLastError());
     return LRVB_OK;
 }
+
+// C (PA x PB) = A^T B for operands of a few hundred rows and columns (A: K x PA, B: K x PB, row-major): 16 x 16 output tiles, the
+// contraction staged through LDS 16 rows at a time.  The generic 64 x 64-tile GEMM puts a 254 x 254 product (configuration 2's
+// free conversion) on 16 workgroups (22 us); this one fills the chip.
+__global__ __launch_bounds__(256)
+void gemm_tn_small_kernel(i64 K, i64 PA, i64 PB, const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C)
+{
+    __shared__ double As[16][17];
+    __shared__ double Bs[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const i64 i0 = (i64)blockIdx.y * 16, j0 = (i64)blockIdx.x * 16;
+    double acc = 0.0;
+    for (i64 k0 = 0; k0 < K; k0 += 16) {
+        const i64 k = k0 + ty;
+        As[ty][tx] = (k < K && i0 + tx < PA) ? A[k * PA + i0 + tx] : 0.0;
+        Bs[ty][tx] = (k < K && j0 + tx < PB) ? B[k * PB + j0 + tx] : 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) acc += As[kk][ty] * Bs[kk][tx];
+        __syncthreads();
+    }
+    if (i0 + ty < PA && j0 + tx < PB) C[(i0 + ty) * PB + j0 + tx] = acc;
+}
+int launch_gemm_tn_small(lrvb_ctx* c, i64 K, i64 PA, i64 PB, const double* A, const double* B, double* C) {
+    dim3 grid((unsigned)((PB + 15) / 16), (unsigned)((PA + 15) / 16));
+    hipLaunchKernelGGL(gemm_tn_small_kernel, grid, dim3(256), 0, c->stream, K, PA, PB, A, B, C);
+    HIP_TRY(hipGetLastError());
+    return LRVB_OK;
+}

@@ -407,19 +407,23 @@ __device__ __forceinline__ void vech_rc(int k, int& r, int& c) {
     r = a; c = k - a * (a + 1) / 2;
 }
 __global__ __launch_bounds__(1024)
-void lmm_closed_forms_kernel(LmmIdx ix, const double* __restrict__ S, const double* __restrict__ sums, const double* __restrict__ Md,
-                             const double* __restrict__ hp, double* __restrict__ T /* scratch: p^2 */, double* __restrict__ PSP /* scratch: p^2 */,
-                             double* __restrict__ g, double* __restrict__ H, double* __restrict__ Gc)
+void lmm_closed_forms_kernel(LmmIdx ix, const double* __restrict__ Sg, const double* __restrict__ sums, const double* __restrict__ Md,
+                             const double* __restrict__ hp, double* __restrict__ g, double* __restrict__ H, double* __restrict__ Gc)
 {
+    extern __shared__ double lds[];                       // S (q^2) | P (p^2) | T (p^2) | PSP (p^2): one global read each, then LDS
     __shared__ double sh[1024];
     __shared__ double um[64];
     __shared__ double sc[16];
     const int p = ix.p, q = p + 1, tid = threadIdx.x;
+    double* S = lds; double* P = S + q * q; double* T = P + p * p; double* PSP = T + p * p;
+    for (int e = tid; e < q * q; e += 1024) S[e] = Sg[e];
+    for (int e = tid; e < p * p; e += 1024) P[e] = hp[32 + 2 * p + e];
+    __syncthreads();
     const i64 ld = ix.ld;
     const double ty = hp[0], tm = hp[1], e_mu = hp[2], i_mu = hp[3], ay = hp[4], by = hp[5], am = hp[6], bm = hp[7];
     const double tay = hp[8], tby = hp[9], tam = hp[10], tbm = hp[11], kappa0 = hp[12], mu0 = hp[13];
     const double a0y = hp[14], b0y = hp[15], a0m = hp[16], b0m = hp[17], Gn = hp[18];
-    const double* m = hp + 32; const double* beta0 = m + p; const double* P = beta0 + p; const double* lam0 = P + p * p; const double* PL0P = lam0 + p * p;
+    const double* m = hp + 32; const double* beta0 = m + p; const double* lam0 = beta0 + p + p * p; const double* PL0P = lam0 + p * p;
     // T = Sxx P; um = Sxx m - Sxy + v1; rss; trace(T)
     double tr = 0.0;
     for (int e = tid; e < p * p; e += 1024) {
@@ -511,9 +515,16 @@ void lmm_closed_forms_kernel(LmmIdx ix, const double* __restrict__ S, const doub
         H[(i64)row_of(a) * ld + row_of(b)] = v;
     }
 }
+static int closed_forms_lds(const void* kernel, size_t bytes) {
+    if (bytes > 64 * 1024) HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return LRVB_OK;
+}
 int launch_lmm_closed_forms(lrvb_ctx* c, const LmmIdx& ix, const double* S, const double* sums, const double* Md, const double* hp,
                             double* scratch, double* g, double* H, double* Gc) {
-    hipLaunchKernelGGL(lmm_closed_forms_kernel, dim3(1), dim3(1024), 0, c->stream, ix, S, sums, Md, hp, scratch, scratch + (size_t)ix.p * ix.p, g, H, Gc);
+    (void)scratch;
+    const size_t bytes = ((size_t)(ix.p + 1) * (ix.p + 1) + 3 * (size_t)ix.p * ix.p) * sizeof(double);
+    LRVB_TRY(closed_forms_lds(reinterpret_cast<const void*>(lmm_closed_forms_kernel), bytes));
+    hipLaunchKernelGGL(lmm_closed_forms_kernel, dim3(1), dim3(1024), bytes, c->stream, ix, S, sums, Md, hp, g, H, Gc);
     HIP_TRY(hipGetLastError());
     return LRVB_OK;
 }
@@ -548,7 +559,7 @@ __global__ void add_padded_kernel(i64 total, i64 n, const double* __restrict__ s
     const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
     const i64 i = e / n, j = e - i * n;
-    dst[i * ldd + j] += src[i * lds + j];
+    dst[i * ldd + j] = src[i * lds + j];
 }
 int launch_add_padded(lrvb_ctx* c, i64 n, const double* src, i64 lds, double* dst, i64 ldd) {
     const i64 total = n * n;
@@ -561,16 +572,20 @@ int launch_add_padded(lrvb_ctx* c, i64 n, const double* src, i64 lds, double* ds
 // vector-coordinate Hessian from [S ((k + 1)^2) | W] where they lie.  hp: [0] a [1] b [2] a0 [3] b0 [4] psi(a) [5] psi1(a)
 // [6] psi2(a) [7] gammaln(a) [8] log|Lambda|; from [32]: m (k), mu0 (k), P (k x k), Lambda0 (k x k), P Lambda0 P (k x k).
 __global__ __launch_bounds__(1024)
-void mvnreg_closed_forms_kernel(MvnRegIdx ix, const double* __restrict__ S, const double* __restrict__ hp, double* __restrict__ T,
-                                double* __restrict__ PSP, double* __restrict__ g, double* __restrict__ H, double* __restrict__ Gc,
-                                double* __restrict__ value_out)
+void mvnreg_closed_forms_kernel(MvnRegIdx ix, const double* __restrict__ Sg, const double* __restrict__ hp,
+                                double* __restrict__ g, double* __restrict__ H, double* __restrict__ Gc, double* __restrict__ value_out)
 {
+    extern __shared__ double lds[];                       // S (q^2 + 1) | P (k^2) | T (k^2) | PSP (k^2)
     __shared__ double sh[1024];
     __shared__ double u[64];
     const int k = ix.k, q = k + 1, tid = threadIdx.x;
+    double* S = lds; double* P = S + q * q + 1; double* T = P + k * k; double* PSP = T + k * k;
+    for (int t = tid; t < q * q + 1; t += 1024) S[t] = Sg[t];
+    for (int t = tid; t < k * k; t += 1024) P[t] = hp[32 + 2 * k + t];
+    __syncthreads();
     const i64 ld = ix.ld;
     const double a = hp[0], b = hp[1], a0 = hp[2], b0 = hp[3], dig = hp[4], p1 = hp[5], p2 = hp[6], lgam = hp[7], logdet = hp[8];
-    const double* m = hp + 32; const double* mu0 = m + k; const double* P = mu0 + k; const double* lam0 = P + k * k; const double* PL0P = lam0 + k * k;
+    const double* m = hp + 32; const double* mu0 = m + k; const double* lam0 = mu0 + k + k * k; const double* PL0P = lam0 + k * k;
     const double W = S[q * q];
     const double e = a / b, L = dig - log(b);
     double tr = 0.0, trl = 0.0;
@@ -632,7 +647,10 @@ void mvnreg_closed_forms_kernel(MvnRegIdx ix, const double* __restrict__ S, cons
 }
 int launch_mvnreg_closed_forms(lrvb_ctx* c, const MvnRegIdx& ix, const double* S, const double* hp, double* scratch,
                                double* g, double* H, double* Gc, double* value_out) {
-    hipLaunchKernelGGL(mvnreg_closed_forms_kernel, dim3(1), dim3(1024), 0, c->stream, ix, S, hp, scratch, scratch + (size_t)ix.k * ix.k, g, H, Gc, value_out);
+    (void)scratch;
+    const size_t bytes = ((size_t)(ix.k + 1) * (ix.k + 1) + 1 + 3 * (size_t)ix.k * ix.k) * sizeof(double);
+    LRVB_TRY(closed_forms_lds(reinterpret_cast<const void*>(mvnreg_closed_forms_kernel), bytes));
+    hipLaunchKernelGGL(mvnreg_closed_forms_kernel, dim3(1), dim3(1024), bytes, c->stream, ix, S, hp, g, H, Gc, value_out);
     HIP_TRY(hipGetLastError());
     return LRVB_OK;
 }

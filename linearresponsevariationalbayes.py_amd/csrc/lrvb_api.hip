@@ -1075,9 +1075,8 @@ static int free_conversion_padded(lrvb_ctx* c, const double* theta_dev, i64 Vp) 
     LRVB_TRY(launch_dense_jac(c, theta_dev, c->Jdense.p, Dp, Vp));
     LRVB_TRY(gemm_tn(c, Vp, Vp, Dp, c->Heta.p, c->Jdense.p, c->work1.p));          // H_vec is symmetric: H J = H^T J
     LRVB_TRY(gemm_tn(c, Vp, Dp, Dp, c->Jdense.p, c->work1.p, c->Tdense.p));        // J^T (H J)
-    HIP_TRY(hipMemsetAsync(c->Hfree.p, 0, (size_t)D * (size_t)D * sizeof(double), c->stream));
-    LRVB_TRY(launch_third_order(c, theta_dev, c->g_eta.p, c->Hfree.p));
-    return launch_add_padded(c, D, c->Tdense.p, Dp, c->Hfree.p, D);
+    LRVB_TRY(launch_add_padded(c, D, c->Tdense.p, Dp, c->Hfree.p, D));             // Hfree = J^T H J (compacted to leading dimension D) ...
+    return launch_third_order(c, theta_dev, c->g_eta.p, c->Hfree.p);                // ... + sum_k g_k d2 eta_k
 }
 
 extern "C" int lrvb_mvnreg_hessian(lrvb_ctx* c, const double* free_in, int64_t D, const double* hp, int64_t n_hp, const int32_t* idx,
@@ -1766,7 +1765,10 @@ static int gemm_tn(lrvb_ctx* c, i64 K, i64 PA, i64 PB, const double* A, const do
         return LRVB_OK;
     }
     const bool fast = big && !(PA % 2) && !(PB % 2) && !(((uintptr_t)A) & 15) && !(((uintptr_t)B) & 15);
-    if (!fast) return launch_gemm(c, true, false, PA, PB, K, 1.0, A, PA, B, PB, 0.0, C, PB);
+    if (!fast) {
+        if (PA <= 512 && PB <= 512 && K <= 4096 && PA * PB >= 4096) return launch_gemm_tn_small(c, K, PA, PB, A, B, C);   // a few hundred wide: 16 x 16 tiles fill the chip
+        return launch_gemm(c, true, false, PA, PB, K, 1.0, A, PA, B, PB, 0.0, C, PB);
+    }
     if (c->ones_n != K) {                      // the kernel reads up to 32 weights past K: they must be zero
         LRVB_TRY(buf_reserve(c, c->ones, (size_t)(K + 64)));
         EW(fill_kernel, K, 1.0, c->ones.p);

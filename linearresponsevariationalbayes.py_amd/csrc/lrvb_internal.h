@@ -179,6 +179,7 @@ int  launch_grouped_stats_fused(lrvb_ctx* c, double* S_dense_dev /* q x q */, do
 // k_linalg.hip
 int launch_gemm(lrvb_ctx* c, bool transA, bool transB, i64 M, i64 Nn, i64 K, double alpha,
                 const double* A, i64 lda, const double* B, i64 ldb, double beta, double* C, i64 ldc);
+int launch_gemm_tn_small(lrvb_ctx* c, i64 K, i64 PA, i64 PB, const double* A, const double* B, double* C);
 int launch_gemm_lower(lrvb_ctx* c, i64 M, i64 K, double alpha, const double* A, i64 lda,
                       double beta, double* C, i64 ldc);
 int launch_potrf_lower(lrvb_ctx* c, double* A, i64 n, i64 lda, int* info_dev);

@@ -78,7 +78,7 @@ class LMMObjective(DeclaredHypers):
         self._declare_hyper('tau_mu_prior', HyperVectorParam('tau_mu_prior', 2, lb=0.0, val=np.array(list(map(float, tau_mu_prior)))))
 
     beta0 = property(lambda self: self._hyper_vec('beta_prior_mean'))
-    lam0 = property(lambda self: vech_to_sym(self._hyper_vec('beta_prior_info')))
+    lam0 = property(lambda self: self._hyper_derived('beta_prior_info', vech_to_sym))
     mu0 = property(lambda self: float(self._hyper_vec('mu_prior')[0]))
     kappa0 = property(lambda self: float(self._hyper_vec('mu_prior')[1]))
     a0y = property(lambda self: float(self._hyper_vec('tau_y_prior')[0]))

@@ -17,7 +17,7 @@ import ctypes
 import numpy as np
 
 from . import _hip
-from .packing import VectorParam, HyperVectorParam, ResidentVector
+from .packing import VectorParam, HyperVectorParam, ResidentVector, tril_indices
 
 _LOSSES = {None: _hip.LOSS_NONE, 'none': _hip.LOSS_NONE, 'gaussian': _hip.LOSS_GAUSSIAN,
            'logistic': _hip.LOSS_LOGISTIC, 'poisson': _hip.LOSS_POISSON, 'data_only': _hip.LOSS_DATA_ONLY}
@@ -28,14 +28,14 @@ def sym_to_vech(A):
     (LRVB/MatrixParameters.py:16-41, index j + i (i + 1) / 2)."""
     A = _hip.as_f64(A)
     A = 0.5 * (A + A.T)
-    return np.ascontiguousarray(A[np.tril_indices(A.shape[0])])
+    return np.ascontiguousarray(A[tril_indices(A.shape[0])])
 
 
 def vech_to_sym(v):
     v = _hip.as_f64(v).ravel()
     k = int(round((np.sqrt(8.0 * v.size + 1.0) - 1.0) / 2.0))
     L = np.zeros((k, k))
-    L[np.tril_indices(k)] = v
+    L[tril_indices(k)] = v
     return L + L.T - np.diag(np.diag(L))
 
 
@@ -809,6 +809,19 @@ class DeclaredHypers(object):
 
     def _hyper_vec(self, name):
         return np.asarray(getattr(self, name + '_par').get_vector(), dtype=np.float64).ravel()
+
+    def _hyper_derived(self, name, make):
+        """make(vector value of the hyper-parameter), computed once per value (version stamp) of the parameter object."""
+        par = getattr(self, name + '_par')
+        version = getattr(par, 'version', None)
+        memo = self.__dict__.setdefault('_hyper_memo', {})
+        hit = memo.get(name)
+        if version is not None and hit is not None and hit[0] == (id(par), version):
+            return hit[1]
+        val = make(self._hyper_vec(name))
+        if version is not None:
+            memo[name] = ((id(par), version), val)
+        return val
 
     def _hyper_state_key(self, skip=('weights',)):
         """Cheap identity of the current values of the hyper-parameters (for result memos): version stamps where the

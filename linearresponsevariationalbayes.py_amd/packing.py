@@ -352,6 +352,22 @@ class ArrayParam(_BoxParam):
 
 
 # ------------------------------------------------------------------------------ psd maps
+_TRIL_CACHE = {}
+
+
+def tril_indices(k):
+    """np.tril_indices(k), computed once per k (numpy builds two k x k index grids per call: ~50 us at k = 21, which was a
+    third of configuration 2's host time per step)."""
+    k = int(k)
+    hit = _TRIL_CACHE.get(k)
+    if hit is None:
+        r, c = np.tril_indices(k)
+        r.flags.writeable = False
+        c.flags.writeable = False
+        hit = _TRIL_CACHE[k] = (r, c)
+    return hit
+
+
 def SymIndex(k1, k2):
     """Index of (k1, k2) in the row-major lower-triangle vector.  MatrixParameters.py:16-23."""
     a, b = (k1, k2) if k2 <= k1 else (k2, k1)
@@ -362,7 +378,7 @@ def vectorize_ld_matrix(mat):
     nrow, ncol = np.shape(mat)
     if nrow != ncol:
         raise ValueError('mat must be square')
-    return mat[np.tril_indices(nrow)]
+    return mat[tril_indices(nrow)]
 
 
 def _ld_size_to_dim(n):
@@ -376,7 +392,7 @@ def unvectorize_ld_matrix(vec):
     vec = np.asarray(vec)
     k = _ld_size_to_dim(vec.size)
     mat = np.zeros((k, k))
-    mat[np.tril_indices(k)] = vec
+    mat[tril_indices(k)] = vec
     return mat
 
 

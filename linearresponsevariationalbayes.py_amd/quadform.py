@@ -362,7 +362,7 @@ class MVNRegressionObjective(QuadraticDataObjective):
         self._declare_hyper('prior_rate', HyperVectorParam('prior_rate', 1, lb=0.0, val=np.array([float(prior_rate)])))
 
     mu0 = property(lambda self: self._hyper_vec('prior_mean'))
-    lam0 = property(lambda self: vech_to_sym(self._hyper_vec('prior_info')))
+    lam0 = property(lambda self: self._hyper_derived('prior_info', vech_to_sym))
     a0 = property(lambda self: float(self._hyper_vec('prior_shape')[0]))
     b0 = property(lambda self: float(self._hyper_vec('prior_rate')[0]))
 
@@ -566,9 +566,9 @@ class WishartMVNObjective(QuadraticDataObjective):
         self._declare_hyper('prior_inv_scale', HyperVectorParam('prior_inv_scale', mm, val=sym_to_vech(np.eye(d) if prior_inv_scale is None else prior_inv_scale)))
 
     mu0 = property(lambda self: self._hyper_vec('prior_mean'))
-    lam0 = property(lambda self: vech_to_sym(self._hyper_vec('prior_info')))
+    lam0 = property(lambda self: self._hyper_derived('prior_info', vech_to_sym))
     nu0 = property(lambda self: float(self._hyper_vec('prior_df')[0]))
-    w0 = property(lambda self: vech_to_sym(self._hyper_vec('prior_inv_scale')))
+    w0 = property(lambda self: self._hyper_derived('prior_inv_scale', vech_to_sym))
 
     def _prior_hyper(self, kind, eta, want):
         """Wishart prior (LRVB/ExponentialFamilies.py:72-94 terms): -1/2 (nu0 - d - 1) E log|Lambda| + 1/2 nu tr(W0 V)."""
