@@ -76,3 +76,56 @@ void cg_multi_tail_kernel(i64 D, double sq, const double* __restrict__ quadA /* 
     double* x = X + q * D; double* r = R + q * D;
     for (i64 d = threadIdx.x; d < D; d += 256) { x[d] += alpha * p[d]; r[d] -= alpha * qv(d); }
 }
+
+// W (Q x D) = U (Q x D) H for a SYMMETRIC resident matrix H (D x D, row-major), Q <= 16 per launch group: the block product of
+// the blocked CG when the Hessian of the point is resident.  H is read ONCE (8 MB at D = 1024), in 128-byte row segments: a
+// workgroup owns 16 columns, wave w the rows k = 4 w + (lane >> 4) (mod 16), lane & 15 the column; the 16 x 256-row chunk of U the
+// rows need is staged in LDS and read as broadcasts.  Per-lane partial sums meet in LDS in a fixed order (no atomics: bitwise
+// reproducible).  The generic 64 x 64-tile GEMM put this skinny product on 16 workgroups (~100 us per CG iteration).
+__global__ __launch_bounds__(256)
+void symm_block_kernel(i64 D, int Q, const double* __restrict__ U, const double* __restrict__ H, double* __restrict__ W)
+{
+    constexpr int QB = 16, KC = 256;
+    __shared__ double Us[QB][KC + 1];
+    __shared__ double red[16][QB][17];                    // [row slot of the workgroup][q][column]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, rslot = wave * 4 + (lane >> 4);           // 16 row slots per workgroup
+    const i64 j = (i64)blockIdx.x * 16 + col;
+    double acc[QB];
+#pragma unroll
+    for (int q = 0; q < QB; ++q) acc[q] = 0.0;
+    for (i64 k0 = 0; k0 < D; k0 += KC) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < QB * KC; e += 256) {
+            const int q = e / KC, kk = e - q * KC;
+            Us[q][kk] = (q < Q && k0 + kk < D) ? U[(i64)q * D + k0 + kk] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int kk = rslot; kk < KC; kk += 16) {
+            const i64 k = k0 + kk;
+            const double h = (k < D && j < D) ? H[k * D + j] : 0.0;
+#pragma unroll
+            for (int q = 0; q < QB; ++q) acc[q] += Us[q][kk] * h;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < QB; ++q) red[rslot][q][col] = acc[q];
+    __syncthreads();
+    {   // 256 threads = 16 q x 16 columns: each sums the 16 row slots in order
+        const int q = threadIdx.x >> 4, cc = threadIdx.x & 15;
+        const i64 jj = (i64)blockIdx.x * 16 + cc;
+        double s = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += red[r][q][cc];
+        if (q < Q && jj < D) W[(i64)q * D + jj] = s;
+    }
+}
+int launch_symm_block(lrvb_ctx* c, i64 Q, i64 D, const double* U, const double* H, double* W) {
+    for (i64 q0 = 0; q0 < Q; q0 += 16) {
+        const int qn = (int)((Q - q0 < 16) ? Q - q0 : 16);
+        hipLaunchKernelGGL(symm_block_kernel, dim3((unsigned)((D + 15) / 16)), dim3(256), 0, c->stream, D, qn, U + q0 * D, H, W + q0 * D);
+        HIP_TRY(hipGetLastError());
+    }
+    return LRVB_OK;
+}

@@ -2615,7 +2615,7 @@ static int cg_multi_fused_loop(lrvb_ctx* c, i64 Q, i64 D, double tol, i64 maxite
         HIP_TRY(hipMemcpyAsync(status + (it & 1) * 1024, s + (5 + (it & 1)) * Q, (size_t)Q * sizeof(double), hipMemcpyDeviceToHost, c->aux_stream));
         if (resident) {
             // W = U H: the whole block against the resident matrix (H symmetric), identical on every rank -- no reduction
-            LRVB_TRY(launch_gemm(c, false, false, Q, D, D, 1.0, U, D, c->Hres.p, D, 0.0, W, D));
+            LRVB_TRY(launch_symm_block(c, Q, D, U, c->Hres.p, W));
         } else {
         HIP_TRY(hipMemsetAsync(W, 0, (size_t)(Q * D) * sizeof(double), c->stream));
         for (i64 q0 = 0; q0 < Q; q0 += 16) {
@@ -2696,7 +2696,7 @@ extern "C" int lrvb_cg_solve_multi(lrvb_ctx* c, const double* free_in, const dou
         if (!prepared) LRVB_TRY(prepare_general_hvp(c, c->theta.p));
     }
     auto block_product = [&](const double* Vb, double* Out) -> int {
-        return resident ? launch_gemm(c, false, false, Q, D, D, 1.0, Vb, D, c->Hres.p, D, 0.0, Out, D) : hvp_apply_multi(c, Q, Vb, Out);
+        return resident ? launch_symm_block(c, Q, D, Vb, c->Hres.p, Out) : hvp_apply_multi(c, Q, Vb, Out);
     };
     // scalars: s[0..Q) = ||b||^2 | rr | rz | pq | alpha | beta | minus_alpha | one
     LRVB_TRY(buf_reserve(c, c->scal, (size_t)(8 * Q + 16)));

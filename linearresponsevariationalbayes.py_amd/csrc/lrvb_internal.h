@@ -198,6 +198,9 @@ int launch_hyper_cross(lrvb_ctx* c, int kind, i64 Ph, const double* r, const dou
 int launch_hyper_grad(lrvb_ctx* c, int kind, i64 Ph, const double* eta, const double* r, const double* Ar, double* g /* Ph */);
 int launch_hyper_col(lrvb_ctx* c, double a, const double* x, double bcoef, const double* y, double* out /* V */);
 
+// k_cg.hip
+int launch_symm_block(lrvb_ctx* c, i64 Q, i64 D, const double* U, const double* H /* symmetric, D x D */, double* W);
+
 // k_finish.hip
 int launch_quad_diff(lrvb_ctx* c, const double* eta_dev);    // vtmp = eta - m, vtmp2 = A (eta - m)
 int launch_quad_grad_value(lrvb_ctx* c, const double* eta_dev, double* g_eta_dev /* += */, double* value_dev /* += */);
