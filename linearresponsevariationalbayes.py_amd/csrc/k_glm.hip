@@ -296,7 +296,172 @@ static int launch_pass_nit(lrvb_ctx* c, PassMode mode, const double* beta, const
 }
 
 
-// ---- wide designs (n_cols > PASS_MAX_COLS): the row no longer fits in the registers of one wavefront ----
+
+// ---- wide designs in ONE pass (round 4): 1024 < n_cols <= 4096 --------------------------------------------------------------
+// A row of up to 4096 columns (32 KB) does not fit the registers of one wavefront, but it fits those of a WORKGROUP: wave w of
+// the four holds the columns [w NIT 128, (w + 1) NIT 128) of the stage's rows, exactly as the narrow kernel holds a whole row.
+// The dot product is the only thing the waves share: each reduces its quarter with the butterfly, the four partial sums meet in
+// LDS (two slots, alternating by stage: ONE barrier per stage) and are added in wave order, so every wave sees the same z; the
+// rank-one update then runs from the registers again and the waves write disjoint columns of the block partial.  X is read
+// once, as for narrow designs (the two-pass route below read it twice).
+template <int NIT, int MODE>
+__global__ __launch_bounds__(PASS_THREADS)
+void glm_pass_wide1_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
+                           const double* __restrict__ y, const double* __restrict__ w,
+                           const double* __restrict__ beta, const double* __restrict__ u,
+                           int loss, double lik_info,
+                           double* __restrict__ lp_out, double* __restrict__ cw_io,
+                           double* __restrict__ part_vec, double* __restrict__ part_val,
+                           int vec_ok_i, int store_obs)
+{
+    constexpr int R = (MODE == PASS_HVP) ? 1 : 2;
+    __shared__ double zpart[2][R][2][4];             // [stage parity][row][z | t][wave]
+    const bool vec_ok = vec_ok_i != 0;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int cbase = wave * NIT * 128;
+
+    double bt[NIT][2], ut[NIT][2], acc[NIT][2];
+    int colc[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int col = cbase + it * 128 + 2 * lane;
+        bt[it][0] = (MODE != PASS_HVP_C && col < P) ? beta[col] : 0.0;
+        bt[it][1] = (MODE != PASS_HVP_C && col + 1 < P) ? beta[col + 1] : 0.0;
+        ut[it][0] = (MODE != PASS_GRAD && col < P) ? u[col] : 0.0;
+        ut[it][1] = (MODE != PASS_GRAD && col + 1 < P) ? u[col + 1] : 0.0;
+        acc[it][0] = 0.0; acc[it][1] = 0.0;
+        colc[it] = col < P ? col : 0;                // clamped: always readable (the product with a zero of beta / u discards it)
+    }
+    double val = 0.0;
+
+    auto load_stage = [&](double (&x)[R][NIT][2], double (&sc)[R][2], i64 base) {
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            i64 n = base + rr; if (n > N - 1) n = N - 1;
+            const double* rowp = X + n * ldx;
+            if (MODE == PASS_HVP_C) { sc[rr][0] = cw_io[n]; sc[rr][1] = 0.0; }
+            else { sc[rr][0] = y[n]; sc[rr][1] = w[n]; }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                if (vec_ok) {
+                    typedef double v2d __attribute__((ext_vector_type(2)));
+                    const v2d tv = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(rowp + colc[it]));
+                    x[rr][it][0] = tv[0]; x[rr][it][1] = tv[1];
+                } else {
+                    const int c1 = colc[it] + 1 < P ? colc[it] + 1 : 0;
+                    x[rr][it][0] = rowp[colc[it]]; x[rr][it][1] = rowp[c1];
+                }
+            }
+        }
+    };
+    auto consume = [&](double (&x)[R][NIT][2], double (&sc)[R][2], i64 base, int parity) {
+        // this wave's quarter of the dot products
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            double z = 0.0, tt = 0.0;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                if (MODE != PASS_HVP_C) z += x[rr][it][0] * bt[it][0] + x[rr][it][1] * bt[it][1];
+                if (MODE != PASS_GRAD)  tt += x[rr][it][0] * ut[it][0] + x[rr][it][1] * ut[it][1];
+            }
+            if (MODE != PASS_HVP_C) z = wave_sum(z);
+            if (MODE != PASS_GRAD)  tt = wave_sum(tt);
+            if (lane == 0) { zpart[parity][rr][0][wave] = z; zpart[parity][rr][1][wave] = tt; }
+        }
+        __syncthreads();                              // the only barrier of the stage (the other parity's slots are free until the next one)
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            const i64 n = base + rr;
+            const bool live = n < N;
+            const double z = ((zpart[parity][rr][0][0] + zpart[parity][rr][0][1]) + zpart[parity][rr][0][2]) + zpart[parity][rr][0][3];
+            const double tt = ((zpart[parity][rr][1][0] + zpart[parity][rr][1][1]) + zpart[parity][rr][1][2]) + zpart[parity][rr][1][3];
+            double coef;
+            if (MODE == PASS_HVP_C) {
+                coef = sc[rr][0] * tt;
+            } else {
+                double l0, l1, l2;
+                loss_eval(loss, lik_info, sc[rr][0], z, l0, l1, l2);
+                const double wn = sc[rr][1];
+                if (MODE == PASS_GRAD) {
+                    coef = wn * l1;
+                    if (live) val += wn * l0;
+                    if (store_obs && live && tid == 0) { lp_out[n] = l1; cw_io[n] = wn * l2; }
+                } else {
+                    coef = wn * l2 * tt;
+                }
+            }
+            if (!live) coef = 0.0;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                acc[it][0] += coef * x[rr][it][0];
+                acc[it][1] += coef * x[rr][it][1];
+            }
+        }
+    };
+
+    // every workgroup runs the SAME number of stages (the barrier is workgroup-wide): rows past N are dead slots
+    const i64 step = (i64)gridDim.x * R;
+    const i64 n_stages = (N + step - 1) / step;
+    i64 base = (i64)blockIdx.x * R;
+    {
+        double xa[R][NIT][2], xb[R][NIT][2], sa[R][2], sb[R][2];
+        load_stage(xa, sa, base);
+        for (i64 s = 0; s < n_stages; s += 2) {
+            if (s + 1 < n_stages) load_stage(xb, sb, base + step);
+            consume(xa, sa, base, 0);
+            if (s + 1 >= n_stages) break;
+            base += step;
+            if (s + 2 < n_stages) load_stage(xa, sa, base + step);
+            consume(xb, sb, base, 1);
+            base += step;
+        }
+    }
+    double* dst = part_vec + (i64)blockIdx.x * P;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int col = cbase + it * 128 + 2 * lane;
+        if (col < P) dst[col] = acc[it][0];
+        if (col + 1 < P) dst[col + 1] = acc[it][1];
+    }
+    if (tid == 0 && MODE == PASS_GRAD) part_val[blockIdx.x] = val;     // every wave holds the same val (workgroup-uniform z)
+}
+
+template <int NIT>
+static int launch_pass_wide1_nit(lrvb_ctx* c, PassMode mode, const double* beta, const double* u, int grid, int vec_ok, int store_obs) {
+    dim3 g(grid), b(PASS_THREADS);
+#define WIDE1_LAUNCH(M) hipLaunchKernelGGL((glm_pass_wide1_kernel<NIT, M>), g, b, 0, c->stream, c->X.p, c->P, c->N, (int)c->P, \
+        c->y.p, c->w.p, beta, u, c->loss, c->lik_info, c->lp.p, c->cw.p, c->part_vec.p, c->part_val.p, vec_ok, store_obs)
+    if (mode == PASS_GRAD) WIDE1_LAUNCH(PASS_GRAD); else if (mode == PASS_HVP) WIDE1_LAUNCH(PASS_HVP); else WIDE1_LAUNCH(PASS_HVP_C);
+#undef WIDE1_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return LRVB_OK;
+}
+static int launch_glm_pass_wide1(lrvb_ctx* c, PassMode mode, const double* beta, const double* u,
+                                 double* out_vec_P, double* value_out_dev, bool store_obs) {
+    const i64 R = (mode == PASS_HVP) ? 1 : 2;
+    i64 grid = (c->N + R - 1) / R;
+    if (grid > 1024) grid = 1024;                         // four workgroups per CU's worth of row pairs
+    if (grid < 1) grid = 1;
+    LRVB_TRY(buf_reserve(c, c->part_vec, (size_t)(grid * c->P)));
+    LRVB_TRY(buf_reserve(c, c->part_val, (size_t)grid));
+    LRVB_TRY(buf_reserve(c, c->lp, (size_t)c->N));
+    LRVB_TRY(reserve_obs_vec(c, c->cw));
+    const int vec_ok = ((c->P % 2) == 0) && ((((uintptr_t)c->X.p) & 15) == 0);
+    if (c->prof_on && mode == PASS_GRAD) LRVB_TRY(prof_mark(c, PROF_PASS));
+    const int so = store_obs ? 1 : 0;
+    // columns per wave = NIT x 128: the smallest that covers a quarter of the row (idle lanes still issue their clamped loads)
+    if (c->P <= 1536)      LRVB_TRY(launch_pass_wide1_nit<3>(c, mode, beta, u, (int)grid, vec_ok, so));
+    else if (c->P <= 2048) LRVB_TRY(launch_pass_wide1_nit<4>(c, mode, beta, u, (int)grid, vec_ok, so));
+    else if (c->P <= 3072) LRVB_TRY(launch_pass_wide1_nit<6>(c, mode, beta, u, (int)grid, vec_ok, so));
+    else                   LRVB_TRY(launch_pass_wide1_nit<8>(c, mode, beta, u, (int)grid, vec_ok, so));
+    if (c->prof_on && mode == PASS_GRAD) LRVB_TRY(prof_mark(c, PROF_PASS));
+    LRVB_TRY(launch_pass_reduce(c, (int)grid, (int)c->P, out_vec_P, (mode == PASS_GRAD) ? value_out_dev : nullptr));
+    if (c->prof_on && mode == PASS_GRAD) c->prof.pass_bytes = 8.0 * (double)c->N * (double)(c->P + 3);
+    return LRVB_OK;
+}
+
+// ---- designs wider than 4096 columns: the row no longer fits in the registers of one workgroup ----
+// (and, under tuning bit 0, every design wider than 1024 columns: the route round 3 had for them)
 // Two passes over X instead of one: (1) one wavefront per row streams the row in 128-column chunks and
 // reduces the dot product(s), evaluates the loss terms and leaves the rank-one coefficient of the row in
 // coef[n]; (2) one workgroup per (row block, 128-column tile) accumulates sum_n coef_n x_n over its rows.
@@ -408,6 +573,9 @@ static int launch_glm_pass_wide(lrvb_ctx* c, PassMode mode, const double* beta, 
 
 int launch_glm_pass(lrvb_ctx* c, PassMode mode, const double* beta_dev, const double* u_dev,
                     double* out_vec_P, double* value_out_dev, bool store_obs) {
+    if (c->P > 4 * PASS_MAX_COLS) return launch_glm_pass_wide(c, mode, beta_dev, u_dev, out_vec_P, value_out_dev, store_obs);
+    if (c->P > PASS_MAX_COLS && !c->force_generic_wsyrk)      // (the tuning bit that forces the generic kernels keeps the two-pass route testable)
+        return launch_glm_pass_wide1(c, mode, beta_dev, u_dev, out_vec_P, value_out_dev, store_obs);
     if (c->P > PASS_MAX_COLS) return launch_glm_pass_wide(c, mode, beta_dev, u_dev, out_vec_P, value_out_dev, store_obs);
     // 8 blocks per CU worth of row pairs, capped by the work available
     const i64 rows_per_stage = (mode == PASS_HVP) ? 1 : 2;

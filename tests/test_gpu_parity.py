@@ -564,10 +564,13 @@ def test_edge_shapes(vb, N, P):
     assert rel_err(obj.fun_free_hessian(theta), model.hessian(theta)) < TOL
 
 
-@pytest.mark.parametrize('loss,N,P', [(om.GAUSSIAN, 300, 1030), (om.POISSON, 2051, 1153), (om.LOGISTIC, 1000, 2048)])
+@pytest.mark.parametrize('loss,N,P', [(om.GAUSSIAN, 300, 1030), (om.POISSON, 2051, 1153), (om.LOGISTIC, 1000, 2048),
+                                      (om.LOGISTIC, 777, 3000), (om.GAUSSIAN, 5, 4096), (om.POISSON, 1, 2050), (om.POISSON, 40, 4100)])
 def test_wide_designs(vb, loss, N, P):
-    """n_cols > 1024: the row no longer fits in one wavefront's registers; the two-pass route
-    (row dots, then column accumulation) must give the same value, gradient, Hessian, HVP and CG."""
+    """n_cols > 1024: the row no longer fits in one wavefront's registers.  Up to 4096 columns the four waves of a workgroup
+    hold a row between them and X is still read ONCE (round 4); wider still, the two-pass route (row dots, then column
+    accumulation).  Both must give the same value, gradient, Hessian, HVP and CG -- and the same as each other (tuning bit 0
+    sends every wide design down the two-pass route)."""
     rng = np.random.default_rng(P)
     p1 = P // 2
     par, lay = make_par(vb, [('box', 'u', p1, -np.inf, np.inf), ('box', 'pos', P - p1, 0.0, np.inf)])
@@ -580,6 +583,11 @@ def test_wide_designs(vb, loss, N, P):
     assert abs(obj.fun_free(theta) - model.value(theta)) <= 1e-12 * max(1.0, abs(model.value(theta)))
     assert rel_err(obj.fun_free_grad(theta), model.grad(theta)) < TOL
     Hw = model.hessian(theta)
+    assert rel_err(obj.fun_free_hvp(theta, v), Hw @ v) < TOL              # matrix-free: before the build leaves its matrix resident
+    g_one = obj.fun_free_grad(theta)
+    fun.ctx.set_tuning(0, 1)                                             # the two-pass route for the same design
+    assert rel_err(obj.fun_free_grad(theta), g_one) < 1e-12 and rel_err(obj.fun_free_hvp(theta, v), Hw @ v) < TOL
+    fun.ctx.set_tuning(0, 0)
     assert rel_err(obj.fun_free_hessian(theta), Hw) < TOL
     assert rel_err(obj.fun_free_hvp(theta, v), Hw @ v) < TOL
     eta = lay.constrain(theta)
