@@ -1,9 +1,9 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun): rocprofv3 kernel stats + separate PMC passes of the SAME
 # bench command; raw output under gpurun_out/, condensed summaries for profiles/.
-# usage: tools/collect_profiles.sh r03 [headline|configs|all]
+# usage: tools/collect_profiles.sh r04 [headline|configs|all]
 set -euo pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 WHAT=${2:-all}
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -29,10 +29,12 @@ if [ "$WHAT" = configs ] || [ "$WHAT" = all ]; then
   for c in c2 c3 c4; do python3 bench.py --config $c --steps 20 --warmup 5 > $O/${TAG}_bench_$c.json 2> $O/bench_$c.err; done
   python3 bench.py --config c5 --steps 3 --warmup 1 > $O/${TAG}_bench_c5.json 2> $O/bench_c5.err
   cd /tmp
-  for c in c3 c4; do
+  for c in c2 c3 c4; do
     rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$c -- python3 $R/bench.py --config $c --steps 10 --warmup 3 > /dev/null 2> $O/stats_$c.err
     python3 $R/tools/summarise_profile.py stats $(ls $O/stats_$c/*/*kernel_stats.csv | head -1) $O/${TAG}_${c}_kernel_stats.csv
   done
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c5 -- python3 $R/bench.py --config c5 --steps 2 --warmup 1 > /dev/null 2> $O/stats_c5.err
+  python3 $R/tools/summarise_profile.py stats $(ls $O/stats_c5/*/*kernel_stats.csv | head -1) $O/${TAG}_c5_kernel_stats.csv
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_lmm -- python3 $R/tools/time_lmm_stats.py > $O/lmm_stats.log 2> $O/stats_lmm.err
   python3 $R/tools/summarise_profile.py stats $(ls $O/stats_lmm/*/*kernel_stats.csv | head -1) $O/${TAG}_lmm_stats_kernel_stats.csv
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cg -- python3 $R/tools/time_hvp_multi.py > $O/cg.log 2> $O/stats_cg.err
