@@ -852,18 +852,25 @@ int launch_gemv(lrvb_ctx* c, bool trans, i64 M, i64 Nn, double alpha, const doub
 __global__ __launch_bounds__(256)
 void gemm_tn_small_kernel(i64 K, i64 PA, i64 PB, const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C)
 {
-    __shared__ double As[16][17];
-    __shared__ double Bs[16][17];
+    constexpr int KC = 64;                                 // 64 rows of the contraction per stage: four global loads per operand and
+    __shared__ double As[KC][17];                          // thread in flight at once (16-row stages were a chain of 16 load latencies)
+    __shared__ double Bs[KC][17];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const i64 i0 = (i64)blockIdx.y * 16, j0 = (i64)blockIdx.x * 16;
     double acc = 0.0;
-    for (i64 k0 = 0; k0 < K; k0 += 16) {
-        const i64 k = k0 + ty;
-        As[ty][tx] = (k < K && i0 + tx < PA) ? A[k * PA + i0 + tx] : 0.0;
-        Bs[ty][tx] = (k < K && j0 + tx < PB) ? B[k * PB + j0 + tx] : 0.0;
-        __syncthreads();
+    for (i64 k0 = 0; k0 < K; k0 += KC) {
+        double a[4], b[4];
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) acc += As[kk][ty] * Bs[kk][tx];
+        for (int r = 0; r < 4; ++r) {
+            const i64 k = k0 + ty + 16 * r;
+            a[r] = (k < K && i0 + tx < PA) ? A[k * PA + i0 + tx] : 0.0;
+            b[r] = (k < K && j0 + tx < PB) ? B[k * PB + j0 + tx] : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { As[ty + 16 * r][tx] = a[r]; Bs[ty + 16 * r][tx] = b[r]; }
+        __syncthreads();
+#pragma unroll 16
+        for (int kk = 0; kk < KC; ++kk) acc += As[kk][ty] * Bs[kk][tx];
         __syncthreads();
     }
     if (i0 + ty < PA && j0 + tx < PB) C[(i0 + ty) * PB + j0 + tx] = acc;
