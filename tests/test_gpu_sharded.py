@@ -404,7 +404,8 @@ def test_two_ranks_statistics_calls_of_every_model_family(tmp_path):
     kron = nbk * (nbk + 1) // 2 * 128 * 128 + qw * qw + 1
     mixn = 4100 + (21 + 21 % 2) * (10 + 10 % 2)             # [S64 | val2 | bad | pad | packed R]: q = 6 -> 21, K = 4 -> 10 packed columns
     assert list(rec['counts']) == [q * q + G * (q + 1), G * (q + 1), q * q + G * (q + 1),      # grouped_stats, group_sums, global_hessian
-                                   q * q + 1, q * q + 1, kron, qw * qw + 1,                     # weighted_gram_sum, the class's own (cached after), gram, Wishart stats
+                                   q * q + 1, q * q + 1, q * q + 1, kron, qw * qw + 1,          # weighted_gram_sum, the one-call Hessian's own statistics (round 4: formed
+                                                                                                # inside the call, not cached on the host), value's (cached after), gram, Wishart stats
                                    mixn, 4100, 3 * P * P + 2 * P + 1, 3 * P * P + 2 * P + 1]
 
 
