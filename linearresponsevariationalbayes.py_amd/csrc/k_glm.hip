@@ -25,6 +25,55 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// DPP moves of a double inside a row of 16 lanes (quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror = 0x141,
+// row_mirror = 0x140): the four last steps of a butterfly sum without the LDS crossbar
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+// gfx950's lane swaps (checked on the chip by tools/lab/permlane_probe.hip): v_permlane32_swap(a, b) leaves [a.lo, b.lo] and
+// [a.hi, b.hi] (halves of 32 lanes), v_permlane16_swap(a, b) leaves [a.r0, b.r0, a.r2, b.r2] and [a.r1, b.r1, a.r3, b.r3] (rows of
+// 16 lanes).  The sums of the two results: one exchange step of a butterfly for TWO values at once, without the LDS crossbar.
+__device__ __forceinline__ double swap_add32(double a, double b) {       // [a.lo + a.hi | b.lo + b.hi]
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double swap_add16(double a, double b) {       // [a.r0 + a.r1 | b.r0 + b.r1 | a.r2 + a.r3 | b.r2 + b.r3]
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+// Sums of R <= 4 per-lane values over the wavefront in ONE butterfly: the swap steps exchange different rows in the two
+// directions, so the number of live values halves with the lane distance; lane L ends with the wave total of row
+// L / (64 / G), G = 1, 2, 4 groups for R = 1, 2, 3..4 (row 3 of R = 3 is zero).  Fixed order of additions.
+template <int R>
+__device__ __forceinline__ double group_sums(const double (&v)[R], int lane) {
+    double s;
+    if (R == 1) {
+        s = swap_add32(v[0], v[0]);
+        s = swap_add16(s, s);
+    } else if (R == 2) {
+        s = swap_add32(v[0], v[1]);
+        s = swap_add16(s, s);
+    } else {
+        const double p = swap_add16(v[0], v[1]);                           // [a01 | b01 | a23 | b23]
+        const double q = swap_add16(v[2], R > 3 ? v[R - 1] : 0.0);         // [c01 | d01 | c23 | d23]
+        s = swap_add32(p, q);                                              // [a | b | c | d]
+    }
+    s += dpp_f64<0x140>(s);          // lane i <-> 15 - i
+    s += dpp_f64<0x141>(s);          // i <-> 7 - i of each half row
+    s += dpp_f64<0x4E>(s);
+    s += dpp_f64<0xB1>(s);
+    return s;
+}
+
 __device__ __forceinline__ void loss_eval(int loss, double lik_info, double y, double z,
                                           double& l0, double& l1, double& l2) {
     if (loss == LRVB_LOSS_GAUSSIAN) {
@@ -101,36 +150,50 @@ void glm_pass_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
             }
         }
     };
+    // The R rows of a stage share ONE butterfly (group_sums: lane L ends with the dot product of row L / GS) and ONE evaluation
+    // of the loss terms (row L / GS in lane L: exp / log1p of the logistic and Poisson losses cost more than the row's
+    // multiply-adds); the rank-one coefficients come back through scalar registers.
+    constexpr int GS = R == 1 ? 64 : 32;
+    const int gr = lane / GS;
+    const bool glead = (lane & (GS - 1)) == 0;
     auto consume = [&](double (&x)[R][NIT][2], double (&sc)[R][2], i64 base) {
+        double zr[R], tr[R];
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
-            const i64 n = base + rr;
-            const bool live = n < N;
-            const i64 ne = live ? n : N - 1;
             double z = 0.0, tt = 0.0;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 if (MODE != PASS_HVP_C) z += x[rr][it][0] * bt[it][0] + x[rr][it][1] * bt[it][1];
                 if (MODE != PASS_GRAD)  tt += x[rr][it][0] * ut[it][0] + x[rr][it][1] * ut[it][1];
             }
-            if (MODE != PASS_HVP_C) z = wave_sum(z);
-            if (MODE != PASS_GRAD)  tt = wave_sum(tt);
-            double coef;
-            if (MODE == PASS_HVP_C) {
-                coef = sc[rr][0] * tt;
+            zr[rr] = z; tr[rr] = tt;
+        }
+        double z = 0.0, tt = 0.0;
+        if (MODE != PASS_HVP_C) z = group_sums<R>(zr, lane);
+        if (MODE != PASS_GRAD)  tt = group_sums<R>(tr, lane);
+        double s0 = sc[0][0], s1 = sc[0][1];
+#pragma unroll
+        for (int rr = 1; rr < R; ++rr) if (gr == rr) { s0 = sc[rr][0]; s1 = sc[rr][1]; }
+        const i64 n = base + gr;
+        const bool live = n < N;
+        double coef_l;
+        if (MODE == PASS_HVP_C) {
+            coef_l = s0 * tt;
+        } else {
+            double l0, l1, l2;
+            loss_eval(loss, lik_info, s0, z, l0, l1, l2);
+            if (MODE == PASS_GRAD) {
+                coef_l = s1 * l1;
+                if (live && glead) val += s1 * l0;
+                if (store_obs && live && glead) { lp_out[n] = l1; cw_io[n] = s1 * l2; }
             } else {
-                double l0, l1, l2;
-                loss_eval(loss, lik_info, sc[rr][0], z, l0, l1, l2);
-                const double wn = sc[rr][1];
-                if (MODE == PASS_GRAD) {
-                    coef = wn * l1;
-                    if (live) val += wn * l0;
-                    if (store_obs && live && lane == 0) { lp_out[n] = l1; cw_io[n] = wn * l2; }
-                } else {
-                    coef = wn * l2 * tt;
-                }
+                coef_l = s1 * l2 * tt;
             }
-            if (!live) coef = 0.0;
+        }
+        if (!live) coef_l = 0.0;
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            const double coef = readlane_f64(coef_l, rr * GS);
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 acc[it][0] += coef * x[rr][it][0];
@@ -167,7 +230,12 @@ void glm_pass_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
             red[wave - 1][it * 128 + 2 * lane + 1] = acc[it][1];
         }
     }
-    if (lane == 0) redv[wave] = val;     // every lane holds the same val (wave-uniform z)
+    {                                    // the group leaders' sums, in row order
+        double vt = 0.0;
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) vt += readlane_f64(val, rr * GS);
+        if (lane == 0) redv[wave] = vt;
+    }
     __syncthreads();
     if (wave == 0) {
         double* dst = part_vec + (i64)blockIdx.x * P;
@@ -304,8 +372,8 @@ static int launch_pass_nit(lrvb_ctx* c, PassMode mode, const double* beta, const
 // LDS (two slots, alternating by stage: ONE barrier per stage) and are added in wave order, so every wave sees the same z; the
 // rank-one update then runs from the registers again and the waves write disjoint columns of the block partial.  X is read
 // once, as for narrow designs (the two-pass route below read it twice).
-template <int NIT, int MODE>
-__global__ __launch_bounds__(PASS_THREADS)
+template <int NW, int NIT, int R, int MODE>
+__global__ __launch_bounds__(NW * 64)
 void glm_pass_wide1_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
                            const double* __restrict__ y, const double* __restrict__ w,
                            const double* __restrict__ beta, const double* __restrict__ u,
@@ -314,8 +382,7 @@ void glm_pass_wide1_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
                            double* __restrict__ part_vec, double* __restrict__ part_val,
                            int vec_ok_i, int store_obs)
 {
-    constexpr int R = (MODE == PASS_HVP) ? 1 : 2;
-    __shared__ double zpart[2][R][2][4];             // [stage parity][row][z | t][wave]
+    __shared__ double zpart[2][R][2][NW];            // [stage parity][row][z | t][wave]
     const bool vec_ok = vec_ok_i != 0;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int cbase = wave * NIT * 128;
@@ -354,8 +421,14 @@ void glm_pass_wide1_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
             }
         }
     };
+    // lane groups of the merged butterfly: lane L works for row L / GS of the stage after it
+    constexpr int GS = R == 1 ? 64 : (R == 2 ? 32 : 16);
+    const int grp = lane / GS;
+    const int gr = grp < R ? grp : 0;
+    const bool glead = (lane & (GS - 1)) == 0 && grp < R;
     auto consume = [&](double (&x)[R][NIT][2], double (&sc)[R][2], i64 base, int parity) {
-        // this wave's quarter of the dot products
+        // this wave's quarter of the dot products, all R rows in one butterfly
+        double zr[R], tr[R];
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
             double z = 0.0, tt = 0.0;
@@ -364,33 +437,41 @@ void glm_pass_wide1_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
                 if (MODE != PASS_HVP_C) z += x[rr][it][0] * bt[it][0] + x[rr][it][1] * bt[it][1];
                 if (MODE != PASS_GRAD)  tt += x[rr][it][0] * ut[it][0] + x[rr][it][1] * ut[it][1];
             }
-            if (MODE != PASS_HVP_C) z = wave_sum(z);
-            if (MODE != PASS_GRAD)  tt = wave_sum(tt);
-            if (lane == 0) { zpart[parity][rr][0][wave] = z; zpart[parity][rr][1][wave] = tt; }
+            zr[rr] = z; tr[rr] = tt;
         }
+        double zs = 0.0, ts = 0.0;
+        if (MODE != PASS_HVP_C) zs = group_sums<R>(zr, lane);
+        if (MODE != PASS_GRAD)  ts = group_sums<R>(tr, lane);
+        if (glead) { zpart[parity][gr][0][wave] = zs; zpart[parity][gr][1][wave] = ts; }
         __syncthreads();                              // the only barrier of the stage (the other parity's slots are free until the next one)
+        // the loss terms of the R rows are evaluated ONCE per wave, row L / GS in lane L (exp / log1p of the logistic and
+        // Poisson losses cost more than the row's multiply-adds), then broadcast through scalar registers
+        double z = zpart[parity][gr][0][0], tt = zpart[parity][gr][1][0];
+#pragma unroll
+        for (int ww = 1; ww < NW; ++ww) { z += zpart[parity][gr][0][ww]; tt += zpart[parity][gr][1][ww]; }     // in wave order
+        double s0 = sc[0][0], s1 = sc[0][1];
+#pragma unroll
+        for (int rr = 1; rr < R; ++rr) if (gr == rr) { s0 = sc[rr][0]; s1 = sc[rr][1]; }
+        const i64 n = base + gr;
+        const bool live = n < N;
+        double coef_l;
+        if (MODE == PASS_HVP_C) {
+            coef_l = s0 * tt;
+        } else {
+            double l0, l1, l2;
+            loss_eval(loss, lik_info, s0, z, l0, l1, l2);
+            if (MODE == PASS_GRAD) {
+                coef_l = s1 * l1;
+                if (live && glead) val += s1 * l0;
+                if (store_obs && live && glead && wave == 0) { lp_out[n] = l1; cw_io[n] = s1 * l2; }
+            } else {
+                coef_l = s1 * l2 * tt;
+            }
+        }
+        if (!live) coef_l = 0.0;
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
-            const i64 n = base + rr;
-            const bool live = n < N;
-            const double z = ((zpart[parity][rr][0][0] + zpart[parity][rr][0][1]) + zpart[parity][rr][0][2]) + zpart[parity][rr][0][3];
-            const double tt = ((zpart[parity][rr][1][0] + zpart[parity][rr][1][1]) + zpart[parity][rr][1][2]) + zpart[parity][rr][1][3];
-            double coef;
-            if (MODE == PASS_HVP_C) {
-                coef = sc[rr][0] * tt;
-            } else {
-                double l0, l1, l2;
-                loss_eval(loss, lik_info, sc[rr][0], z, l0, l1, l2);
-                const double wn = sc[rr][1];
-                if (MODE == PASS_GRAD) {
-                    coef = wn * l1;
-                    if (live) val += wn * l0;
-                    if (store_obs && live && tid == 0) { lp_out[n] = l1; cw_io[n] = wn * l2; }
-                } else {
-                    coef = wn * l2 * tt;
-                }
-            }
-            if (!live) coef = 0.0;
+            const double coef = readlane_f64(coef_l, rr * GS);
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 acc[it][0] += coef * x[rr][it][0];
@@ -423,41 +504,63 @@ void glm_pass_wide1_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
         if (col < P) dst[col] = acc[it][0];
         if (col + 1 < P) dst[col + 1] = acc[it][1];
     }
-    if (tid == 0 && MODE == PASS_GRAD) part_val[blockIdx.x] = val;     // every wave holds the same val (workgroup-uniform z)
+    if (MODE == PASS_GRAD) {                            // the group leaders' sums, in row order (every wave holds the same ones)
+        double vt = 0.0;
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) vt += readlane_f64(val, rr * GS);
+        if (tid == 0) part_val[blockIdx.x] = vt;
+    }
 }
 
-template <int NIT>
-static int launch_pass_wide1_nit(lrvb_ctx* c, PassMode mode, const double* beta, const double* u, int grid, int vec_ok, int store_obs) {
-    dim3 g(grid), b(PASS_THREADS);
-#define WIDE1_LAUNCH(M) hipLaunchKernelGGL((glm_pass_wide1_kernel<NIT, M>), g, b, 0, c->stream, c->X.p, c->P, c->N, (int)c->P, \
-        c->y.p, c->w.p, beta, u, c->loss, c->lik_info, c->lp.p, c->cw.p, c->part_vec.p, c->part_val.p, vec_ok, store_obs)
-    if (mode == PASS_GRAD) WIDE1_LAUNCH(PASS_GRAD); else if (mode == PASS_HVP) WIDE1_LAUNCH(PASS_HVP); else WIDE1_LAUNCH(PASS_HVP_C);
-#undef WIDE1_LAUNCH
-    HIP_TRY(hipGetLastError());
-    return LRVB_OK;
-}
-static int launch_glm_pass_wide1(lrvb_ctx* c, PassMode mode, const double* beta, const double* u,
-                                 double* out_vec_P, double* value_out_dev, bool store_obs) {
-    const i64 R = (mode == PASS_HVP) ? 1 : 2;
+// One launch of the one-pass kernel with R rows per stage.  The grid is the number of workgroups the chip holds at once
+// (occupancy x CUs, asked of the runtime once per instantiation): every workgroup runs the same number of stages, so a grid
+// above the resident count would run its surplus as a second, partly filled round (NIT = 3 at 161 registers: 768 of 1024
+// workgroups resident, 4.2 TB/s).
+template <int NW, int NIT, int R>
+static int wide1_run(lrvb_ctx* c, PassMode mode, const double* beta, const double* u,
+                     double* out_vec_P, double* value_out_dev, bool store_obs) {
+    static int slots[3] = {0, 0, 0};
+    const int mi = (int)mode;
+    if (!slots[mi]) {
+        const void* k = mode == PASS_GRAD ? (const void*)glm_pass_wide1_kernel<NW, NIT, R, PASS_GRAD>
+                      : mode == PASS_HVP  ? (const void*)glm_pass_wide1_kernel<NW, NIT, R, PASS_HVP>
+                                          : (const void*)glm_pass_wide1_kernel<NW, NIT, R, PASS_HVP_C>;
+        int per_cu = 0, n_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, NW * 64, 0));
+        HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device));
+        if (per_cu < 1) per_cu = 1;
+        if (n_cu < 1) n_cu = 256;
+        slots[mi] = per_cu * n_cu;
+    }
     i64 grid = (c->N + R - 1) / R;
-    if (grid > 1024) grid = 1024;                         // four workgroups per CU's worth of row pairs
+    if (grid > slots[mi]) grid = slots[mi];
     if (grid < 1) grid = 1;
     LRVB_TRY(buf_reserve(c, c->part_vec, (size_t)(grid * c->P)));
     LRVB_TRY(buf_reserve(c, c->part_val, (size_t)grid));
     LRVB_TRY(buf_reserve(c, c->lp, (size_t)c->N));
     LRVB_TRY(reserve_obs_vec(c, c->cw));
     const int vec_ok = ((c->P % 2) == 0) && ((((uintptr_t)c->X.p) & 15) == 0);
-    if (c->prof_on && mode == PASS_GRAD) LRVB_TRY(prof_mark(c, PROF_PASS));
     const int so = store_obs ? 1 : 0;
-    // columns per wave = NIT x 128: the smallest that covers a quarter of the row (idle lanes still issue their clamped loads)
-    if (c->P <= 1536)      LRVB_TRY(launch_pass_wide1_nit<3>(c, mode, beta, u, (int)grid, vec_ok, so));
-    else if (c->P <= 2048) LRVB_TRY(launch_pass_wide1_nit<4>(c, mode, beta, u, (int)grid, vec_ok, so));
-    else if (c->P <= 3072) LRVB_TRY(launch_pass_wide1_nit<6>(c, mode, beta, u, (int)grid, vec_ok, so));
-    else                   LRVB_TRY(launch_pass_wide1_nit<8>(c, mode, beta, u, (int)grid, vec_ok, so));
+    if (c->prof_on && mode == PASS_GRAD) LRVB_TRY(prof_mark(c, PROF_PASS));
+    dim3 g((unsigned)grid), b(NW * 64);
+#define WIDE1_LAUNCH(M) hipLaunchKernelGGL((glm_pass_wide1_kernel<NW, NIT, R, M>), g, b, 0, c->stream, c->X.p, c->P, c->N, (int)c->P, \
+        c->y.p, c->w.p, beta, u, c->loss, c->lik_info, c->lp.p, c->cw.p, c->part_vec.p, c->part_val.p, vec_ok, so)
+    if (mode == PASS_GRAD) WIDE1_LAUNCH(PASS_GRAD); else if (mode == PASS_HVP) WIDE1_LAUNCH(PASS_HVP); else WIDE1_LAUNCH(PASS_HVP_C);
+#undef WIDE1_LAUNCH
+    HIP_TRY(hipGetLastError());
     if (c->prof_on && mode == PASS_GRAD) LRVB_TRY(prof_mark(c, PROF_PASS));
     LRVB_TRY(launch_pass_reduce(c, (int)grid, (int)c->P, out_vec_P, (mode == PASS_GRAD) ? value_out_dev : nullptr));
     if (c->prof_on && mode == PASS_GRAD) c->prof.pass_bytes = 8.0 * (double)c->N * (double)(c->P + 3);
     return LRVB_OK;
+}
+static int launch_glm_pass_wide1(lrvb_ctx* c, PassMode mode, const double* beta, const double* u,
+                                 double* out_vec_P, double* value_out_dev, bool store_obs) {
+    // NW waves x NIT x 128 columns: the smallest shape that covers the row (idle lanes still issue their clamped loads); the
+    // fewer waves share a row, the fewer wait at its barrier and the more doubles of X each lane has in flight
+    if (c->P <= 1536) return wide1_run<2, 6, 2>(c, mode, beta, u, out_vec_P, value_out_dev, store_obs);
+    if (c->P <= 2048) return wide1_run<2, 8, 2>(c, mode, beta, u, out_vec_P, value_out_dev, store_obs);
+    if (c->P <= 3072) return wide1_run<4, 6, 2>(c, mode, beta, u, out_vec_P, value_out_dev, store_obs);
+    return wide1_run<4, 8, 2>(c, mode, beta, u, out_vec_P, value_out_dev, store_obs);
 }
 
 // ---- designs wider than 4096 columns: the row no longer fits in the registers of one workgroup ----
