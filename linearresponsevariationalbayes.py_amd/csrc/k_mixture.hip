@@ -82,9 +82,7 @@ int launch_mixture_rows(lrvb_ctx* c, int K, const double* theta_z_dev, const dou
     if (c->N > 2147483647LL) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "mixture kernel indexes rows with 32 bits");
     if (lda != (i64)mixture_rows_lda(K)) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "mixture kernel writes rows of K (K + 1) / 2 doubles padded to an even length (got lda = %lld)", (long long)lda);
     i64 grid = ((c->N + 1) / 2 + 3) / 4;                  // two rows per wavefront, four wavefronts per workgroup
-    i64 grid_cap = 4096;
-    if (const char* e = getenv("LRVB_MX_GRID")) { const i64 v = atoll(e); if (v >= 1 && v <= 65536) grid_cap = v; }   // lab knob
-    if (grid > grid_cap) grid = grid_cap;
+    if (grid > 4096) grid = 4096;
     LRVB_TRY(buf_reserve(c, c->part_val, (size_t)(2 * grid)));
     // todo list of rows for the dense pass: N ints + the counter, in the observation scratch buffer
     LRVB_TRY(buf_reserve(c, c->lp, (size_t)(c->N / 2 + 2)));

@@ -366,10 +366,28 @@ int launch_unconstrain(lrvb_ctx* c, const double* eta_dev, double* theta_dev, in
     return LRVB_OK;
 }
 
-int launch_dense_jac(lrvb_ctx* c, const double* theta_dev, double* J_dev, i64 ld, i64 rows_alloc) {
+// Two buffers cleared by ONE launch (the one-call steps of configurations 2 and 4 are chains of short launches: every node
+// of the chain costs 3-5 us whatever it does).
+__global__ __launch_bounds__(256)
+void zero2_kernel(double* __restrict__ a, i64 na, double* __restrict__ b, i64 nb) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < na; i += stride) a[i] = 0.0;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += stride) b[i] = 0.0;
+}
+int launch_zero2(lrvb_ctx* c, double* a, size_t na, double* b, size_t nb) {
+    const size_t n = na > nb ? na : nb;
+    if (n == 0) return LRVB_OK;
+    size_t grid = (n + 255) / 256;
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(zero2_kernel, dim3((unsigned)grid), dim3(256), 0, c->stream, a, (i64)na, b, (i64)nb);
+    HIP_TRY(hipGetLastError());
+    return LRVB_OK;
+}
+
+int launch_dense_jac(lrvb_ctx* c, const double* theta_dev, double* J_dev, i64 ld, i64 rows_alloc, bool zeroed) {
     // ld / rows_alloc: the caller's (zero-padded, even-width) allocation; 0 = the plain V x D matrix
     const i64 ldj = ld > 0 ? ld : c->D;
-    HIP_TRY(hipMemsetAsync(J_dev, 0, sizeof(double) * (size_t)(rows_alloc > 0 ? rows_alloc : c->V) * (size_t)ldj, c->stream));
+    if (!zeroed) HIP_TRY(hipMemsetAsync(J_dev, 0, sizeof(double) * (size_t)(rows_alloc > 0 ? rows_alloc : c->V) * (size_t)ldj, c->stream));
     const bool fused = box_fused(c);
     if (fused) LRVB_TRY(launch_box_all<1>(c, theta_dev, nullptr, J_dev, nullptr, nullptr, ldj, nullptr));
     for (const auto& b : c->blocks) {

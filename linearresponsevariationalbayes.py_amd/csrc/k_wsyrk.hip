@@ -469,7 +469,7 @@ void wsyrk_glds_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
 template <int NPAIR, bool ALIGNED16>      // NPAIR = ceil(P / 32): 1 -> 2 tiles (3 MFMAs per k-step), 2 -> 4 tiles (10)
 __global__ __launch_bounds__(256)
 void gram_small_kernel(const double* __restrict__ Z, i64 ldz, i64 N, int P,
-                       const double* __restrict__ cpad, double* __restrict__ partial /* [grid][64*64] */)
+                       const double* __restrict__ cpad, double* __restrict__ partial /* [grid][64*64] */, int ones_col)
 {
     constexpr int NT = 2 * NPAIR;
     constexpr int NACC = NT * (NT + 1) / 2;
@@ -485,10 +485,14 @@ void gram_small_kernel(const double* __restrict__ Z, i64 ldz, i64 N, int P,
 
     int colp[NPAIR];                            // first column of this lane's pair, clamped for the load
     bool in0[NPAIR], in1[NPAIR];
+    // ones_col = P (a spare column of the 32 NPAIR the tiles hold; -1 = none): a virtual column of ones, so that entry (P, P) of
+    // the block partial is sum_n c_n and row P the weighted column sums -- no separate pass for the sum of the weights
+    bool one0[NPAIR], one1[NPAIR];
 #pragma unroll
     for (int m = 0; m < NPAIR; ++m) {
         const int c0 = 32 * m + 2 * li;
         in0[m] = c0 < P; in1[m] = c0 + 1 < P;
+        one0[m] = c0 == ones_col; one1[m] = c0 + 1 == ones_col;
         colp[m] = in1[m] ? c0 : (P >= 2 ? P - 2 : 0);
     }
 
@@ -502,8 +506,9 @@ void gram_small_kernel(const double* __restrict__ Z, i64 ldz, i64 N, int P,
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             i64 n = row0 + ks * 4 + lk;
-            cv[ks] = cpad[n] * live;                            // zero padding past N
-            if (n > N - 1) n = N - 1;
+            const bool inside = n < N;
+            if (!inside) n = N - 1;
+            cv[ks] = inside ? cpad[n] * live : 0.0;             // rows past N weigh nothing (the vector needs no padding here)
             const double* rowp = Z + n * ldz;
 #pragma unroll
             for (int m = 0; m < NPAIR; ++m) {
@@ -527,8 +532,8 @@ void gram_small_kernel(const double* __restrict__ Z, i64 ldz, i64 N, int P,
                 // (a select of two registers: written as x[ks][m][P >= 2 ? 1 : 0] it became a dynamic register index, i.e. a
                 // readfirstlane loop in every k-step)
                 const double xl = (P >= 2) ? x[ks][m][1] : x[ks][m][0];
-                const double v0 = in1[m] ? x[ks][m][0] : (in0[m] ? xl : 0.0);
-                const double v1 = in1[m] ? x[ks][m][1] : 0.0;
+                const double v0 = in1[m] ? x[ks][m][0] : (in0[m] ? xl : (one0[m] ? 1.0 : 0.0));
+                const double v1 = in1[m] ? x[ks][m][1] : (one1[m] ? 1.0 : 0.0);
                 b[2 * m] = v0; b[2 * m + 1] = v1;
                 a[2 * m] = v0 * cv[ks]; a[2 * m + 1] = v1 * cv[ks];
             }
@@ -597,58 +602,74 @@ void gram_small_kernel(const double* __restrict__ Z, i64 ldz, i64 N, int P,
     }
 }
 
-// tiles[0] (128 x 128) <- sum_b partial[b] (64 x 64), fixed order, two levels: slice s of S sums the blocks
-// s, s + S, ... (grid 16 x S: 1024 block partials were 75 us on one level of 16 workgroups), then the slices in order.
+// tiles[0] (128 x 128) <- sum_b partial[b] (64 x 64), fixed order, ONE launch over the used C x C corner only (C = 32 or 64):
+// a workgroup owns 16 consecutive corner entries, slice s of its 16 sums the blocks s, s + 16, ... on four independent chains,
+// the slices meet in LDS and are added in order.  (Round 3: two launches over all 4096 entries of up to 1024 blocks, 11 + 6 us
+// around a 14 us kernel at N = 1e5 x 22.)
 __global__ __launch_bounds__(256)
-void gram_small_reduce_l1_kernel(const double* __restrict__ partial, int nblk, int S, double* __restrict__ lvl)
+void gram_small_reduce_kernel(const double* __restrict__ partial, int nblk, int C, int P, double* __restrict__ tile0,
+                              double* __restrict__ dense_out /* nullable: P x P, leading dimension ldd */, i64 ldd,
+                              double* __restrict__ csum_out /* nullable: entry (P, P) = sum of the weights (ones column) */)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    const int sl = blockIdx.y;
+    __shared__ double sh[16][17];
+    {   // the rest of the 128 x 128 tile is zeroed here (it is never read, but it travels in the sum over ranks and must stay
+        // finite): every workgroup clears its share, skipping the P x P entries that are written below -- no separate memset
+        const int per = (WS_TILE * WS_TILE) / (int)gridDim.x;
+        for (int i = (int)blockIdx.x * per + (int)threadIdx.x; i < ((int)blockIdx.x + 1) * per; i += 256) {
+            const int r = i / WS_TILE, cc = i - r * WS_TILE;
+            if (r >= P || cc >= P) tile0[i] = 0.0;
+        }
+    }
+    const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int id = blockIdx.x * 16 + el;                       // entry of the C x C corner (C * C is a multiple of 16)
+    const int row = id / C, col = id - row * C;
+    const double* src = partial + row * 64 + col;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int b = sl;
-    for (; b + 3 * S < nblk; b += 4 * S) {
-        s0 += partial[(i64)b * 4096 + e]; s1 += partial[(i64)(b + S) * 4096 + e];
-        s2 += partial[(i64)(b + 2 * S) * 4096 + e]; s3 += partial[(i64)(b + 3 * S) * 4096 + e];
+    for (; b + 48 < nblk; b += 64) {
+        s0 += src[(i64)b * 4096]; s1 += src[(i64)(b + 16) * 4096];
+        s2 += src[(i64)(b + 32) * 4096]; s3 += src[(i64)(b + 48) * 4096];
     }
-    for (; b < nblk; b += S) s0 += partial[(i64)b * 4096 + e];
-    lvl[(i64)sl * 4096 + e] = (s0 + s1) + (s2 + s3);
-}
-__global__ __launch_bounds__(256)
-void gram_small_reduce_kernel(const double* __restrict__ lvl, int S, int P, double* __restrict__ tile0)
-{
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= 64 * 64) return;
-    const int row = e >> 6, col = e & 63;
-    if (row >= P || col >= P) return;
-    double a = 0.0;
-    for (int sl = 0; sl < S; ++sl) a += lvl[(i64)sl * 4096 + e];
-    tile0[row * WS_TILE + col] = a;
+    for (; b < nblk; b += 16) s0 += src[(i64)b * 4096];
+    sh[sl][el] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    const bool inner = row < P && col < P, corner = csum_out && row == P && col == P;
+    if (sl == 0 && (inner || corner)) {
+        double a = sh[0][el];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) a += sh[q][el];
+        if (inner) { tile0[row * WS_TILE + col] = a; if (dense_out) dense_out[row * ldd + col] = a; }
+        else *csum_out = a;
+    }
 }
 
-int launch_gram_small_on(lrvb_ctx* c, const double* Z, i64 N, i64 P, const double* cvec_dev, double* tiles_out_dev) {
+// dense_out (nullable): the P x P result also as a dense matrix of leading dimension ldd (saves the unpacking launch);
+// csum_out (nullable; needs a spare column, P not 32 or 64): sum_n c_n through a virtual column of ones.
+int launch_gram_small_on(lrvb_ctx* c, const double* Z, i64 N, i64 P, const double* cvec_dev, double* tiles_out_dev,
+                         double* dense_out, i64 ldd, double* csum_out) {
     if (P > 64) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "narrow Gram kernel supports at most 64 columns");
+    if (csum_out && (P == 32 || P == 64)) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "no spare column for the sum of the weights");
+    const int ones_col = csum_out ? (int)P : -1;
+    // stages of 16 rows.  P <= 32 (four workgroups per CU resident): at least four stages per wave where the matrix is small --
+    // fewer block partials to add afterwards (N = 1e5 x 22: 391 workgroups instead of 1024).  Wider (one wave per SIMD, one stage
+    // in flight: latency-bound): one stage per wave up to 1024 workgroups -- 256 resident ones were 236 us against 157 at 1e6 x 64.
     const i64 stages = (N + 15) / 16;
-    i64 grid = (stages + 3) / 4;
+    i64 grid = P <= 32 ? (stages + 15) / 16 : (stages + 3) / 4;
     if (grid > 1024) grid = 1024;
     if (grid < 1) grid = 1;
-    const int S = grid >= 64 ? 32 : 1;
-    LRVB_TRY(buf_reserve(c, c->tile_part, (size_t)(grid + S) * 4096));
-    double* lvl = c->tile_part.p + (size_t)grid * 4096;
+    LRVB_TRY(buf_reserve(c, c->tile_part, (size_t)grid * 4096));
     const bool aligned16 = ((P % 2) == 0) && ((((uintptr_t)Z) & 15) == 0);
     if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
 #define GS_LAUNCH(NP, AL) hipLaunchKernelGGL((gram_small_kernel<NP, AL>), dim3((unsigned)grid), dim3(256), 0, c->stream, \
-                                             Z, P, N, (int)P, cvec_dev, c->tile_part.p)
+                                             Z, P, N, (int)P, cvec_dev, c->tile_part.p, ones_col)
     if (P <= 32) { if (aligned16) GS_LAUNCH(1, true); else GS_LAUNCH(1, false); }
     else         { if (aligned16) GS_LAUNCH(2, true); else GS_LAUNCH(2, false); }
 #undef GS_LAUNCH
     HIP_TRY(hipGetLastError());
     if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
-    HIP_TRY(hipMemsetAsync(tiles_out_dev, 0, sizeof(double) * WS_TILE * WS_TILE, c->stream));   // unused entries stay finite
-    hipLaunchKernelGGL(gram_small_reduce_l1_kernel, dim3(16, (unsigned)S), dim3(256), 0, c->stream,
-                       (const double*)c->tile_part.p, (int)grid, S, lvl);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(gram_small_reduce_kernel, dim3(16), dim3(256), 0, c->stream,
-                       (const double*)lvl, S, (int)P, tiles_out_dev);
+    const int C = P <= 32 ? 32 : 64;                          // C * C / 16 = 64 or 256 workgroups: both divide the 16384 tile entries
+    hipLaunchKernelGGL(gram_small_reduce_kernel, dim3((unsigned)(C * C / 16)), dim3(256), 0, c->stream,
+                       (const double*)c->tile_part.p, (int)grid, C, (int)P, tiles_out_dev, dense_out, ldd, csum_out);
     HIP_TRY(hipGetLastError());
     if (c->prof_on) {
         c->prof.wsyrk_flops = (double)N * (double)P * (double)(P + 1);

@@ -1066,16 +1066,25 @@ static int lmm_group_terms_device(lrvb_ctx* c, const double* par, int64_t n_par,
 // the padding zero) with theta on the device and g in c->g_eta; the result in c->Hfree (leading dimension D), where
 // lrvb_chol_factor_last finds it.  Even widths throughout: the two products run on the LDS-DMA MFMA kernel without the padded
 // copies of gemm_tn (three rectangular copies and a memset per product at the 995 parameters of configuration 4).
-static int free_conversion_padded(lrvb_ctx* c, const double* theta_dev, i64 Vp) {
+static int free_conversion_reserve(lrvb_ctx* c, i64 Vp) {
     const i64 D = c->D, Dp = D + (D & 1);
     LRVB_TRY(buf_reserve(c, c->Jdense, (size_t)Vp * (size_t)Dp));
     LRVB_TRY(buf_reserve(c, c->work1, (size_t)Vp * (size_t)Dp));
     LRVB_TRY(buf_reserve(c, c->Tdense, (size_t)Dp * (size_t)Dp));
-    LRVB_TRY(buf_reserve(c, c->Hfree, (size_t)D * (size_t)D));
-    LRVB_TRY(launch_dense_jac(c, theta_dev, c->Jdense.p, Dp, Vp));
+    return buf_reserve(c, c->Hfree, (size_t)D * (size_t)D);
+}
+// cleared: the caller has zeroed c->Jdense (Vp x Dp) together with c->Heta in one launch (launch_zero2).
+static int free_conversion_padded(lrvb_ctx* c, const double* theta_dev, i64 Vp, bool cleared = false) {
+    const i64 D = c->D, Dp = D + (D & 1);
+    LRVB_TRY(free_conversion_reserve(c, Vp));
+    LRVB_TRY(launch_dense_jac(c, theta_dev, c->Jdense.p, Dp, Vp, cleared));
     LRVB_TRY(gemm_tn(c, Vp, Vp, Dp, c->Heta.p, c->Jdense.p, c->work1.p));          // H_vec is symmetric: H J = H^T J
-    LRVB_TRY(gemm_tn(c, Vp, Dp, Dp, c->Jdense.p, c->work1.p, c->Tdense.p));        // J^T (H J)
-    LRVB_TRY(launch_add_padded(c, D, c->Tdense.p, Dp, c->Hfree.p, D));             // Hfree = J^T H J (compacted to leading dimension D) ...
+    if (Dp == D) {                                                                  // even D: J^T (H J) lands where the result lives
+        LRVB_TRY(gemm_tn(c, Vp, Dp, Dp, c->Jdense.p, c->work1.p, c->Hfree.p));
+    } else {
+        LRVB_TRY(gemm_tn(c, Vp, Dp, Dp, c->Jdense.p, c->work1.p, c->Tdense.p));    // J^T (H J)
+        LRVB_TRY(launch_add_padded(c, D, c->Tdense.p, Dp, c->Hfree.p, D));         // ... compacted to leading dimension D
+    }
     return launch_third_order(c, theta_dev, c->g_eta.p, c->Hfree.p);                // ... + sum_k g_k d2 eta_k
 }
 
@@ -1099,25 +1108,39 @@ extern "C" int lrvb_mvnreg_hessian(lrvb_ctx* c, const double* free_in, int64_t D
     LRVB_TRY(buf_reserve(c, c->qstats, (size_t)(q * q) + 1 + 256));
     LRVB_TRY(buf_reserve(c, c->Heta, (size_t)Vp * (size_t)Vp));
     LRVB_TRY(buf_reserve(c, c->vtmp3, (size_t)(3 * k * k + 1) > (size_t)(V > D ? V : D) ? (size_t)(3 * k * k + 1) : (size_t)(V > D ? V : D)));
+    LRVB_TRY(free_conversion_reserve(c, Vp));
     LRVB_TRY(h2d(c, c->hprog.p, pack.data(), pack.size()));
-    // statistics [S | sum w] (weights resident), summed over the ranks once
-    LRVB_TRY(reserve_obs_vec(c, c->zbuf));
-    HIP_TRY(hipMemcpyAsync(c->zbuf.p, c->w.p, (size_t)c->N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    // statistics [S | sum w] (weights resident, read in place), summed over the ranks once.  ONE stream: running what does not
+    // need the statistics (the zeroing of the vector-coordinate matrix, the packing Jacobian, the sum of the weights) on a side
+    // stream beside the pass was measured and lost -- 0.170 against 0.154 ms per step on the same box: the two event hand-offs
+    // cost more than the seven short launches they take off the chain.
+    const i64 Dp = D + (D & 1);
+    LRVB_TRY(launch_zero2(c, c->Heta.p, (size_t)Vp * (size_t)Vp, c->Jdense.p, (size_t)Vp * (size_t)Dp));
     double* tiles = c->stats.p + 1 + c->P;
-    LRVB_TRY(launch_wsyrk(c, c->zbuf.p, tiles));
-    LRVB_TRY(launch_tiles_to_dense(c, tiles, q, c->qstats.p, q, 0, 0, false));
-    hipLaunchKernelGGL(vec_block_sums_kernel, dim3(256), dim3(256), 0, c->stream, c->N, (const double*)c->w.p, c->qstats.p + q * q + 1);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)(c->qstats.p + q * q + 1), (i64)256, c->qstats.p + q * q);
-    HIP_TRY(hipGetLastError());
+    if (!c->force_generic_wsyrk && q != 32 && q != 64) {
+        // the Gram kernel leaves S as a dense q x q matrix and, through its spare column of ones, the sum of the weights beside it
+        LRVB_TRY(launch_gram_small_on(c, c->X.p, c->N, q, c->w.p, tiles, c->qstats.p, q, c->qstats.p + q * q));
+    } else {
+        if (!c->force_generic_wsyrk) {
+            LRVB_TRY(launch_gram_small_on(c, c->X.p, c->N, q, c->w.p, tiles, c->qstats.p, q));
+        } else {
+            LRVB_TRY(reserve_obs_vec(c, c->zbuf));
+            HIP_TRY(hipMemcpyAsync(c->zbuf.p, c->w.p, (size_t)c->N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+            LRVB_TRY(launch_wsyrk(c, c->zbuf.p, tiles));
+            LRVB_TRY(launch_tiles_to_dense(c, tiles, q, c->qstats.p, q, 0, 0, false));
+        }
+        hipLaunchKernelGGL(vec_block_sums_kernel, dim3(256), dim3(256), 0, c->stream, c->N, (const double*)c->w.p, c->qstats.p + q * q + 1);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)(c->qstats.p + q * q + 1), (i64)256, c->qstats.p + q * q);
+        HIP_TRY(hipGetLastError());
+    }
     LRVB_TRY(obs_reduce(c, c->qstats.p, q * q + 1));
     // closed forms where the statistics lie, the Kronecker block, the conversion to free coordinates
-    HIP_TRY(hipMemsetAsync(c->Heta.p, 0, (size_t)Vp * (size_t)Vp * sizeof(double), c->stream));
     const double* hp_dev = c->hprog.p + D;
     double* scratch = c->vtmp3.p; double* Gc = scratch + 2 * k * k; double* val = Gc + k * k;
     LRVB_TRY(launch_mvnreg_closed_forms(c, ix, c->qstats.p, hp_dev, scratch, c->g_eta.p, c->Heta.p, Gc, val));
     LRVB_TRY(launch_symkron3(c, (int)k, Gc, hp_dev + 32 + 2 * k, c->Heta.p, Vp, ix.ls));
-    LRVB_TRY(free_conversion_padded(c, c->hprog.p, Vp));
+    LRVB_TRY(free_conversion_padded(c, c->hprog.p, Vp, true));
     if (value_out) LRVB_TRY(d2h(c, value_out, val, 1));
     if (H_out) LRVB_TRY(d2h(c, H_out, c->Hfree.p, (size_t)D * (size_t)D));
     return LRVB_OK;
@@ -1143,6 +1166,7 @@ extern "C" int lrvb_lmm_global_hessian(lrvb_ctx* c, lrvb_ctx* gc, const double* 
     LRVB_TRY(buf_reserve(gc, gc->hprog, (size_t)(ng + n_hp)));
     LRVB_TRY(buf_reserve(gc, gc->Heta, (size_t)Vp * (size_t)Vp));
     LRVB_TRY(buf_reserve(gc, gc->vtmp3, (size_t)(3 * p * p) > (size_t)V ? (size_t)(3 * p * p) : (size_t)V));
+    LRVB_TRY(free_conversion_reserve(gc, Vp));
     // (a) the data context: [S | group sums] in one pass, summed over the ranks; the 2 G local parameters eliminated there
     LRVB_TRY(grouped_stats_device(c));
     std::vector<double> par((size_t)(8 + p));
@@ -1156,14 +1180,14 @@ extern "C" int lrvb_lmm_global_hessian(lrvb_ctx* c, lrvb_ctx* gc, const double* 
     memcpy(pack.data(), free_val, (size_t)ng * sizeof(double));
     memcpy(pack.data() + ng, hp, (size_t)n_hp * sizeof(double));
     LRVB_TRY(h2d(gc, gc->hprog.p, pack.data(), pack.size()));
-    HIP_TRY(hipMemsetAsync(gc->Heta.p, 0, (size_t)Vp * (size_t)Vp * sizeof(double), gc->stream));
+    LRVB_TRY(launch_zero2(gc, gc->Heta.p, (size_t)Vp * (size_t)Vp, gc->Jdense.p, (size_t)Vp * (size_t)(ng + (ng & 1))));
     LRVB_TRY(stream_handoff(c, c->stream, gc->stream));
     const double* hp_dev = gc->hprog.p + ng;
     double* scratch = gc->vtmp3.p; double* Gc = scratch + 2 * p * p;
     LRVB_TRY(launch_lmm_closed_forms(gc, ix, c->gstats.p, sums, sums + 128, hp_dev, scratch, gc->g_eta.p, gc->Heta.p, Gc));
     LRVB_TRY(stream_handoff(gc, gc->stream, c->stream));        // the data context's next call may overwrite what was just read
     LRVB_TRY(launch_symkron3(gc, (int)p, Gc, hp_dev + 32 + 2 * p, gc->Heta.p, Vp, ix.ls));
-    LRVB_TRY(free_conversion_padded(gc, gc->hprog.p, Vp));
+    LRVB_TRY(free_conversion_padded(gc, gc->hprog.p, Vp, true));      // (the packing Jacobian queued BEFORE the hand-off, beside the data context's pass, lost: 0.365 against 0.336 ms)
     if (sums_out) LRVB_TRY(d2h(c, sums_out, sums, 128));
     if (H_out) LRVB_TRY(d2h(gc, H_out, gc->Hfree.p, (size_t)ng * (size_t)ng));
     return LRVB_OK;
@@ -1386,11 +1410,14 @@ static int weighted_gram_impl(lrvb_ctx* c, double* S_out, int64_t ld, double* ws
     if (!S_out) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
     if (c->loss == LRVB_LOSS_NONE || !c->have_X) LRVB_FAIL(LRVB_ERR_STATE, "no data matrix: call lrvb_set_data(LRVB_SLOT_X) first");
     if (ld < c->P) LRVB_FAIL(LRVB_ERR_SIZE, "leading dimension too small");
-    // c = w (padded copy: the LDS-DMA stage over-reads up to 31 entries past N)
-    LRVB_TRY(reserve_obs_vec(c, c->zbuf));
-    HIP_TRY(hipMemcpyAsync(c->zbuf.p, c->w.p, (size_t)c->N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     double* tiles = c->stats.p + 1 + c->P;
-    LRVB_TRY(launch_wsyrk(c, c->zbuf.p, tiles));
+    if (c->P <= 64 && !c->force_generic_wsyrk) {
+        LRVB_TRY(launch_gram_small_on(c, c->X.p, c->N, c->P, c->w.p, tiles));   // reads the resident weights in place (no padding needed)
+    } else {                                                     // c = w (padded copy: the LDS-DMA stage over-reads up to 31 entries past N)
+        LRVB_TRY(reserve_obs_vec(c, c->zbuf));
+        HIP_TRY(hipMemcpyAsync(c->zbuf.p, c->w.p, (size_t)c->N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        LRVB_TRY(launch_wsyrk(c, c->zbuf.p, tiles));
+    }
     const i64 PP = c->P * c->P;
     LRVB_TRY(buf_reserve(c, c->Hfree, (size_t)PP + 1 + 256));
     LRVB_TRY(launch_tiles_to_dense(c, tiles, c->P, c->Hfree.p, c->P, 0, 0, false));

@@ -131,7 +131,9 @@ void buf_free(DevBuf& b);
 int upload_boxmap(lrvb_ctx* c);
 int launch_constrain(lrvb_ctx* c, const double* theta_dev, double* eta_dev, double* j1_dev, double* j2_dev);
 int launch_unconstrain(lrvb_ctx* c, const double* eta_dev, double* theta_dev, int* bad_flag_dev);
-int launch_dense_jac(lrvb_ctx* c, const double* theta_dev, double* J_dev /* V x D */, i64 ld = 0, i64 rows_alloc = 0);
+int launch_dense_jac(lrvb_ctx* c, const double* theta_dev, double* J_dev /* V x D */, i64 ld = 0, i64 rows_alloc = 0,
+                     bool zeroed = false /* the caller has cleared J (launch_zero2) */);
+int launch_zero2(lrvb_ctx* c, double* a, size_t na, double* b, size_t nb);       // two buffers cleared by one launch
 int launch_third_order(lrvb_ctx* c, const double* theta_dev, const double* g_eta_dev, double* T_dev /* D x D */);
 
 // k_glm.hip
@@ -151,7 +153,8 @@ int  wsyrk_auto_splits(const lrvb_ctx* c);
 int  launch_wsyrk(lrvb_ctx* c, const double* cvec_dev, double* tiles_out_dev /* T*128*128 */);
 bool wsyrk_fast_path(const lrvb_ctx* c);
 int  launch_wsyrk_r(lrvb_ctx* c, const double* cvec_dev, double* tiles_out_dev, const double* cy_dev /* nullable */, double* r_out_dev /* P */);
-int  launch_gram_small_on(lrvb_ctx* c, const double* Z, i64 N, i64 P, const double* cvec_dev, double* tiles_out_dev);
+int  launch_gram_small_on(lrvb_ctx* c, const double* Z, i64 N, i64 P, const double* cvec_dev, double* tiles_out_dev,
+                          double* dense_out = nullptr, i64 ldd = 0, double* csum_out = nullptr);
 int  launch_mixture_rows(lrvb_ctx* c, int K, const double* theta_z_dev, const double* lam_dev,
                          double* Amat_dev, i64 lda, double* U_dev, double* gfree_dev, double* val2_dev, int* bad_dev);
 int  launch_kron_rows(lrvb_ctx* c, double* Xk_dev, i64 ldk);
