@@ -10,6 +10,7 @@
 // (Parameters.py:63-64, MatrixParameters.py:132-135) and of simplex rows from closed forms
 // (SimplexParams.py:33-63); here all three are closed forms (derivations in DESIGN.md).
 #include "lrvb_internal.h"
+#include <cstring>
 #include <math.h>
 
 __device__ __forceinline__ i64 ld_idx(i64 a, i64 b) { return b + a * (a + 1) / 2; }   // a >= b
@@ -363,6 +364,170 @@ int launch_unconstrain(lrvb_ctx* c, const double* eta_dev, double* theta_dev, in
         }
         HIP_TRY(hipGetLastError());
     }
+    return LRVB_OK;
+}
+
+// ---- J^T A without the dense Jacobian (layouts of box and log-Cholesky blocks) ------------------------------------------------
+// The packing Jacobian is diagonal on box blocks and, on a k x k log-Cholesky block, has at most k + 1 entries per column:
+//   J[(i, j), (a, b)] = dL_ab (d_ia L_jb + d_ja L_ib)            (psd_jac_kernel above; (i, j), (a, b) packed lower triangles)
+// so row (a, b) of J^T A is dL_ab sum_{t >= b} L_tb G_a[t, :], where G_a gathers k rows of A: A[(a, t)] for t < a, 2 A[(a, a)],
+// A[(t, a)] for t > a.  One workgroup stages G_a for 64 columns of A in LDS once and serves all a + 1 rows (a, 0..a) from it:
+// k^2 rows of A are read per block instead of ~k^3 / 3 by a row-at-a-time product, and nothing like the two dense 2 V^3
+// products of convert_vector_to_free_hessian (LRVB/Parameters.py:397-424): at the 995 parameters of configuration 4 (one
+// 43 x 43 block) 2 x 59 us of MFMA products, reductions and unpacking become two launches of ~10 us.
+// TRANS_IN: A is read transposed (A[c][v]: the second product, J^T (J^T H)^T).  Table rows (5 x i64 per blockIdx.y):
+// [1, a, free_off, vec_off, k] or [0, first box entry, one past the last, -, -].
+typedef double jt_d4 __attribute__((ext_vector_type(4)));
+template <bool TRANS_IN, int NB>                      // NB >= ceil(k / 4): staging rows per wavefront
+__global__ __launch_bounds__(256)
+void jt_apply_kernel(const i64* __restrict__ rows, const i64* __restrict__ bfoff, const i64* __restrict__ bvoff,
+                     const double* __restrict__ blb, const double* __restrict__ bub, const double* __restrict__ theta,
+                     const double* __restrict__ A, i64 lda, i64 n, double* __restrict__ out, i64 ldo)
+{
+    extern __shared__ double jt_sm[];                 // G[kr][65] | L[kr][KP]   (kr = k rounded up to 4, KP to 16; zero padding)
+    constexpr int GS = 65;                            // row stride of G: the transposed staging writes down a column
+    const int tid = threadIdx.x, cx = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const i64 c0 = (i64)blockIdx.x * 64, c = c0 + cx;
+    const i64* r = rows + 5 * (i64)blockIdx.y;
+    if (r[0] == 0) {                                  // a chunk of box coordinates: a row scaling
+        for (i64 e = r[1] + wave; e < r[2]; e += 4) {
+            const i64 f = bfoff[e], v = bvoff[e];
+            double ev, d1, d2;
+            box_eval(theta[f], blb[e], bub[e], ev, d1, d2);
+            if (c < n) out[f * ldo + c] = d1 * (TRANS_IN ? A[c * lda + v] : A[v * lda + c]);
+        }
+        return;
+    }
+    const int a = (int)r[1], k = (int)r[4];
+    const int kr = (k + 3) & ~3, KP = (k + 15) & ~15;
+    const i64 fo = r[2], vo = r[3];
+    double* G = jt_sm;
+    double* Ls = jt_sm + (size_t)kr * GS;
+    const double* f = theta + fo;
+    // Staging: every global load of the block is issued before the first one is used (fully unrolled, values parked in
+    // registers).
+    {
+        double raw[NB], gv[16];
+        const int lc = cx < k ? cx : 0;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {                                          // row t = wave + 4 j of L, entry lc
+            const int t = wave + 4 * j;
+            const int tt = t < k ? t : k - 1;
+            raw[j] = f[ld_idx(tt, lc <= tt ? lc : 0)];
+        }
+        if (!TRANS_IN) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int t = wave + 4 * j;
+                const int tt = t < k ? t : k - 1;
+                const i64 v = vo + (tt <= a ? ld_idx(a, tt) : ld_idx(tt, a));
+                gv[j] = A[v * lda + (c < n ? c : n - 1)];
+            }
+        } else {                                      // lane <-> t: the entries (a, 0..a) of a row of A are contiguous
+            const i64 v = vo + (lc <= a ? ld_idx(a, lc) : ld_idx(lc, a));
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const i64 col = c0 + wave + 4 * j;
+                gv[j] = A[(col < n ? col : n - 1) * lda + v];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int t = wave + 4 * j;
+            if (t < kr && cx < KP) Ls[t * KP + cx] = (t >= k || cx > t) ? 0.0 : (cx == t ? exp(raw[j]) : raw[j]);   // zero above the diagonal and in the padding
+        }
+        if (!TRANS_IN) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int t = wave + 4 * j;
+                if (t < kr) G[t * GS + cx] = (t < k && c < n) ? gv[j] * (t == a ? 2.0 : 1.0) : 0.0;
+            }
+        } else if (cx < kr) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int cc = wave + 4 * j;
+                G[cx * GS + cc] = (cx < k && c0 + cc < n) ? gv[j] * (cx == a ? 2.0 : 1.0) : 0.0;
+            }
+        }
+    }
+    __syncthreads();
+    // rows (a, 0..a) of the result for this block's 64 columns = L[:, 0..a]^T G: 16 x 16 MFMA tiles, wave w <-> columns
+    // [16 w, 16 w + 16), one tile of 16 rows b at a time; the k-steps below the tile's first row are zeros of L and skipped.
+    // (Two VALU versions -- L from LDS per (b, t), and L through v_readlane -- took 24-29 us per launch at k = 43, n = 996:
+    // ~40 times the useful multiply-adds in overhead instructions.)
+    const int l15 = cx & 15, l4 = cx >> 4;
+    const i64 col = c0 + 16 * wave + l15;
+    for (int mt = 0; 16 * mt <= a; ++mt) {
+        jt_d4 acc = (jt_d4){0.0, 0.0, 0.0, 0.0};
+        for (int kk = 4 * mt; 4 * kk < kr; ++kk) {
+            const int t = 4 * kk + l4;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ls[t * KP + 16 * mt + l15], G[t * GS + 16 * wave + l15], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int b = 16 * mt + l4 + 4 * q;
+            if (b <= a && col < n) out[(fo + ld_idx(a, b)) * ldo + col] = (b == a) ? acc[q] * Ls[a * KP + a] : acc[q];      // dL_aa = exp(f_aa) = L_aa
+        }
+    }
+}
+
+// called once by lrvb_ctx_create: the row table of jt_apply_kernel (none when the layout has a simplex block or a
+// log-Cholesky block too large for LDS: the dense route stays)
+int upload_jtmap(lrvb_ctx* c) {
+    c->jt_rows = 0; c->jt_lds = 0;
+    i64 nbe = 0; int kmax = 0;
+    for (const auto& b : c->blocks) {
+        if (b.kind == LRVB_BLOCK_BOX) nbe += b.free_size;
+        else if (b.kind == LRVB_BLOCK_PSD) { if (b.dim0 > 63) return LRVB_OK; if ((int)b.dim0 > kmax) kmax = (int)b.dim0; }
+        else return LRVB_OK;
+    }
+    std::vector<i64> rows;
+    for (const auto& b : c->blocks)
+        if (b.kind == LRVB_BLOCK_PSD)
+            for (i64 a = 0; a < b.dim0; ++a) { rows.push_back(1); rows.push_back(a); rows.push_back(b.free_off); rows.push_back(b.vec_off); rows.push_back(b.dim0); }
+    for (i64 e = 0; e < nbe; e += 16) { rows.push_back(0); rows.push_back(e); rows.push_back(e + 16 < nbe ? e + 16 : nbe); rows.push_back(0); rows.push_back(0); }
+    const size_t nrows = rows.size() / 5;
+    if (nrows == 0 || nrows > 65535) return LRVB_OK;
+    // [rows (5 i64 each) | box free index | box vector index | lb | ub]
+    std::vector<double> host(rows.size() + (size_t)(4 * nbe));
+    memcpy(host.data(), rows.data(), rows.size() * sizeof(i64));
+    i64* foff = reinterpret_cast<i64*>(host.data() + rows.size());
+    i64* voff = foff + nbe;
+    double* lbs = host.data() + rows.size() + 2 * nbe; double* ubs = lbs + nbe;
+    i64 e = 0;
+    for (const auto& b : c->blocks)
+        if (b.kind == LRVB_BLOCK_BOX)
+            for (i64 i = 0; i < b.free_size; ++i, ++e) { foff[e] = b.free_off + i; voff[e] = b.vec_off + i; lbs[e] = b.lb; ubs[e] = b.ub; }
+    LRVB_TRY(buf_reserve(c, c->jtmap, host.size()));
+    HIP_TRY(hipMemcpyAsync(c->jtmap.p, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->jt_rows = (i64)nrows; c->jt_box = nbe; {
+        const int kr = (kmax + 3) & ~3, KP = (kmax + 15) & ~15;
+        c->jt_lds = (size_t)(kr * 65 + kr * KP) * sizeof(double); c->jt_kmax = kmax;
+        if (c->jt_lds > 65536) {                       // 61 <= k <= 63: past the default dynamic-LDS limit
+            HIP_TRY(hipFuncSetAttribute((const void*)jt_apply_kernel<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->jt_lds));
+            HIP_TRY(hipFuncSetAttribute((const void*)jt_apply_kernel<false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->jt_lds));
+        }
+    }
+    return LRVB_OK;
+}
+
+// out (D x n, leading dimension ldo) = J(theta)^T A  (A: V x n, leading dimension lda; trans_in: A given as n x V)
+int launch_jt_apply(lrvb_ctx* c, const double* theta_dev, const double* A, i64 lda, i64 n, double* out, i64 ldo, bool trans_in) {
+    if (c->jt_rows <= 0) LRVB_FAIL(LRVB_ERR_STATE, "no structured Jacobian for this layout");
+    const i64* rows = reinterpret_cast<const i64*>(c->jtmap.p);
+    const i64* foff = rows + 5 * c->jt_rows;
+    const i64* voff = foff + c->jt_box;
+    const double* lbs = c->jtmap.p + 5 * c->jt_rows + 2 * c->jt_box;
+    const double* ubs = lbs + c->jt_box;
+    dim3 grid((unsigned)((n + 63) / 64), (unsigned)c->jt_rows);
+#define JT_LAUNCH(TR, NB) hipLaunchKernelGGL((jt_apply_kernel<TR, NB>), grid, dim3(256), c->jt_lds, c->stream, rows, foff, voff, lbs, ubs, theta_dev, A, lda, n, out, ldo)
+    if (c->jt_kmax <= 16)      { if (trans_in) JT_LAUNCH(true, 4);  else JT_LAUNCH(false, 4); }
+    else if (c->jt_kmax <= 32) { if (trans_in) JT_LAUNCH(true, 8);  else JT_LAUNCH(false, 8); }
+    else                       { if (trans_in) JT_LAUNCH(true, 16); else JT_LAUNCH(false, 16); }
+#undef JT_LAUNCH
+    HIP_TRY(hipGetLastError());
     return LRVB_OK;
 }
 

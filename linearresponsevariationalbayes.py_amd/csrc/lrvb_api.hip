@@ -178,6 +178,7 @@ extern "C" int lrvb_ctx_create(lrvb_ctx** out, int device_id, const lrvb_model_d
     if (e != hipSuccess) { lrvb_set_error("context init: %s", hipGetErrorString(e)); delete c; return LRVB_ERR_HIP; }
 
     int st = upload_boxmap(c);
+    if (st == LRVB_OK) st = upload_jtmap(c);
     auto need = [&](DevBuf& b, size_t n) { if (st == LRVB_OK) st = buf_reserve(c, b, n); };
     need(c->theta, (size_t)(V > D ? V : D)); need(c->eta, (size_t)V); need(c->j1, (size_t)D); need(c->j2, (size_t)D);
     need(c->g_eta, (size_t)V); need(c->g_free, (size_t)D);
@@ -223,7 +224,7 @@ extern "C" int lrvb_ctx_destroy(lrvb_ctx* c) {
     DevBuf* all[] = { &c->X, &c->y, &c->w, &c->quadA, &c->quadM, &c->quadB, &c->theta, &c->eta, &c->j1, &c->j2,
                       &c->vtmp, &c->vtmp2, &c->vtmp3, &c->g_eta, &c->g_free, &c->lp, &c->cw, &c->zbuf,
                       &c->part_vec, &c->part_val, &c->stats, &c->tile_part, &c->Heta, &c->Hfree, &c->Jdense,
-                      &c->Tdense, &c->work1, &c->chol, &c->cholW, &c->hprog, &c->cgH, &c->groups, &c->mx_theta, &c->mx_lam, &c->mx_A, &c->mx_U, &c->mx_g, &c->mx_Xk, &c->mx_R, &c->cgT, &c->ones, &c->cgm[0], &c->cgm[1], &c->cgm[2], &c->cgm[3], &c->cgm[4], &c->cgm[5], &c->cgm[6], &c->cgm[7], &c->cgm[8], &c->rhs, &c->cgx, &c->cgr, &c->cgp, &c->cgq, &c->cgz, &c->scal, &c->opt, &c->dkw, &c->cyv, &c->rvec, &c->red_scratch, &c->gstats, &c->Zs, &c->ws, &c->bpart, &c->gpad, &c->boxmap, &c->Hres, &c->hres_theta, &c->qstats };
+                      &c->Tdense, &c->work1, &c->chol, &c->cholW, &c->hprog, &c->cgH, &c->groups, &c->mx_theta, &c->mx_lam, &c->mx_A, &c->mx_U, &c->mx_g, &c->mx_Xk, &c->mx_R, &c->cgT, &c->ones, &c->cgm[0], &c->cgm[1], &c->cgm[2], &c->cgm[3], &c->cgm[4], &c->cgm[5], &c->cgm[6], &c->cgm[7], &c->cgm[8], &c->rhs, &c->cgx, &c->cgr, &c->cgp, &c->cgq, &c->cgz, &c->scal, &c->opt, &c->dkw, &c->cyv, &c->rvec, &c->red_scratch, &c->gstats, &c->Zs, &c->ws, &c->bpart, &c->gpad, &c->boxmap, &c->jtmap, &c->Hres, &c->hres_theta, &c->qstats };
     for (DevBuf* b : all) buf_free(*b);
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
     if (c->up_ring) { for (int k = 0; k < lrvb_ctx::UP_SLOTS; ++k) if (c->up_ev[k]) (void)hipEventDestroy(c->up_ev[k]); (void)hipHostFree(c->up_ring); }
@@ -688,6 +689,19 @@ static int hessian_finish(lrvb_ctx* c, const double* point_dev, bool is_free, co
     LRVB_TRY(buf_reserve(c, c->Heta, (size_t)c->V * (size_t)c->V));
     LRVB_TRY(buf_reserve(c, c->work1, (size_t)c->V * (size_t)c->D));
     LRVB_TRY(launch_build_Heta(c, tiles, c->Heta.p));
+    if (c->jt_rows > 0) {
+        // box and log-Cholesky blocks: two structured products instead of the dense Jacobian and two V^2 D products
+        LRVB_TRY(launch_jt_apply(c, point_dev, c->Heta.p, c->V, c->V, c->work1.p, c->V, false));      // W = J^T H_eta (D x V)
+        if (ld == c->D) {
+            LRVB_TRY(launch_jt_apply(c, point_dev, c->work1.p, c->V, c->D, H_dev, ld, true));         // J^T W^T
+            return launch_third_order(c, point_dev, c->g_eta.p, H_dev);
+        }
+        LRVB_TRY(buf_reserve(c, c->Tdense, (size_t)c->D * (size_t)c->D));
+        LRVB_TRY(launch_jt_apply(c, point_dev, c->work1.p, c->V, c->D, c->Tdense.p, c->D, true));
+        LRVB_TRY(launch_third_order(c, point_dev, c->g_eta.p, c->Tdense.p));
+        HIP_TRY(hipMemcpy2DAsync(H_dev, (size_t)ld * 8, c->Tdense.p, (size_t)c->D * 8, (size_t)c->D * 8, (size_t)c->D, hipMemcpyDeviceToDevice, c->stream));
+        return LRVB_OK;
+    }
     LRVB_TRY(ensure_dense_J(c, point_dev));
     LRVB_TRY(launch_gemm(c, false, false, c->V, c->D, c->V, 1.0, c->Heta.p, c->V, c->Jdense.p, c->D, 0.0, c->work1.p, c->D));
     // T into H_dev (respecting ld), then H += J^T work1
@@ -1073,11 +1087,21 @@ static int free_conversion_reserve(lrvb_ctx* c, i64 Vp) {
     LRVB_TRY(buf_reserve(c, c->Tdense, (size_t)Dp * (size_t)Dp));
     return buf_reserve(c, c->Hfree, (size_t)D * (size_t)D);
 }
-// cleared: the caller has zeroed c->Jdense (Vp x Dp) together with c->Heta in one launch (launch_zero2).
-static int free_conversion_padded(lrvb_ctx* c, const double* theta_dev, i64 Vp, bool cleared = false) {
+// Clears c->Heta (Vp x Vp) and, where the conversion below builds the dense Jacobian, c->Jdense with it -- one launch.
+static int free_conversion_clear(lrvb_ctx* c, i64 Vp) {
+    const i64 Dp = c->D + (c->D & 1);
+    return launch_zero2(c, c->Heta.p, (size_t)Vp * (size_t)Vp, c->Jdense.p, c->jt_rows > 0 ? 0 : (size_t)Vp * (size_t)Dp);
+}
+// (after free_conversion_reserve + free_conversion_clear and the assembly of c->Heta)
+static int free_conversion_padded(lrvb_ctx* c, const double* theta_dev, i64 Vp) {
     const i64 D = c->D, Dp = D + (D & 1);
-    LRVB_TRY(free_conversion_reserve(c, Vp));
-    LRVB_TRY(launch_dense_jac(c, theta_dev, c->Jdense.p, Dp, Vp, cleared));
+    if (c->jt_rows > 0) {
+        // box and log-Cholesky blocks only: J^T H J as two structured products (k_pack.hip), no dense Jacobian
+        LRVB_TRY(launch_jt_apply(c, theta_dev, c->Heta.p, Vp, Vp, c->work1.p, Vp, false));      // W = J^T H       (D x Vp)
+        LRVB_TRY(launch_jt_apply(c, theta_dev, c->work1.p, Vp, D, c->Hfree.p, D, true));        // J^T W^T = J^T H J
+        return launch_third_order(c, theta_dev, c->g_eta.p, c->Hfree.p);                        // ... + sum_k g_k d2 eta_k
+    }
+    LRVB_TRY(launch_dense_jac(c, theta_dev, c->Jdense.p, Dp, Vp, true));
     LRVB_TRY(gemm_tn(c, Vp, Vp, Dp, c->Heta.p, c->Jdense.p, c->work1.p));          // H_vec is symmetric: H J = H^T J
     if (Dp == D) {                                                                  // even D: J^T (H J) lands where the result lives
         LRVB_TRY(gemm_tn(c, Vp, Dp, Dp, c->Jdense.p, c->work1.p, c->Hfree.p));
@@ -1114,8 +1138,7 @@ extern "C" int lrvb_mvnreg_hessian(lrvb_ctx* c, const double* free_in, int64_t D
     // need the statistics (the zeroing of the vector-coordinate matrix, the packing Jacobian, the sum of the weights) on a side
     // stream beside the pass was measured and lost -- 0.170 against 0.154 ms per step on the same box: the two event hand-offs
     // cost more than the seven short launches they take off the chain.
-    const i64 Dp = D + (D & 1);
-    LRVB_TRY(launch_zero2(c, c->Heta.p, (size_t)Vp * (size_t)Vp, c->Jdense.p, (size_t)Vp * (size_t)Dp));
+    LRVB_TRY(free_conversion_clear(c, Vp));
     double* tiles = c->stats.p + 1 + c->P;
     if (!c->force_generic_wsyrk && q != 32 && q != 64) {
         // the Gram kernel leaves S as a dense q x q matrix and, through its spare column of ones, the sum of the weights beside it
@@ -1140,7 +1163,7 @@ extern "C" int lrvb_mvnreg_hessian(lrvb_ctx* c, const double* free_in, int64_t D
     double* scratch = c->vtmp3.p; double* Gc = scratch + 2 * k * k; double* val = Gc + k * k;
     LRVB_TRY(launch_mvnreg_closed_forms(c, ix, c->qstats.p, hp_dev, scratch, c->g_eta.p, c->Heta.p, Gc, val));
     LRVB_TRY(launch_symkron3(c, (int)k, Gc, hp_dev + 32 + 2 * k, c->Heta.p, Vp, ix.ls));
-    LRVB_TRY(free_conversion_padded(c, c->hprog.p, Vp, true));
+    LRVB_TRY(free_conversion_padded(c, c->hprog.p, Vp));
     if (value_out) LRVB_TRY(d2h(c, value_out, val, 1));
     if (H_out) LRVB_TRY(d2h(c, H_out, c->Hfree.p, (size_t)D * (size_t)D));
     return LRVB_OK;
@@ -1180,14 +1203,14 @@ extern "C" int lrvb_lmm_global_hessian(lrvb_ctx* c, lrvb_ctx* gc, const double* 
     memcpy(pack.data(), free_val, (size_t)ng * sizeof(double));
     memcpy(pack.data() + ng, hp, (size_t)n_hp * sizeof(double));
     LRVB_TRY(h2d(gc, gc->hprog.p, pack.data(), pack.size()));
-    LRVB_TRY(launch_zero2(gc, gc->Heta.p, (size_t)Vp * (size_t)Vp, gc->Jdense.p, (size_t)Vp * (size_t)(ng + (ng & 1))));
+    LRVB_TRY(free_conversion_clear(gc, Vp));
     LRVB_TRY(stream_handoff(c, c->stream, gc->stream));
     const double* hp_dev = gc->hprog.p + ng;
     double* scratch = gc->vtmp3.p; double* Gc = scratch + 2 * p * p;
     LRVB_TRY(launch_lmm_closed_forms(gc, ix, c->gstats.p, sums, sums + 128, hp_dev, scratch, gc->g_eta.p, gc->Heta.p, Gc));
     LRVB_TRY(stream_handoff(gc, gc->stream, c->stream));        // the data context's next call may overwrite what was just read
     LRVB_TRY(launch_symkron3(gc, (int)p, Gc, hp_dev + 32 + 2 * p, gc->Heta.p, Vp, ix.ls));
-    LRVB_TRY(free_conversion_padded(gc, gc->hprog.p, Vp, true));      // (the packing Jacobian queued BEFORE the hand-off, beside the data context's pass, lost: 0.365 against 0.336 ms)
+    LRVB_TRY(free_conversion_padded(gc, gc->hprog.p, Vp));      // (the packing Jacobian queued BEFORE the hand-off, beside the data context's pass, lost: 0.365 against 0.336 ms)
     if (sums_out) LRVB_TRY(d2h(c, sums_out, sums, 128));
     if (H_out) LRVB_TRY(d2h(gc, H_out, gc->Hfree.p, (size_t)ng * (size_t)ng));
     return LRVB_OK;
@@ -1912,9 +1935,14 @@ static int quadform_gram_impl(lrvb_ctx* c, const double* M, const WishartGen* ge
         if (hipGetLastError() != hipSuccess) st = LRVB_ERR_HIP;
     }
     // free coordinates: J^T Av J
-    if (st == LRVB_OK) st = launch_dense_jac(c, c->theta.p, c->Jdense.p);
-    if (st == LRVB_OK) st = gemm_tn(c, V, V, D, Av.p, c->Jdense.p, T1.p);             // Av is symmetric
-    if (st == LRVB_OK) st = gemm_tn(c, V, D, D, c->Jdense.p, T1.p, c->Hfree.p);
+    if (c->jt_rows > 0) {                                                             // two structured products (k_pack.hip): no dense Jacobian, no 2 V^2 D products
+        if (st == LRVB_OK) st = launch_jt_apply(c, c->theta.p, Av.p, V, V, T1.p, V, false);          // J^T Av   (D x V)
+        if (st == LRVB_OK) st = launch_jt_apply(c, c->theta.p, T1.p, V, D, c->Hfree.p, D, true);     // J^T (J^T Av)^T
+    } else {
+        if (st == LRVB_OK) st = launch_dense_jac(c, c->theta.p, c->Jdense.p);
+        if (st == LRVB_OK) st = gemm_tn(c, V, V, D, Av.p, c->Jdense.p, T1.p);         // Av is symmetric
+        if (st == LRVB_OK) st = gemm_tn(c, V, D, D, c->Jdense.p, T1.p, c->Hfree.p);
+    }
     if (st == LRVB_OK && GtG_out) {
         if (hipMemcpy2DAsync(GtG_out, (size_t)ld * 8, c->Hfree.p, (size_t)D * 8, (size_t)D * 8, (size_t)D, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
             hipStreamSynchronize(c->stream) != hipSuccess) { lrvb_set_error("copy back failed"); st = LRVB_ERR_HIP; }

@@ -38,6 +38,7 @@ struct lrvb_ctx {
     // layout
     std::vector<lrvb_block_desc> blocks;
     lrvb_block_desc* blocks_dev = nullptr;
+    DevBuf jtmap; i64 jt_rows = 0, jt_box = 0; size_t jt_lds = 0; int jt_kmax = 0;      // structured J^T product: row table, box entries, dynamic LDS bytes
     DevBuf boxmap; int n_box_blocks = 0; i64 n_box_entries = 0;   // per-entry [free index | vector index | lb | ub] of all box blocks (k_pack.hip: one launch per map)
     i64 D = 0, V = 0;
     bool all_box = true;
@@ -129,6 +130,8 @@ void buf_free(DevBuf& b);
 // ---- kernel launchers (each returns an lrvb status) ----------------------------------
 // k_pack.hip
 int upload_boxmap(lrvb_ctx* c);
+int upload_jtmap(lrvb_ctx* c);            // row table of the structured J^T product (k_pack.hip); c->jt_rows = 0 where the layout has none
+int launch_jt_apply(lrvb_ctx* c, const double* theta_dev, const double* A, i64 lda, i64 n, double* out, i64 ldo, bool trans_in);
 int launch_constrain(lrvb_ctx* c, const double* theta_dev, double* eta_dev, double* j1_dev, double* j2_dev);
 int launch_unconstrain(lrvb_ctx* c, const double* eta_dev, double* theta_dev, int* bad_flag_dev);
 int launch_dense_jac(lrvb_ctx* c, const double* theta_dev, double* J_dev /* V x D */, i64 ld = 0, i64 rows_alloc = 0,
