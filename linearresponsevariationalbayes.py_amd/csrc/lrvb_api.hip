@@ -1369,8 +1369,12 @@ extern "C" int lrvb_jac_t_matmul(lrvb_ctx* c, const double* free_in, int64_t D, 
     LRVB_TRY(buf_reserve(c, c->work1, (size_t)V * (size_t)Q));
     LRVB_TRY(buf_reserve(c, c->Hfree, (size_t)D * (size_t)Q));
     LRVB_TRY(h2d(c, c->work1.p, B, (size_t)V * (size_t)Q));
-    LRVB_TRY(ensure_dense_J(c, c->theta.p));
-    LRVB_TRY(launch_gemm(c, true, false, D, Q, V, 1.0, c->Jdense.p, D, c->work1.p, Q, 0.0, c->Hfree.p, Q));
+    if (c->jt_rows > 0) {
+        LRVB_TRY(launch_jt_apply(c, c->theta.p, c->work1.p, Q, Q, c->Hfree.p, Q, false));      // the structured product (k_pack.hip)
+    } else {
+        LRVB_TRY(ensure_dense_J(c, c->theta.p));
+        LRVB_TRY(launch_gemm(c, true, false, D, Q, V, 1.0, c->Jdense.p, D, c->work1.p, Q, 0.0, c->Hfree.p, Q));
+    }
     return d2h(c, out, c->Hfree.p, (size_t)D * (size_t)Q);
 }
 
@@ -1394,9 +1398,14 @@ static int gram_dev_impl(lrvb_ctx* c, const double* free_dev, double* G_dev, i64
         st = buf_reserve(c, c->Heta, (size_t)c->V * (size_t)c->V);
         if (st == LRVB_OK) st = buf_reserve(c, c->work1, (size_t)c->V * (size_t)c->D);
         if (st == LRVB_OK) st = launch_build_Heta(c, tiles, c->Heta.p);
-        if (st == LRVB_OK) st = ensure_dense_J(c, free_dev);
-        if (st == LRVB_OK) st = launch_gemm(c, false, false, c->V, c->D, c->V, 1.0, c->Heta.p, c->V, c->Jdense.p, c->D, 0.0, c->work1.p, c->D);
-        if (st == LRVB_OK) st = launch_gemm(c, true, false, c->D, c->D, c->V, 1.0, c->Jdense.p, c->D, c->work1.p, c->D, 0.0, G_dev, ld);
+        if (c->jt_rows > 0) {                                    // the structured products (k_pack.hip)
+            if (st == LRVB_OK) st = launch_jt_apply(c, free_dev, c->Heta.p, c->V, c->V, c->work1.p, c->V, false);
+            if (st == LRVB_OK) st = launch_jt_apply(c, free_dev, c->work1.p, c->V, c->D, G_dev, ld, true);
+        } else {
+            if (st == LRVB_OK) st = ensure_dense_J(c, free_dev);
+            if (st == LRVB_OK) st = launch_gemm(c, false, false, c->V, c->D, c->V, 1.0, c->Heta.p, c->V, c->Jdense.p, c->D, 0.0, c->work1.p, c->D);
+            if (st == LRVB_OK) st = launch_gemm(c, true, false, c->D, c->D, c->V, 1.0, c->Jdense.p, c->D, c->work1.p, c->D, 0.0, G_dev, ld);
+        }
     }
     c->quad_kind = saved_quad;
     return st;

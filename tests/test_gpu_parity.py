@@ -747,3 +747,33 @@ def test_hvec_program_equals_the_call_per_block_route(vb):
     st = ctx._lib.lrvb_hvec_program(ctx._h, ops.ctypes.data_as(ctypes.c_void_p), 1, vb._hip.ptr(blk.ravel().copy()), 25,
                                     vb._hip.ptr(np.zeros(V)), V, 0, vb._hip.ptr(g), None)
     assert st != 0
+
+
+@pytest.mark.parametrize('k1,k2', [(1, 2), (5, 17), (33, 16), (63, 3)])
+def test_structured_jacobian_products(vb, k1, k2):
+    """Layouts of box and log-Cholesky blocks convert to free coordinates without the dense Jacobian (`jt_apply_kernel`:
+    J^T A as MFMA tiles over gathered rows): J^T B against the oracle's dense Jacobian, and the Hessian
+    J^T H_vec J + sum_k g_k d2 eta_k (LRVB/Parameters.py:397-424) of a model with a data term and a dense quadratic term,
+    for block orders from 1 to 63 (the largest the kernel's LDS holds), two blocks per layout, bounded and unbounded boxes."""
+    rng = np.random.default_rng(100 + k1)
+    spec = [('box', 'pre', 3, 0.0, np.inf), ('psd', 'm1', k1, 0.0), ('box', 'beta', 5, -1.0, 2.0), ('psd', 'm2', k2, 0.3), ('box', 'post', 2, -np.inf, np.inf)]
+    par, lay = make_par(vb, spec)
+    N, P = 300, 5
+    x, y, w = glm_data(rng, N, P, om.LOGISTIC)
+    A = rng.normal(size=(lay.V, lay.V)); A = A @ A.T / lay.V + np.eye(lay.V)
+    m, b = rng.normal(size=lay.V) * 0.2, rng.normal(size=lay.V) * 0.3
+    fun = vb.DeviceObjective(par, x=x, y=y, loss='logistic', glm_param='beta', quad_A=A, quad_m=m, quad_b=b, weights=w)
+    glm_off = 3 + k1 * (k1 + 1) // 2
+    model = om.DeclaredModel(lay, loss=om.LOGISTIC, x=x, y=y, w=w, glm_off=glm_off, quad_A=A, quad_m=m, quad_b=b)
+    theta = rng.normal(size=lay.D) * 0.3
+    J = lay.jac(theta)
+    for Q in (1, 70):
+        B = rng.normal(size=(lay.V, Q))
+        assert rel_err(fun.ctx.jac_t_matmul(theta, B), J.T @ B) < 1e-13
+    obj = vb.Objective(par, fun)
+    Hw = model.hessian(theta)
+    assert rel_err(obj.fun_free_grad(theta), model.grad(theta)) < TOL
+    assert rel_err(obj.fun_free_hessian(theta), Hw) < TOL
+    v = rng.normal(size=lay.D)
+    assert rel_err(obj.fun_free_hvp(theta, v), Hw @ v) < TOL
+    assert rel_err(fun.gram(theta), model.gram(theta)) < TOL
