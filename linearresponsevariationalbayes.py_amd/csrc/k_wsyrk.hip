@@ -608,7 +608,7 @@ void gram_small_kernel(const double* __restrict__ Z, i64 ldz, i64 N, int P,
 // around a 14 us kernel at N = 1e5 x 22.)
 __global__ __launch_bounds__(256)
 void gram_small_reduce_kernel(const double* __restrict__ partial, int nblk, int C, int P, double* __restrict__ tile0,
-                              double* __restrict__ dense_out /* nullable: P x P, leading dimension ldd */, i64 ldd,
+                              double* __restrict__ dense_out /* nullable: the leading pd x pd entries, leading dimension ldd */, i64 ldd, int pd,
                               double* __restrict__ csum_out /* nullable: entry (P, P) = sum of the weights (ones column) */)
 {
     __shared__ double sh[16][17];
@@ -638,23 +638,26 @@ void gram_small_reduce_kernel(const double* __restrict__ partial, int nblk, int 
         double a = sh[0][el];
 #pragma unroll
         for (int q = 1; q < 16; ++q) a += sh[q][el];
-        if (inner) { tile0[row * WS_TILE + col] = a; if (dense_out) dense_out[row * ldd + col] = a; }
+        if (inner) { tile0[row * WS_TILE + col] = a; if (dense_out && row < pd && col < pd) dense_out[row * ldd + col] = a; }
         else *csum_out = a;
     }
 }
 
-// dense_out (nullable): the P x P result also as a dense matrix of leading dimension ldd (saves the unpacking launch);
-// csum_out (nullable; needs a spare column, P not 32 or 64): sum_n c_n through a virtual column of ones.
+// dense_out (nullable): the leading pd x pd entries (pd = 0: P) of the result also as a dense matrix of leading dimension
+// ldd (saves the unpacking launch); csum_out (nullable; needs a spare column, P not 32 or 64): sum_n c_n through a virtual
+// column of ones.  Rows past N are never read (clamped, weight zero): Z and cvec_dev need no padding.
 int launch_gram_small_on(lrvb_ctx* c, const double* Z, i64 N, i64 P, const double* cvec_dev, double* tiles_out_dev,
-                         double* dense_out, i64 ldd, double* csum_out) {
+                         double* dense_out, i64 ldd, double* csum_out, i64 pd) {
     if (P > 64) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "narrow Gram kernel supports at most 64 columns");
     if (csum_out && (P == 32 || P == 64)) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "no spare column for the sum of the weights");
     const int ones_col = csum_out ? (int)P : -1;
     // stages of 16 rows.  P <= 32 (four workgroups per CU resident): at least four stages per wave where the matrix is small --
     // fewer block partials to add afterwards (N = 1e5 x 22: 391 workgroups instead of 1024).  Wider (one wave per SIMD, one stage
-    // in flight: latency-bound): one stage per wave up to 1024 workgroups -- 256 resident ones were 236 us against 157 at 1e6 x 64.
+    // in flight: latency-bound): two stages per wave (2e4 x 48, tools/lab/time_gram_small.py: 157 workgroups 20.7 us, 313 -- one
+    // stage per wave -- 35.6 us, 79: 23.7 us), up to 1024 workgroups (1e6 x 64 inside a configuration-3 step: 157 us; with the
+    // 256 resident ones only: 236 us).
     const i64 stages = (N + 15) / 16;
-    i64 grid = P <= 32 ? (stages + 15) / 16 : (stages + 3) / 4;
+    i64 grid = P <= 32 ? (stages + 15) / 16 : (stages + 7) / 8;
     if (grid > 1024) grid = 1024;
     if (grid < 1) grid = 1;
     LRVB_TRY(buf_reserve(c, c->tile_part, (size_t)grid * 4096));
@@ -669,7 +672,7 @@ int launch_gram_small_on(lrvb_ctx* c, const double* Z, i64 N, i64 P, const doubl
     if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
     const int C = P <= 32 ? 32 : 64;                          // C * C / 16 = 64 or 256 workgroups: both divide the 16384 tile entries
     hipLaunchKernelGGL(gram_small_reduce_kernel, dim3((unsigned)(C * C / 16)), dim3(256), 0, c->stream,
-                       (const double*)c->tile_part.p, (int)grid, C, (int)P, tiles_out_dev, dense_out, ldd, csum_out);
+                       (const double*)c->tile_part.p, (int)grid, C, (int)P, tiles_out_dev, dense_out, ldd, (int)(pd > 0 ? pd : P), csum_out);
     HIP_TRY(hipGetLastError());
     if (c->prof_on) {
         c->prof.wsyrk_flops = (double)N * (double)P * (double)(P + 1);

@@ -1619,8 +1619,6 @@ static int lmm_group_terms_device(lrvb_ctx* c, const double* par, int64_t n_par,
         memcpy(pack.data() + 8 + p, f_local, (size_t)(2 * G) * sizeof(double));
         LRVB_TRY(h2d(c, dpar, pack.data(), pack.size()));
     }
-    HIP_TRY(hipMemsetAsync(Cm + (size_t)(2 * G) * ldc, 0, (size_t)16 * ldc * sizeof(double), c->stream));
-    HIP_TRY(hipMemsetAsync(wts + 2 * G, 0, 64 * sizeof(double), c->stream));
     if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
     hipLaunchKernelGGL(lmm_group_kernel, dim3((unsigned)grid), dim3(256), 0, c->stream,
                        (const double*)(c->gstats.p + q * q), G, (int)p, (const double*)dpar, (const double*)dloc, Cm, ldc, wts, part);
@@ -1629,8 +1627,7 @@ static int lmm_group_terms_device(lrvb_ctx* c, const double* par, int64_t n_par,
     HIP_TRY(hipGetLastError());
     if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
     LRVB_TRY(buf_reserve(c, c->Tdense, (size_t)WS_TILE * WS_TILE));
-    LRVB_TRY(launch_gram_small_on(c, Cm, 2 * G, ldc, wts, c->Tdense.p));
-    LRVB_TRY(launch_tiles_to_dense(c, c->Tdense.p, R, Md, R, 0, 0, false));
+    LRVB_TRY(launch_gram_small_on(c, Cm, 2 * G, ldc, wts, c->Tdense.p, Md, R, nullptr, R));      // M as a dense R x R matrix, no unpacking launch (the kernel clamps rows past 2 G: no padding to clear)
     *sums_dev = sums;
     return LRVB_OK;
 }

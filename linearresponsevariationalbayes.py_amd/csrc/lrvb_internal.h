@@ -157,7 +157,7 @@ int  launch_wsyrk(lrvb_ctx* c, const double* cvec_dev, double* tiles_out_dev /* 
 bool wsyrk_fast_path(const lrvb_ctx* c);
 int  launch_wsyrk_r(lrvb_ctx* c, const double* cvec_dev, double* tiles_out_dev, const double* cy_dev /* nullable */, double* r_out_dev /* P */);
 int  launch_gram_small_on(lrvb_ctx* c, const double* Z, i64 N, i64 P, const double* cvec_dev, double* tiles_out_dev,
-                          double* dense_out = nullptr, i64 ldd = 0, double* csum_out = nullptr);
+                          double* dense_out = nullptr, i64 ldd = 0, double* csum_out = nullptr, i64 pd = 0);
 int  launch_mixture_rows(lrvb_ctx* c, int K, const double* theta_z_dev, const double* lam_dev,
                          double* Amat_dev, i64 lda, double* U_dev, double* gfree_dev, double* val2_dev, int* bad_dev);
 int  launch_kron_rows(lrvb_ctx* c, double* Xk_dev, i64 ldk);
