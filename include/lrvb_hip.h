@@ -413,9 +413,9 @@ int lrvb_mixture_stats(lrvb_ctx* ctx, int32_t K, const double* theta_z, const do
 int lrvb_mixture_schur_dirichlet(lrvb_ctx* ctx, int32_t K, int32_t q, const double* vecs, const double* consts, double* H_out);
 
 /* Gram matrix G^T G (D x D, free coordinates) of the per-observation gradients
- * g_n[k] = 1/2 z_n^T M_k z_n + c_k (K = V matrices, one per vector coordinate): the Kronecker rows
- * z_n (x) z_n are generated on chip and contracted on the fp64 matrix cores; G (N x D) is never
- * materialised (BASELINE.json config 5).  n_cols <= 64.                                        */
+ * g_n[k] = 1/2 z_n^T M_k z_n + c_k (K = V matrices, one per vector coordinate, not necessarily symmetric): the Kronecker
+ * rows -- the packed lower triangle of z_n z_n^T, q (q + 1) / 2 virtual columns, the matrices folded onto it -- are generated
+ * on chip and contracted on the fp64 matrix cores; G (N x D) is never materialised (BASELINE.json config 5).  n_cols <= 64. */
 int lrvb_quadform_gram(lrvb_ctx* ctx, const double* M, const double* c, int64_t K,
                        const double* free_in, double* GtG_out, int64_t ld);
 /* The same Gram matrix for the Wishart + MVN model (BASELINE.json configuration 5: y_n ~ N(mu, Lambda^-1), q(mu) = MVNParam(d),

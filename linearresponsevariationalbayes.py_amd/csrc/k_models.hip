@@ -180,20 +180,32 @@ __global__ void dirichlet_blocks_kernel(i64 total, i64 n, int K, const double* _
     out[e] = colscale ? v * colscale[cc] : v;
 }
 
-// M~ (64 q x V) holds vec(M_k) in the virtual index v = 64 a + b.  Everything stays on the device.
-__global__ void mtilde_kernel(const double* __restrict__ M, i64 V, int q, double* __restrict__ Mt /* (64 q) x V */) {
+// M~ (Pv x V, Pv = q (q + 1) / 2) holds M_k FOLDED onto the packed lower triangle v = a (a + 1) / 2 + b, b <= a:
+// z^T M_k z = sum_{a >= b} (M_k[a][b] + M_k[b][a]) z_a z_b (the diagonal once) -- the Kronecker kernel forms z_a z_b for b <= a
+// only (wsyrk_kron_kernel).  Everything stays on the device.
+__device__ __forceinline__ void tri_pair(i64 v, int& a, int& b) {
+    a = (int)((sqrt(8.0 * (double)v + 1.0) - 1.0) * 0.5);
+    while ((i64)a * (a + 1) / 2 > v) --a;
+    while ((i64)(a + 1) * (a + 2) / 2 <= v) ++a;
+    b = (int)(v - (i64)a * (a + 1) / 2);
+}
+__global__ void mtilde_kernel(const double* __restrict__ M, i64 V, int q, double* __restrict__ Mt /* Pv x V */) {
     const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    const i64 v = blockIdx.y;                       // virtual row index 64 a + b
+    const i64 v = blockIdx.y;                       // packed row index
     if (k >= V) return;
-    const int a = (int)(v >> 6), b = (int)(v & 63);
-    Mt[v * V + k] = (b < q) ? M[k * (i64)q * q + a * q + b] : 0.0;
+    int a, b;
+    tri_pair(v, a, b);
+    const double* Mk = M + k * (i64)q * q;
+    Mt[v * V + k] = (b == a) ? Mk[a * q + a] : Mk[a * q + b] + Mk[b * q + a];
 }
 
-__global__ void svec_kernel(const double* __restrict__ S1 /* q x q */, int q, double* __restrict__ sv /* 64 q */) {
+// s in the same packed order (the entries of the symmetric q x q matrix of second moments)
+__global__ void svec_kernel(const double* __restrict__ S1 /* q x q */, int q, double* __restrict__ sv /* Pv */) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= 64 * q) return;
-    const int a = v >> 6, b = v & 63;
-    sv[v] = (b < q) ? S1[a * q + b] : 0.0;
+    if (v >= q * (q + 1) / 2) return;
+    int a, b;
+    tri_pair(v, a, b);
+    sv[v] = S1[a * q + b];
 }
 
 __global__ void rank_terms_kernel(i64 V, const double* __restrict__ n_obs_dev, const double* __restrict__ t, const double* __restrict__ cvec,

@@ -1052,19 +1052,29 @@ int launch_atb_kron32(lrvb_ctx* c, const double* X31, const double* B, i64 N, co
     return LRVB_OK;
 }
 
-// ---- Kronecker-row variant: K4 = sum_n c_n (z_n (x) z_n)(z_n (x) z_n)^T ---------------------------
+// ---- Kronecker-row variant: K4 = sum_n c_n u_n u_n^T,  u_n = packed lower triangle of z_n z_n^T ------------------
 // The Gram matrix G^T G of per-observation gradients of an objective that is QUADRATIC IN THE DATA
-// (g_n[k] = 1/2 z_n^T M_k z_n + c_k) is M~^T K4 M~ (+ rank-one terms), where K4 is the weighted SYRK
-// of the VIRTUAL N x 64 q matrix whose row n is z_n (x) z_n (column v = 64 a + b <-> z_na z_nb).
-// The virtual rows are generated on chip and never touch HBM (BASELINE.json config 5: D = 4096,
-// N P (P+1) = 1.7e13 flops from 0.5 GB of data).  Same tiling and queue order as wsyrk_glds_kernel;
-// the stage is just the 16 x 64 block of z (zero-padded past q) plus c, and the MFMA operands are
-// formed at fragment-read time:  A[i][k] = c_k z_k[a_w] z_k[16 m + i],  B[k][j] = z_k[b_w] z_k[16 n + j]
-// -- the four z_k[16 m + i] reads serve both operands.
-constexpr int KR_STRIDE = 80;            // 64 z values + c at [64]; (stride mod 32) == 16 -> conflict-free
+// (g_n[k] = 1/2 z_n^T M_k z_n + c_k) is M~^T K4 M~ (+ rank-one terms).  z z^T is symmetric, so the virtual operand row
+// is its packed lower triangle (column v = a (a + 1) / 2 + b <-> z_na z_nb, b <= a: q (q + 1) / 2 = 2080 columns at q = 64)
+// and the caller folds M_k onto the triangle (mtilde_kernel): N Pv (Pv + 1) = 4.3e12 flops for BASELINE.json config 5
+// instead of the 1.7e13 of the full 64 q-column Kronecker product rounds 1-3 formed (the same symmetry configuration 3's
+// operand uses).  The virtual rows are generated on chip and never touch HBM.  Same tiling and queue order as
+// wsyrk_glds_kernel; the stage is the 16 x 64 block of z (zero-padded past q) plus c, and an MFMA operand element is the
+// product of two LDS reads at per-lane offsets (the pair (a, b) of its column, computed once per kernel); columns past Pv
+// read a constant zero slot.
+constexpr int KR_STRIDE = 80;            // 64 z values, c at [64], 0.0 at [65]; (stride mod 32) == 16 -> conflict-free
+constexpr int KR_ZERO = 65;
+
+__device__ __forceinline__ void kr_pair(int v, int pv, int& a, int& b) {
+    if (v >= pv) { a = KR_ZERO; b = KR_ZERO; return; }
+    a = (int)((sqrtf(8.f * (float)v + 1.f) - 1.f) * 0.5f);
+    while (a * (a + 1) / 2 > v) --a;
+    while ((a + 1) * (a + 2) / 2 <= v) ++a;
+    b = v - a * (a + 1) / 2;
+}
 
 __global__ __launch_bounds__(WS_THREADS, 2)
-void wsyrk_kron_kernel(const double* __restrict__ Z, i64 ldz, i64 N, int q,
+void wsyrk_kron_kernel(const double* __restrict__ Z, i64 ldz, i64 N, int q, int pv,
                        const double* __restrict__ cpad, int n_splits, int nb, i64 rows_per_split,
                        double* __restrict__ partial)
 {
@@ -1121,6 +1131,7 @@ void wsyrk_kron_kernel(const double* __restrict__ Z, i64 ldz, i64 N, int q,
         for (int j = 0; j < 4; ++j) { const int col = 4 * seg + j; dst[col] = col < q ? sv[j] : 0.0; }
         if (seg == 0) dst[64] = sc;
     };
+    if (tid < 2 * WS_KC) lds[tid * KR_STRIDE + KR_ZERO] = 0.0;      // the zero slot of every row of both buffers (never rewritten)
 
     if (nch > 0) { load_stage(0); store_stage(0); }
     __syncthreads();
@@ -1129,19 +1140,23 @@ void wsyrk_kron_kernel(const double* __restrict__ Z, i64 ldz, i64 N, int q,
     int buf = 0;
     if (!diag) {
         const int wr = wave >> 1, wc = wave & 1;
-        const int a_w = 2 * bi + wr, b_w = 2 * bj + wc;     // the "outer" Kronecker index of this wave's rows / columns
+        // this lane's four columns on the row side (A operand) and on the column side (B operand) of the wave's 64 x 64 block
+        int ia[4], ib[4], ja[4], jb[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            kr_pair(bi * WS_TILE + wr * 64 + 16 * m + l15, pv, ia[m], ib[m]);
+            kr_pair(bj * WS_TILE + wc * 64 + 16 * m + l15, pv, ja[m], jb[m]);
+        }
         for (int ch = 0; ch < nch; ++ch) {
             const bool more = ch + 1 < nch;
             if (more) load_stage(ch + 1);
             const double* zs = lds + buf * (WS_KC * KR_STRIDE);
-            double zv[2][4], za[2];
+            double xa[2][4], xb[2][4], ya[2][4], yb[2][4], cv[2];
             auto read_frags = [&](int kk, int set) {
                 const double* rowp = zs + (kk * 4 + l4) * KR_STRIDE;
 #pragma unroll
-                for (int m = 0; m < 4; ++m) zv[set][m] = rowp[16 * m + l15];
-                // A[k][i] B[k][j] = z_k[16 m + i] z_k[16 n + j] (c_k z_k[a_w] z_k[b_w]): the whole per-row scalar goes on the A side,
-                // the B fragments are the plain z values -- 6 instead of 9 multiplies per k-step beside the 16 MFMAs
-                za[set] = rowp[a_w] * rowp[64] * rowp[b_w];
+                for (int m = 0; m < 4; ++m) { xa[set][m] = rowp[ia[m]]; xb[set][m] = rowp[ib[m]]; ya[set][m] = rowp[ja[m]]; yb[set][m] = rowp[jb[m]]; }
+                cv[set] = rowp[64];
             };
             read_frags(0, 0);
 #pragma unroll
@@ -1149,7 +1164,7 @@ void wsyrk_kron_kernel(const double* __restrict__ Z, i64 ldz, i64 N, int q,
                 const int set = kk & 1;
                 double af[4], bf[4];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) { af[m] = zv[set][m] * za[set]; bf[m] = zv[set][m]; }
+                for (int m = 0; m < 4; ++m) { af[m] = xa[set][m] * xb[set][m] * cv[set]; bf[m] = ya[set][m] * yb[set][m]; }
                 __builtin_amdgcn_sched_barrier(0);
                 if (kk + 1 < WS_KC / 4) read_frags(kk + 1, set ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
@@ -1176,44 +1191,42 @@ void wsyrk_kron_kernel(const double* __restrict__ Z, i64 ldz, i64 N, int q,
                     out[(wr * 64 + m * 16 + l4 + 4 * r) * WS_TILE + wc * 64 + n * 16 + l15] = acc[m * 4 + n][r];
     } else {
         const int rb0 = wave, rb1 = 7 - wave;
-        const int a0i = 2 * bi + (rb0 >> 2), a1i = 2 * bi + (rb1 >> 2);
+        // row blocks rb0 / rb1 (A operand) and all eight column blocks of the tile (B operand; block n is used iff n <= rb)
+        int i0a, i0b, i1a, i1b, ja[8], jb[8];
+        kr_pair(bi * WS_TILE + 16 * rb0 + l15, pv, i0a, i0b);
+        kr_pair(bi * WS_TILE + 16 * rb1 + l15, pv, i1a, i1b);
+#pragma unroll
+        for (int n = 0; n < 8; ++n) kr_pair(bi * WS_TILE + 16 * n + l15, pv, ja[n], jb[n]);
         for (int ch = 0; ch < nch; ++ch) {
             const bool more = ch + 1 < nch;
             if (more) load_stage(ch + 1);
             const double* zs = lds + buf * (WS_KC * KR_STRIDE);
-            double zv[2][4], s0[2], s1[2], zlo[2], zhi[2];
+            double ya[2][8], yb[2][8], a0[2], a1[2];
             auto read_frags = [&](int kk, int set) {
                 const double* rowp = zs + (kk * 4 + l4) * KR_STRIDE;
 #pragma unroll
-                for (int m = 0; m < 4; ++m) zv[set][m] = rowp[16 * m + l15];
+                for (int n = 0; n < 8; ++n) { ya[set][n] = rowp[ja[n]]; yb[set][n] = rowp[jb[n]]; }
                 const double cv = rowp[64];
-                s0[set] = rowp[a0i] * cv;
-                s1[set] = rowp[a1i] * cv;
-                zlo[set] = rowp[2 * bi];
-                zhi[set] = rowp[2 * bi + 1];
+                a0[set] = rowp[i0a] * rowp[i0b] * cv;
+                a1[set] = rowp[i1a] * rowp[i1b] * cv;
             };
             read_frags(0, 0);
 #pragma unroll
             for (int kk = 0; kk < WS_KC / 4; ++kk) {
                 const int set = kk & 1;
-                // A fragments of row blocks rb0 / rb1: z[16 (rb & 3) + i] * (z[a] c); B fragment n: z[16 (n & 3) + j] * z[2 bi + (n >> 2)]
-                double a0 = 0.0, a1 = 0.0, bf[8];
+                double bf[8];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    if ((rb0 & 3) == m) a0 = zv[set][m] * s0[set];
-                    if ((rb1 & 3) == m) a1 = zv[set][m] * s1[set];
-                    bf[m] = zv[set][m] * zlo[set];
-                    bf[4 + m] = zv[set][m] * zhi[set];
-                }
+                for (int n = 0; n < 8; ++n) bf[n] = ya[set][n] * yb[set][n];
+                const double af0 = a0[set], af1 = a1[set];
                 __builtin_amdgcn_sched_barrier(0);
                 if (kk + 1 < WS_KC / 4) read_frags(kk + 1, set ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int n = 0; n < 4; ++n)
-                    if (n <= rb0) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bf[n], acc[n], 0, 0, 0);
+                    if (n <= rb0) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af0, bf[n], acc[n], 0, 0, 0);
 #pragma unroll
                 for (int n = 0; n < 8; ++n)
-                    if (n <= rb1) acc[4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bf[n], acc[4 + n], 0, 0, 0);
+                    if (n <= rb1) acc[4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af1, bf[n], acc[4 + n], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (more) store_stage(buf ^ 1);
@@ -1233,11 +1246,12 @@ void wsyrk_kron_kernel(const double* __restrict__ Z, i64 ldz, i64 N, int q,
     }
 }
 
-// K4 tiles (virtual dimension Pv = 64 q, nb = ceil(q / 2) tile rows) from the context's data matrix.
+// K4 tiles (virtual dimension Pv = q (q + 1) / 2, nb = ceil(Pv / 128) tile rows) from the context's data matrix.
 int launch_wsyrk_kron(lrvb_ctx* c, const double* cvec_dev, double* tiles_out_dev) {
     const int q = (int)c->P;
     if (q > 64) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "Kronecker Gram kernel supports n_cols <= 64 (got %d)", q);
-    const int nb = (q + 1) / 2;
+    const int pv = q * (q + 1) / 2;
+    const int nb = (pv + WS_TILE - 1) / WS_TILE;
     const int T = nb * (nb + 1) / 2;
     i64 S = (4608 + T / 2) / T;
     S = ((S + 7) / 8) * 8;
@@ -1251,7 +1265,7 @@ int launch_wsyrk_kron(lrvb_ctx* c, const double* cvec_dev, double* tiles_out_dev
     LRVB_TRY(buf_reserve(c, c->tile_part, (size_t)(tile_elems * S)));
     if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
     hipLaunchKernelGGL(wsyrk_kron_kernel, dim3((unsigned)(S * T)), dim3(WS_THREADS), 0, c->stream,
-                       c->X.p, c->P, c->N, q, cvec_dev, (int)S, nb, rps, c->tile_part.p);
+                       c->X.p, c->P, c->N, q, pv, cvec_dev, (int)S, nb, rps, c->tile_part.p);
     HIP_TRY(hipGetLastError());
     if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
     const i64 nthreads = tile_elems / 2;
@@ -1259,9 +1273,9 @@ int launch_wsyrk_kron(lrvb_ctx* c, const double* cvec_dev, double* tiles_out_dev
                        c->tile_part.p, (int)S, tile_elems, tiles_out_dev);
     HIP_TRY(hipGetLastError());
     if (c->prof_on) {
-        const double pv = 64.0 * q;
-        c->prof.wsyrk_flops = (double)c->N * pv * (pv + 1.0);
-        c->prof.wsyrk_bytes = 8.0 * (double)c->N * (q + 1.0) + 8.0 * 0.5 * pv * (pv + 1.0);
+        const double pvd = (double)pv;
+        c->prof.wsyrk_flops = (double)c->N * pvd * (pvd + 1.0);
+        c->prof.wsyrk_bytes = 8.0 * (double)c->N * (q + 1.0) + 8.0 * 0.5 * pvd * (pvd + 1.0);
     }
     return LRVB_OK;
 }

@@ -1877,8 +1877,8 @@ static int quadform_gram_impl(lrvb_ctx* c, const double* M, const WishartGen* ge
     if (c->P > 64) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "Kronecker Gram kernel supports n_cols <= 64");
     if (ld < c->D) LRVB_FAIL(LRVB_ERR_SIZE, "leading dimension too small");
     const int q = (int)c->P;
-    const i64 V = c->V, D = c->D, Pv = 64 * (i64)q;
-    const int nbk = (q + 1) / 2;
+    const i64 V = c->V, D = c->D, Pv = (i64)q * (q + 1) / 2;      // packed lower triangle of z z^T
+    const int nbk = (int)((Pv + WS_TILE - 1) / WS_TILE);
     const i64 Pv_t = (i64)nbk * WS_TILE;                 // tile-padded virtual dimension (>= Pv)
     // unweighted sums: c_n = 1 (zero padded)
     LRVB_TRY(reserve_obs_vec(c, c->zbuf));
@@ -1929,7 +1929,7 @@ static int quadform_gram_impl(lrvb_ctx* c, const double* M, const WishartGen* ge
     }
     int st = (hipGetLastError() == hipSuccess) ? LRVB_OK : LRVB_ERR_HIP;
     DevBuf T1, Av;
-    if (st == LRVB_OK) st = buf_reserve(c, T1, (size_t)Pv_t * (size_t)V);
+    if (st == LRVB_OK) st = buf_reserve(c, T1, (size_t)(Pv_t > D ? Pv_t : D) * (size_t)V);      // K4 M~ (Pv_t x V), later J^T Av (D x V)
     if (st == LRVB_OK) st = buf_reserve(c, Av, (size_t)V * (size_t)V);
     // T1 = K4 M~ ;  Av = M~^T T1 ;  t = M~^T s
     if (st == LRVB_OK) st = gemm_tn(c, Pv_t, Pv_t, V, c->Heta.p, Mt.p, T1.p);        // K4 is symmetric: K4 M~ = K4^T M~

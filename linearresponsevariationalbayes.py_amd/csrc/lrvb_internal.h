@@ -165,7 +165,7 @@ int  launch_mixture_expand(lrvb_ctx* c, const double* Rs, i64 lda, int q, int K,
 int  launch_atb(lrvb_ctx* c, const double* A, i64 PA, const double* B, i64 PB, i64 N,
                 const double* cvec_dev, double* C_dev, bool rows_padded = false /* 16 finite rows past N in A and B */);
 int  launch_atb_kron32(lrvb_ctx* c, const double* X31, const double* B, i64 N, const double* cvec_dev, double* C_dev);
-int  launch_wsyrk_kron(lrvb_ctx* c, const double* cvec_dev, double* tiles_out_dev /* nb = ceil(q/2) tile rows */);
+int  launch_wsyrk_kron(lrvb_ctx* c, const double* cvec_dev, double* tiles_out_dev /* nb = ceil(q (q + 1) / 2 / 128) tile rows */);
 int  launch_tiles_to_dense(lrvb_ctx* c, const double* tiles_dev, i64 P, double* dense_dev, i64 ld,
                            i64 row_off, i64 col_off, bool accumulate);
 

@@ -400,7 +400,7 @@ def test_two_ranks_statistics_calls_of_every_model_family(tmp_path):
     q, G, p = pr['p'] + 1, pr['G'], pr['p']
     d = pr['d']; qw = d + 1
     P = pr['P']
-    nbk = (qw + 1) // 2
+    nbk = (qw * (qw + 1) // 2 + 127) // 128                  # tile rows of the Kronecker SYRK over the packed triangle of z z^T
     kron = nbk * (nbk + 1) // 2 * 128 * 128 + qw * qw + 1
     mixn = 4100 + (21 + 21 % 2) * (10 + 10 % 2)             # [S64 | val2 | bad | pad | packed R]: q = 6 -> 21, K = 4 -> 10 packed columns
     assert list(rec['counts']) == [q * q + G * (q + 1), G * (q + 1), q * q + G * (q + 1),      # grouped_stats, group_sums, global_hessian
