@@ -203,3 +203,26 @@ def test_gram_with_device_generated_matrices(vb, d, N):
     assert rel_err(cov_host, np.linalg.inv(got + shift * np.eye(lay.D))[:3, :3]) < 1e-7
     with pytest.raises(ValueError):
         fun.ctx.wishart_gram(d, [0, d, d + d * (d + 1) // 2, d + d * (d + 1) // 2 + 1], nu, m[:-1] if d > 1 else np.zeros(2), v, c2, theta)
+
+
+@pytest.mark.parametrize('q,N', [(2, 40), (7, 900), (18, 2500), (64, 700)])
+def test_quadform_gram_folds_general_matrices_onto_the_triangle(vb, q, N):
+    """`lrvb_quadform_gram` for matrices M_k that are NOT symmetric (the Kronecker SYRK forms the packed lower triangle of
+    z z^T only -- q (q + 1) / 2 virtual columns -- and `mtilde_kernel` folds M_k[a][b] + M_k[b][a] onto it): G^T G against
+    numpy with the rows g_n[k] = 1/2 z_n^T M_k z_n + c_k written out, a box layout so that the free conversion is a scaling;
+    q = 64 is the largest row the kernel takes (configuration 5's shape: 2080 virtual columns, 17 tile rows)."""
+    rng = np.random.default_rng(500 + q)
+    V = 9
+    z = rng.normal(size=(N, q)) / np.sqrt(q)
+    M = rng.normal(size=(V, q, q))                                   # general, not symmetric
+    c = rng.normal(size=V)
+    blocks = [dict(kind=0, free_size=4, vec_size=4, dim0=4, dim1=0, lb=0.0, ub=np.inf),
+              dict(kind=0, free_size=5, vec_size=5, dim0=5, dim1=0, lb=-np.inf, ub=np.inf)]
+    ctx = vb.DeviceContext(blocks, loss='data_only', n_obs=N, n_cols=q, device=0)
+    ctx.set_data(vb._hip.SLOT_X, z)
+    theta = rng.normal(size=V) * 0.3
+    got = ctx.quadform_gram(M, c, theta)
+    G = 0.5 * np.einsum('na,kab,nb->nk', z, M, z) + c[None, :]
+    j = np.concatenate([np.exp(theta[:4]), np.ones(5)])
+    want = (G.T @ G) * j[:, None] * j[None, :]
+    assert rel_err(got, want) < 1e-12
