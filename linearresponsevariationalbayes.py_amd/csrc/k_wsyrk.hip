@@ -1062,8 +1062,9 @@ int launch_atb_kron32(lrvb_ctx* c, const double* X31, const double* B, i64 N, co
 // wsyrk_glds_kernel; the stage is the 16 x 64 block of z (zero-padded past q) plus c, and an MFMA operand element is the
 // product of two LDS reads at per-lane offsets (the pair (a, b) of its column, computed once per kernel); columns past Pv
 // read a constant zero slot.
-constexpr int KR_STRIDE = 80;            // 64 z values, c at [64], 0.0 at [65]; (stride mod 32) == 16 -> conflict-free
-constexpr int KR_ZERO = 65;
+constexpr int KR_STRIDE = 176;           // [0, 64): z, [64]: c, [65]: 0.0, [80, 144): c z, [145]: 0.0; (stride mod 32) == 16 -> conflict-free
+constexpr int KR_ZERO = 65;              // (the row-side operand reads c z_a from the second copy: one multiply per element on either side)
+constexpr int KR_CZ = 80;
 
 __device__ __forceinline__ void kr_pair(int v, int pv, int& a, int& b) {
     if (v >= pv) { a = KR_ZERO; b = KR_ZERO; return; }
@@ -1128,10 +1129,9 @@ void wsyrk_kron_kernel(const double* __restrict__ Z, i64 ldz, i64 N, int q, int 
         asm volatile("" : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3]), "+v"(sc));
         double* dst = lds + buf * (WS_KC * KR_STRIDE) + srow * KR_STRIDE;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const int col = 4 * seg + j; dst[col] = col < q ? sv[j] : 0.0; }
-        if (seg == 0) dst[64] = sc;
+        for (int j = 0; j < 4; ++j) { const int col = 4 * seg + j; const double zv = col < q ? sv[j] : 0.0; dst[col] = zv; dst[KR_CZ + col] = zv * sc; }
     };
-    if (tid < 2 * WS_KC) lds[tid * KR_STRIDE + KR_ZERO] = 0.0;      // the zero slot of every row of both buffers (never rewritten)
+    if (tid < 2 * WS_KC) { lds[tid * KR_STRIDE + KR_ZERO] = 0.0; lds[tid * KR_STRIDE + KR_CZ + KR_ZERO] = 0.0; }      // the zero slots of every row of both buffers (never rewritten)
 
     if (nch > 0) { load_stage(0); store_stage(0); }
     __syncthreads();
@@ -1147,16 +1147,19 @@ void wsyrk_kron_kernel(const double* __restrict__ Z, i64 ldz, i64 N, int q, int 
             kr_pair(bi * WS_TILE + wr * 64 + 16 * m + l15, pv, ia[m], ib[m]);
             kr_pair(bj * WS_TILE + wc * 64 + 16 * m + l15, pv, ja[m], jb[m]);
         }
+        // 16-row blocks of this wave that hold real columns: fewer than four only in the last tile row (Pv = 2080 = 16 x 128 + 32),
+        // whose other blocks are padding and are skipped (wave-uniform); the column side of an off-diagonal tile is always full
+        int mt_a = (pv - (bi * WS_TILE + wr * 64) + 15) / 16;
+        mt_a = __builtin_amdgcn_readfirstlane(mt_a < 0 ? 0 : (mt_a > 4 ? 4 : mt_a));
         for (int ch = 0; ch < nch; ++ch) {
             const bool more = ch + 1 < nch;
             if (more) load_stage(ch + 1);
             const double* zs = lds + buf * (WS_KC * KR_STRIDE);
-            double xa[2][4], xb[2][4], ya[2][4], yb[2][4], cv[2];
+            double xa[2][4], xb[2][4], ya[2][4], yb[2][4];
             auto read_frags = [&](int kk, int set) {
                 const double* rowp = zs + (kk * 4 + l4) * KR_STRIDE;
 #pragma unroll
-                for (int m = 0; m < 4; ++m) { xa[set][m] = rowp[ia[m]]; xb[set][m] = rowp[ib[m]]; ya[set][m] = rowp[ja[m]]; yb[set][m] = rowp[jb[m]]; }
-                cv[set] = rowp[64];
+                for (int m = 0; m < 4; ++m) { xa[set][m] = rowp[KR_CZ + ia[m]]; xb[set][m] = rowp[ib[m]]; ya[set][m] = rowp[ja[m]]; yb[set][m] = rowp[jb[m]]; }
             };
             read_frags(0, 0);
 #pragma unroll
@@ -1164,7 +1167,7 @@ void wsyrk_kron_kernel(const double* __restrict__ Z, i64 ldz, i64 N, int q, int 
                 const int set = kk & 1;
                 double af[4], bf[4];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) { af[m] = xa[set][m] * xb[set][m] * cv[set]; bf[m] = ya[set][m] * yb[set][m]; }
+                for (int m = 0; m < 4; ++m) { af[m] = xa[set][m] * xb[set][m]; bf[m] = ya[set][m] * yb[set][m]; }
                 __builtin_amdgcn_sched_barrier(0);
                 if (kk + 1 < WS_KC / 4) read_frags(kk + 1, set ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
@@ -1173,7 +1176,8 @@ void wsyrk_kron_kernel(const double* __restrict__ Z, i64 ldz, i64 N, int q, int 
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
                     for (int n = 0; n < 4; ++n)
-                        acc[m * 4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m], bf[n], acc[m * 4 + n], 0, 0, 0);
+                        if (m < mt_a)
+                            acc[m * 4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m], bf[n], acc[m * 4 + n], 0, 0, 0);
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1191,6 +1195,7 @@ void wsyrk_kron_kernel(const double* __restrict__ Z, i64 ldz, i64 N, int q, int 
                     out[(wr * 64 + m * 16 + l4 + 4 * r) * WS_TILE + wc * 64 + n * 16 + l15] = acc[m * 4 + n][r];
     } else {
         const int rb0 = wave, rb1 = 7 - wave;
+        const int nreal = (pv - bi * WS_TILE + 15) / 16;             // 16-column blocks of this tile that hold real columns (8 except in the last tile)
         // row blocks rb0 / rb1 (A operand) and all eight column blocks of the tile (B operand; block n is used iff n <= rb)
         int i0a, i0b, i1a, i1b, ja[8], jb[8];
         kr_pair(bi * WS_TILE + 16 * rb0 + l15, pv, i0a, i0b);
@@ -1206,9 +1211,8 @@ void wsyrk_kron_kernel(const double* __restrict__ Z, i64 ldz, i64 N, int q, int 
                 const double* rowp = zs + (kk * 4 + l4) * KR_STRIDE;
 #pragma unroll
                 for (int n = 0; n < 8; ++n) { ya[set][n] = rowp[ja[n]]; yb[set][n] = rowp[jb[n]]; }
-                const double cv = rowp[64];
-                a0[set] = rowp[i0a] * rowp[i0b] * cv;
-                a1[set] = rowp[i1a] * rowp[i1b] * cv;
+                a0[set] = rowp[KR_CZ + i0a] * rowp[i0b];
+                a1[set] = rowp[KR_CZ + i1a] * rowp[i1b];
             };
             read_frags(0, 0);
 #pragma unroll
@@ -1223,10 +1227,10 @@ void wsyrk_kron_kernel(const double* __restrict__ Z, i64 ldz, i64 N, int q, int 
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int n = 0; n < 4; ++n)
-                    if (n <= rb0) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af0, bf[n], acc[n], 0, 0, 0);
+                    if (n <= rb0 && rb0 < nreal) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af0, bf[n], acc[n], 0, 0, 0);
 #pragma unroll
                 for (int n = 0; n < 8; ++n)
-                    if (n <= rb1) acc[4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af1, bf[n], acc[4 + n], 0, 0, 0);
+                    if (n <= rb1 && rb1 < nreal) acc[4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af1, bf[n], acc[4 + n], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (more) store_stage(buf ^ 1);

@@ -123,26 +123,30 @@ def test_statistics_are_not_reduced_twice_under_a_hook(vb):
     fun.set_reduced_stats(None)
 
 
-@pytest.mark.parametrize('N,k', [(300, 1), (5000, 6), (20000, 21)])
+@pytest.mark.parametrize('N,k', [(300, 1), (5000, 6), (20000, 21), (4000, 31), (4000, 32), (3000, 63)])
 def test_one_call_hessian_matches_the_stepwise_route_and_ad(vb, N, k):
     """`MVNRegressionObjective.device_hessian` (lrvb_mvnreg_hessian: statistics, closed forms in (m, Lambda, a, b) evaluated on
     the device where the statistics lie, Kronecker block, free conversion -- one call, no copy back inside) against round 3's
     stepwise route (statistics to the host, numpy closed forms, blocks sent up) and against exact AD; the value comes from the
-    same kernel; want_host=False leaves the matrix where the Cholesky finds it."""
+    same kernel; want_host=False leaves the matrix where the Cholesky finds it.  k = 31 and 63 (q = 32, 64: no spare column in
+    the narrow Gram kernel for the sum of the weights), k = 32 (an odd row width on the two-pair instantiation) and k = 63 (the
+    largest log-Cholesky block the structured Jacobian product takes) are compared with the stepwise route only."""
     rng = np.random.default_rng(N + k)
     x, y, par, fun, lay, ft = _build(vb, rng, N, k)
     w = rng.uniform(0.5, 1.5, N)
     fun.weights_par.set_vector(w)
-    theta = rng.normal(size=lay.D) * 0.3
+    theta = rng.normal(size=lay.D) * (0.3 if k <= 21 else 0.05)      # (the larger information matrices stay well conditioned: the two routes invert them differently)
     H1, val = fun.device_hessian(theta, want_value=True)
     fun.stepwise = True
     H0 = vb.Objective(par, fun).fun_free_hessian(theta)
     fun.stepwise = False
-    assert rel_err(H1, H0) < 1e-12
+    assert rel_err(H1, H0) < (1e-12 if k <= 21 else 1e-11)
     assert np.max(np.abs(H1 - H1.T)) < 1e-12 * np.max(np.abs(H1))
     tt, tw = torch.tensor(theta), torch.tensor(w)
-    assert rel_err(H1, torch.func.hessian(ft)(tt, tw).numpy()) < 1e-9
     assert abs(val - ft(tt, tw).item()) < 1e-11 * abs(ft(tt, tw).item())
+    if k > 21:
+        return
+    assert rel_err(H1, torch.func.hessian(ft)(tt, tw).numpy()) < 1e-9
     assert rel_err(vb.Objective(par, fun).fun_free_hessian(theta), H1) == 0.0          # the Objective route IS the one call
     # resident result: factor it where it lies (shifted copy on the host for the comparison)
     assert fun.device_hessian(theta, want_host=False)[0] is None
