@@ -45,6 +45,7 @@ from . import families as NormalParams
 from .hierarchical import LMMObjective
 from .mixture import MixtureObjective
 from .logitnormal import LogitNormalRegressionObjective
+from .torch_closure import TorchObjective
 from . import regression as regression_utils
 from . import packing as ProjectionParams
 from . import families as GammaParams

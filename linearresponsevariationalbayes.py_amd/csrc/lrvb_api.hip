@@ -924,6 +924,14 @@ extern "C" int lrvb_free_hessian_from_vector(lrvb_ctx* c, const double* free_in,
     LRVB_TRY(buf_reserve(c, c->work1, (size_t)V * (size_t)D));
     LRVB_TRY(buf_reserve(c, c->Hfree, (size_t)D * (size_t)D));
     LRVB_TRY(h2d(c, c->Heta.p, H_vec, (size_t)V * (size_t)V));
+    if (c->jt_rows > 0) {                                  // box and log-Cholesky blocks: the structured products (k_pack.hip).
+        // H_vec is taken as given (J^T H_vec J also for a matrix that is not exactly symmetric): both products read their
+        // operand transposed -- W = J^T H_vec^T = (H_vec J)^T, then J^T W^T = J^T H_vec J
+        LRVB_TRY(launch_jt_apply(c, c->theta.p, c->Heta.p, V, V, c->work1.p, V, true));             // (H_vec J)^T    (D x V)
+        LRVB_TRY(launch_jt_apply(c, c->theta.p, c->work1.p, V, D, c->Hfree.p, D, true));            // J^T (H_vec J)
+        LRVB_TRY(launch_third_order(c, c->theta.p, c->g_eta.p, c->Hfree.p));
+        return d2h(c, H_free_out, c->Hfree.p, (size_t)D * (size_t)D);
+    }
     LRVB_TRY(ensure_dense_J(c, c->theta.p));
     LRVB_TRY(launch_gemm(c, false, false, V, D, V, 1.0, c->Heta.p, V, c->Jdense.p, D, 0.0, c->work1.p, D));
     HIP_TRY(hipMemsetAsync(c->Hfree.p, 0, (size_t)D * (size_t)D * sizeof(double), c->stream));
@@ -1064,6 +1072,12 @@ static int hvec_finish_impl(lrvb_ctx* c, const double* point, int64_t n_in, int 
     LRVB_TRY(buf_reserve(c, c->work1, (size_t)V * (size_t)D));
     LRVB_TRY(buf_reserve(c, c->Hfree, (size_t)D * (size_t)D));
     LRVB_TRY(buf_reserve(c, c->Tdense, (size_t)D * (size_t)D));
+    if (c->jt_rows > 0) {                                  // box and log-Cholesky blocks: the structured products (k_pack.hip)
+        LRVB_TRY(launch_jt_apply(c, c->theta.p, c->Heta.p, V, V, c->work1.p, V, false));            // J^T H_vec (H_vec is symmetric by construction)
+        LRVB_TRY(launch_jt_apply(c, c->theta.p, c->work1.p, V, D, c->Hfree.p, D, true));
+        LRVB_TRY(launch_third_order(c, c->theta.p, c->g_eta.p, c->Hfree.p));
+        return H_out ? d2h(c, H_out, c->Hfree.p, (size_t)D * (size_t)D) : LRVB_OK;
+    }
     LRVB_TRY(ensure_dense_J(c, c->theta.p));
     LRVB_TRY(gemm_tn(c, V, V, D, c->Heta.p, c->Jdense.p, c->work1.p));          // H_vec is symmetric: H J = H^T J
     LRVB_TRY(gemm_tn(c, V, D, D, c->Jdense.p, c->work1.p, c->Tdense.p));        // J^T (H J)
