@@ -480,7 +480,7 @@ def embedded_configs(args, env, budget_s=90.0):
     """Short runs of c2..c5 inside the headline's process (N = 1): {cfg: {ms_per_step, kernel_ms, roofline...}} for the
     `configs` object of the one JSON line.  Bounded: a configuration is skipped once the budget is spent."""
     out, t0 = {}, time.perf_counter()
-    order = (('c2', 100, 20), ('c4', 100, 20), ('c3', 8, 2), ('c5', 2, 1))      # (sub-millisecond steps: enough of them for a steady reading)
+    order = (('c2', 100, 20), ('c4', 100, 20), ('c3', 8, 2), ('c5', 5, 2))      # (sub-millisecond steps: enough of them for a steady reading)
     if os.environ.get('LRVB_EMBED_ORDER'):
         order = tuple(o for name in os.environ['LRVB_EMBED_ORDER'].split(',') for o in order if o[0] == name)
     for cfg, steps, warmup in order:
