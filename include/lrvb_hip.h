@@ -542,6 +542,10 @@ typedef struct lrvb_opt_result {
     double  trust_radius;    /* final radius                                         */
     int32_t status, nit;     /* see above; outer iterations                          */
     int32_t nfev, njev, nhev;/* value / gradient / Hessian-vector evaluations        */
+    int32_t nbuild;          /* Hessians built inside the CG runs (256 <= D <= 8192, models with a data term): after
+                                max(8, D / 64) products at one point the point's Hessian is built (about D / 86 passes over
+                                the observations) and the remaining products of the run are D x D matrix-vector products;
+                                0 under tuning bit 3.  (Occupies what was tail padding: the struct size is unchanged.)   */
 } lrvb_opt_result;
 int lrvb_minimize_trust_ncg(lrvb_ctx* ctx, const double* y0, int64_t D, const double* precond,
                             double gtol, int64_t maxiter, double initial_trust_radius,

@@ -149,7 +149,7 @@ class OptResult(ctypes.Structure):
     """lrvb_opt_result of include/lrvb_hip.h."""
     _fields_ = [('fun', ctypes.c_double), ('jac_mag', ctypes.c_double), ('trust_radius', ctypes.c_double),
                 ('status', ctypes.c_int32), ('nit', ctypes.c_int32),
-                ('nfev', ctypes.c_int32), ('njev', ctypes.c_int32), ('nhev', ctypes.c_int32)]
+                ('nfev', ctypes.c_int32), ('njev', ctypes.c_int32), ('nhev', ctypes.c_int32), ('nbuild', ctypes.c_int32)]
 
 
 _lib = None

@@ -2446,7 +2446,25 @@ namespace {
 struct TrustNcg {
     lrvb_ctx* c; i64 D; const double* A;       // A on the device or nullptr
     double *y, *x, *g, *gc, *p, *z, *r, *d, *Bd, *t1, *t2, *yp;
-    int nfev = 0, njev = 0, nhev = 0;
+    int nfev = 0, njev = 0, nhev = 0, nbuild = 0;
+    // The products of one Steihaug-CG run share a point.  A pass over X per product is the cheaper route for a handful of them;
+    // a BUILD of the point's Hessian costs about D / 86 passes (weighted SYRK on the matrix cores against an HBM-bound pass:
+    // 12 at D = 1024) and makes every further product a D x D matrix-vector product (microseconds).  Ski rental: after `thr`
+    // products at a point -- or at once, if the previous point needed that many -- the Hessian is built and used.
+    double* Hm = nullptr; bool h_ready = false; i64 n_here = 0, prev_here = 0, thr = 0;
+    int build_H() {
+        LRVB_TRY(hessian_partial(c, x, true, c->stats.p));
+        LRVB_TRY(stats_reduce(c));
+        LRVB_TRY(hessian_finish(c, x, true, c->stats.p, Hm, D));
+        h_ready = true; ++nbuild;
+        return LRVB_OK;
+    }
+    int h_apply(const double* v, double* out) {         // H v at the point of the last eval_point
+        ++n_here;
+        if (Hm && !h_ready && (n_here > thr || prev_here > thr)) LRVB_TRY(build_H());
+        if (h_ready) return launch_gemv(c, false, D, D, 1.0, Hm, D, v, 0.0, out);
+        return hvp_apply(c, x, true, v, out);
+    }
 
     int eval_point(const double* yv, double* f, double* gmag) {
         if (A) LRVB_TRY(launch_gemv(c, false, D, D, 1.0, A, D, yv, 0.0, x));
@@ -2462,13 +2480,14 @@ struct TrustNcg {
         LRVB_TRY(d2h(c, h, c->scal.p, 1));
         *gmag = sqrt(h[0]);
         ++nfev; ++njev;
+        prev_here = n_here; n_here = 0; h_ready = false;       // a new point: its Hessian is not built yet
         return LRVB_OK;
     }
     int hessp(const double* v, double* out) {          // at the point of the last eval_point
         ++nhev;
-        if (!A) return hvp_apply(c, x, true, v, out);
+        if (!A) return h_apply(v, out);
         LRVB_TRY(launch_gemv(c, false, D, D, 1.0, A, D, v, 0.0, t1));
-        LRVB_TRY(hvp_apply(c, x, true, t1, t2));
+        LRVB_TRY(h_apply(t1, t2));
         return launch_gemv(c, true, D, D, 1.0, A, D, t2, 0.0, out);
     }
     int dots(int n, const double* const* a, const double* const* b, double* host) {
@@ -2509,9 +2528,16 @@ extern "C" int lrvb_minimize_trust_ncg(lrvb_ctx* c, const double* y0, int64_t D,
     if (!(eta >= 0.0 && eta < 0.25)) LRVB_FAIL(LRVB_ERR_INVALID, "eta must lie in [0, 0.25)");
     if (maxiter <= 0) maxiter = 200 * D;
     const size_t nA = precond ? (size_t)D * (size_t)D : 0;
-    LRVB_TRY(buf_reserve(c, c->opt, 12 * (size_t)D + nA));
+    // the point's Hessian may be built inside the CG runs (TrustNcg::h_apply) where the model has a data term and the
+    // resident-Hessian route is not switched off (tuning bit 3)
+    // (from 256 parameters on: below, a pass and a build are both a handful of launches and the run keeps scipy's exact path)
+    const bool can_build = c->loss != LRVB_LOSS_NONE && !c->no_resident && D >= 256 && D <= 8192;
+    const size_t nH = can_build ? (size_t)D * (size_t)D : 0;
+    LRVB_TRY(buf_reserve(c, c->opt, 12 * (size_t)D + nA + nH));
     TrustNcg o;
     o.c = c; o.D = D;
+    o.Hm = can_build ? c->opt.p + 12 * (size_t)D + nA : nullptr;
+    o.thr = D / 64 > 8 ? D / 64 : 8;
     double* base = c->opt.p;
     o.y = base; o.x = base + D; o.g = base + 2 * D; o.p = base + 4 * D; o.z = base + 5 * D; o.r = base + 6 * D;
     o.d = base + 7 * D; o.Bd = base + 8 * D; o.t1 = base + 9 * D; o.t2 = base + 10 * D; o.yp = base + 11 * D;
@@ -2600,7 +2626,7 @@ extern "C" int lrvb_minimize_trust_ncg(lrvb_ctx* c, const double* y0, int64_t D,
     LRVB_TRY(d2h(c, y_out, o.y, (size_t)D));
     if (x_out) LRVB_TRY(d2h(c, x_out, o.x, (size_t)D));
     res->fun = f; res->jac_mag = gmag; res->trust_radius = radius;
-    res->status = status; res->nit = (int32_t)k; res->nfev = o.nfev; res->njev = o.njev; res->nhev = o.nhev;
+    res->status = status; res->nit = (int32_t)k; res->nfev = o.nfev; res->njev = o.njev; res->nhev = o.nhev; res->nbuild = o.nbuild;
     return LRVB_OK;
 }
 

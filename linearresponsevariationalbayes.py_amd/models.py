@@ -705,7 +705,7 @@ class DeviceContext(object):
                                                      float(initial_trust_radius), float(max_trust_radius), float(eta),
                                                      _hip.ptr(y), _hip.ptr(x), ctypes.byref(res)))
         info = dict(fun=res.fun, jac_mag=res.jac_mag, trust_radius=res.trust_radius, status=res.status, nit=res.nit,
-                    nfev=res.nfev, njev=res.njev, nhev=res.nhev)
+                    nfev=res.nfev, njev=res.njev, nhev=res.nhev, nbuild=res.nbuild)
         return y, x, info
 
     def cg_solve_multi(self, free, B, X0=None, Minv=None, tol=1e-8, maxiter=0):

@@ -84,7 +84,7 @@ def _trust_ncg_on_device(objective, init_x, precondition, maxiter, gtol, disp):
     res = scipy.optimize.OptimizeResult(
         x=y, fun=info['fun'], status=info['status'], success=info['status'] == 0,
         message=_TRUST_NCG_MESSAGES[info['status']], nit=info['nit'], nfev=info['nfev'], njev=info['njev'],
-        nhev=info['nhev'], jac_mag=info['jac_mag'], trust_radius=info['trust_radius'])
+        nhev=info['nhev'], nbuild=info.get('nbuild', 0), jac_mag=info['jac_mag'], trust_radius=info['trust_radius'])
     if disp:
         print('{}\n         Current function value: {:f}\n         Iterations: {:d}\n         Function evaluations: {:d}'
               '\n         Gradient evaluations: {:d}\n         Hessian evaluations: {:d}'.format(

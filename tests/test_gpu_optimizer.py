@@ -189,3 +189,29 @@ def test_sharded_objective_on_the_device(vb):
     finally:
         if started:
             dist.destroy_process_group()
+
+
+def test_hessian_is_built_inside_long_cg_runs(vb):
+    """After max(8, D / 64) products at one point the optimiser builds that point's Hessian (about D / 86 passes over the
+    observations) and serves the rest of the Steihaug-CG run from it: same iterates as the matrix-free route (tuning bit 3),
+    `nbuild` reports the builds, and far fewer passes over X are made."""
+    spec = [('box', 'u', 230, -np.inf, np.inf), ('box', 'pos', 58, 0.0, np.inf)]       # D = 288 (the route starts at 256 parameters)
+    obj, model, rng = build(vb, om.LOGISTIC, 6000, spec, seed=21, prior=0.05)
+    D = model.layout.D
+    x0 = rng.normal(size=D) * 0.5
+    ctx = obj.fun.ctx
+    ctx.set_tuning(0, 8)                                       # tuning bit 3: matrix-free products only
+    x_free, r_free = vb.OptimizationUtils.minimize_objective_trust_ncg(obj, x0, False, maxiter=100, gtol=1e-7, disp=False, on_device=True)
+    ctx.set_tuning(0, 0)
+    ctx.profile_enable(True); ctx.profile_reset()
+    x_res, r_res = vb.OptimizationUtils.minimize_objective_trust_ncg(obj, x0, False, maxiter=100, gtol=1e-7, disp=False, on_device=True)
+    prof = ctx.profile_get()
+    ctx.profile_enable(False)
+    assert r_free.success and r_res.success
+    assert r_free.nbuild == 0 and r_res.nbuild >= 1
+    assert abs(r_res.nit - r_free.nit) <= 1                                # the same path up to rounding in the last iterations
+    assert rel_err(x_res, x_free) < 1e-7
+    assert np.linalg.norm(model.grad(x_res)) < 1e-6
+    # the products behind the threshold of each built point made no pass over X
+    assert r_res.nhev > 8 * r_res.nbuild
+    assert prof['wsyrk_calls'] == r_res.nbuild

@@ -23,10 +23,16 @@ for rep in range(2):
     res = scipy.optimize.minimize(ctx.value, x0, jac=ctx.grad, hessp=ctx.hvp, method='trust-ncg',
                                   options=dict(gtol=1e-4, maxiter=100))
     t1 = time.perf_counter()
-    yd, xd, info = ctx.minimize_trust_ncg(x0, gtol=1e-4, maxiter=100)
+    ctx.set_tuning(0, 8)                                   # tuning bit 3: every product a pass over X (rounds 2-3)
+    ymf, xmf, info_mf = ctx.minimize_trust_ncg(x0, gtol=1e-4, maxiter=100)
+    ctx.set_tuning(0, 0)
     t2 = time.perf_counter()
+    yd, xd, info = ctx.minimize_trust_ncg(x0, gtol=1e-4, maxiter=100)
+    t2b = time.perf_counter()
 print('scipy + device callbacks: %.1f ms, nit %d, nfev %d, njev %d, nhev %d, f = %.6f' % ((t1 - t0) * 1e3, res.nit, res.nfev, res.njev, res.nhev, res.fun))
-print('device loop:              %.1f ms, nit %d, nfev %d, njev %d, nhev %d, f = %.6f' % ((t2 - t1) * 1e3, info['nit'], info['nfev'], info['njev'], info['nhev'], info['fun']))
+print('device loop, matrix-free: %.1f ms, nit %d, nfev %d, njev %d, nhev %d, f = %.6f' % ((t2 - t1) * 1e3, info_mf['nit'], info_mf['nfev'], info_mf['njev'], info_mf['nhev'], info_mf['fun']))
+print('device loop (Hessian built inside long CG runs): %.1f ms, nit %d, nhev %d, nbuild %d, f = %.6f, max |x - x_matrix_free| = %.2e'
+      % ((t2b - t2) * 1e3, info['nit'], info['nhev'], info['nbuild'], info['fun'], np.max(np.abs(xd - xmf))))
 print('max |x_dev - x_scipy| = %.2e' % np.max(np.abs(xd - res.x)))
 # the preconditioned route of the reference (`set_objective_preconditioner` + the `_cond` family, LRVB/OptimizationUtils.py:25-41,
 # SparseObjectives.py:202-240, restarted as `repeatedly_optimize` does, :114-162): a few plain iterations, then A = H^-1/2 from ONE
