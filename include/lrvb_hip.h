@@ -582,7 +582,11 @@ int lrvb_profile_reset (lrvb_ctx* ctx);
  * reference's ConjugateGradientSolver is used exactly so: fun_free_hessian / fun_free_hvp at one optimum, many right-hand
  * sides (LRVB/ConjugateGradient.py:63-105).  The copy is dropped by lrvb_set_data(_dev), lrvb_set_weights(_dev),
  * lrvb_set_quad_scale (new value), lrvb_set_lik_info, lrvb_set_reduce_hook and lrvb_comm_init / _destroy;
- * buffers adopted with the `_dev` setters must be installed again after their contents change.                        */
+ * buffers adopted with the `_dev` setters must be installed again after their contents change.
+ * A long run of products at ONE point builds the matrix by itself: past max(8, D / 64) matrix-free products at the point
+ * lrvb_hvp / lrvb_cg_solve last named (256 <= D <= 8192, models with a data term) the point's Hessian is built -- about
+ * D / 86 passes over the observations -- and made resident; lrvb_minimize_trust_ncg does the same inside its CG runs
+ * (lrvb_opt_result.nbuild).  Tuning bit 3 switches both off.                                                            */
 int lrvb_set_tuning(lrvb_ctx* ctx, int n_splits, int reserved);
 
 #pragma GCC visibility pop

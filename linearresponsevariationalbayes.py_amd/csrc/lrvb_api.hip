@@ -842,6 +842,27 @@ extern "C" int lrvb_hvp_dev(lrvb_ctx* c, const double* free_dev, const double* v
     if (!free_dev || !v_dev || !out_dev) LRVB_FAIL(LRVB_ERR_INVALID, "null argument");
     return hvp_dev_impl(c, free_dev, true, v_dev, out_dev);
 }
+// Many products at ONE point (scipy's trust-ncg or cg driving lrvb_hvp, right-hand sides solved one by one): a pass over X per
+// product is the cheaper route for a handful; a build of the point's Hessian costs about D / 86 passes and makes every further
+// product a D x D matrix-vector product.  Past max(8, D / 64) matrix-free products at the remembered point the Hessian is
+// built into the resident slot (as lrvb_hessian would leave it) and *resident set.  The point state must be current
+// (c->theta on the device, set_point + eval_grad_eta done); every rank counts the same products, so a sharded run builds
+// on all ranks at the same product.
+static int maybe_build_resident(lrvb_ctx* c, const double* point_host, i64 D, bool* resident) {
+    if (*resident || c->no_resident || c->loss == LRVB_LOSS_NONE || D < 256 || D > 8192) return LRVB_OK;
+    const i64 thr = D / 64 > 8 ? D / 64 : 8;
+    if (c->pt_products <= thr) return LRVB_OK;
+    c->hres_valid = false;
+    LRVB_TRY(buf_reserve(c, c->Hres, (size_t)D * (size_t)D));
+    LRVB_TRY(hessian_partial(c, c->theta.p, true, c->stats.p));
+    LRVB_TRY(stats_reduce(c));
+    LRVB_TRY(hessian_finish(c, c->theta.p, true, c->stats.p, c->Hres.p, D));
+    c->hres_pt.assign(point_host, point_host + D); c->hres_pt_host = true;
+    c->hres_valid = true;
+    *resident = true;
+    return LRVB_OK;
+}
+
 static int hvp_host(lrvb_ctx* c, const double* point, const double* v, i64 n_in, bool is_free, double* out) {
     // same point as the previous call, nothing else in between: its eta / J / g_eta / curvature are still in place
     const bool reuse = same_point(c, point, n_in, is_free);
@@ -867,6 +888,16 @@ static int hvp_host(lrvb_ctx* c, const double* point, const double* v, i64 n_in,
         LRVB_TRY(h2d(c, c->theta.p, point, (size_t)n));
         LRVB_TRY(set_point(c, c->theta.p, is_free));
         LRVB_TRY(eval_grad_eta(c, c->stats.p, true));
+        c->pt_products = 0;
+    }
+    if (is_free) {
+        ++c->pt_products;
+        bool built = false;
+        LRVB_TRY(maybe_build_resident(c, point, n, &built));
+        if (built) {
+            LRVB_TRY(launch_gemv(c, false, n, n, 1.0, c->Hres.p, n, c->cgp.p, 0.0, c->cgq.p));
+            return d2h(c, out, c->cgq.p, (size_t)n);
+        }
     }
     if (!prepared && is_free) LRVB_TRY(prepare_general_hvp(c, c->theta.p));
     LRVB_TRY(hvp_apply(c, c->theta.p, is_free, c->cgp.p, c->cgq.p));
@@ -2206,10 +2237,15 @@ extern "C" int lrvb_cg_solve(lrvb_ctx* c, const double* free_in, const double* b
             LRVB_TRY(h2d(c, c->theta.p, free_in, (size_t)D));
             LRVB_TRY(set_point(c, c->theta.p, true));
             LRVB_TRY(eval_grad_eta(c, c->stats.p, true));
+            c->pt_products = 0;
         }
         if (!prepared) LRVB_TRY(prepare_general_hvp(c, c->theta.p));
     }
     auto product = [&](const double* vin, double* vout) -> int {
+        if (!resident) {                                   // (the right-hand sides of one point, solved one by one: see maybe_build_resident)
+            ++c->pt_products;
+            LRVB_TRY(maybe_build_resident(c, free_in, D, &resident));
+        }
         return resident ? launch_gemv(c, false, D, D, 1.0, c->Hres.p, D, vin, 0.0, vout) : hvp_apply(c, c->theta.p, true, vin, vout);
     };
 

@@ -80,6 +80,8 @@ struct lrvb_ctx {
     // and hyper-parameters (lrvb_hvp, lrvb_cg_solve, lrvb_cg_solve_multi) are D x D matrix products instead of passes over X
     DevBuf Hres, hres_theta; bool hres_valid = false; bool hres_pt_host = false; std::vector<double> hres_pt;
     bool no_resident = false;      // tuning/testing: always take the matrix-free products
+    i64 pt_products = 0;           // matrix-free products made at the remembered point (lrvb_hvp / lrvb_cg_solve): past
+                                   // max(8, D / 64) of them the point's Hessian is built and made resident (lrvb_api.hip)
     DevBuf chol, cholW;            // D x D Cholesky factor (lower); inverses of its 64 x 64 diagonal blocks
     DevBuf hprog;                  // operands of an lrvb_hvec_program call
     bool chol_valid = false;

@@ -168,6 +168,7 @@ def test_point_state_is_reused_only_when_nothing_changed(vb):
     fun = vb.DeviceObjective(par, x=x, y=y, loss='logistic', quad_A=np.full(P, 1.0), weights=w)
     fun._push_state()
     ctx = fun.ctx
+    ctx.set_tuning(0, 8)                               # matrix-free products only (from 256 parameters on, a long run of products at one point builds the point's Hessian: test_many_products_at_one_point_build_the_hessian)
     B = rng.normal(size=(Q, P))
     th1, th2 = rng.normal(size=P) * 0.1, rng.normal(size=P) * 0.1
 
@@ -268,3 +269,41 @@ def test_products_use_the_resident_hessian_after_a_build(vb):
     eta = lay.constrain(theta)
     hvv, nv = passes(lambda: ctx.hvp(eta, v, is_free=False))
     assert nv >= 1 and rel_err(hvv, model.hessian_vec(eta) @ v) < 1e-11
+
+
+def test_many_products_at_one_point_build_the_hessian(vb):
+    """Right-hand sides solved ONE BY ONE at a point (`lrvb_cg_solve`, what the reference's ConjugateGradientSolver does,
+    LRVB/ConjugateGradient.py:87-105) and scipy-style product callbacks (`lrvb_hvp`): past max(8, D / 64) matrix-free products
+    at the point its Hessian is built and made resident (D >= 256), the remaining products make no pass over the observations,
+    the answers are those of the matrix-free route, and a new point starts counting again."""
+    rng = np.random.default_rng(77)
+    N, P, Q = 5000, 320, 5
+    par, lay = make_par(vb, [('box', 'a', P - 64, -np.inf, np.inf), ('box', 'b', 64, 0.0, np.inf)])
+    x, y, w = glm_data(rng, N, P, om.LOGISTIC)
+    fun = vb.DeviceObjective(par, x=x, y=y, loss='logistic', quad_A=np.full(P, 0.5), weights=w)
+    fun._push_state()
+    ctx = fun.ctx
+    model = om.DeclaredModel(lay, loss=om.LOGISTIC, x=x, y=y, w=w, quad_A=np.full(P, 0.5))
+    B = rng.normal(size=(Q, P))
+    for theta in (rng.normal(size=P) * 0.1, rng.normal(size=P) * 0.1):
+        H = model.hessian(theta)
+        ctx.profile_enable(True); ctx.profile_reset()
+        sols = [ctx.cg_solve(theta, B[q], tol=1e-10) for q in range(Q)]
+        prof = ctx.profile_get()
+        ctx.profile_enable(False)
+        for q, (xq, info, its) in enumerate(sols):
+            assert info == 0 and np.max(np.abs(xq - np.linalg.solve(H, B[q]))) < 1e-7
+        assert sum(s[2] for s in sols) > 40                    # far more products than the threshold ...
+        assert prof['wsyrk_calls'] == 1                        # ... one build of the point's Hessian ...
+        v = rng.normal(size=P)
+        assert rel_err(ctx.hvp(theta, v), H @ v) < 1e-11       # ... which then serves lrvb_hvp too
+    # product callbacks alone (scipy's trust-ncg / cg over lrvb_hvp): the tenth product at one point is served by the matrix
+    theta = rng.normal(size=P) * 0.1
+    H = model.hessian(theta)
+    ctx.profile_enable(True); ctx.profile_reset()
+    for k in range(12):
+        v = rng.normal(size=P)
+        assert rel_err(ctx.hvp(theta, v), H @ v) < 1e-11
+    prof = ctx.profile_get()
+    ctx.profile_enable(False)
+    assert prof['wsyrk_calls'] == 1
