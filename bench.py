@@ -775,6 +775,15 @@ def main(args):
         t8 = time.perf_counter()
         out['lrvb_solve_ms']['cg_16_rhs_tol1e-8_after_build_resident_hessian'] = (t8 - t7) * 1e3
         out['lrvb_solve_ms']['cg_iterations_resident_hessian'] = [int(i) if f == 0 else -1 for i, f in zip(its_r, infos_r)]
+        # ... and one by one at a point NOBODY built (the reference's solver loop over masks): past max(8, D / 64) matrix-free
+        # products at the point the library builds its Hessian itself and serves the remaining solves from it
+        theta_new = theta_h + 1e-3                           # a point whose Hessian is not resident
+        ctx.sync()
+        t9 = time.perf_counter()
+        for q in range(16):
+            ctx.cg_solve(theta_new, rhs[q], tol=1e-8)
+        t10 = time.perf_counter()
+        out['lrvb_solve_ms']['cg_16_rhs_one_by_one_hessian_built_on_the_way'] = (t10 - t9) * 1e3
         if args.loss == 'gaussian':
             # the headline (Gaussian) build needs no separate pass over X; a loss whose curvature depends on the linear
             # predictor does (pass -> SYRK).  Same X, same layout, logistic loss on thresholded responses, for the record:
