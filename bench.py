@@ -246,18 +246,27 @@ def cpu_baseline(fetch_rows, n_total, D, n_pos, loss, lik_info, prior_info, thet
 # call, once per call).  The headline run (`--config h`, what the driver runs) also embeds a short run of c2..c5 at N = 1 in
 # its line (`configs`), so that all five rooflines are in the driver's record.
 def _timed_steps(step, warmup, steps, ctx, fence):
+    """EXACTLY `steps` steps between two fences, timed WITHOUT the library's profile marks (under them a one-call step runs its
+    launch chain as plain launches instead of the captured graph); the marks -- HIP-event time of the statistics kernels and of
+    the sum-over-ranks hook -- come from a second, shorter run, scaled to `steps` so that the callers' per-step divisions hold."""
     for _ in range(warmup):
         step()
     fence()
-    ctx.profile_enable(True)
-    ctx.profile_reset()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    n_prof = max(1, min(steps, 10))
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    for _ in range(n_prof):
+        step()
+    fence()
     prof = ctx.profile_get()
     ctx.profile_enable(False)
+    scale = steps / float(n_prof)
+    prof = {k: (v * scale if isinstance(v, float) else int(round(v * scale)) if isinstance(v, int) else v) for k, v in prof.items()}
     return elapsed, prof
 
 

@@ -40,6 +40,7 @@ int buf_reserve(lrvb_ctx* c, DevBuf& b, size_t n) {
     b.p = nullptr; b.n = 0; b.owned = true;
     HIP_TRY(hipMalloc((void**)&b.p, n * sizeof(double)));
     b.n = n;
+    ++c->buf_epoch;                                      // captured graphs hold the old address
     return LRVB_OK;
 }
 int reserve_obs_vec(lrvb_ctx* c, DevBuf& b) {
@@ -231,6 +232,7 @@ extern "C" int lrvb_ctx_destroy(lrvb_ctx* c) {
     for (int k = 0; k < PROF_POOLS; ++k) for (hipEvent_t e : c->ev_pool[k]) (void)hipEventDestroy(e);
     if (c->ev_order) (void)hipEventDestroy(c->ev_order);
     for (int k = 0; k < 2; ++k) if (c->aux_ev[k]) (void)hipEventDestroy(c->aux_ev[k]);
+    if (c->mv_graph.exec) (void)hipGraphExecDestroy(c->mv_graph.exec);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->stream && c->stream_owned) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -327,7 +329,7 @@ extern "C" int lrvb_set_data_dev(lrvb_ctx* c, int slot, const double* data_dev, 
     DevBuf* b = nullptr; size_t n = 0;
     LRVB_TRY(slot_shape_check(c, slot, rows, cols, &b, &n));
     if (b->p && b->owned) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(b->p)); }
-    b->p = const_cast<double*>(data_dev); b->n = n; b->owned = false;
+    b->p = const_cast<double*>(data_dev); b->n = n; b->owned = false; ++c->buf_epoch;
     if (slot == LRVB_SLOT_X) { c->have_X = true; c->x2_ready = false; c->gstats_valid = false; c->zs_valid = false; }
     if (slot == LRVB_SLOT_Y) c->have_y = true;
     c->hres_valid = false;
@@ -349,7 +351,7 @@ extern "C" int lrvb_set_weights_dev(lrvb_ctx* c, const double* w_dev, int64_t n)
     if (c->loss == LRVB_LOSS_NONE) LRVB_FAIL(LRVB_ERR_STATE, "model has no data term");
     if (!w_dev || n != c->N) LRVB_FAIL(LRVB_ERR_SIZE, "weights must have %lld entries (got %lld)", (long long)c->N, (long long)n);
     if (c->w.p && c->w.owned) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->w.p)); }
-    c->w.p = const_cast<double*>(w_dev); c->w.n = (size_t)n; c->w.owned = false;
+    c->w.p = const_cast<double*>(w_dev); c->w.n = (size_t)n; c->w.owned = false; ++c->buf_epoch;
     c->gstats_valid = false; c->ws_valid = false; c->hres_valid = false;
     return LRVB_OK;
 }
@@ -1179,36 +1181,64 @@ extern "C" int lrvb_mvnreg_hessian(lrvb_ctx* c, const double* free_in, int64_t D
     LRVB_TRY(buf_reserve(c, c->vtmp3, (size_t)(3 * k * k + 1) > (size_t)(V > D ? V : D) ? (size_t)(3 * k * k + 1) : (size_t)(V > D ? V : D)));
     LRVB_TRY(free_conversion_reserve(c, Vp));
     LRVB_TRY(h2d(c, c->hprog.p, pack.data(), pack.size()));
-    // statistics [S | sum w] (weights resident, read in place), summed over the ranks once.  ONE stream: running what does not
-    // need the statistics (the zeroing of the vector-coordinate matrix, the packing Jacobian, the sum of the weights) on a side
-    // stream beside the pass was measured and lost -- 0.170 against 0.154 ms per step on the same box: the two event hand-offs
-    // cost more than the seven short launches they take off the chain.
-    LRVB_TRY(free_conversion_clear(c, Vp));
-    double* tiles = c->stats.p + 1 + c->P;
-    if (!c->force_generic_wsyrk && q != 32 && q != 64) {
-        // the Gram kernel leaves S as a dense q x q matrix and, through its spare column of ones, the sum of the weights beside it
-        LRVB_TRY(launch_gram_small_on(c, c->X.p, c->N, q, c->w.p, tiles, c->qstats.p, q, c->qstats.p + q * q));
-    } else {
-        if (!c->force_generic_wsyrk) {
-            LRVB_TRY(launch_gram_small_on(c, c->X.p, c->N, q, c->w.p, tiles, c->qstats.p, q));
-        } else {
-            LRVB_TRY(reserve_obs_vec(c, c->zbuf));
-            HIP_TRY(hipMemcpyAsync(c->zbuf.p, c->w.p, (size_t)c->N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-            LRVB_TRY(launch_wsyrk(c, c->zbuf.p, tiles));
-            LRVB_TRY(launch_tiles_to_dense(c, tiles, q, c->qstats.p, q, 0, 0, false));
-        }
-        hipLaunchKernelGGL(vec_block_sums_kernel, dim3(256), dim3(256), 0, c->stream, c->N, (const double*)c->w.p, c->qstats.p + q * q + 1);
-        HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)(c->qstats.p + q * q + 1), (i64)256, c->qstats.p + q * q);
-        HIP_TRY(hipGetLastError());
-    }
-    LRVB_TRY(obs_reduce(c, c->qstats.p, q * q + 1));
-    // closed forms where the statistics lie, the Kronecker block, the conversion to free coordinates
     const double* hp_dev = c->hprog.p + D;
     double* scratch = c->vtmp3.p; double* Gc = scratch + 2 * k * k; double* val = Gc + k * k;
-    LRVB_TRY(launch_mvnreg_closed_forms(c, ix, c->qstats.p, hp_dev, scratch, c->g_eta.p, c->Heta.p, Gc, val));
-    LRVB_TRY(launch_symkron3(c, (int)k, Gc, hp_dev + 32 + 2 * k, c->Heta.p, Vp, ix.ls));
-    LRVB_TRY(free_conversion_padded(c, c->hprog.p, Vp));
+    // The device part of the step: statistics [S | sum w] (weights resident, read in place), summed over the ranks once; closed
+    // forms where the statistics lie; the Kronecker block; the conversion to free coordinates.  ONE stream: running what does
+    // not need the statistics (the zeroing of the vector-coordinate matrix, the packing Jacobian, the sum of the weights) on a
+    // side stream beside the pass was measured and lost -- 0.170 against 0.154 ms per step on the same box: the two event
+    // hand-offs cost more than the seven short launches they take off the chain.
+    auto chain = [&]() -> int {
+        LRVB_TRY(free_conversion_clear(c, Vp));
+        double* tiles = c->stats.p + 1 + c->P;
+        if (!c->force_generic_wsyrk && q != 32 && q != 64) {
+            // the Gram kernel leaves S as a dense q x q matrix and, through its spare column of ones, the sum of the weights beside it
+            LRVB_TRY(launch_gram_small_on(c, c->X.p, c->N, q, c->w.p, tiles, c->qstats.p, q, c->qstats.p + q * q));
+        } else {
+            if (!c->force_generic_wsyrk) {
+                LRVB_TRY(launch_gram_small_on(c, c->X.p, c->N, q, c->w.p, tiles, c->qstats.p, q));
+            } else {
+                LRVB_TRY(reserve_obs_vec(c, c->zbuf));
+                HIP_TRY(hipMemcpyAsync(c->zbuf.p, c->w.p, (size_t)c->N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+                LRVB_TRY(launch_wsyrk(c, c->zbuf.p, tiles));
+                LRVB_TRY(launch_tiles_to_dense(c, tiles, q, c->qstats.p, q, 0, 0, false));
+            }
+            hipLaunchKernelGGL(vec_block_sums_kernel, dim3(256), dim3(256), 0, c->stream, c->N, (const double*)c->w.p, c->qstats.p + q * q + 1);
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)(c->qstats.p + q * q + 1), (i64)256, c->qstats.p + q * q);
+            HIP_TRY(hipGetLastError());
+        }
+        LRVB_TRY(obs_reduce(c, c->qstats.p, q * q + 1));
+        LRVB_TRY(launch_mvnreg_closed_forms(c, ix, c->qstats.p, hp_dev, scratch, c->g_eta.p, c->Heta.p, Gc, val));
+        LRVB_TRY(launch_symkron3(c, (int)k, Gc, hp_dev + 32 + 2 * k, c->Heta.p, Vp, ix.ls));
+        return free_conversion_padded(c, c->hprog.p, Vp);
+    };
+    // The chain is a dozen dependent launches of 3-15 us: from the THIRD call of one shape on it is replayed as a captured graph
+    // (the first call warms every buffer, the second is captured).  Not under the profile marks, a sum-over-ranks hook or the
+    // generic-kernel tuning bit, and never across a change of shape, stream or buffer addresses.
+    lrvb_ctx::GraphSlot& gs = c->mv_graph;
+    const i64 gkey[6] = { D, q, c->N, (i64)idx[0] | ((i64)idx[1] << 32), (i64)idx[2] | ((i64)idx[3] << 32), 0 };
+    const bool graphable = !c->prof_on && !c->reduce_fn && !c->force_generic_wsyrk;
+    const bool same = gs.epoch == c->buf_epoch && gs.stream == c->stream && memcmp(gs.key, gkey, sizeof(gkey)) == 0;
+    if (graphable && same && gs.exec) {
+        HIP_TRY(hipGraphLaunch(gs.exec, c->stream));
+    } else if (graphable && same && gs.warmed) {
+        if (gs.exec) { (void)hipGraphExecDestroy(gs.exec); gs.exec = nullptr; }
+        hipGraph_t graph = nullptr;
+        HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        const int st = chain();
+        const hipError_t ec = hipStreamEndCapture(c->stream, &graph);
+        if (st != LRVB_OK) { if (graph) (void)hipGraphDestroy(graph); return st; }
+        HIP_TRY(ec);
+        const hipError_t ei = hipGraphInstantiate(&gs.exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        HIP_TRY(ei);
+        HIP_TRY(hipGraphLaunch(gs.exec, c->stream));
+    } else {
+        if (gs.exec) { (void)hipGraphExecDestroy(gs.exec); gs.exec = nullptr; }
+        LRVB_TRY(chain());
+        memcpy(gs.key, gkey, sizeof(gkey)); gs.epoch = c->buf_epoch; gs.stream = c->stream; gs.warmed = graphable;
+    }
     if (value_out) LRVB_TRY(d2h(c, value_out, val, 1));
     if (H_out) LRVB_TRY(d2h(c, H_out, c->Hfree.p, (size_t)D * (size_t)D));
     return LRVB_OK;

@@ -80,6 +80,12 @@ struct lrvb_ctx {
     // and hyper-parameters (lrvb_hvp, lrvb_cg_solve, lrvb_cg_solve_multi) are D x D matrix products instead of passes over X
     DevBuf Hres, hres_theta; bool hres_valid = false; bool hres_pt_host = false; std::vector<double> hres_pt;
     bool no_resident = false;      // tuning/testing: always take the matrix-free products
+    // captured launch chains (hipGraph): the device part of a one-call step is a dozen dependent launches of 3-15 us; replayed as
+    // a graph the gaps between them go.  A slot is valid for one shape, one set of buffer addresses (buf_epoch moves whenever a
+    // buffer is reallocated or adopted) and one stream.
+    struct GraphSlot { hipGraphExec_t exec = nullptr; i64 key[6] = {0, 0, 0, 0, 0, 0}; unsigned long long epoch = 0; hipStream_t stream = nullptr; bool warmed = false; };
+    GraphSlot mv_graph;            // lrvb_mvnreg_hessian
+    unsigned long long buf_epoch = 1;
     i64 pt_products = 0;           // matrix-free products made at the remembered point (lrvb_hvp / lrvb_cg_solve): past
                                    // max(8, D / 64) of them the point's Hessian is built and made resident (lrvb_api.hip)
     DevBuf chol, cholW;            // D x D Cholesky factor (lower); inverses of its 64 x 64 diagonal blocks

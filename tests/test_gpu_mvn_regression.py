@@ -160,3 +160,44 @@ def test_one_call_hessian_matches_the_stepwise_route_and_ad(vb, N, k):
     fun.prior_mean_par.set_vector(np.full(k, 0.3))
     ft2 = tr.mvn_regression_objective(x, y, k, np.full(k, 0.3), 0.1 * np.eye(k), 2.0, 1.5, layout=lay)
     assert rel_err(fun.device_hessian(theta)[0], torch.func.hessian(ft2)(tt, 1.5 * tw).numpy()) < 1e-9
+
+
+def test_replayed_launch_chain_follows_every_change(vb):
+    """From the third call of one shape on, `lrvb_mvnreg_hessian` replays its launch chain as a captured graph.  The replay must
+    see everything a plain call sees: a new point and new prior values (they travel in the per-call upload), new weights (same
+    buffer: contents; a larger problem: new buffers, the graph is rebuilt), the profile marks (plain launches under them) and a
+    change of stream; results compared with exact AD each time."""
+    rng = np.random.default_rng(909)
+    N, k = 3000, 5
+    x, y, par, fun, lay, ft = _build(vb, rng, N, k)
+    w = rng.uniform(0.5, 1.5, N)
+    fun.weights_par.set_vector(w)
+
+    def check(theta, weights, ftorch=ft):
+        H = fun.device_hessian(theta)[0]
+        want = torch.func.hessian(ftorch)(torch.tensor(theta), torch.tensor(weights)).numpy()
+        assert rel_err(H, want) < 1e-9
+        return H
+    th = rng.normal(size=lay.D) * 0.3
+    H1 = check(th, w)                                          # call 1: plain (warms the buffers)
+    H2 = check(th, w)                                          # call 2: captured
+    H3 = check(th, w)                                          # call 3: replayed
+    assert np.array_equal(H1, H2) and np.array_equal(H2, H3)
+    th2 = rng.normal(size=lay.D) * 0.3
+    check(th2, w)                                              # a new point through the replay
+    w2 = rng.uniform(0.5, 1.5, N)
+    fun.weights_par.set_vector(w2)
+    check(th2, w2)                                             # new weights
+    fun.prior_mean_par.set_vector(np.full(k, 0.3))
+    ft2 = tr.mvn_regression_objective(x, y, k, np.full(k, 0.3), 0.1 * np.eye(k), 2.0, 1.5, layout=lay)
+    check(th2, w2, ft2)                                        # a new prior
+    fun.ctx.profile_enable(True)
+    Hp = check(th, w2, ft2)                                    # under the profile marks: plain launches
+    fun.ctx.profile_enable(False)
+    assert np.array_equal(Hp, check(th, w2, ft2))              # and the replay again: the same bits
+    s = torch.cuda.Stream()
+    fun.ctx.set_stream(s.cuda_stream)
+    for _ in range(3):
+        Hs = check(th, w2, ft2)                                # another stream: warmed, captured and replayed there
+    fun.ctx.set_stream(None)
+    assert np.array_equal(Hs, Hp)
