@@ -1123,6 +1123,9 @@ static int hvec_finish_impl(lrvb_ctx* c, const double* point, int64_t n_in, int 
 // ---- configurations 2 and 4 as ONE call: statistics, closed forms, assembly, free conversion -- no host round trip ------------
 static int grouped_stats_device(lrvb_ctx* c);
 static int lmm_group_terms_device(lrvb_ctx* c, const double* par, int64_t n_par, const double* f_local, int64_t n_local, double** sums_dev);
+struct LmmTermsLayout { double *Cm, *wts, *dpar, *dloc, *part, *sums, *Md; int ldc; i64 grid, n_waves, G, p, R; };
+static int lmm_group_terms_prepare(lrvb_ctx* c, const double* par, int64_t n_par, const double* f_local, int64_t n_local, LmmTermsLayout& L);
+static int lmm_group_terms_launch(lrvb_ctx* c, const LmmTermsLayout& L);
 // J^T H_vec J + sum_k g_k d2 eta_k for the vector-coordinate matrix in c->Heta (leading dimension Vp = V rounded up to even,
 // the padding zero) with theta on the device and g in c->g_eta; the result in c->Hfree (leading dimension D), where
 // lrvb_chol_factor_last finds it.  Even widths throughout: the two products run on the LDS-DMA MFMA kernel without the padded
@@ -1265,27 +1268,42 @@ extern "C" int lrvb_lmm_global_hessian(lrvb_ctx* c, lrvb_ctx* gc, const double* 
     LRVB_TRY(buf_reserve(gc, gc->Heta, (size_t)Vp * (size_t)Vp));
     LRVB_TRY(buf_reserve(gc, gc->vtmp3, (size_t)(3 * p * p) > (size_t)V ? (size_t)(3 * p * p) : (size_t)V));
     LRVB_TRY(free_conversion_reserve(gc, Vp));
-    // (a) the data context: [S | group sums] in one pass, summed over the ranks; the 2 G local parameters eliminated there
-    LRVB_TRY(grouped_stats_device(c));
+    // The whole step is ONE chain on the data context's stream: the global context's launches are queued there too (its own
+    // stream waits once, before and after), so there is no event hand-off inside the step.
+    // Uploads first: [par | local free parameters] for the elimination of the 2 G local parameters, [theta_g | hp] for the
+    // closed forms.
+    const hipStream_t gc_stream = gc->stream;
+    LRVB_TRY(stream_handoff(gc, gc_stream, c->stream));        // whatever the global context still runs (a factorisation of the last result) comes first
+    struct Restore { lrvb_ctx* g; hipStream_t st; ~Restore() { g->stream = st; } } restore{ gc, gc_stream };
+    gc->stream = c->stream;
     std::vector<double> par((size_t)(8 + p));
     par[0] = hp[0]; par[1] = hp[1]; par[2] = hp[2]; par[3] = hp[8]; par[4] = hp[9]; par[5] = hp[10]; par[6] = hp[11]; par[7] = info_lb;
     memcpy(par.data() + 8, hp + 32, (size_t)p * sizeof(double));
-    double* sums = nullptr;
-    LRVB_TRY(lmm_group_terms_device(c, par.data(), 8 + p, free_val + ng, 2 * G, &sums));
-    // (b) the global context continues in stream order behind it: one upload [theta_g | hp], the closed forms where the
-    // statistics lie, the Kronecker block, the conversion to free coordinates
+    LmmTermsLayout L;
+    LRVB_TRY(lmm_group_terms_prepare(c, par.data(), 8 + p, free_val + ng, 2 * G, L));
     std::vector<double> pack((size_t)(ng + n_hp));
     memcpy(pack.data(), free_val, (size_t)ng * sizeof(double));
     memcpy(pack.data() + ng, hp, (size_t)n_hp * sizeof(double));
     LRVB_TRY(h2d(gc, gc->hprog.p, pack.data(), pack.size()));
-    LRVB_TRY(free_conversion_clear(gc, Vp));
-    LRVB_TRY(stream_handoff(c, c->stream, gc->stream));
     const double* hp_dev = gc->hprog.p + ng;
     double* scratch = gc->vtmp3.p; double* Gc = scratch + 2 * p * p;
-    LRVB_TRY(launch_lmm_closed_forms(gc, ix, c->gstats.p, sums, sums + 128, hp_dev, scratch, gc->g_eta.p, gc->Heta.p, Gc));
-    LRVB_TRY(stream_handoff(gc, gc->stream, c->stream));        // the data context's next call may overwrite what was just read
-    LRVB_TRY(launch_symkron3(gc, (int)p, Gc, hp_dev + 32 + 2 * p, gc->Heta.p, Vp, ix.ls));
-    LRVB_TRY(free_conversion_padded(gc, gc->hprog.p, Vp));      // (the packing Jacobian queued BEFORE the hand-off, beside the data context's pass, lost: 0.365 against 0.336 ms)
+    double* sums = L.sums;
+    auto chain = [&]() -> int {
+        // (a) [S | group sums] in one pass, summed over the ranks; the 2 G local parameters eliminated
+        LRVB_TRY(grouped_stats_device(c));
+        LRVB_TRY(lmm_group_terms_launch(c, L));
+        // (b) the closed forms where the statistics lie, the Kronecker block, the conversion to free coordinates
+        LRVB_TRY(free_conversion_clear(gc, Vp));
+        LRVB_TRY(launch_lmm_closed_forms(gc, ix, c->gstats.p, sums, sums + 128, hp_dev, scratch, gc->g_eta.p, gc->Heta.p, Gc));
+        LRVB_TRY(launch_symkron3(gc, (int)p, Gc, hp_dev + 32 + 2 * p, gc->Heta.p, Vp, ix.ls));
+        return free_conversion_padded(gc, gc->hprog.p, Vp);
+    };
+    // (Replaying this chain as a captured graph, as lrvb_mvnreg_hessian does, was built and measured: 296 against 291 us per
+    // step.  The host queues these ~19 launches in a third of the time the device needs for them -- the 90 us statistics kernel
+    // goes first -- so the device never waits for a launch; configuration 2's chain of 5 us kernels does.)
+    LRVB_TRY(chain());
+    gc->stream = gc_stream;
+    LRVB_TRY(stream_handoff(c, c->stream, gc_stream));          // the global context's own stream (lrvb_chol_factor_last, copies) continues behind the step
     if (sums_out) LRVB_TRY(d2h(c, sums_out, sums, 128));
     if (H_out) LRVB_TRY(d2h(gc, H_out, gc->Hfree.p, (size_t)ng * (size_t)ng));
     return LRVB_OK;
@@ -1674,10 +1692,12 @@ extern "C" int lrvb_lmm_group_terms(lrvb_ctx* c, const double* par, int64_t n_pa
     // [sums (128) | M (R x R)] are adjacent: one copy
     return d2h(c, out, sums, (size_t)(128 + R * R));
 }
-// the same, the result [sums (128) | M (R x R)] left on the device (in c->work1; valid until the next use of that buffer)
-static int lmm_group_terms_device(lrvb_ctx* c, const double* par, int64_t n_par, const double* f_local, int64_t n_local, double** sums_dev) {
-    if (!c->gstats_valid) LRVB_FAIL(LRVB_ERR_STATE, "no grouped statistics resident: call lrvb_grouped_stats first");
+// the same, the result [sums (128) | M (R x R)] left on the device (in c->work1; valid until the next use of that buffer).
+// Two halves, so that lrvb_lmm_global_hessian can put every upload of a step in front of its launch chain (and replay the chain as
+// a captured graph): `prepare` checks, reserves and uploads [par | f_local]; `launch` queues the kernels.
+static int lmm_group_terms_prepare(lrvb_ctx* c, const double* par, int64_t n_par, const double* f_local, int64_t n_local, LmmTermsLayout& L) {
     const i64 G = c->n_groups, q = c->P, p = q - 1, R = p + 5;
+    if (G <= 0) LRVB_FAIL(LRVB_ERR_STATE, "no groups: call lrvb_set_groups first");
     if (p < 1 || p + 7 > 64) LRVB_FAIL(LRVB_ERR_UNSUPPORTED, "1 <= p <= 57 regressors");
     LRVB_TRY(check_len(n_par, 8 + p, "par"));
     LRVB_TRY(check_len(n_local, 2 * G, "local free vector"));
@@ -1686,24 +1706,35 @@ static int lmm_group_terms_device(lrvb_ctx* c, const double* par, int64_t n_par,
     const i64 n_waves = grid * 4;
     const size_t nC = (size_t)(2 * G + 16) * (size_t)ldc, nW = (size_t)(2 * G + 64);
     LRVB_TRY(buf_reserve(c, c->work1, nC + nW + (size_t)(8 + p) + (size_t)(2 * G) + (size_t)n_waves * 128 + 128 + 64 * 64));
-    double* Cm = c->work1.p; double* wts = Cm + nC; double* dpar = wts + nW; double* dloc = dpar + (8 + p);
-    double* part = dloc + 2 * G; double* sums = part + n_waves * 128; double* Md = sums + 128;
-    {   // dpar and dloc are adjacent: one upload
-        std::vector<double> pack((size_t)(8 + p + 2 * G));
-        memcpy(pack.data(), par, (size_t)(8 + p) * sizeof(double));
-        memcpy(pack.data() + 8 + p, f_local, (size_t)(2 * G) * sizeof(double));
-        LRVB_TRY(h2d(c, dpar, pack.data(), pack.size()));
-    }
-    if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
-    hipLaunchKernelGGL(lmm_group_kernel, dim3((unsigned)grid), dim3(256), 0, c->stream,
-                       (const double*)(c->gstats.p + q * q), G, (int)p, (const double*)dpar, (const double*)dloc, Cm, ldc, wts, part);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(lmm_sums_kernel, dim3(1), dim3(1024), 0, c->stream, (const double*)part, (int)n_waves, sums);
-    HIP_TRY(hipGetLastError());
-    if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
     LRVB_TRY(buf_reserve(c, c->Tdense, (size_t)WS_TILE * WS_TILE));
-    LRVB_TRY(launch_gram_small_on(c, Cm, 2 * G, ldc, wts, c->Tdense.p, Md, R, nullptr, R));      // M as a dense R x R matrix, no unpacking launch (the kernel clamps rows past 2 G: no padding to clear)
-    *sums_dev = sums;
+    L.Cm = c->work1.p; L.wts = L.Cm + nC; L.dpar = L.wts + nW; L.dloc = L.dpar + (8 + p);
+    L.part = L.dloc + 2 * G; L.sums = L.part + n_waves * 128; L.Md = L.sums + 128;
+    L.ldc = ldc; L.grid = grid; L.n_waves = n_waves; L.G = G; L.p = p; L.R = R;
+    // dpar and dloc are adjacent: one upload
+    std::vector<double> pack((size_t)(8 + p + 2 * G));
+    memcpy(pack.data(), par, (size_t)(8 + p) * sizeof(double));
+    memcpy(pack.data() + 8 + p, f_local, (size_t)(2 * G) * sizeof(double));
+    return h2d(c, L.dpar, pack.data(), pack.size());
+}
+static int lmm_group_terms_launch(lrvb_ctx* c, const LmmTermsLayout& L) {
+    if (!c->gstats_valid) LRVB_FAIL(LRVB_ERR_STATE, "no grouped statistics resident: call lrvb_grouped_stats first");
+    const i64 q = c->P;
+    if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
+    hipLaunchKernelGGL(lmm_group_kernel, dim3((unsigned)L.grid), dim3(256), 0, c->stream,
+                       (const double*)(c->gstats.p + q * q), L.G, (int)L.p, (const double*)L.dpar, (const double*)L.dloc, L.Cm, L.ldc, L.wts, L.part);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(lmm_sums_kernel, dim3(1), dim3(1024), 0, c->stream, (const double*)L.part, (int)L.n_waves, L.sums);
+    HIP_TRY(hipGetLastError());
+    if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
+    // M as a dense R x R matrix, no unpacking launch (the Gram kernel clamps rows past 2 G: no padding to clear)
+    return launch_gram_small_on(c, L.Cm, 2 * L.G, L.ldc, L.wts, c->Tdense.p, L.Md, L.R, nullptr, L.R);
+}
+static int lmm_group_terms_device(lrvb_ctx* c, const double* par, int64_t n_par, const double* f_local, int64_t n_local, double** sums_dev) {
+    if (!c->gstats_valid) LRVB_FAIL(LRVB_ERR_STATE, "no grouped statistics resident: call lrvb_grouped_stats first");
+    LmmTermsLayout L;
+    LRVB_TRY(lmm_group_terms_prepare(c, par, n_par, f_local, n_local, L));
+    LRVB_TRY(lmm_group_terms_launch(c, L));
+    *sums_dev = L.sums;
     return LRVB_OK;
 }
 
