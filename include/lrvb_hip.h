@@ -367,11 +367,14 @@ int lrvb_lmm_group_terms(lrvb_ctx* ctx, const double* par, int64_t n_par, const 
  *
  * lrvb_mvnreg_hessian: MVNParam regression (configuration 2; LRVB/NormalParams.py:6-23, GammaParams.py:4-16,
  *   regression_utils.py:59-132), the context holds the rows [x | y]; idx = vector positions of [mean, vech(information),
- *   shape, rate].
+ *   shape, rate].  From the third call of one shape on, the launch chain behind the upload is replayed as a captured
+ *   hipGraph (a dozen dependent kernels of ~5 us: 117 -> 92 us per step); plain launches under lrvb_profile_enable, a
+ *   sum-over-ranks hook or tuning bit 0, and after any change of stream, shape or buffer addresses (re-captured).
  * lrvb_lmm_global_hessian: hierarchical LMM (configuration 4; doc/lmm.lyx:77-160): `data_ctx` holds the rows [x | y] and the
  *   groups, `global_ctx` the packing of the global parameters; idx = vector positions of [mean, vech(information), e_mu,
  *   i_mu, a_y, b_y, a_mu, b_mu]; free_val = [global free parameters | e_1..e_G | log(i_g - info_lb)].  Result: the Schur
- *   complement of the arrow Hessian onto the global block, in free coordinates, in global_ctx.                         */
+ *   complement of the arrow Hessian onto the global block, in free coordinates, in global_ctx.  Both contexts' launches
+ *   are queued on data_ctx's stream for the length of the call; global_ctx's own stream waits for it before and after.  */
 int lrvb_mvnreg_hessian(lrvb_ctx* ctx, const double* free_in, int64_t D, const double* hp, int64_t n_hp, const int32_t* idx,
                         double* value_out, double* H_out);
 int lrvb_lmm_global_hessian(lrvb_ctx* data_ctx, lrvb_ctx* global_ctx, const double* free_val, int64_t n_free, const double* hp,
