@@ -487,12 +487,12 @@ void gram_small_kernel(const double* __restrict__ Z, i64 ldz, i64 N, int P,
     bool in0[NPAIR], in1[NPAIR];
     // ones_col = P (a spare column of the 32 NPAIR the tiles hold; -1 = none): a virtual column of ones, so that entry (P, P) of
     // the block partial is sum_n c_n and row P the weighted column sums -- no separate pass for the sum of the weights
-    bool one0[NPAIR], one1[NPAIR];
+    double fill0[NPAIR], fill1[NPAIR];          // what a lane past the last column contributes: 0, or 1 in the column of ones (the selects of the loop below stay the same)
 #pragma unroll
     for (int m = 0; m < NPAIR; ++m) {
         const int c0 = 32 * m + 2 * li;
         in0[m] = c0 < P; in1[m] = c0 + 1 < P;
-        one0[m] = c0 == ones_col; one1[m] = c0 + 1 == ones_col;
+        fill0[m] = c0 == ones_col ? 1.0 : 0.0; fill1[m] = c0 + 1 == ones_col ? 1.0 : 0.0;
         colp[m] = in1[m] ? c0 : (P >= 2 ? P - 2 : 0);
     }
 
@@ -506,9 +506,9 @@ void gram_small_kernel(const double* __restrict__ Z, i64 ldz, i64 N, int P,
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             i64 n = row0 + ks * 4 + lk;
-            const bool inside = n < N;
-            if (!inside) n = N - 1;
-            cv[ks] = inside ? cpad[n] * live : 0.0;             // rows past N weigh nothing (the vector needs no padding here)
+            const double lv = n < N ? live : 0.0;               // rows past N weigh nothing (the vector needs no padding here)
+            if (n > N - 1) n = N - 1;
+            cv[ks] = cpad[n] * lv;
             const double* rowp = Z + n * ldz;
 #pragma unroll
             for (int m = 0; m < NPAIR; ++m) {
@@ -532,8 +532,8 @@ void gram_small_kernel(const double* __restrict__ Z, i64 ldz, i64 N, int P,
                 // (a select of two registers: written as x[ks][m][P >= 2 ? 1 : 0] it became a dynamic register index, i.e. a
                 // readfirstlane loop in every k-step)
                 const double xl = (P >= 2) ? x[ks][m][1] : x[ks][m][0];
-                const double v0 = in1[m] ? x[ks][m][0] : (in0[m] ? xl : (one0[m] ? 1.0 : 0.0));
-                const double v1 = in1[m] ? x[ks][m][1] : (one1[m] ? 1.0 : 0.0);
+                const double v0 = in1[m] ? x[ks][m][0] : (in0[m] ? xl : fill0[m]);
+                const double v1 = in1[m] ? x[ks][m][1] : fill1[m];
                 b[2 * m] = v0; b[2 * m + 1] = v1;
                 a[2 * m] = v0 * cv[ks]; a[2 * m + 1] = v1 * cv[ks];
             }
