@@ -104,10 +104,16 @@ void lmm_group_kernel(const double* __restrict__ gs, i64 G, int p, const double*
         sc[0] += eg * rg; sc[1] += W * (eg * eg + 1.0 / ig); sc[2] += d * d + 1.0 / ig; sc[3] += d;
         sc[4] += log(ig); sc[5] += W; sc[6] += g_e * g_e + (g_i * jl) * (g_i * jl);
     }
-    double* dst = part + gw * 128;
-    dst[lane] = (lane >= 1 && lane <= p) ? v1 : 0.0;          // shifted by one: slot 1 + j
-    if (lane < 7) dst[64 + lane] = sc[lane];
-    else dst[64 + lane] = 0.0;
+    // one partial row per WORKGROUP (the four waves added in wave order): few groups per wave keep the dependent chain of a
+    // wave short (G = 1e4: four groups per wave, 625 workgroups; 20 per wave on 128 workgroups took 25 us), and the partial
+    // count stays what lmm_sums_kernel adds in one workgroup
+    __shared__ double red[4][128];
+    const int wave = threadIdx.x >> 6;
+    red[wave][lane] = (lane >= 1 && lane <= p) ? v1 : 0.0;    // shifted by one: slot 1 + j
+    red[wave][64 + lane] = lane < 7 ? sc[lane] : 0.0;
+    __syncthreads();
+    if (threadIdx.x < 128)
+        part[(i64)blockIdx.x * 128 + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
 // sums[k] = sum over the wave partials in a fixed order (eight interleaved slices, then the slices in order); the vector

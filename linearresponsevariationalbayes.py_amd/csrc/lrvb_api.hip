@@ -1702,8 +1702,8 @@ static int lmm_group_terms_prepare(lrvb_ctx* c, const double* par, int64_t n_par
     LRVB_TRY(check_len(n_par, 8 + p, "par"));
     LRVB_TRY(check_len(n_local, 2 * G, "local free vector"));
     const int ldc = (int)((R + 1) & ~(i64)1);                     // even width: 16-byte loads in the narrow Gram kernel
-    i64 grid = (G + 31) / 32; if (grid > 128) grid = 128; if (grid < 1) grid = 1;       // <= 512 wave partials
-    const i64 n_waves = grid * 4;
+    i64 grid = (G + 15) / 16; if (grid > 1024) grid = 1024; if (grid < 1) grid = 1;     // four groups per wave; one partial row per workgroup
+    const i64 n_waves = grid;
     const size_t nC = (size_t)(2 * G + 16) * (size_t)ldc, nW = (size_t)(2 * G + 64);
     LRVB_TRY(buf_reserve(c, c->work1, nC + nW + (size_t)(8 + p) + (size_t)(2 * G) + (size_t)n_waves * 128 + 128 + 64 * 64));
     LRVB_TRY(buf_reserve(c, c->Tdense, (size_t)WS_TILE * WS_TILE));
