@@ -392,11 +392,17 @@ int launch_grouped_stats_fused(lrvb_ctx* c, double* S_dense_dev, double* gs_dev)
 // sums / Md: the output of the group elimination (lmm_group_kernel + lmm_sums_kernel + Gram), S the q x q weighted Gram.
 // Formulas: LMMObjective._arrow / _global_hessian_device of hierarchical.py (doc/lmm.lyx:105-160), pinned against exact AD in
 // tests/test_lmm_host_math.py.
+// sum over the 1024 threads of the workgroup, the same value in every thread: a butterfly inside each wavefront, the 16 wave
+// sums through LDS, added in wave order (two barriers; the ten-round tree through LDS this replaces cost ~2.5 us per sum, and
+// the closed-forms kernels take two and four of them)
 __device__ __forceinline__ double block_sum_1024(double v, double* sh) {
-    sh[threadIdx.x] = v;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
     __syncthreads();
-    for (int off = 512; off > 0; off >>= 1) { if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off]; __syncthreads(); }
-    const double r = sh[0];
+    double r = sh[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) r += sh[w];
     __syncthreads();
     return r;
 }
@@ -424,15 +430,34 @@ void lmm_closed_forms_kernel(LmmIdx ix, const double* __restrict__ Sg, const dou
     const double tay = hp[8], tby = hp[9], tam = hp[10], tbm = hp[11], kappa0 = hp[12], mu0 = hp[13];
     const double a0y = hp[14], b0y = hp[15], a0m = hp[16], b0m = hp[17], Gn = hp[18];
     const double* m = hp + 32; const double* beta0 = m + p; const double* lam0 = beta0 + p + p * p; const double* PL0P = lam0 + p * p;
-    // T = Sxx P; um = Sxx m - Sxy + v1; rss; trace(T)
+    // T = Sxx P; um = Sxx m - Sxy + v1; rss; trace(T).  The two p x p x p products of this kernel run on the matrix cores: wave w
+    // owns the 16 x 16 tile w of the result (ceil(p / 16)^2 <= 16 tiles), operands straight from LDS (as scalar loops over LDS
+    // the two products were about half of the kernel's 27 us at p = 43: one CU's LDS bandwidth)
+    const int lane = tid & 63, wv = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int nt = (p + 15) / 16;
+    auto tile_product = [&](const double* A_, int lda_, const double* B_, int ldb_, double* C_) {
+        if (wv < nt * nt) {
+            const int ti = wv / nt, tj = wv - ti * nt;
+            const int ai = 16 * ti + l15, bj = 16 * tj + l15;
+            typedef double cf_d4 __attribute__((ext_vector_type(4)));
+            cf_d4 acc = (cf_d4){0.0, 0.0, 0.0, 0.0};
+            for (int kk = 0; 4 * kk < p; ++kk) {
+                const int k = 4 * kk + l4;
+                const double av = (ai < p && k < p) ? A_[ai * lda_ + k] : 0.0;
+                const double bv = (bj < p && k < p) ? B_[k * ldb_ + bj] : 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * ti + l4 + 4 * r;
+                if (i < p && bj < p) C_[i * p + bj] = acc[r];
+            }
+        }
+    };
+    tile_product(S, q, P, p, T);
+    __syncthreads();
     double tr = 0.0;
-    for (int e = tid; e < p * p; e += 1024) {
-        const int i = e / p, j = e - i * p;
-        double a = 0.0;
-        for (int k = 0; k < p; ++k) a += S[i * q + k] * P[k * p + j];
-        T[e] = a;
-        if (i == j) tr += a;
-    }
+    if (tid < p) tr = T[tid * p + tid];
     double rs = 0.0;
     if (tid < p) {
         double a = 0.0;
@@ -443,13 +468,9 @@ void lmm_closed_forms_kernel(LmmIdx ix, const double* __restrict__ Sg, const dou
     const double trT = block_sum_1024(tr, sh);
     const double rss = block_sum_1024(rs, sh) + S[p * q + p];
     // PSP = P T; Gc = ty PSP + P Lambda0 P
-    for (int e = tid; e < p * p; e += 1024) {
-        const int i = e / p, j = e - i * p;
-        double a = 0.0;
-        for (int k = 0; k < p; ++k) a += P[i * p + k] * T[k * p + j];
-        PSP[e] = a;
-        Gc[e] = ty * a + PL0P[e];
-    }
+    tile_product(P, p, T, p, PSP);
+    __syncthreads();
+    for (int e = tid; e < p * p; e += 1024) Gc[e] = ty * PSP[e] + PL0P[e];
     if (tid == 0) {
         const double s_eg_rg = sums[64], s_W_e2 = sums[65], s_d2 = sums[66], W = sums[69];
         const double Ay = rss + trT - 2.0 * s_eg_rg + s_W_e2, Am = s_d2 + Gn / i_mu;
