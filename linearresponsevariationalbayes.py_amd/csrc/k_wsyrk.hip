@@ -1257,7 +1257,9 @@ int launch_wsyrk_kron(lrvb_ctx* c, const double* cvec_dev, double* tiles_out_dev
     const int pv = q * (q + 1) / 2;
     const int nb = (pv + WS_TILE - 1) / WS_TILE;
     const int T = nb * (nb + 1) / 2;
-    i64 S = (4608 + T / 2) / T;
+    // ~9200 workgroups (18 rounds of the 512 resident ones): the tiles of the packed triangle differ in weight (diagonal tiles, the
+    // ragged last tile row), and more, shorter workgroups even that out -- 64 splits 80.4 ms, 32 splits 82.2-82.8 ms at q = 64
+    i64 S = (9216 + T / 2) / T;
     S = ((S + 7) / 8) * 8;
     i64 max_by_rows = (c->N / 256 / 8) * 8;
     if (S > max_by_rows) S = max_by_rows;
