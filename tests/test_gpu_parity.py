@@ -777,3 +777,23 @@ def test_structured_jacobian_products(vb, k1, k2):
     v = rng.normal(size=lay.D)
     assert rel_err(obj.fun_free_hvp(theta, v), Hw @ v) < TOL
     assert rel_err(fun.gram(theta), model.gram(theta)) < TOL
+
+
+@pytest.mark.parametrize('N', [1, 5, 16, 17, 33, 1000, 40003])
+@pytest.mark.parametrize('P', [1, 2, 3, 22, 31, 32, 33, 48, 63, 64])
+def test_narrow_gram_kernel_edge_shapes(vb, N, P):
+    """`lrvb_weighted_gram_sum` (S = X^T diag(w) X and the sum of the weights) on the narrow Gram kernel for every corner of
+    its shape handling: fewer rows than a 16-row stage, a ragged last stage, odd and even widths (8- / 16-byte loads), the
+    one- and the two-pair instantiation, the weights read in place without padding; against numpy."""
+    rng = np.random.default_rng(1000 * P + N)
+    x = rng.normal(size=(N, P))
+    w = rng.uniform(0.5, 1.5, N)
+    blocks = [dict(kind=0, free_size=3, vec_size=3, dim0=3, dim1=0, lb=-np.inf, ub=np.inf)]
+    ctx = vb.DeviceContext(blocks, loss='data_only', n_obs=N, n_cols=P, device=0)
+    ctx.set_data(vb._hip.SLOT_X, x)
+    ctx.set_weights(w)
+    S, W = ctx.weighted_gram(with_sum=True)
+    want = x.T @ (w[:, None] * x)
+    assert np.max(np.abs(S - want)) < 1e-12 * max(1.0, np.max(np.abs(want)))
+    assert abs(W - w.sum()) < 1e-12 * w.sum()
+    assert np.array_equal(S, S.T)
