@@ -1226,21 +1226,31 @@ extern "C" int lrvb_mvnreg_hessian(lrvb_ctx* c, const double* free_in, int64_t D
     if (graphable && same && gs.exec) {
         HIP_TRY(hipGraphLaunch(gs.exec, c->stream));
     } else if (graphable && same && gs.warmed) {
+        // capture; if anything about it fails (a launch that cannot be captured, an instantiation error) nothing has run yet:
+        // the chain is queued as plain launches and this slot stops trying until its key changes
         if (gs.exec) { (void)hipGraphExecDestroy(gs.exec); gs.exec = nullptr; }
         hipGraph_t graph = nullptr;
-        HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-        const int st = chain();
-        const hipError_t ec = hipStreamEndCapture(c->stream, &graph);
-        if (st != LRVB_OK) { if (graph) (void)hipGraphDestroy(graph); return st; }
-        HIP_TRY(ec);
-        const hipError_t ei = hipGraphInstantiate(&gs.exec, graph, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(graph);
-        HIP_TRY(ei);
-        HIP_TRY(hipGraphLaunch(gs.exec, c->stream));
+        bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+            const int st = chain();
+            const hipError_t ec = hipStreamEndCapture(c->stream, &graph);
+            ok = st == LRVB_OK && ec == hipSuccess && graph != nullptr;
+            if (ok) ok = hipGraphInstantiate(&gs.exec, graph, nullptr, nullptr, 0) == hipSuccess;
+            if (graph) (void)hipGraphDestroy(graph);
+        }
+        if (ok) {
+            HIP_TRY(hipGraphLaunch(gs.exec, c->stream));
+        } else {
+            (void)hipGetLastError();
+            gs.exec = nullptr; gs.warmed = false; gs.broken = true;
+            LRVB_TRY(chain());
+        }
     } else {
         if (gs.exec) { (void)hipGraphExecDestroy(gs.exec); gs.exec = nullptr; }
         LRVB_TRY(chain());
-        memcpy(gs.key, gkey, sizeof(gkey)); gs.epoch = c->buf_epoch; gs.stream = c->stream; gs.warmed = graphable;
+        if (!same) gs.broken = false;                                    // (a failed capture is not retried for the same shape, stream and buffers)
+        memcpy(gs.key, gkey, sizeof(gkey)); gs.epoch = c->buf_epoch; gs.stream = c->stream;
+        gs.warmed = graphable && !gs.broken;
     }
     if (value_out) LRVB_TRY(d2h(c, value_out, val, 1));
     if (H_out) LRVB_TRY(d2h(c, H_out, c->Hfree.p, (size_t)D * (size_t)D));

@@ -83,7 +83,7 @@ struct lrvb_ctx {
     // captured launch chains (hipGraph): the device part of a one-call step is a dozen dependent launches of 3-15 us; replayed as
     // a graph the gaps between them go.  A slot is valid for one shape, one set of buffer addresses (buf_epoch moves whenever a
     // buffer is reallocated or adopted) and one stream.
-    struct GraphSlot { hipGraphExec_t exec = nullptr; i64 key[6] = {0, 0, 0, 0, 0, 0}; unsigned long long epoch = 0; hipStream_t stream = nullptr; bool warmed = false; };
+    struct GraphSlot { hipGraphExec_t exec = nullptr; i64 key[6] = {0, 0, 0, 0, 0, 0}; unsigned long long epoch = 0; hipStream_t stream = nullptr; bool warmed = false, broken = false; };
     GraphSlot mv_graph;            // lrvb_mvnreg_hessian
     unsigned long long buf_epoch = 1;
     i64 pt_products = 0;           // matrix-free products made at the remembered point (lrvb_hvp / lrvb_cg_solve): past
