@@ -68,8 +68,6 @@ __global__ void mixture_tail_kernel(i64 n, const double* __restrict__ val2, cons
 __global__ void mixture_permute_kernel(i64 total, int q, int K, const double* __restrict__ R, double* __restrict__ Rm);
 __global__ void mixture_schur_finish_kernel(i64 total, i64 n, const double* __restrict__ Hgg, const double* __restrict__ sc,
                                             const double* __restrict__ dg, const double* __restrict__ S, double* __restrict__ H);
-__global__ void dirichlet_blocks_kernel(i64 total, i64 n, int K, const double* __restrict__ diag, const double* __restrict__ gconst,
-                                        const double* __restrict__ colscale, double* __restrict__ out);
 __global__ void mtilde_kernel(const double* __restrict__ M, i64 V, int q, double* __restrict__ Mt /* (64 q) x V */);
 __global__ void svec_kernel(const double* __restrict__ S1 /* q x q */, int q, double* __restrict__ sv /* 64 q */);
 __global__ void rank_terms_kernel(i64 V, const double* __restrict__ n_obs_dev, const double* __restrict__ t, const double* __restrict__ cvec,
@@ -88,6 +86,17 @@ void logitnormal_coef_kernel(i64 n, const double* __restrict__ mu, const double*
                              const double* __restrict__ w, const double* __restrict__ gx, const double* __restrict__ gw, int K,
                              double* __restrict__ a1, double* __restrict__ a2, double* __restrict__ c11, double* __restrict__ c12,
                              double* __restrict__ c22, double* __restrict__ vpart);
+
+__global__ __launch_bounds__(256)
+void dirichlet_rowsums_kernel(i64 n, int K, const double* __restrict__ R, double* __restrict__ RS);
+__global__ __launch_bounds__(256)
+void dirichlet_colsums_kernel(i64 n, int K, const double* __restrict__ R, double* __restrict__ SR);
+__global__ void dirichlet_blocksums_kernel(i64 n, int K, const double* __restrict__ RS, double* __restrict__ SRS);
+__global__ void dirichlet_schur_finish_kernel(i64 total, i64 n, int K, const double* __restrict__ R, const double* __restrict__ RS,
+                                              const double* __restrict__ SR, const double* __restrict__ SRS,
+                                              const double* __restrict__ d, const double* __restrict__ gam,
+                                              const double* __restrict__ h_diag, const double* __restrict__ h_const,
+                                              const double* __restrict__ sc, const double* __restrict__ dg, double* __restrict__ H);
 
 // k_cg.hip
 __global__ void cg_multi_alpha_kernel(int Q, double* __restrict__ s);

@@ -169,21 +169,70 @@ __global__ void mixture_schur_finish_kernel(i64 total, i64 n, const double* __re
     H[e] = v - 0.5 * (S[e] + S[cc * n + r]);
 }
 
-// A matrix that is diagonal plus a constant on the blocks of a partition, times a column scaling:
-//   out[r, c] = ( [r == c] diag[r] + [group(r) == group(c)] gconst[group(r)] ) * colscale[c],
-// group(r) = 0 for r < K (the Dirichlet over the K mixture weights), 1 + (r mod K) otherwise (the K Dirichlets over the
-// vocabulary, parameter (v, k) at index K + v K + k): the shape of d E log p / d alpha and of the Dirichlet entropy /
-// expectation Hessians (diag(psi1(alpha)) - psi1(alpha_0): LRVB/ExponentialFamilies.py:118-120, DirichletParams.py:19-26).
-__global__ void dirichlet_blocks_kernel(i64 total, i64 n, int K, const double* __restrict__ diag, const double* __restrict__ gconst,
-                                        const double* __restrict__ colscale, double* __restrict__ out)
+// ---- J^T R J for J = "diagonal + constant per Dirichlet" without forming J (configuration 3's Schur assembly) ----------------
+// d E log p / d alpha of a Dirichlet and the Dirichlet entropy / expectation Hessians are diagonal plus a constant on the
+// blocks of a partition (diag(psi1(alpha)) - psi1(alpha_0): LRVB/ExponentialFamilies.py:118-120, DirichletParams.py:19-26):
+//   J[r, c] = ( [r == c] d[r] + [g(r) == g(c)] gam[g(r)] ) * s[c],
+// g(r) = 0 for r < K (the Dirichlet over the K mixture weights), 1 + (r mod K) otherwise (the K Dirichlets over the vocabulary,
+// parameter (v, k) at index K + v K + k).  Rounds 2-3 wrote such matrices out (dirichlet_blocks_kernel) and multiplied.
+// With J[k, i] = ([k == i] d_k + [g(k) == g(i)] gam_g(k)) s_i,
+//   (J^T R J)[i, j] = s_i s_j ( d_i d_j R[i, j] + d_i gam_g(j) RS[i, g(j)] + gam_g(i) SR[g(i), j] d_j + gam_g(i) gam_g(j) SRS[g(i), g(j)] ),
+// RS[i, b] = sum_{l in b} R[i, l], SR[a, j] = sum_{k in a} R[k, j], SRS[a, b] = sum_{k in a} RS[k, b]: O(n^2) work instead of the two
+// dense n^3 products (2 x (43 + 33 + 6) us of MFMA product, split reduction and unpacking at n = 1024).  Groups: 0 = indices
+// [0, K), 1 + k = indices K + v K + k.
+__global__ __launch_bounds__(256)
+void dirichlet_rowsums_kernel(i64 n, int K, const double* __restrict__ R, double* __restrict__ RS /* n x (K + 1) */) {
+    const i64 i = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const double* row = R + i * n;
+    for (int b = threadIdx.x & 63; b <= K; b += 64) {
+        double a = 0.0;
+        if (b == 0) { for (int l = 0; l < K; ++l) a += row[l]; }
+        else        { for (i64 l = K + (b - 1); l < n; l += K) a += row[l]; }
+        RS[i * (K + 1) + b] = a;
+    }
+}
+__global__ __launch_bounds__(256)
+void dirichlet_colsums_kernel(i64 n, int K, const double* __restrict__ R, double* __restrict__ SR /* (K + 1) x n */) {
+    const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const int a = blockIdx.y;
+    if (j >= n) return;
+    double s = 0.0;
+    if (a == 0) { for (int k = 0; k < K; ++k) s += R[(i64)k * n + j]; }
+    else        { for (i64 k = K + (a - 1); k < n; k += K) s += R[k * n + j]; }
+    SR[(i64)a * n + j] = s;
+}
+__global__ void dirichlet_blocksums_kernel(i64 n, int K, const double* __restrict__ RS, double* __restrict__ SRS /* (K + 1)^2 */) {
+    const int a = blockIdx.x;
+    for (int b = threadIdx.x; b <= K; b += blockDim.x) {
+        double s = 0.0;
+        if (a == 0) { for (int k = 0; k < K; ++k) s += RS[(i64)k * (K + 1) + b]; }
+        else        { for (i64 k = K + (a - 1); k < n; k += K) s += RS[k * (K + 1) + b]; }
+        SRS[a * (K + 1) + b] = s;
+    }
+}
+// H = Hgg o (sc sc^T) + diag(dg) - 1/2 (S + S^T), S = J^T R J as above, Hgg = "diagonal h_diag + constant h_const per Dirichlet"
+__global__ void dirichlet_schur_finish_kernel(i64 total, i64 n, int K, const double* __restrict__ R, const double* __restrict__ RS,
+                                              const double* __restrict__ SR, const double* __restrict__ SRS,
+                                              const double* __restrict__ d, const double* __restrict__ gam,
+                                              const double* __restrict__ h_diag, const double* __restrict__ h_const,
+                                              const double* __restrict__ sc, const double* __restrict__ dg, double* __restrict__ H)
 {
     const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
-    const i64 r = e / n, cc = e - r * n;
-    const int gr = r < K ? 0 : 1 + (int)(r % K), gc = cc < K ? 0 : 1 + (int)(cc % K);
-    double v = (gr == gc) ? gconst[gr] : 0.0;
-    if (r == cc) v += diag[r];
-    out[e] = colscale ? v * colscale[cc] : v;
+    const i64 i = e / n, j = e - i * n;
+    const int gi = i < K ? 0 : 1 + (int)(i % K), gj = j < K ? 0 : 1 + (int)(j % K);
+    const int nb = K + 1;
+    const double di = d[i], dj = d[j], ci = gam[gi], cj = gam[gj];
+    const double blk = ci * cj * SRS[gi * nb + gj];
+    const double sij = di * dj * R[i * n + j] + di * cj * RS[i * nb + gj] + ci * SR[(i64)gi * n + j] * dj + blk;
+    const double sji = dj * di * R[j * n + i] + dj * ci * RS[j * nb + gi] + cj * SR[(i64)gj * n + i] * di + cj * ci * SRS[gj * nb + gi];
+    double v = (gi == gj) ? h_const[gi] : 0.0;
+    if (i == j) v += h_diag[i];
+    const double ss = sc[i] * sc[j];
+    v *= ss;
+    if (i == j) v += dg[i];
+    H[e] = v - 0.5 * ss * (sij + sji);
 }
 
 // M~ (Pv x V, Pv = q (q + 1) / 2) holds M_k FOLDED onto the packed lower triangle v = a (a + 1) / 2 + b, b <= a:

@@ -1893,15 +1893,14 @@ extern "C" int lrvb_mixture_schur_dirichlet(lrvb_ctx* c, int32_t K, int32_t q, c
     if (c->mx_res_K != K || c->mx_res_q != q) LRVB_FAIL(LRVB_ERR_STATE, "no lrvb_mixture_rows / lrvb_mixture_stats result of this shape is resident");
     const i64 n = (i64)K * q, nn = n * n;
     if (c->D != n) LRVB_FAIL(LRVB_ERR_SIZE, "the context's layout has %lld free parameters, the Dirichlet blocks %lld", (long long)c->D, (long long)n);
-    DevBuf &Jd = c->mx_U, &Hd = c->mx_g;
     c->x2_ready = false;
-    LRVB_TRY(buf_reserve(c, Jd, (size_t)nn));
-    LRVB_TRY(buf_reserve(c, Hd, (size_t)nn));
-    const i64 nv = 4 * n + 2 * (K + 1);
+    const i64 nv = 4 * n + 2 * (K + 1), nb = K + 1;
     LRVB_TRY(buf_reserve(c, c->Hfree, (size_t)(nn + nv)));
     double* v = c->Hfree.p + nn;
-    LRVB_TRY(buf_reserve(c, c->work1, (size_t)nv));
-    {   // one upload: through the pinned page when it fits, else pageable
+    DevBuf &Rfull = c->mx_A, &Rm = c->mx_Xk, &Sums = c->mx_R;
+    LRVB_TRY(buf_reserve(c, Rm, (size_t)nn));
+    LRVB_TRY(buf_reserve(c, Sums, (size_t)(2 * n * nb + nb * nb)));
+    {   // one upload
         std::vector<double> pack((size_t)nv);
         memcpy(pack.data(), vecs, (size_t)(4 * n) * sizeof(double));
         memcpy(pack.data() + 4 * n, consts, (size_t)(2 * (K + 1)) * sizeof(double));
@@ -1909,9 +1908,19 @@ extern "C" int lrvb_mixture_schur_dirichlet(lrvb_ctx* c, int32_t K, int32_t q, c
     }
     const double* dl_diag = v; const double* h_diag = v + n; const double* sc = v + 2 * n; const double* dg = v + 3 * n;
     const double* dl_const = v + 4 * n; const double* h_const = dl_const + (K + 1);
-    EW(dirichlet_blocks_kernel, nn, n, (int)K, dl_diag, dl_const, sc, Jd.p);                        // Jlam = DLam diag(scale)
-    EW(dirichlet_blocks_kernel, nn, n, (int)K, h_diag, h_const, (const double*)nullptr, Hd.p);       // Hgg (vector coordinates)
-    return mixture_schur_core(c, K, q, sc, dg, H_out);
+    // J^T R J for the "diagonal + constant per Dirichlet" Jacobian in O(n^2) (k_models.hip): block row / column sums of R and the
+    // (K + 1)^2 sums of those, then one element-wise kernel that also adds the Dirichlet Hessian blocks -- neither matrix is formed
+    double* RS = Sums.p; double* SR = RS + n * nb; double* SRS = SR + n * nb;
+    EW(mixture_permute_kernel, nn, (int)q, (int)K, Rfull.p, Rm.p);
+    hipLaunchKernelGGL(dirichlet_rowsums_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, n, (int)K, (const double*)Rm.p, RS);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(dirichlet_colsums_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nb), dim3(256), 0, c->stream, n, (int)K, (const double*)Rm.p, SR);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(dirichlet_blocksums_kernel, dim3((unsigned)nb), dim3(64), 0, c->stream, n, (int)K, (const double*)RS, SRS);
+    HIP_TRY(hipGetLastError());
+    EW(dirichlet_schur_finish_kernel, nn, n, (int)K, (const double*)Rm.p, (const double*)RS, (const double*)SR, (const double*)SRS,
+       dl_diag, dl_const, h_diag, h_const, sc, dg, c->Hfree.p);
+    return H_out ? d2h(c, H_out, c->Hfree.p, (size_t)nn) : LRVB_OK;
 }
 
 // Gram matrix of per-observation gradients g_n[k] = 1/2 z_n^T M_k z_n + c_k, in FREE coordinates:
