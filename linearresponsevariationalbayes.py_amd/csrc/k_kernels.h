@@ -3,7 +3,7 @@
 #pragma once
 #include "lrvb_internal.h"
 
-// operands of wishart_obs_matrices_kernel (k_models.hip)
+// the Wishart + MVN model's per-coordinate matrices in O(d^2) numbers (wish_entry, k_models.hip)
 struct WishartGen { i64 d, ms, ls, inu, vs; double nu, mvm; const double* m; const double* vm; const double* v; };
 
 // k_elementwise.hip
@@ -72,8 +72,6 @@ __global__ void mtilde_kernel(const double* __restrict__ M, i64 V, int q, double
 __global__ void svec_kernel(const double* __restrict__ S1 /* q x q */, int q, double* __restrict__ sv /* 64 q */);
 __global__ void rank_terms_kernel(i64 V, const double* __restrict__ n_obs_dev, const double* __restrict__ t, const double* __restrict__ cvec,
                                   double* __restrict__ A /* V x V, holds M~^T K4 M~ */);
-__global__ __launch_bounds__(256)
-void wishart_obs_matrices_kernel(i64 total, i64 V, WishartGen g, double* __restrict__ M);
 __global__ void dk_coef_kernel(i64 n, int loss, double lik, int m, const double* __restrict__ w, const double* __restrict__ y,
                                const double* __restrict__ T, int Q, double* __restrict__ coef);
 __global__ void obs_loss_kernel(i64 n, int loss, double lik, const double* __restrict__ y, const double* __restrict__ z,
@@ -97,6 +95,13 @@ __global__ void dirichlet_schur_finish_kernel(i64 total, i64 n, int K, const dou
                                               const double* __restrict__ d, const double* __restrict__ gam,
                                               const double* __restrict__ h_diag, const double* __restrict__ h_const,
                                               const double* __restrict__ sc, const double* __restrict__ dg, double* __restrict__ H);
+
+__global__ void wishart_nu_coef_kernel(WishartGen g, i64 pv, double* __restrict__ cnu);
+__global__ void scatter_column_kernel(i64 n, const double* __restrict__ x, double* __restrict__ M, i64 ld, i64 col);
+__global__ __launch_bounds__(256)
+void wishart_sparse_right_kernel(WishartGen g, i64 pv, i64 V, const double* __restrict__ A, i64 lda, double* __restrict__ out, i64 ldo);
+__global__ __launch_bounds__(256)
+void wishart_sparse_left_kernel(WishartGen g, i64 pv, i64 n, const double* __restrict__ B, i64 ldb, double* __restrict__ out, i64 ldo);
 
 // k_cg.hip
 __global__ void cg_multi_alpha_kernel(int Q, double* __restrict__ s);

@@ -263,6 +263,84 @@ __global__ void svec_kernel(const double* __restrict__ S1 /* q x q */, int q, do
     sv[v] = S1[a * q + b];
 }
 
+// ---- the per-coordinate matrices of the Wishart + MVN model as a SPARSE operand (configuration 5, lrvb_wishart_gram) ----------
+// The per-observation term of the model, l_n = 1/2 nu ((y_n - m)^T V (y_n - m) + tr(V Sigma_mu)) - 1/2 E log|Lambda|
+// (LRVB/NormalParams.py:6-23, WishartParams.py:6-35), is quadratic in z = [y; 1]: d l_n / d eta_k = 1/2 z^T M_k z + c_k with
+//   d/d m_i     : M = -nu (e_q (V e_i)^T + (V e_i) e_q^T) + 2 nu (V m)_i e_q e_q^T            (e_q: the slot of the constant 1)
+//   d/d nu      : M = [[V, -V m], [-(V m)^T, m^T V m]]
+//   d/d V_(r c) : M = nu (E_rc + E_cr [r != c]) - nu (em e_q^T + e_q em^T) + nu m_r m_c (2 [r != c] + [r == c]) e_q e_q^T,
+//                 em = m_c e_r + [r != c] m_r e_c
+//   d/d Lambda_mu: M = 0 (it enters through c only).
+// Folded onto the packed lower triangle of z z^T (mtilde_kernel's rule), column k of M~ has 64 nonzeros for a mean coordinate
+// (the last triangle row (d, 0..d)), at most four for a coordinate of V ((r, c), (d, r), (d, c), (d, d)), none for the information
+// block of q(mu), and is dense for nu only: 14 K of 8.5 M entries at d = 63.  The two products around K4 -- 2176^2 x 4096 and
+// 2176 x 4096^2 on the matrix cores, 1.9 ms, until the end of round 4 -- are gathers of a few rows each; the 134 MB of matrices
+// (8 V q^2 bytes) and the 71 MB of M~ that rounds 3-4 wrote on the device are never formed.  Pinned against the generic entry
+// point fed with host-built matrices (tests/test_gpu_wishart.py::test_gram_with_device_generated_matrices, 1e-13) and exact AD.
+__device__ __forceinline__ int wish_nnz(const WishartGen& g, i64 k, i64 pv) {
+    const i64 d = g.d, mm = d * (d + 1) / 2;
+    if (k >= g.ms && k < g.ms + d) return (int)d + 1;
+    if (k == g.inu) return 0;                             // the dense column: a matrix-vector product of its own (wishart_nu_coef_kernel)
+    if (k >= g.vs && k < g.vs + mm) return 4;             // (the third entry of a diagonal coordinate has coefficient zero)
+    return 0;
+}
+__device__ __forceinline__ void wish_entry(const WishartGen& g, i64 k, int t, i64& row, double& coef) {
+    const i64 d = g.d;
+    const i64 rd = d * (d + 1) / 2;                       // first packed index of triangle row d
+    if (k >= g.ms && k < g.ms + d) {
+        const i64 i = k - g.ms;
+        row = rd + t;
+        coef = t < d ? -2.0 * g.nu * g.v[(i64)t * d + i] : 2.0 * g.nu * g.vm[i];
+    } else {
+        int r, cc; tri_pair(k - g.vs, r, cc);
+        const bool off = r != cc;
+        if (t == 0)      { row = (i64)r * (r + 1) / 2 + cc; coef = off ? 2.0 * g.nu : g.nu; }
+        else if (t == 1) { row = rd + r;  coef = -2.0 * g.nu * g.m[cc]; }
+        else if (t == 2) { row = rd + cc; coef = off ? -2.0 * g.nu * g.m[r] : 0.0; }
+        else             { row = rd + d;  coef = g.nu * g.m[r] * g.m[cc] * (off ? 2.0 : 1.0); }
+    }
+}
+// the dense column of M~ (the coordinate nu), written out: pv coefficients
+__global__ void wishart_nu_coef_kernel(WishartGen g, i64 pv, double* __restrict__ cnu) {
+    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= pv) return;
+    const i64 d = g.d;
+    int a, b; tri_pair(t, a, b);
+    double coef;
+    if (a < d) coef = a == b ? g.v[(i64)a * d + a] : g.v[(i64)a * d + b] + g.v[(i64)b * d + a];
+    else if (b < d) coef = -2.0 * g.vm[b];
+    else coef = g.mvm;
+    cnu[t] = coef;
+}
+__global__ void scatter_column_kernel(i64 n, const double* __restrict__ x, double* __restrict__ M, i64 ld, i64 col) {
+    const i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) M[r * ld + col] = x[r];
+}
+// out (rows x V, leading dimension ldo) = A M~ for a row-major A (rows x Pv-or-more, leading dimension lda): thread <-> column k
+__global__ __launch_bounds__(256)
+void wishart_sparse_right_kernel(WishartGen g, i64 pv, i64 V, const double* __restrict__ A, i64 lda, double* __restrict__ out, i64 ldo) {
+    const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 r = blockIdx.y;
+    if (k >= V) return;
+    if (k == g.inu) return;                               // written by the matrix-vector product with the nu coefficients
+    const double* arow = A + r * lda;
+    const int nz = wish_nnz(g, k, pv);
+    double s = 0.0;
+    for (int t = 0; t < nz; ++t) { i64 row; double coef; wish_entry(g, k, t, row, coef); s += coef * arow[row]; }
+    out[r * ldo + k] = s;
+}
+// out (V x n, leading dimension ldo) = M~^T B for a row-major B (Pv-or-more x n, leading dimension ldb): thread <-> column j of B
+__global__ __launch_bounds__(256)
+void wishart_sparse_left_kernel(WishartGen g, i64 pv, i64 n, const double* __restrict__ B, i64 ldb, double* __restrict__ out, i64 ldo) {
+    const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 k = blockIdx.y;
+    if (j >= n || k == g.inu) return;                     // (row nu: a matrix-vector product of its own)
+    const int nz = wish_nnz(g, k, pv);
+    double s = 0.0;
+    for (int t = 0; t < nz; ++t) { i64 row; double coef; wish_entry(g, k, t, row, coef); s += coef * B[row * ldb + j]; }
+    out[k * ldo + j] = s;
+}
+
 __global__ void rank_terms_kernel(i64 V, const double* __restrict__ n_obs_dev, const double* __restrict__ t, const double* __restrict__ cvec,
                                   double* __restrict__ A /* V x V, holds M~^T K4 M~ */) {
     const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -272,40 +350,6 @@ __global__ void rank_terms_kernel(i64 V, const double* __restrict__ n_obs_dev, c
     A[i * V + j] = 0.25 * A[i * V + j] + 0.5 * (t[i] * cvec[j] + cvec[i] * t[j]) + n_obs * cvec[i] * cvec[j];
 }
 
-__global__ __launch_bounds__(256)
-void wishart_obs_matrices_kernel(i64 total, i64 V, WishartGen g, double* __restrict__ M)
-{
-    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= total) return;
-    const i64 d = g.d, q = d + 1;
-    const i64 k = e / (q * q), rem = e - k * q * q;
-    const i64 a = rem / q, b = rem - a * q;
-    double val = 0.0;
-    if (k >= g.ms && k < g.ms + d) {                          // d/d m_i
-        const i64 i = k - g.ms;
-        if (a < d && b == d) val = -g.nu * g.v[a * d + i];
-        else if (a == d && b < d) val = -g.nu * g.v[b * d + i];
-        else if (a == d && b == d) val = 2.0 * g.nu * g.vm[i];
-    } else if (k == g.inu) {                                  // d/d nu: Q / nu
-        if (a < d && b < d) val = g.v[a * d + b];
-        else if (a < d) val = -g.vm[a];
-        else if (b < d) val = -g.vm[b];
-        else val = g.mvm;
-    } else if (k >= g.vs && k < g.vs + d * (d + 1) / 2) {     // d/d V_(rc) in the vector form of V (row-major lower triangle)
-        const i64 kk = k - g.vs;
-        i64 r = (i64)((sqrt(8.0 * (double)kk + 1.0) - 1.0) * 0.5);
-        while (r * (r + 1) / 2 > kk) --r;
-        while ((r + 1) * (r + 2) / 2 <= kk) ++r;
-        const i64 cc = kk - r * (r + 1) / 2;
-        const bool off = r != cc;
-        auto em = [&](i64 t) { return (t == r ? g.m[cc] : 0.0) + ((off && t == cc) ? g.m[r] : 0.0); };
-        if (a < d && b < d) val = g.nu * (((a == r && b == cc) ? 1.0 : 0.0) + ((off && a == cc && b == r) ? 1.0 : 0.0));
-        else if (a < d) val = -g.nu * em(a);
-        else if (b < d) val = -g.nu * em(b);
-        else val = g.nu * (g.m[r] * g.m[cc] * (off ? 2.0 : 1.0));
-    }
-    M[e] = val;                                               // the information block of q(mu) (ls) enters through c only: M = 0
-}
 
 // D^j g_eta [u_1 .. u_j] for the declared objective: the building block of the reference's higher-order
 // sensitivity (`ParametricSensitivityTaylorExpansion`, LRVB/ModelSensitivity.py:382-515, which obtains the

@@ -225,7 +225,7 @@ extern "C" int lrvb_ctx_destroy(lrvb_ctx* c) {
     DevBuf* all[] = { &c->X, &c->y, &c->w, &c->quadA, &c->quadM, &c->quadB, &c->theta, &c->eta, &c->j1, &c->j2,
                       &c->vtmp, &c->vtmp2, &c->vtmp3, &c->g_eta, &c->g_free, &c->lp, &c->cw, &c->zbuf,
                       &c->part_vec, &c->part_val, &c->stats, &c->tile_part, &c->Heta, &c->Hfree, &c->Jdense,
-                      &c->Tdense, &c->work1, &c->chol, &c->cholW, &c->hprog, &c->cgH, &c->groups, &c->mx_theta, &c->mx_lam, &c->mx_A, &c->mx_U, &c->mx_g, &c->mx_Xk, &c->mx_R, &c->cgT, &c->ones, &c->cgm[0], &c->cgm[1], &c->cgm[2], &c->cgm[3], &c->cgm[4], &c->cgm[5], &c->cgm[6], &c->cgm[7], &c->cgm[8], &c->rhs, &c->cgx, &c->cgr, &c->cgp, &c->cgq, &c->cgz, &c->scal, &c->opt, &c->dkw, &c->cyv, &c->rvec, &c->red_scratch, &c->gstats, &c->Zs, &c->ws, &c->bpart, &c->gpad, &c->boxmap, &c->jtmap, &c->Hres, &c->hres_theta, &c->qstats };
+                      &c->Tdense, &c->work1, &c->chol, &c->cholW, &c->hprog, &c->cgH, &c->groups, &c->mx_theta, &c->mx_lam, &c->mx_A, &c->mx_U, &c->mx_g, &c->mx_Xk, &c->mx_R, &c->cgT, &c->ones, &c->cgm[0], &c->cgm[1], &c->cgm[2], &c->cgm[3], &c->cgm[4], &c->cgm[5], &c->cgm[6], &c->cgm[7], &c->cgm[8], &c->rhs, &c->cgx, &c->cgr, &c->cgp, &c->cgq, &c->cgz, &c->scal, &c->opt, &c->dkw, &c->cyv, &c->rvec, &c->red_scratch, &c->gstats, &c->Zs, &c->ws, &c->bpart, &c->gpad, &c->boxmap, &c->jtmap, &c->qg_Mt, &c->qg_T1, &c->qg_Av, &c->Hres, &c->hres_theta, &c->qstats };
     for (DevBuf* b : all) buf_free(*b);
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
     if (c->up_ring) { for (int k = 0; k < lrvb_ctx::UP_SLOTS; ++k) if (c->up_ev[k]) (void)hipEventDestroy(c->up_ev[k]); (void)hipHostFree(c->up_ring); }
@@ -2025,18 +2025,16 @@ static int quadform_gram_impl(lrvb_ctx* c, const double* M, const WishartGen* ge
     // the Kronecker kernel runs (they used to wait for it on the context's stream and then cost 12 ms of a 287 ms step).
     LRVB_TRY(buf_reserve(c, c->vtmp2, (size_t)(Pv_t > V ? Pv_t : V)));
     LRVB_TRY(buf_reserve(c, c->Heta, (size_t)Pv_t * (size_t)Pv_t));
-    LRVB_TRY(buf_reserve(c, c->work1, (size_t)V * (size_t)q * (size_t)q));
+    if (M) LRVB_TRY(buf_reserve(c, c->work1, (size_t)V * (size_t)q * (size_t)q));
     LRVB_TRY(buf_reserve(c, c->Jdense, (size_t)Pv_t * (size_t)V > (size_t)V * (size_t)D ? (size_t)Pv_t * (size_t)V : (size_t)V * (size_t)D));
     LRVB_TRY(buf_reserve(c, c->vtmp3, (size_t)(V > D ? V : D)));
     LRVB_TRY(buf_reserve(c, c->Hfree, (size_t)D * (size_t)D));
+    DevBuf &Mt = c->qg_Mt, &T1 = c->qg_T1, &Av = c->qg_Av;       // kept in the context between calls
+    if (M) LRVB_TRY(buf_reserve(c, Mt, (size_t)Pv_t * (size_t)V));
+    LRVB_TRY(buf_reserve(c, T1, (size_t)(Pv_t > D ? Pv_t : D) * (size_t)V));      // K4 M~ (Pv_t x V), later J^T Av (D x V)
+    LRVB_TRY(buf_reserve(c, Av, (size_t)V * (size_t)V));
     LRVB_TRY(launch_wsyrk_kron(c, c->zbuf.p, c->Tdense.p));
-    if (M) {
-        LRVB_TRY(h2d_beside(c, c->work1.p, M, (size_t)V * (size_t)q * (size_t)q));
-    } else {                                              // the matrices are written on the device, behind the Kronecker kernel
-        const i64 total = V * (i64)q * q;
-        hipLaunchKernelGGL(wishart_obs_matrices_kernel, dim3(nb256(total)), dim3(256), 0, c->stream, total, V, *gen, c->work1.p);
-        HIP_TRY(hipGetLastError());
-    }
+    if (M) LRVB_TRY(h2d_beside(c, c->work1.p, M, (size_t)V * (size_t)q * (size_t)q));       // 134 MB at configuration 5's size: beside the Kronecker kernel
     LRVB_TRY(h2d_beside(c, c->g_eta.p, cvec, (size_t)V));
     LRVB_TRY(h2d_beside(c, c->theta.p, free_in, (size_t)D));
     LRVB_TRY(obs_reduce(c, c->Tdense.p, (i64)(tiles_n + (size_t)q * q + 1)));
@@ -2044,44 +2042,59 @@ static int quadform_gram_impl(lrvb_ctx* c, const double* M, const WishartGen* ge
     hipLaunchKernelGGL(svec_kernel, dim3(nb256(Pv)), dim3(256), 0, c->stream, sdense, q, c->vtmp2.p);
     HIP_TRY(hipGetLastError());
     LRVB_TRY(launch_tiles_to_dense(c, c->Tdense.p, Pv_t, c->Heta.p, Pv_t, 0, 0, false));
-    // M~ (Pv_t x V) from the uploaded M (work1)
-    DevBuf Mt;                                            // scoped device buffers for this call
-    LRVB_TRY(buf_reserve(c, Mt, (size_t)Pv_t * (size_t)V));
-    HIP_TRY(hipMemsetAsync(Mt.p, 0, (size_t)Pv_t * (size_t)V * sizeof(double), c->stream));
-    {
-        dim3 grid(nb256(V), (unsigned)Pv);
-        hipLaunchKernelGGL(mtilde_kernel, grid, dim3(256), 0, c->stream, c->work1.p, V, q, Mt.p);
-    }
-    int st = (hipGetLastError() == hipSuccess) ? LRVB_OK : LRVB_ERR_HIP;
-    DevBuf T1, Av;
-    if (st == LRVB_OK) st = buf_reserve(c, T1, (size_t)(Pv_t > D ? Pv_t : D) * (size_t)V);      // K4 M~ (Pv_t x V), later J^T Av (D x V)
-    if (st == LRVB_OK) st = buf_reserve(c, Av, (size_t)V * (size_t)V);
     // T1 = K4 M~ ;  Av = M~^T T1 ;  t = M~^T s
-    if (st == LRVB_OK) st = gemm_tn(c, Pv_t, Pv_t, V, c->Heta.p, Mt.p, T1.p);        // K4 is symmetric: K4 M~ = K4^T M~
-    if (st == LRVB_OK) st = gemm_tn(c, Pv_t, V, V, Mt.p, T1.p, Av.p);
-    if (st == LRVB_OK) st = launch_gemv(c, true, Pv_t, V, 1.0, Mt.p, V, c->vtmp2.p, 0.0, c->vtmp3.p);
-    if (st == LRVB_OK) {
+    if (M) {
+        // general matrices: M~ (Pv_t x V) written out, two products on the matrix cores
+        HIP_TRY(hipMemsetAsync(Mt.p, 0, (size_t)Pv_t * (size_t)V * sizeof(double), c->stream));
+        {
+            dim3 grid(nb256(V), (unsigned)Pv);
+            hipLaunchKernelGGL(mtilde_kernel, grid, dim3(256), 0, c->stream, c->work1.p, V, q, Mt.p);
+            HIP_TRY(hipGetLastError());
+        }
+        LRVB_TRY(gemm_tn(c, Pv_t, Pv_t, V, c->Heta.p, Mt.p, T1.p));        // K4 is symmetric: K4 M~ = K4^T M~
+        LRVB_TRY(gemm_tn(c, Pv_t, V, V, Mt.p, T1.p, Av.p));
+        LRVB_TRY(launch_gemv(c, true, Pv_t, V, 1.0, Mt.p, V, c->vtmp2.p, 0.0, c->vtmp3.p));
+    } else {
+        // the Wishart + MVN model: M~ is 0.2 % dense and is never written -- every column is a gather of a few rows (k_models.hip)
+        // (the one dense column, the coordinate nu, is a matrix-vector product with its Pv coefficients; they and the product
+        // vector live in c->Jdense, which this route does not use otherwise)
+        double* cnu = c->Jdense.p; double* tmpv = cnu + Pv_t;
+        hipLaunchKernelGGL(wishart_nu_coef_kernel, dim3(nb256(Pv)), dim3(256), 0, c->stream, *gen, Pv, cnu);
+        HIP_TRY(hipGetLastError());
+        dim3 gr(nb256(V), (unsigned)Pv);
+        hipLaunchKernelGGL(wishart_sparse_right_kernel, gr, dim3(256), 0, c->stream, *gen, Pv, V, (const double*)c->Heta.p, Pv_t, T1.p, V);
+        HIP_TRY(hipGetLastError());
+        LRVB_TRY(launch_gemv(c, false, Pv, Pv, 1.0, c->Heta.p, Pv_t, cnu, 0.0, tmpv));                  // K4 c_nu
+        hipLaunchKernelGGL(scatter_column_kernel, dim3(nb256(Pv)), dim3(256), 0, c->stream, Pv, (const double*)tmpv, T1.p, V, gen->inu);
+        HIP_TRY(hipGetLastError());
+        dim3 gl(nb256(V), (unsigned)V);
+        hipLaunchKernelGGL(wishart_sparse_left_kernel, gl, dim3(256), 0, c->stream, *gen, Pv, V, (const double*)T1.p, V, Av.p, V);
+        HIP_TRY(hipGetLastError());
+        LRVB_TRY(launch_gemv(c, true, Pv, V, 1.0, T1.p, V, cnu, 0.0, Av.p + gen->inu * V));             // row nu of M~^T T1
+        dim3 gt(1, (unsigned)V);
+        hipLaunchKernelGGL(wishart_sparse_left_kernel, gt, dim3(256), 0, c->stream, *gen, Pv, (i64)1, (const double*)c->vtmp2.p, (i64)1, c->vtmp3.p, (i64)1);
+        HIP_TRY(hipGetLastError());
+        LRVB_TRY(launch_gemv(c, true, Pv, 1, 1.0, c->vtmp2.p, 1, cnu, 0.0, c->vtmp3.p + gen->inu));     // t[nu] = c_nu . s
+    }
+    {
         dim3 grid(nb256(V), (unsigned)V);
         hipLaunchKernelGGL(rank_terms_kernel, grid, dim3(256), 0, c->stream, V, (const double*)ncount, c->vtmp3.p, c->g_eta.p, Av.p);
-        if (hipGetLastError() != hipSuccess) st = LRVB_ERR_HIP;
+        HIP_TRY(hipGetLastError());
     }
     // free coordinates: J^T Av J
     if (c->jt_rows > 0) {                                                             // two structured products (k_pack.hip): no dense Jacobian, no 2 V^2 D products
-        if (st == LRVB_OK) st = launch_jt_apply(c, c->theta.p, Av.p, V, V, T1.p, V, false);          // J^T Av   (D x V)
-        if (st == LRVB_OK) st = launch_jt_apply(c, c->theta.p, T1.p, V, D, c->Hfree.p, D, true);     // J^T (J^T Av)^T
+        LRVB_TRY(launch_jt_apply(c, c->theta.p, Av.p, V, V, T1.p, V, false));          // J^T Av   (D x V)
+        LRVB_TRY(launch_jt_apply(c, c->theta.p, T1.p, V, D, c->Hfree.p, D, true));     // J^T (J^T Av)^T
     } else {
-        if (st == LRVB_OK) st = launch_dense_jac(c, c->theta.p, c->Jdense.p);
-        if (st == LRVB_OK) st = gemm_tn(c, V, V, D, Av.p, c->Jdense.p, T1.p);         // Av is symmetric
-        if (st == LRVB_OK) st = gemm_tn(c, V, D, D, c->Jdense.p, T1.p, c->Hfree.p);
+        LRVB_TRY(launch_dense_jac(c, c->theta.p, c->Jdense.p));
+        LRVB_TRY(gemm_tn(c, V, V, D, Av.p, c->Jdense.p, T1.p));         // Av is symmetric
+        LRVB_TRY(gemm_tn(c, V, D, D, c->Jdense.p, T1.p, c->Hfree.p));
     }
-    if (st == LRVB_OK && GtG_out) {
-        if (hipMemcpy2DAsync(GtG_out, (size_t)ld * 8, c->Hfree.p, (size_t)D * 8, (size_t)D * 8, (size_t)D, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-            hipStreamSynchronize(c->stream) != hipSuccess) { lrvb_set_error("copy back failed"); st = LRVB_ERR_HIP; }
-    } else {
-        (void)hipStreamSynchronize(c->stream);               // (the scoped buffers below are freed: their users must be done)
+    if (GtG_out) {
+        HIP_TRY(hipMemcpy2DAsync(GtG_out, (size_t)ld * 8, c->Hfree.p, (size_t)D * 8, (size_t)D * 8, (size_t)D, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
     }
-    buf_free(Mt); buf_free(T1); buf_free(Av);
-    return st;
+    return LRVB_OK;
 }
 
 // Conjugate gradients on a dense symmetric matrix held on the device (objectives whose Hessian is

@@ -38,6 +38,7 @@ struct lrvb_ctx {
     // layout
     std::vector<lrvb_block_desc> blocks;
     lrvb_block_desc* blocks_dev = nullptr;
+    DevBuf qg_Mt, qg_T1, qg_Av;    // lrvb_quadform_gram / lrvb_wishart_gram: M~, K4 M~, M~^T K4 M~ (kept between calls: three allocations and a synchronising free per step before)
     DevBuf jtmap; i64 jt_rows = 0, jt_box = 0; size_t jt_lds = 0; int jt_kmax = 0;      // structured J^T product: row table, box entries, dynamic LDS bytes
     DevBuf boxmap; int n_box_blocks = 0; i64 n_box_entries = 0;   // per-entry [free index | vector index | lb | ub] of all box blocks (k_pack.hip: one launch per map)
     i64 D = 0, V = 0;
