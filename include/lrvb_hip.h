@@ -422,9 +422,11 @@ int lrvb_mixture_schur_dirichlet(lrvb_ctx* ctx, int32_t K, int32_t q, const doub
 int lrvb_quadform_gram(lrvb_ctx* ctx, const double* M, const double* c, int64_t K,
                        const double* free_in, double* GtG_out, int64_t ld);
 /* The same Gram matrix for the Wishart + MVN model (BASELINE.json configuration 5: y_n ~ N(mu, Lambda^-1), q(mu) = MVNParam(d),
- * q(Lambda) = WishartParam(d); LRVB/NormalParams.py:6-23, WishartParams.py:6-35) with the V matrices M_k GENERATED ON THE
- * DEVICE from (nu, m, V): the 8 V (d + 1)^2-byte operand (134 MB at d = 63) no longer crosses PCIe, and with GtG_out == NULL the
- * result stays in HBM as well (lrvb_chol_factor_last factors it; a sharded step then moves nothing over PCIe but c and theta).
+ * q(Lambda) = WishartParam(d); LRVB/NormalParams.py:6-23, WishartParams.py:6-35) with the V matrices M_k described by
+ * (nu, m, V) alone: they are 0.2 % dense (64 entries per mean coordinate, four per coordinate of V, one dense matrix for nu) and
+ * enter the contraction as gathers -- the 8 V (d + 1)^2-byte operand (134 MB at d = 63) is never formed, on either side of PCIe --
+ * and with GtG_out == NULL the result stays in HBM as well (lrvb_chol_factor_last factors it; a sharded step then moves
+ * nothing over PCIe but c and theta).
  * offsets = vector-coordinate positions of [mean of q(mu), vech(information of q(mu)), nu, vech(V)]; v is d x d row-major;
  * cvec (V) the constants c_k of the per-observation gradient, as for lrvb_quadform_gram.                                  */
 int lrvb_wishart_gram(lrvb_ctx* ctx, int64_t d, const int64_t* offsets, double nu, const double* m, const double* v,
