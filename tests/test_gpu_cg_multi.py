@@ -307,3 +307,37 @@ def test_many_products_at_one_point_build_the_hessian(vb):
     prof = ctx.profile_get()
     ctx.profile_enable(False)
     assert prof['wsyrk_calls'] == 1
+
+
+def test_automatic_build_under_a_reduce_hook(vb):
+    """With a sum-over-ranks hook installed (a one-rank identity hook that records what it is handed), the automatic build
+    of the point's Hessian inside a run of `lrvb_cg_solve` calls reduces its statistics buffer exactly once -- every rank
+    counts the same products, so every rank builds at the same product -- and the products after it hand nothing to the
+    hook; the solutions are those of a direct solve."""
+    rng = np.random.default_rng(78)
+    N, P, Q = 4000, 288, 4
+    par, lay = make_par(vb, [('box', 'a', P, -np.inf, np.inf)])
+    x, y, w = glm_data(rng, N, P, om.POISSON)
+    fun = vb.DeviceObjective(par, x=x, y=y, loss='poisson', quad_A=np.full(P, 0.5), weights=w)
+    fun._push_state()
+    ctx = fun.ctx
+    model = om.DeclaredModel(lay, loss=om.POISSON, x=x, y=y, w=w, quad_A=np.full(P, 0.5))
+    theta = rng.normal(size=P) * 0.1
+    H = model.hessian(theta)
+    B = rng.normal(size=(Q, P))
+    calls = []
+    ctx.set_reduce_hook(lambda ptr, n, stream: calls.append(n))
+    try:
+        sols = [ctx.cg_solve(theta, B[q], tol=1e-10) for q in range(Q)]
+    finally:
+        ctx.set_reduce_hook(None)
+    for q, (xq, info, its) in enumerate(sols):
+        assert info == 0 and np.max(np.abs(xq - np.linalg.solve(H, B[q]))) < 1e-7
+    stats_size = 1 + P + 6 * 128 * 128                   # [value | gradient | lower-triangle tiles] of a 288-column design: 3 x 4 / 2 = 6 tiles
+    assert calls.count(stats_size) == 1
+    n_products = sum(s[2] for s in sols)
+    thr = max(8, P // 64)
+    # one gradient pass ([value | gradient]) at the start, `thr` matrix-free products handing their P-vector to the hook, then --
+    # in front of product thr + 1 -- the build; nothing after it, however many products follow
+    assert n_products > 4 * thr
+    assert calls == [1 + P] + [P] * thr + [stats_size]
