@@ -413,17 +413,41 @@ __device__ __forceinline__ void vech_rc(int k, int& r, int& c) {
     r = a; c = k - a * (a + 1) / 2;
 }
 __global__ __launch_bounds__(1024)
-void lmm_closed_forms_kernel(LmmIdx ix, const double* __restrict__ Sg, const double* __restrict__ sums, const double* __restrict__ Md,
-                             const double* __restrict__ hp, double* __restrict__ g, double* __restrict__ H, double* __restrict__ Gc)
+void lmm_closed_forms_kernel(LmmIdx ix, const double* __restrict__ Sg, const double* __restrict__ sums_g, const double* __restrict__ Md,
+                             const double* __restrict__ hp, double* __restrict__ g, double* __restrict__ H, double* __restrict__ Gc,
+                             const double* __restrict__ part, int n_part, double* __restrict__ sums_out)
 {
     extern __shared__ double lds[];                       // S (q^2) | P (p^2) | T (p^2) | PSP (p^2): one global read each, then LDS
     __shared__ double sh[1024];
     __shared__ double um[64];
     __shared__ double sc[16];
+    __shared__ double sums[128];
     const int p = ix.p, q = p + 1, tid = threadIdx.x;
     double* S = lds; double* P = S + q * q; double* T = P + p * p; double* PSP = T + p * p;
     for (int e = tid; e < q * q; e += 1024) S[e] = Sg[e];
     for (int e = tid; e < p * p; e += 1024) P[e] = hp[32 + 2 * p + e];
+    // the sums over groups: given (sums_g), or formed here from the partial rows of lmm_group_kernel in lmm_sums_kernel's order
+    // (eight interleaved slices, then the slices in order; the vector part moved down by one slot) -- one launch less per step
+    if (part) {
+        const int k = tid & 127, sl = tid >> 7;
+        double a0 = 0.0, a1 = 0.0;
+        int wv = sl;
+        for (; wv + 8 < n_part; wv += 16) { a0 += part[(i64)wv * 128 + k]; a1 += part[(i64)(wv + 8) * 128 + k]; }
+        if (wv < n_part) a0 += part[(i64)wv * 128 + k];
+        sh[sl * 128 + k] = a0 + a1;
+        __syncthreads();
+        if (sl == 0) {
+            double a = 0.0;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) a += sh[t * 128 + k];
+            if (k < 64) { if (k >= 1) sums[k - 1] = a; if (k == 63) sums[63] = 0.0; }
+            else sums[k] = a;
+        }
+        __syncthreads();
+        if (sums_out && tid < 128) sums_out[tid] = sums[tid];
+    } else {
+        if (tid < 128) sums[tid] = sums_g[tid];
+    }
     __syncthreads();
     const i64 ld = ix.ld;
     const double ty = hp[0], tm = hp[1], e_mu = hp[2], i_mu = hp[3], ay = hp[4], by = hp[5], am = hp[6], bm = hp[7];
@@ -540,12 +564,14 @@ static int closed_forms_lds(const void* kernel, size_t bytes) {
     if (bytes > 64 * 1024) HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return LRVB_OK;
 }
-int launch_lmm_closed_forms(lrvb_ctx* c, const LmmIdx& ix, const double* S, const double* sums, const double* Md, const double* hp,
-                            double* scratch, double* g, double* H, double* Gc) {
+// sums: the 128 sums over groups on the device; or part / n_part: the partial rows of lmm_group_kernel, summed inside the kernel
+// and written to sums (for the caller's diagnostics)
+int launch_lmm_closed_forms(lrvb_ctx* c, const LmmIdx& ix, const double* S, double* sums, const double* Md, const double* hp,
+                            double* scratch, double* g, double* H, double* Gc, const double* part, int n_part) {
     (void)scratch;
     const size_t bytes = ((size_t)(ix.p + 1) * (ix.p + 1) + 3 * (size_t)ix.p * ix.p) * sizeof(double);
     LRVB_TRY(closed_forms_lds(reinterpret_cast<const void*>(lmm_closed_forms_kernel), bytes));
-    hipLaunchKernelGGL(lmm_closed_forms_kernel, dim3(1), dim3(1024), bytes, c->stream, ix, S, sums, Md, hp, g, H, Gc);
+    hipLaunchKernelGGL(lmm_closed_forms_kernel, dim3(1), dim3(1024), bytes, c->stream, ix, S, (const double*)sums, Md, hp, g, H, Gc, part, n_part, sums);
     HIP_TRY(hipGetLastError());
     return LRVB_OK;
 }

@@ -1125,7 +1125,7 @@ static int grouped_stats_device(lrvb_ctx* c);
 static int lmm_group_terms_device(lrvb_ctx* c, const double* par, int64_t n_par, const double* f_local, int64_t n_local, double** sums_dev);
 struct LmmTermsLayout { double *Cm, *wts, *dpar, *dloc, *part, *sums, *Md; int ldc; i64 grid, n_waves, G, p, R; };
 static int lmm_group_terms_prepare(lrvb_ctx* c, const double* par, int64_t n_par, const double* f_local, int64_t n_local, LmmTermsLayout& L);
-static int lmm_group_terms_launch(lrvb_ctx* c, const LmmTermsLayout& L);
+static int lmm_group_terms_launch(lrvb_ctx* c, const LmmTermsLayout& L, bool with_sums);
 // J^T H_vec J + sum_k g_k d2 eta_k for the vector-coordinate matrix in c->Heta (leading dimension Vp = V rounded up to even,
 // the padding zero) with theta on the device and g in c->g_eta; the result in c->Hfree (leading dimension D), where
 // lrvb_chol_factor_last finds it.  Even widths throughout: the two products run on the LDS-DMA MFMA kernel without the padded
@@ -1301,10 +1301,11 @@ extern "C" int lrvb_lmm_global_hessian(lrvb_ctx* c, lrvb_ctx* gc, const double* 
     auto chain = [&]() -> int {
         // (a) [S | group sums] in one pass, summed over the ranks; the 2 G local parameters eliminated
         LRVB_TRY(grouped_stats_device(c));
-        LRVB_TRY(lmm_group_terms_launch(c, L));
-        // (b) the closed forms where the statistics lie, the Kronecker block, the conversion to free coordinates
+        LRVB_TRY(lmm_group_terms_launch(c, L, false));
+        // (b) the closed forms where the statistics lie (the sums over groups formed inside the kernel from the partial rows),
+        // the Kronecker block, the conversion to free coordinates
         LRVB_TRY(free_conversion_clear(gc, Vp));
-        LRVB_TRY(launch_lmm_closed_forms(gc, ix, c->gstats.p, sums, sums + 128, hp_dev, scratch, gc->g_eta.p, gc->Heta.p, Gc));
+        LRVB_TRY(launch_lmm_closed_forms(gc, ix, c->gstats.p, sums, sums + 128, hp_dev, scratch, gc->g_eta.p, gc->Heta.p, Gc, L.part, (int)L.n_waves));
         LRVB_TRY(launch_symkron3(gc, (int)p, Gc, hp_dev + 32 + 2 * p, gc->Heta.p, Vp, ix.ls));
         return free_conversion_padded(gc, gc->hprog.p, Vp);
     };
@@ -1726,15 +1727,18 @@ static int lmm_group_terms_prepare(lrvb_ctx* c, const double* par, int64_t n_par
     memcpy(pack.data() + 8 + p, f_local, (size_t)(2 * G) * sizeof(double));
     return h2d(c, L.dpar, pack.data(), pack.size());
 }
-static int lmm_group_terms_launch(lrvb_ctx* c, const LmmTermsLayout& L) {
+// with_sums = false: the sums over groups are left to the consumer of the partial rows (lmm_closed_forms_kernel forms them itself)
+static int lmm_group_terms_launch(lrvb_ctx* c, const LmmTermsLayout& L, bool with_sums) {
     if (!c->gstats_valid) LRVB_FAIL(LRVB_ERR_STATE, "no grouped statistics resident: call lrvb_grouped_stats first");
     const i64 q = c->P;
     if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
     hipLaunchKernelGGL(lmm_group_kernel, dim3((unsigned)L.grid), dim3(256), 0, c->stream,
                        (const double*)(c->gstats.p + q * q), L.G, (int)L.p, (const double*)L.dpar, (const double*)L.dloc, L.Cm, L.ldc, L.wts, L.part);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(lmm_sums_kernel, dim3(1), dim3(1024), 0, c->stream, (const double*)L.part, (int)L.n_waves, L.sums);
-    HIP_TRY(hipGetLastError());
+    if (with_sums) {
+        hipLaunchKernelGGL(lmm_sums_kernel, dim3(1), dim3(1024), 0, c->stream, (const double*)L.part, (int)L.n_waves, L.sums);
+        HIP_TRY(hipGetLastError());
+    }
     if (c->prof_on) LRVB_TRY(prof_mark(c, PROF_WSYRK));
     // M as a dense R x R matrix, no unpacking launch (the Gram kernel clamps rows past 2 G: no padding to clear)
     return launch_gram_small_on(c, L.Cm, 2 * L.G, L.ldc, L.wts, c->Tdense.p, L.Md, L.R, nullptr, L.R);
@@ -1743,7 +1747,7 @@ static int lmm_group_terms_device(lrvb_ctx* c, const double* par, int64_t n_par,
     if (!c->gstats_valid) LRVB_FAIL(LRVB_ERR_STATE, "no grouped statistics resident: call lrvb_grouped_stats first");
     LmmTermsLayout L;
     LRVB_TRY(lmm_group_terms_prepare(c, par, n_par, f_local, n_local, L));
-    LRVB_TRY(lmm_group_terms_launch(c, L));
+    LRVB_TRY(lmm_group_terms_launch(c, L, true));
     *sums_dev = L.sums;
     return LRVB_OK;
 }

@@ -180,8 +180,8 @@ int  launch_tiles_to_dense(lrvb_ctx* c, const double* tiles_dev, i64 P, double* 
 
 // k_lmm.hip
 struct LmmIdx { int p, ms, ls, iem, iim, iay, iby, iam, ibm; i64 ld; };    // vector-coordinate positions of the global parameters
-int  launch_lmm_closed_forms(lrvb_ctx* c, const LmmIdx& ix, const double* S, const double* sums, const double* Md, const double* hp,
-                             double* scratch /* 2 p^2 */, double* g, double* H, double* Gc);
+int  launch_lmm_closed_forms(lrvb_ctx* c, const LmmIdx& ix, const double* S, double* sums, const double* Md, const double* hp,
+                             double* scratch, double* g, double* H, double* Gc, const double* part = nullptr, int n_part = 0);
 int  launch_symkron3(lrvb_ctx* c, int k, const double* G, const double* P, double* H, i64 ld, i64 off);
 struct MvnRegIdx { int k, ms, ls, ia, ib; i64 ld; };
 int  launch_mvnreg_closed_forms(lrvb_ctx* c, const MvnRegIdx& ix, const double* S /* (k+1)^2 | W */, const double* hp, double* scratch,
