@@ -424,6 +424,12 @@ def run_config(args, cfg=None, steps=None, warmup=None, env=None):
         # 64 q = 4096 columns of z (x) z, N 4096 4097 = 1.68e13 flops, and priced the step against that)
         pv = (d + 1) * (d + 2) // 2
         bound, alg, unit, peak = 'mfma', float(r1 - r0) * pv * (pv + 1), 'TFLOP/s', PEAK_FP64_MFMA_TFLOPS
+        extra['survey_8d_flops'] = float(r1 - r0) * D * (D + 1)
+        extra['note'] = ('algorithmic_per_step is the arithmetic of the algorithm that runs: the SYRK over the packed lower triangle of z z^T, '
+                         'N Pv (Pv + 1) with Pv = {} virtual columns.  SURVEY 8(d) prices the naive product of the N x D gradient matrix with itself, '
+                         'N D (D + 1) = survey_8d_flops ({:.2f} x as many), which this library never forms (G is quadratic in the data: '
+                         'G^T G = M~^T K4 M~); priced against that figure the step would read more than the matrix-core peak, so it is carried '
+                         'beside, not used').format(pv, D * (D + 1) / float(pv * (pv + 1)))
         ctx = fun.ctx
 
     def fence():
