@@ -367,11 +367,13 @@ static int launch_pass_nit(lrvb_ctx* c, PassMode mode, const double* beta, const
 
 // ---- wide designs in ONE pass (round 4): 1024 < n_cols <= 4096 --------------------------------------------------------------
 // A row of up to 4096 columns (32 KB) does not fit the registers of one wavefront, but it fits those of a WORKGROUP: wave w of
-// the four holds the columns [w NIT 128, (w + 1) NIT 128) of the stage's rows, exactly as the narrow kernel holds a whole row.
-// The dot product is the only thing the waves share: each reduces its quarter with the butterfly, the four partial sums meet in
-// LDS (two slots, alternating by stage: ONE barrier per stage) and are added in wave order, so every wave sees the same z; the
-// rank-one update then runs from the registers again and the waves write disjoint columns of the block partial.  X is read
-// once, as for narrow designs (the two-pass route below read it twice).
+// its NW (two up to 2048 columns, four beyond: the fewer waves share a row, the fewer wait at its barrier) holds the columns
+// [w NIT 128, (w + 1) NIT 128) of the stage's R rows, exactly as the narrow kernel holds a whole row.  The dot products are the
+// only thing the waves share: each reduces its part for all R rows in one merged butterfly (group_sums), the NW partial sums
+// meet in LDS (two slots, alternating by stage: ONE barrier per stage) and are added in wave order, so every wave sees the same
+// z; the loss terms are evaluated once per stage (row L / (64 / R) in lane L), the rank-one update runs from the registers again
+// and the waves write disjoint columns of the block partial.  X is read once, as for narrow designs (the two-pass route below
+// reads it twice).  The grid is the number of workgroups the chip holds at once (wide1_run).
 template <int NW, int NIT, int R, int MODE>
 __global__ __launch_bounds__(NW * 64)
 void glm_pass_wide1_kernel(const double* __restrict__ X, i64 ldx, i64 N, int P,
